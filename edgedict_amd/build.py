@@ -1,0 +1,83 @@
+"""In-tree build of libedgedict_hip.so (gfx950 only) with hipcc.
+
+Every ``*.hip`` / ``*.cpp`` file under ``edgedict_amd/csrc`` is compiled to an object file
+(in parallel, skipped when up to date) and linked into ``edgedict_amd/csrc/libedgedict_hip.so``.
+hipcc cross-compiles without a GPU, so this runs in the CPU-only build container; the resulting
+``.so`` travels to the GPU box with the repo snapshot.
+
+Run ``python -m edgedict_amd.build`` (add ``--force`` to rebuild everything).
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+INCLUDE = os.path.join(ROOT, "include")
+LIB_NAME = "libedgedict_hip.so"
+LIB_PATH = os.path.join(CSRC, LIB_NAME)
+ARCH = "gfx950"
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+            "-I", INCLUDE, "-I", CSRC]
+
+
+def _sources():
+    out = []
+    for fn in sorted(os.listdir(CSRC)):
+        if fn.endswith(".hip") or fn.endswith(".cpp"):
+            out.append(os.path.join(CSRC, fn))
+    return out
+
+
+def _deps_mtime():
+    m = 0.0
+    for d in (CSRC, INCLUDE):
+        for fn in os.listdir(d):
+            if fn.endswith((".hpp", ".h")):
+                m = max(m, os.path.getmtime(os.path.join(d, fn)))
+    return m
+
+
+def _compile_one(src, force, hdr_mtime):
+    obj = os.path.splitext(src)[0] + ".o"
+    if (not force and os.path.exists(obj)
+            and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_mtime)):
+        return obj, None
+    cmd = [HIPCC, "--offload-arch=" + ARCH, "-x", "hip"] + CXXFLAGS + ["-c", src, "-o", obj]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed for %s:\n%s\n%s" % (src, " ".join(cmd), r.stderr))
+    return obj, r.stderr
+
+
+def build_all(force=False, verbose=True):
+    """Compile + link the HIP library. Returns the path of the shared object."""
+    srcs = _sources()
+    hdr_mtime = _deps_mtime()
+    workers = max(1, min(len(srcs), (os.cpu_count() or 2)))
+    with ThreadPoolExecutor(workers) as ex:
+        results = list(ex.map(lambda s: _compile_one(s, force, hdr_mtime), srcs))
+    objs = [o for o, _ in results]
+    rebuilt = [o for o, msg in results if msg is not None]
+    for o, msg in results:
+        if msg and verbose and msg.strip():
+            sys.stderr.write(msg)
+    need_link = (force or rebuilt or not os.path.exists(LIB_PATH)
+                 or any(os.path.getmtime(o) > os.path.getmtime(LIB_PATH) for o in objs))
+    if need_link:
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
+    if verbose:
+        print("[edgedict_amd.build] %s (%d objects, %d recompiled)" %
+              (LIB_PATH, len(objs), len(rebuilt)))
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

@@ -1,0 +1,401 @@
+// RNN-T forward-backward loss for gfx950.
+//
+// Replaces the third-party warprnnt_pytorch.RNNTLoss operator used at
+// rnnt/models.py:221,238 (reference).  Arithmetic = Graves 2012:
+//   lp = log_softmax(z);  alpha/beta lattice recursions in log space;  cost = -alpha(T-1,U)-lp_blank
+//   d cost / d z(t,u,v) = softmax(v)*exp(a+b-ll) - [v=blank]*exp(a+lp+beta(t+1,u)-ll)
+//                                              - [v=y_{u+1}]*exp(a+lp+beta(t,u+1)-ll)
+//
+// Three HBM-/latency-shaped kernels, none of them GEMM-shaped (no MFMA here on purpose):
+//   1. rnnt_lse_gather : one wave64 per lattice cell row (V logits), 16-byte coalesced loads,
+//                        online max/sum, writes denominator + blank/label log-probs.   HBM-bound.
+//   2. rnnt_alpha_beta : one workgroup per (utterance, direction); one lane per label position,
+//                        anti-diagonal sweep, u-1 / u+1 neighbour exchanged through a
+//                        double-buffered LDS line, next diagonal's log-probs prefetched
+//                        before the barrier.                                   latency-bound.
+//   3. rnnt_grad       : one wave64 per row again; reads logits once, writes grads once. HBM-bound.
+#include "common.hpp"
+
+namespace {
+
+struct WsLayout {
+    size_t cells;  // B*T*U1
+    size_t off_denom, off_lpb, off_lpl, off_alpha, off_beta, off_ll, total;
+};
+
+inline WsLayout ws_layout(int B, int T, int U1) {
+    WsLayout w;
+    w.cells = (size_t)B * T * U1;
+    const size_t cell_bytes = ((w.cells * sizeof(float) + 255) / 256) * 256;
+    w.off_denom = 0;
+    w.off_lpb = cell_bytes;
+    w.off_lpl = 2 * cell_bytes;
+    w.off_alpha = 3 * cell_bytes;
+    w.off_beta = 4 * cell_bytes;
+    w.off_ll = 5 * cell_bytes;
+    w.total = 5 * cell_bytes + (((size_t)2 * B * sizeof(float) + 255) / 256) * 256;
+    return w;
+}
+
+// ------------------------------------------------------------------ kernel 1
+// grid-stride over rows; 4 waves per block, one row per wave per iteration.
+template <typename T>
+__global__ __launch_bounds__(256) void rnnt_lse_gather(
+    const T* __restrict__ acts, const int32_t* __restrict__ labels,
+    const int32_t* __restrict__ act_lens, const int32_t* __restrict__ label_lens, int B, int Tm,
+    int U1, int V, int blank, float* __restrict__ denom, float* __restrict__ lpb,
+    float* __restrict__ lpl, int vec_ok) {
+    constexpr int VEC = ElemIO<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long long rows = (long long)B * Tm * U1;
+    for (long long row = (long long)blockIdx.x * 4 + wave; row < rows;
+         row += (long long)gridDim.x * 4) {
+        const int u = (int)(row % U1);
+        const long long bt = row / U1;
+        const int t = (int)(bt % Tm);
+        const int b = (int)(bt / Tm);
+        const int Tb = act_lens[b], Ub = label_lens[b];
+        if (t >= Tb || u > Ub) continue;  // outside the utterance's lattice: never read
+        const T* z = acts + row * (long long)V;
+        float m = -INFINITY, s = 0.f;
+        if (vec_ok) {
+            for (int v = lane * VEC; v < V; v += 64 * VEC) {
+                float x[VEC];
+                ElemIO<T>::load_vec(z + v, x);
+                float mx = x[0];
+#pragma unroll
+                for (int i = 1; i < VEC; ++i) mx = fmaxf(mx, x[i]);
+                const float mn = fmaxf(m, mx);
+                float acc = 0.f;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) acc += __expf(x[i] - mn);
+                s = s * __expf(m - mn) + acc;
+                m = mn;
+            }
+        } else {
+            for (int v = lane; v < V; v += 64) {
+                const float x = ElemIO<T>::load(z + v);
+                const float mn = fmaxf(m, x);
+                s = s * __expf(m - mn) + __expf(x - mn);
+                m = mn;
+            }
+        }
+        // combine the 64 (m, s) pairs
+        const float M = wave_max(m);
+        const float part = (m == -INFINITY) ? 0.f : s * __expf(m - M);
+        const float S = wave_sum(part);
+        const float lse = M + logf(S);
+        if (lane == 0) {
+            denom[row] = lse;
+            lpb[row] = ElemIO<T>::load(z + blank) - lse;
+            float l = 0.f;
+            if (u < Ub) {
+                const int y = labels[(long long)b * (U1 - 1) + u];
+                l = ElemIO<T>::load(z + y) - lse;
+            }
+            lpl[row] = l;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ kernel 2
+// blockIdx.x = 2*b + dir  (dir 0: alpha, dir 1: beta).  blockDim.x = roundup(U1, 64).
+// Thread u owns lattice column u.  At diagonal d the live cell of column u is t = d - u
+// (alpha) or the mirrored one (beta).
+__global__ void rnnt_alpha_beta(const float* __restrict__ lpb, const float* __restrict__ lpl,
+                                const int32_t* __restrict__ act_lens,
+                                const int32_t* __restrict__ label_lens, int Tm, int U1,
+                                float* __restrict__ alphas, float* __restrict__ betas,
+                                float* __restrict__ ll) {
+    extern __shared__ __attribute__((aligned(16))) float xch[];  // [2][blockDim.x + 2]
+    const int b = blockIdx.x >> 1;
+    const int dir = blockIdx.x & 1;
+    const int u = threadIdx.x;
+    const int Tb = act_lens[b], Ub = label_lens[b];
+    const int stride = blockDim.x + 2;
+    const long long base = (long long)b * Tm * U1;
+    const bool col_ok = (u <= Ub);
+    const int ndiag = Tb + Ub;  // diagonals 0 .. Tb+Ub-1
+
+    // both buffers start at -inf so that out-of-lattice neighbours contribute nothing
+    for (int i = threadIdx.x; i < 2 * stride; i += blockDim.x) xch[i] = -INFINITY;
+    __syncthreads();
+
+    if (dir == 0) {
+        // ---------------- alpha: a(t,u) = lse(a(t-1,u)+lpb(t-1,u), a(t,u-1)+lpl(t,u-1))
+        float stay = -INFINITY;  // a(t-1,u) + lpb(t-1,u), carried in a register
+        // prefetch log-probs of this column's first live cell (t = 0 at diagonal d = u)
+        float nb = 0.f, nl = 0.f;
+        if (col_ok && Tb > 0) {
+            nb = lpb[base + u];
+            nl = lpl[base + u];
+        }
+        for (int d = 0; d < ndiag; ++d) {
+            const int t = d - u;
+            const bool live = col_ok && t >= 0 && t < Tb;
+            float* cur = xch + (d & 1) * stride;
+            const float* prev = xch + ((d + 1) & 1) * stride;
+            if (live) {
+                const float cb = nb, cl = nl;
+                // prefetch (t+1, u) for the next diagonal
+                if (t + 1 < Tb) {
+                    const long long nidx = base + (long long)(t + 1) * U1 + u;
+                    nb = lpb[nidx];
+                    nl = lpl[nidx];
+                }
+                float a;
+                if (t == 0 && u == 0) {
+                    a = 0.f;
+                } else {
+                    const float from_left = prev[u];  // a(t,u-1)+lpl(t,u-1); slot u holds column u-1
+                    a = log_add(stay, from_left);
+                }
+                alphas[base + (long long)t * U1 + u] = a;
+                stay = a + cb;
+                cur[u + 1] = (u < Ub) ? a + cl : -INFINITY;
+                if (t == Tb - 1 && u == Ub) ll[2 * b] = a + cb;
+            } else {
+                cur[u + 1] = -INFINITY;
+            }
+            __syncthreads();
+        }
+    } else {
+        // ---------------- beta: b(t,u) = lse(b(t+1,u)+lpb(t,u), b(t,u+1)+lpl(t,u))
+        // mirrored diagonal index e = (Tb-1-t) + (Ub-u)
+        float up = -INFINITY;  // b(t+1,u)
+        float nb = 0.f, nl = 0.f;
+        if (col_ok && Tb > 0) {
+            const long long idx = base + (long long)(Tb - 1) * U1 + u;
+            nb = lpb[idx];
+            nl = lpl[idx];
+        }
+        for (int e = 0; e < ndiag; ++e) {
+            const int t = Tb - 1 - (e - (Ub - u));
+            const bool live = col_ok && t >= 0 && t < Tb;
+            float* cur = xch + (e & 1) * stride;
+            const float* prev = xch + ((e + 1) & 1) * stride;
+            if (live) {
+                const float cb = nb, cl = nl;
+                if (t - 1 >= 0) {
+                    const long long nidx = base + (long long)(t - 1) * U1 + u;
+                    nb = lpb[nidx];
+                    nl = lpl[nidx];
+                }
+                float bv;
+                if (t == Tb - 1 && u == Ub) {
+                    bv = cb;
+                } else {
+                    const float right = prev[u + 1];  // b(t,u+1) published by column u+1
+                    const float via_label = (u < Ub) ? right + cl : -INFINITY;
+                    const float via_blank = (t < Tb - 1) ? up + cb : -INFINITY;
+                    bv = log_add(via_blank, via_label);
+                }
+                betas[base + (long long)t * U1 + u] = bv;
+                up = bv;
+                cur[u] = bv;
+                if (t == 0 && u == 0) ll[2 * b + 1] = bv;
+            } else {
+                cur[u] = -INFINITY;
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// single block: costs[b] = -ll_alpha[b]; optionally reduced[0] = reduce_scale * sum_b costs[b]
+__global__ __launch_bounds__(256) void rnnt_costs(const float* __restrict__ ll,
+                                                  float* __restrict__ costs, int B,
+                                                  float* __restrict__ reduced, float reduce_scale) {
+    __shared__ float part[4];
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const float c = -ll[2 * b];
+        costs[b] = c;
+        acc += c;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && reduced) reduced[0] = reduce_scale * (part[0] + part[1] + part[2] + part[3]);
+}
+
+// ------------------------------------------------------------------ kernel 3
+template <typename T>
+__global__ __launch_bounds__(256) void rnnt_grad(
+    const T* __restrict__ acts, T* __restrict__ grads, const int32_t* __restrict__ labels,
+    const int32_t* __restrict__ act_lens, const int32_t* __restrict__ label_lens, int B, int Tm,
+    int U1, int V, int blank, const float* __restrict__ denom, const float* __restrict__ alphas,
+    const float* __restrict__ betas, const float* __restrict__ ll, float scale_host,
+    const float* __restrict__ scale_dev, int scale_stride, int vec_ok) {
+    constexpr int VEC = ElemIO<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const long long rows = (long long)B * Tm * U1;
+    for (long long row = (long long)blockIdx.x * 4 + wave; row < rows;
+         row += (long long)gridDim.x * 4) {
+        const int u = (int)(row % U1);
+        const long long bt = row / U1;
+        const int t = (int)(bt % Tm);
+        const int b = (int)(bt / Tm);
+        const int Tb = act_lens[b], Ub = label_lens[b];
+        const float scale = scale_host * (scale_dev ? scale_dev[(long long)b * scale_stride] : 1.f);
+        const T* z = acts + row * (long long)V;
+        T* g = grads + row * (long long)V;
+        const bool inside = (t < Tb && u <= Ub);
+        float c_all = 0.f, c_blank = -INFINITY, c_label = -INFINITY;
+        int y = -1;
+        if (inside) {
+            const float a = alphas[row], bt_ = betas[row], lse = denom[row];
+            const float L = ll[2 * b];
+            c_all = a + bt_ - L - lse;  // exp(z + c_all) = softmax * exp(a+b-L)
+            if (t < Tb - 1)
+                c_blank = a + betas[row + U1] - L - lse;
+            else if (u == Ub)
+                c_blank = a - L - lse;
+            if (u < Ub) {
+                y = labels[(long long)b * (U1 - 1) + u];
+                c_label = a + betas[row + 1] - L - lse;
+            }
+        }
+        if (vec_ok) {
+            for (int v = lane * VEC; v < V; v += 64 * VEC) {
+                float o[VEC];
+                if (inside) {
+                    float x[VEC];
+                    ElemIO<T>::load_vec(z + v, x);
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) {
+                        float gv = __expf(x[i] + c_all);
+                        if (v + i == blank) gv -= __expf(x[i] + c_blank);
+                        if (v + i == y) gv -= __expf(x[i] + c_label);
+                        o[i] = gv * scale;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < VEC; ++i) o[i] = 0.f;
+                }
+                ElemIO<T>::store_vec(g + v, o);
+            }
+        } else {
+            for (int v = lane; v < V; v += 64) {
+                float gv = 0.f;
+                if (inside) {
+                    const float x = ElemIO<T>::load(z + v);
+                    gv = __expf(x + c_all);
+                    if (v == blank) gv -= __expf(x + c_blank);
+                    if (v == y) gv -= __expf(x + c_label);
+                    gv *= scale;
+                }
+                ElemIO<T>::store(g + v, gv);
+            }
+        }
+    }
+}
+
+inline int check_common(int B, int T, int U1, int V, int blank, int dtype) {
+    ED_CHECK_ARG(B > 0 && T > 0 && U1 > 0 && V > 0, "rnnt_loss: B,T,U1,V must be positive (got %d,%d,%d,%d)", B, T, U1, V);
+    ED_CHECK_ARG(U1 <= 1024, "rnnt_loss: U+1 = %d exceeds the supported maximum of 1024", U1);
+    ED_CHECK_ARG(blank >= 0 && blank < V, "rnnt_loss: blank %d outside [0,%d)", blank, V);
+    ED_CHECK_ARG(dtype == ED_F32 || dtype == ED_BF16, "rnnt_loss: unsupported dtype code %d", dtype);
+    return ED_OK;
+}
+
+}  // namespace
+
+extern "C" size_t edgedict_rnnt_workspace_bytes(int B, int T, int U1) {
+    if (B <= 0 || T <= 0 || U1 <= 0) return 0;
+    return ws_layout(B, T, U1).total;
+}
+
+extern "C" const float* edgedict_rnnt_workspace_view(const void* workspace, int B, int T, int U1,
+                                                     int which) {
+    const WsLayout w = ws_layout(B, T, U1);
+    const char* p = (const char*)workspace;
+    switch (which) {
+        case 0: return (const float*)(p + w.off_denom);
+        case 1: return (const float*)(p + w.off_alpha);
+        case 2: return (const float*)(p + w.off_beta);
+        case 3: return (const float*)(p + w.off_ll);
+        case 4: return (const float*)(p + w.off_lpb);
+        case 5: return (const float*)(p + w.off_lpl);
+    }
+    return nullptr;
+}
+
+extern "C" int edgedict_rnnt_loss_forward(const void* acts, int acts_dtype, const int32_t* labels,
+                                          const int32_t* act_lens, const int32_t* label_lens,
+                                          int B, int T, int U1, int V, int blank, float* costs,
+                                          float* reduced, float reduce_scale, void* workspace,
+                                          void* stream_) {
+    if (int rc = check_common(B, T, U1, V, blank, acts_dtype)) return rc;
+    ED_CHECK_ARG(acts && labels && act_lens && label_lens && costs && workspace,
+                 "rnnt_loss_forward: null pointer argument");
+    ED_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "rnnt_loss_forward: workspace must be 16-byte aligned");
+    hipStream_t stream = (hipStream_t)stream_;
+    const WsLayout w = ws_layout(B, T, U1);
+    char* p = (char*)workspace;
+    float* denom = (float*)(p + w.off_denom);
+    float* lpb = (float*)(p + w.off_lpb);
+    float* lpl = (float*)(p + w.off_lpl);
+    float* alphas = (float*)(p + w.off_alpha);
+    float* betas = (float*)(p + w.off_beta);
+    float* ll = (float*)(p + w.off_ll);
+
+    const size_t esz = acts_dtype == ED_F32 ? 4 : 2;
+    const int vec_ok = ((V * esz) % 16 == 0) && (((uintptr_t)acts & 15) == 0);
+    const int grid1 = ed_grid_for((long long)w.cells, 4, 256 * 16);
+    if (acts_dtype == ED_F32)
+        hipLaunchKernelGGL(rnnt_lse_gather<float>, dim3(grid1), dim3(256), 0, stream,
+                           (const float*)acts, labels, act_lens, label_lens, B, T, U1, V, blank,
+                           denom, lpb, lpl, vec_ok);
+    else
+        hipLaunchKernelGGL(rnnt_lse_gather<bf16_t>, dim3(grid1), dim3(256), 0, stream,
+                           (const bf16_t*)acts, labels, act_lens, label_lens, B, T, U1, V, blank,
+                           denom, lpb, lpl, vec_ok);
+    ED_CHECK_LAUNCH("rnnt_lse_gather");
+
+    const int threads = ((U1 + 63) / 64) * 64;
+    const size_t lds = (size_t)2 * (threads + 2) * sizeof(float);
+    hipLaunchKernelGGL(rnnt_alpha_beta, dim3(2 * B), dim3(threads), lds, stream, lpb, lpl,
+                       act_lens, label_lens, T, U1, alphas, betas, ll);
+    ED_CHECK_LAUNCH("rnnt_alpha_beta");
+    hipLaunchKernelGGL(rnnt_costs, dim3(1), dim3(256), 0, stream, ll, costs, B, reduced,
+                       reduce_scale);
+    ED_CHECK_LAUNCH("rnnt_costs");
+    return ED_OK;
+}
+
+extern "C" int edgedict_rnnt_loss_backward(const void* acts, int acts_dtype, void* grads,
+                                           const int32_t* labels, const int32_t* act_lens,
+                                           const int32_t* label_lens, int B, int T, int U1, int V,
+                                           int blank, const void* workspace, float grad_scale_host,
+                                           const float* grad_scale_dev, int grad_scale_stride,
+                                           void* stream_) {
+    if (int rc = check_common(B, T, U1, V, blank, acts_dtype)) return rc;
+    ED_CHECK_ARG(acts && grads && labels && act_lens && label_lens && workspace,
+                 "rnnt_loss_backward: null pointer argument");
+    hipStream_t stream = (hipStream_t)stream_;
+    const WsLayout w = ws_layout(B, T, U1);
+    const char* p = (const char*)workspace;
+    const float* denom = (const float*)(p + w.off_denom);
+    const float* alphas = (const float*)(p + w.off_alpha);
+    const float* betas = (const float*)(p + w.off_beta);
+    const float* ll = (const float*)(p + w.off_ll);
+    const size_t esz = acts_dtype == ED_F32 ? 4 : 2;
+    const int vec_ok = ((V * esz) % 16 == 0) && (((uintptr_t)acts & 15) == 0) &&
+                       (((uintptr_t)grads & 15) == 0);
+    const int grid = ed_grid_for((long long)w.cells, 4, 256 * 16);
+    if (acts_dtype == ED_F32)
+        hipLaunchKernelGGL(rnnt_grad<float>, dim3(grid), dim3(256), 0, stream, (const float*)acts,
+                           (float*)grads, labels, act_lens, label_lens, B, T, U1, V, blank, denom,
+                           alphas, betas, ll, grad_scale_host, grad_scale_dev, grad_scale_stride,
+                           vec_ok);
+    else
+        hipLaunchKernelGGL(rnnt_grad<bf16_t>, dim3(grid), dim3(256), 0, stream,
+                           (const bf16_t*)acts, (bf16_t*)grads, labels, act_lens, label_lens, B, T,
+                           U1, V, blank, denom, alphas, betas, ll, grad_scale_host, grad_scale_dev,
+                           grad_scale_stride, vec_ok);
+    ED_CHECK_LAUNCH("rnnt_grad");
+    return ED_OK;
+}

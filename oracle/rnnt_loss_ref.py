@@ -1,0 +1,219 @@
+"""ORACLE (test infrastructure only — never imported by the product path).
+
+CPU float64 restatement of the RNN-T loss the reference obtains from the third-party,
+un-vendored ``warprnnt_pytorch.RNNTLoss`` (HawkAaron/warp-transducer, cloned from ``master``
+per the reference's ``README.md:161-176``; no pinned commit, ``warp-transducer/`` is an empty
+submodule).  Call sites in the reference: ``rnnt/models.py:221,238``, ``cli/lightning.py:40,91``.
+
+PARITY STATUS: **unpinned by the reference** — the reference holds no test, golden vector or
+fixture at this boundary.  The restatement follows the published algorithm (Graves 2012,
+"Sequence Transduction with Recurrent Neural Networks", eqs. 16-20 + the log-softmax chain
+rule) and is anchored on the one known-answer vector upstream's own
+unit tests use (``KNOWN_ANSWER`` below: cost 4.495666 and its full gradient), which
+``tests/test_oracle_loss.py`` checks.
+
+    lp = log_softmax(z)
+    alpha(0,0)=0;  alpha(t,u) = lse(alpha(t-1,u)+lp(t-1,u,blank), alpha(t,u-1)+lp(t,u-1,y_u))
+    beta(T-1,U)=lp(T-1,U,blank);  beta(t,u) = lse(beta(t+1,u)+lp(t,u,blank), beta(t,u+1)+lp(t,u,y_{u+1}))
+    cost = -(alpha(T-1,U) + lp(T-1,U,blank)) = -beta(0,0)
+"""
+import numpy as np
+
+# Known-answer vector used by the unit tests of warp-transducer / torchaudio's rnnt_loss
+# (B=1, T=2, U+1=3, V=5, blank=0).  Values are inputs to a softmax-free "acts" tensor, i.e.
+# raw logits that the loss log-softmaxes itself.
+KNOWN_ANSWER = {
+    "acts": np.array(
+        [[[[0.1, 0.6, 0.1, 0.1, 0.1], [0.1, 0.1, 0.6, 0.1, 0.1], [0.1, 0.1, 0.2, 0.8, 0.1]],
+          [[0.1, 0.6, 0.1, 0.1, 0.1], [0.1, 0.1, 0.2, 0.1, 0.1], [0.7, 0.1, 0.2, 0.1, 0.1]]]],
+        dtype=np.float64),
+    "labels": np.array([[1, 2]], dtype=np.int32),
+    "act_lens": np.array([2], dtype=np.int32),
+    "label_lens": np.array([2], dtype=np.int32),
+    "cost": 4.495666,
+    "grads": np.array(
+        [[[[-0.13116688, -0.3999269, 0.17703125, 0.17703125, 0.17703125],
+           [-0.18572757, 0.12247056, -0.18168412, 0.12247056, 0.12247056],
+           [-0.32091254, 0.06269141, 0.06928472, 0.12624499, 0.06269141]],
+          [[0.05456069, -0.21824276, 0.05456069, 0.05456069, 0.05456069],
+           [0.12073959, 0.12073959, -0.48295835, 0.12073959, 0.12073959],
+           [-0.6925882, 0.16871116, 0.18645467, 0.16871116, 0.16871116]]]],
+        dtype=np.float64),
+}
+
+
+def _logsumexp2(a, b):
+    m = np.maximum(a, b)
+    if np.isneginf(m):
+        return -np.inf
+    return m + np.log(np.exp(a - m) + np.exp(b - m))
+
+
+def log_softmax(z):
+    z = np.asarray(z, dtype=np.float64)
+    m = z.max(axis=-1, keepdims=True)
+    return z - m - np.log(np.exp(z - m).sum(axis=-1, keepdims=True))
+
+
+def lattice(lp, labels, T, U, blank=0):
+    """alpha, beta [T, U+1] (float64) and log-likelihood for ONE utterance.
+
+    ``lp`` is the log-softmaxed activation block ``[>=T, >=U+1, V]``; ``labels`` has >= U ids.
+    """
+    alpha = np.full((T, U + 1), -np.inf)
+    beta = np.full((T, U + 1), -np.inf)
+    alpha[0, 0] = 0.0
+    for t in range(T):
+        for u in range(U + 1):
+            if t == 0 and u == 0:
+                continue
+            stay = alpha[t - 1, u] + lp[t - 1, u, blank] if t > 0 else -np.inf
+            emit = alpha[t, u - 1] + lp[t, u - 1, labels[u - 1]] if u > 0 else -np.inf
+            alpha[t, u] = _logsumexp2(stay, emit)
+    beta[T - 1, U] = lp[T - 1, U, blank]
+    for t in range(T - 1, -1, -1):
+        for u in range(U, -1, -1):
+            if t == T - 1 and u == U:
+                continue
+            stay = beta[t + 1, u] + lp[t, u, blank] if t < T - 1 else -np.inf
+            emit = beta[t, u + 1] + lp[t, u, labels[u]] if u < U else -np.inf
+            beta[t, u] = _logsumexp2(stay, emit)
+    ll = alpha[T - 1, U] + lp[T - 1, U, blank]
+    return alpha, beta, ll
+
+
+def rnnt_loss(acts, labels, act_lens, label_lens, blank=0, want_grads=True):
+    """Per-utterance costs ``[B]`` and d(sum_b cost_b)/d(acts) ``[B,T,U+1,V]`` in float64.
+
+    Cells outside an utterance's ``(act_lens[b], label_lens[b]+1)`` box get zero gradient.
+    Pure-Python loops: meant for the small shapes the parity tests use.
+    """
+    acts = np.asarray(acts, dtype=np.float64)
+    B, Tm, U1, V = acts.shape
+    costs = np.zeros(B)
+    grads = np.zeros_like(acts) if want_grads else None
+    for b in range(B):
+        T, U = int(act_lens[b]), int(label_lens[b])
+        lp = log_softmax(acts[b, :T, :U + 1])
+        y = np.asarray(labels[b])
+        alpha, beta, ll = lattice(lp, y, T, U, blank)
+        costs[b] = -ll
+        if not want_grads:
+            continue
+        g = np.exp(alpha[:, :, None] + beta[:, :, None] + lp - ll)  # softmax part
+        for t in range(T):
+            for u in range(U + 1):
+                if t < T - 1:
+                    g[t, u, blank] -= np.exp(alpha[t, u] + lp[t, u, blank] + beta[t + 1, u] - ll)
+                elif u == U:
+                    g[t, u, blank] -= np.exp(alpha[t, u] + lp[t, u, blank] - ll)
+                if u < U:
+                    g[t, u, y[u]] -= np.exp(alpha[t, u] + lp[t, u, y[u]] + beta[t, u + 1] - ll)
+        grads[b, :T, :U + 1] = g
+    return costs, grads
+
+
+def rnnt_loss_torch(acts, labels, act_lens, label_lens, blank=0):
+    """Differentiable torch restatement (any float dtype, CPU): anti-diagonal vectorised alpha
+    recursion, used (a) to cross-check the analytic gradient above through autograd and (b) as
+    the timed CPU 'port' baseline in bench.py.  Returns per-utterance costs ``[B]``."""
+    import torch
+
+    B, Tm, U1, V = acts.shape
+    lp = torch.log_softmax(acts, dim=-1)
+    lpb = lp[..., blank]  # [B,T,U1]
+    idx = torch.nn.functional.pad(labels.long(), (0, 1))  # [B,U1]; last column unused
+    lpl = torch.gather(lp, 3, idx[:, None, :, None].expand(B, Tm, U1, 1)).squeeze(-1)
+    neg = torch.full((), float("-inf"), dtype=acts.dtype)
+    costs = []
+    for b in range(B):
+        T, U = int(act_lens[b]), int(label_lens[b])
+        rows = [None] * T  # alpha rows, built t by t with a scan over u inside
+        # vectorise over anti-diagonals: a[d] holds alpha(t, d-t)
+        alpha = {}
+        alpha[(0, 0)] = torch.zeros((), dtype=acts.dtype)
+        for d in range(1, T + U):
+            for t in range(max(0, d - U), min(T - 1, d) + 1):
+                u = d - t
+                stay = alpha[(t - 1, u)] + lpb[b, t - 1, u] if t > 0 else neg
+                emit = alpha[(t, u - 1)] + lpl[b, t, u - 1] if u > 0 else neg
+                alpha[(t, u)] = torch.logaddexp(stay, emit)
+        costs.append(-(alpha[(T - 1, U)] + lpb[b, T - 1, U]))
+    return torch.stack(costs)
+
+
+def rnnt_loss_torch_fast(acts, labels, act_lens, label_lens, blank=0):
+    """Vectorised (over batch and anti-diagonal) torch DP with analytic gradients, CPU.
+
+    Returns (costs [B], grads [B,T,U1,V]) in the dtype of ``acts``.  This is the form timed as
+    the CPU baseline: it does the same work as warp-transducer's CPU path (log-softmax over V,
+    alpha, beta, gradient) with torch ops on the host cores.
+    """
+    import torch
+
+    B, Tm, U1, V = acts.shape
+    dt = acts.dtype
+    lp = torch.log_softmax(acts, dim=-1)
+    lpb = lp[..., blank].contiguous()
+    idx = torch.nn.functional.pad(labels.long(), (0, 1))
+    lpl = torch.gather(lp, 3, idx[:, None, :, None].expand(B, Tm, U1, 1)).squeeze(-1).contiguous()
+    NEG = float("-inf")
+    act_lens = act_lens.long()
+    label_lens = label_lens.long()
+    tt = torch.arange(Tm)[None, :, None]
+    uu = torch.arange(U1)[None, None, :]
+    inside = (tt < act_lens[:, None, None]) & (uu <= label_lens[:, None, None])
+    lab_ok = inside & (uu < label_lens[:, None, None])
+    lpb_m = torch.where(inside, lpb, torch.full_like(lpb, NEG))
+    lpl_m = torch.where(lab_ok, lpl, torch.full_like(lpl, NEG))
+
+    alpha = torch.full((B, Tm, U1), NEG, dtype=dt)
+    alpha[:, 0, 0] = 0
+    for d in range(1, Tm + U1 - 1):
+        t = torch.arange(max(0, d - U1 + 1), min(Tm - 1, d) + 1)
+        u = d - t
+        stay = torch.full((B, len(t)), NEG, dtype=dt)
+        m = t > 0
+        stay[:, m] = alpha[:, t[m] - 1, u[m]] + lpb_m[:, t[m] - 1, u[m]]
+        emit = torch.full((B, len(t)), NEG, dtype=dt)
+        m = u > 0
+        emit[:, m] = alpha[:, t[m], u[m] - 1] + lpl_m[:, t[m], u[m] - 1]
+        alpha[:, t, u] = torch.logaddexp(stay, emit)
+    # beta: per-utterance terminal cell differs, so seed it then sweep all diagonals backwards
+    beta = torch.full((B, Tm, U1), NEG, dtype=dt)
+    bi = torch.arange(B)
+    beta[bi, act_lens - 1, label_lens] = lpb[bi, act_lens - 1, label_lens]
+    term = torch.zeros((B, Tm, U1), dtype=torch.bool)
+    term[bi, act_lens - 1, label_lens] = True
+    for d in range(Tm + U1 - 3, -1, -1):
+        t = torch.arange(max(0, d - U1 + 1), min(Tm - 1, d) + 1)
+        u = d - t
+        stay = torch.full((B, len(t)), NEG, dtype=dt)
+        m = t < Tm - 1
+        stay[:, m] = beta[:, t[m] + 1, u[m]] + lpb_m[:, t[m], u[m]]
+        emit = torch.full((B, len(t)), NEG, dtype=dt)
+        m = u < U1 - 1
+        emit[:, m] = beta[:, t[m], u[m] + 1] + lpl_m[:, t[m], u[m]]
+        new = torch.logaddexp(stay, emit)
+        keep = term[:, t, u]
+        beta[:, t, u] = torch.where(keep, beta[:, t, u], new)
+    ll = beta[:, 0, 0]
+    costs = -ll
+    # gradient wrt logits
+    ab = alpha + beta - ll[:, None, None]
+    ab = torch.where(inside, ab, torch.full_like(ab, NEG))
+    grads = torch.exp(lp + ab[..., None])
+    beta_tn = torch.full_like(beta, NEG)
+    beta_tn[:, :-1] = beta[:, 1:]
+    last = inside & (tt == (act_lens[:, None, None] - 1))
+    beta_tn = torch.where(last, torch.where(uu == label_lens[:, None, None],
+                                            torch.zeros_like(beta), torch.full_like(beta, NEG)),
+                          beta_tn)
+    gb = torch.exp(alpha + lpb_m + beta_tn - ll[:, None, None])
+    grads[..., blank] -= torch.where(inside, gb, torch.zeros_like(gb))
+    beta_un = torch.full_like(beta, NEG)
+    beta_un[:, :, :-1] = beta[:, :, 1:]
+    gl = torch.exp(alpha + lpl_m + beta_un - ll[:, None, None])
+    gl = torch.where(lab_ok, gl, torch.zeros_like(gl))
+    grads.scatter_add_(3, idx[:, None, :, None].expand(B, Tm, U1, 1), -gl[..., None])
+    return costs, grads

@@ -1,0 +1,132 @@
+"""GPU parity: HIP RNN-T loss (through the C ABI) vs the float64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import rnnt_loss_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _case(seed, B, T, U1, V, ragged=True, scale=1.0):
+    rng = np.random.default_rng(seed)
+    acts = (scale * rng.normal(size=(B, T, U1, V))).astype(np.float32)
+    labels = rng.integers(1, V, size=(B, max(U1 - 1, 0))).astype(np.int32)
+    if ragged:
+        al = rng.integers(1, T + 1, size=B).astype(np.int32)
+        ll = rng.integers(0, U1, size=B).astype(np.int32)
+    else:
+        al = np.full(B, T, np.int32)
+        ll = np.full(B, U1 - 1, np.int32)
+    al[0] = T
+    ll[0] = U1 - 1
+    return acts, labels, al, ll
+
+
+def _run_hip(acts, labels, al, ll, dtype=torch.float32, reduction="mean", blank=0):
+    from edgedict_amd.loss import RNNTLoss
+    dev = "cuda:0"
+    ta = torch.tensor(acts, device=dev).to(dtype).requires_grad_(True)
+    loss = RNNTLoss(blank=blank, reduction=reduction)(
+        ta, torch.tensor(labels, device=dev), torch.tensor(al, device=dev),
+        torch.tensor(ll, device=dev))
+    (loss.sum() if reduction == "none" else loss).backward()
+    return loss.detach().float().cpu().numpy(), ta.grad.float().cpu().numpy()
+
+
+def test_known_answer(hip_lib):
+    ka = R.KNOWN_ANSWER
+    loss, grads = _run_hip(ka["acts"].astype(np.float32), ka["labels"], ka["act_lens"],
+                           ka["label_lens"], reduction="sum")
+    assert loss.shape == (1,)
+    assert abs(loss[0] - ka["cost"]) < 1e-5
+    np.testing.assert_allclose(grads, ka["grads"], atol=2e-6)
+
+
+@pytest.mark.parametrize("B,T,U1,V,ragged", [
+    (1, 1, 1, 7, False),       # single cell, empty label sequence
+    (2, 5, 1, 16, True),       # U = 0 for every utterance
+    (3, 7, 5, 11, True),       # V not a multiple of the vector width (scalar path)
+    (4, 33, 9, 64, True),
+    (2, 40, 70, 128, True),    # U+1 > 64: two wavefronts per lattice
+    (4, 84, 21, 2048, True),   # E4D1 / 5 s lattice
+])
+def test_fp32_matches_oracle(hip_lib, B, T, U1, V, ragged):
+    acts, labels, al, ll = _case(B * 1000 + T, B, T, U1, V, ragged)
+    costs, grads = R.rnnt_loss(acts.astype(np.float64), labels, al, ll)
+    loss, g = _run_hip(acts, labels, al, ll, reduction="none")
+    np.testing.assert_allclose(loss, costs, rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(g, grads, rtol=0, atol=2e-5)
+    # mean reduction = sum/B with shape (1,), gradient scaled by 1/B (rnnt/models.py:238 use)
+    loss_m, g_m = _run_hip(acts, labels, al, ll, reduction="mean")
+    assert loss_m.shape == (1,)
+    np.testing.assert_allclose(loss_m[0], costs.mean(), rtol=1e-5)
+    np.testing.assert_allclose(g_m, grads / B, rtol=0, atol=2e-5)
+
+
+def test_large_logit_range_is_stable(hip_lib):
+    acts, labels, al, ll = _case(7, 2, 12, 6, 32, scale=30.0)
+    costs, grads = R.rnnt_loss(acts.astype(np.float64), labels, al, ll)
+    loss, g = _run_hip(acts, labels, al, ll, reduction="none")
+    assert np.isfinite(loss).all() and np.isfinite(g).all()
+    np.testing.assert_allclose(loss, costs, rtol=2e-5)
+    np.testing.assert_allclose(g, grads, atol=5e-5)
+
+
+def test_bf16_logits(hip_lib):
+    acts, labels, al, ll = _case(3, 3, 20, 8, 256)
+    acts_bf = torch.tensor(acts).bfloat16().float().numpy()  # oracle sees the rounded logits
+    costs, grads = R.rnnt_loss(acts_bf.astype(np.float64), labels, al, ll)
+    loss, g = _run_hip(acts, labels, al, ll, dtype=torch.bfloat16, reduction="none")
+    np.testing.assert_allclose(loss, costs, rtol=1e-4)
+    np.testing.assert_allclose(g, grads, atol=4e-3)  # bf16 output rounding (8 mantissa bits)
+
+
+def test_debug_views_alpha_beta(hip_lib):
+    from edgedict_amd.loss import rnnt_loss_debug
+    acts, labels, al, ll = _case(11, 2, 9, 4, 16)
+    dev = "cuda:0"
+    costs, denom, alphas, betas, lls = rnnt_loss_debug(
+        torch.tensor(acts, device=dev), torch.tensor(labels, device=dev),
+        torch.tensor(al, device=dev), torch.tensor(ll, device=dev))
+    for b in range(2):
+        T, U = int(al[b]), int(ll[b])
+        lp = R.log_softmax(acts[b, :T, :U + 1].astype(np.float64))
+        alpha, beta, loglike = R.lattice(lp, labels[b], T, U)
+        np.testing.assert_allclose(alphas[b, :T, :U + 1].cpu().numpy(), alpha, atol=1e-4)
+        np.testing.assert_allclose(betas[b, :T, :U + 1].cpu().numpy(), beta, atol=1e-4)
+        # alpha-side and beta-side log-likelihoods agree (size-independent property)
+        assert abs(lls[b, 0].item() - lls[b, 1].item()) < 1e-3
+        assert abs(lls[b, 0].item() - loglike) < 1e-3
+
+
+def test_full_size_lattice_properties(hip_lib):
+    """E6D2 / B=8 slice of the BASELINE lattice (T'=201, U+1=65, V=2048): too big for the
+    pure-Python oracle, so check size-independent properties instead."""
+    from edgedict_amd.loss import rnnt_loss_debug, RNNTLoss
+    B, T, U1, V = 8, 201, 65, 2048
+    g = torch.Generator(device="cpu").manual_seed(0)
+    acts = torch.randn(B, T, U1, V, generator=g).cuda()
+    labels = torch.randint(4, V, (B, U1 - 1), generator=g, dtype=torch.int32).cuda()
+    al = torch.randint(150, T + 1, (B,), generator=g, dtype=torch.int32)
+    ll = torch.randint(32, U1, (B,), generator=g, dtype=torch.int32)
+    al[0], ll[0] = T, U1 - 1
+    al, ll = al.cuda(), ll.cuda()
+    costs, denom, alphas, betas, lls = rnnt_loss_debug(acts, labels, al, ll)
+    assert torch.isfinite(costs).all()
+    assert (lls[:, 0] - lls[:, 1]).abs().max().item() < 2e-2 * 1  # alpha(T-1,U)+lpb == beta(0,0)
+    rel = ((lls[:, 0] - lls[:, 1]).abs() / lls[:, 0].abs()).max().item()
+    assert rel < 1e-5
+    a = acts.clone().requires_grad_(True)
+    loss = RNNTLoss(reduction="sum")(a, labels, al, ll)
+    loss.backward()
+    gr = a.grad
+    assert gr.sum(-1).abs().max().item() < 1e-4          # rows sum to zero
+    for b in range(B):
+        assert gr[b, int(al[b]):].abs().max().item() == 0 if int(al[b]) < T else True
+        assert gr[b, :, int(ll[b]) + 1:].abs().max().item() == 0 if int(ll[b]) + 1 < U1 else True
+    # cross-check against the vectorised torch port on one utterance (fp64 on CPU)
+    cf, gf = R.rnnt_loss_torch_fast(acts[:1].double().cpu(), labels[:1].cpu(), al[:1].cpu(),
+                                    ll[:1].cpu())
+    assert abs(cf[0].item() - costs[0].item()) / cf[0].item() < 1e-5
+    assert (gf[0].float() - gr[0].cpu()).abs().max().item() < 2e-5
