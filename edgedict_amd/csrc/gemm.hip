@@ -1,0 +1,358 @@
+// MFMA GEMM for gfx950:  C[M,N] (+)= A[M,K] * B[N,K]^T + bias1[N] + bias2[N]
+//
+// One kernel template serves every dense product on the RNN-T path (reference call sites:
+// nn.LSTM input products rnnt/models.py:45-46,65; nn.Linear at rnnt/models.py:129,135,148,156,
+// 165-167 and their autograd transposes).  Both operands are described by (pointer, leading
+// dimension, k_major flag):
+//     k_major = 1 : element (row, k) at  p[row*ld + k]   (K contiguous: x @ W^T forward form)
+//     k_major = 0 : element (row, k) at  p[k*ld + row]   (row contiguous: the transposed
+//                   operand of dX = dY*W and dW = dY^T*X; transposed on the way into LDS)
+// so NT / NN / TN / TT products need no materialised transposes.
+//
+// Tiling (wave64, 256 threads = 2x2 waves): block tile 128x128, wave tile 64x64 = 4x4 MFMA tiles
+// of 16x16.  bf16 inputs use v_mfma_f32_16x16x32_bf16 (BK = 64), fp32 inputs use the exact
+// v_mfma_f32_16x16x4_f32 (BK = 16).  Accumulation is always fp32.  Operand tiles are staged
+// global -> registers -> LDS (rows padded by 16 B against ds_read bank conflicts) with the next
+// tile's global loads issued before the current tile's MFMAs.
+// split_k > 1 partitions K over blockIdx.z and combines with fp32 atomics (gradient "+=").
+#include "common.hpp"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+constexpr int BM = 128, BN = 128;
+constexpr int THREADS = 256;
+
+template <typename TI> struct Cfg;
+template <> struct Cfg<bf16_t> {
+    static constexpr int BK = 64;      // elements of K per LDS tile
+    static constexpr int ROW = BK + 8; // padded LDS row (elements): 144 B
+    static constexpr int VEC = 8;      // elements per 16-byte chunk
+};
+template <> struct Cfg<float> {
+    static constexpr int BK = 16;
+    static constexpr int ROW = BK + 4;  // 80 B
+    static constexpr int VEC = 4;
+};
+
+struct GemmArgs {
+    const void* A;
+    const void* B;
+    void* C;
+    const float* bias1;
+    const float* bias2;
+    long long lda, ldb, ldc;
+    int M, N, K;
+    int a_vec, b_vec;  // 16-byte vector path usable for the operand
+    int accumulate;
+    int split_k;
+    int k_per_split;  // multiple of BK
+};
+
+// ---- staging registers: the 16-byte chunks one thread moves per operand tile
+template <typename TI> struct Stage { uint4 v[Cfg<TI>::BK * BM / Cfg<TI>::VEC / THREADS]; };
+
+template <typename TI>
+__device__ __forceinline__ uint4 load_chunk_guarded(const TI* p, long long ld, int vec_ok,
+                                                    int r0, int rmax, int c0, int cmax,
+                                                    bool along_row) {
+    // Loads VEC elements starting at logical (r0, c0) walking along the contiguous dimension.
+    // along_row: contiguous index is c (k_major: r = row, c = k); else contiguous index is r.
+    constexpr int VEC = Cfg<TI>::VEC;
+    uint4 out = make_uint4(0, 0, 0, 0);
+    TI* o = reinterpret_cast<TI*>(&out);
+    if (along_row) {
+        if (r0 >= rmax) return out;
+        const TI* src = p + (long long)r0 * ld + c0;
+        if (vec_ok && c0 + VEC <= cmax) return *reinterpret_cast<const uint4*>(src);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i)
+            if (c0 + i < cmax) o[i] = src[i];
+    } else {
+        if (c0 >= cmax) return out;
+        const TI* src = p + (long long)c0 * ld + r0;
+        if (vec_ok && r0 + VEC <= rmax) return *reinterpret_cast<const uint4*>(src);
+#pragma unroll
+        for (int i = 0; i < VEC; ++i)
+            if (r0 + i < rmax) o[i] = src[i];
+    }
+    return out;
+}
+
+// K-major operand: chunk c -> (row = c / (BK/VEC), kc = c % (BK/VEC))
+template <typename TI>
+__device__ __forceinline__ void gload_kmajor(Stage<TI>& st, const TI* p, long long ld, int vec_ok,
+                                             int row0, int rows, int k0, int kend) {
+    constexpr int CPR = Cfg<TI>::BK / Cfg<TI>::VEC;
+    constexpr int N = Cfg<TI>::BK * BM / Cfg<TI>::VEC / THREADS;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int c = threadIdx.x + i * THREADS;
+        const int r = c / CPR, kc = c % CPR;
+        st.v[i] = load_chunk_guarded<TI>(p, ld, vec_ok, row0 + r, rows, k0 + kc * Cfg<TI>::VEC,
+                                         kend, true);
+    }
+}
+template <typename TI>
+__device__ __forceinline__ void sstore_kmajor(const Stage<TI>& st, TI* lds) {
+    constexpr int CPR = Cfg<TI>::BK / Cfg<TI>::VEC;
+    constexpr int N = Cfg<TI>::BK * BM / Cfg<TI>::VEC / THREADS;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const int c = threadIdx.x + i * THREADS;
+        const int r = c / CPR, kc = c % CPR;
+        *reinterpret_cast<uint4*>(lds + r * Cfg<TI>::ROW + kc * Cfg<TI>::VEC) = st.v[i];
+    }
+}
+
+// Row-major-in-k ("transposed") operand.  fp32: item = (k, 4 rows); bf16: item = (k pair, 8 rows)
+__device__ __forceinline__ void gload_tr(Stage<float>& st, const float* p, long long ld,
+                                         int vec_ok, int row0, int rows, int k0, int kend) {
+    constexpr int CPK = BM / 4;  // chunks per k line
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = threadIdx.x + i * THREADS;
+        const int k = c / CPK, rc = c % CPK;
+        st.v[i] = load_chunk_guarded<float>(p, ld, vec_ok, row0 + rc * 4, rows, k0 + k, kend, false);
+    }
+}
+__device__ __forceinline__ void sstore_tr(const Stage<float>& st, float* lds) {
+    constexpr int CPK = BM / 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int c = threadIdx.x + i * THREADS;
+        const int k = c / CPK, rc = c % CPK;
+        const float* f = reinterpret_cast<const float*>(&st.v[i]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lds[(rc * 4 + j) * Cfg<float>::ROW + k] = f[j];
+    }
+}
+__device__ __forceinline__ void gload_tr(Stage<bf16_t>& st, const bf16_t* p, long long ld,
+                                         int vec_ok, int row0, int rows, int k0, int kend) {
+    constexpr int CPK = BM / 8;  // 16 chunks per k line
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int item = threadIdx.x + i * THREADS;  // 512 items = 32 k-pairs x 16 chunks
+        const int kp = item / CPK, rc = item % CPK;
+        st.v[2 * i] = load_chunk_guarded<bf16_t>(p, ld, vec_ok, row0 + rc * 8, rows,
+                                                 k0 + 2 * kp, kend, false);
+        st.v[2 * i + 1] = load_chunk_guarded<bf16_t>(p, ld, vec_ok, row0 + rc * 8, rows,
+                                                     k0 + 2 * kp + 1, kend, false);
+    }
+}
+__device__ __forceinline__ void sstore_tr(const Stage<bf16_t>& st, bf16_t* lds) {
+    constexpr int CPK = BM / 8;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int item = threadIdx.x + i * THREADS;
+        const int kp = item / CPK, rc = item % CPK;
+        const unsigned* a = reinterpret_cast<const unsigned*>(&st.v[2 * i]);      // k even
+        const unsigned* b = reinterpret_cast<const unsigned*>(&st.v[2 * i + 1]);  // k odd
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // rows 2j, 2j+1 of this chunk; pack (k, k+1) for each row into one dword
+            const unsigned lo = (a[j] & 0xffffu) | (b[j] << 16);
+            const unsigned hi = (a[j] >> 16) | (b[j] & 0xffff0000u);
+            unsigned* d0 = reinterpret_cast<unsigned*>(lds + (rc * 8 + 2 * j) * Cfg<bf16_t>::ROW + 2 * kp);
+            unsigned* d1 = reinterpret_cast<unsigned*>(lds + (rc * 8 + 2 * j + 1) * Cfg<bf16_t>::ROW + 2 * kp);
+            *d0 = lo;
+            *d1 = hi;
+        }
+    }
+}
+
+template <typename TI, bool KMAJOR>
+__device__ __forceinline__ void gload(Stage<TI>& st, const TI* p, long long ld, int vec_ok,
+                                      int row0, int rows, int k0, int kend) {
+    if constexpr (KMAJOR) gload_kmajor<TI>(st, p, ld, vec_ok, row0, rows, k0, kend);
+    else gload_tr(st, p, ld, vec_ok, row0, rows, k0, kend);
+}
+template <typename TI, bool KMAJOR>
+__device__ __forceinline__ void sstore(const Stage<TI>& st, TI* lds) {
+    if constexpr (KMAJOR) sstore_kmajor<TI>(st, lds);
+    else sstore_tr(st, lds);
+}
+
+// ---- MFMA over one LDS tile pair
+__device__ __forceinline__ void mma_tile(const bf16_t* sA, const bf16_t* sB, f32x4_t (&acc)[4][4],
+                                         int wm, int wn, int lane) {
+    constexpr int ROW = Cfg<bf16_t>::ROW;
+    const int r = lane & 15, kq = (lane >> 4) * 8;
+#pragma unroll
+    for (int ks = 0; ks < Cfg<bf16_t>::BK / 32; ++ks) {
+        bf16x8_t a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i] = *reinterpret_cast<const bf16x8_t*>(sA + (wm * 64 + i * 16 + r) * ROW + ks * 32 + kq);
+            b[i] = *reinterpret_cast<const bf16x8_t*>(sB + (wn * 64 + i * 16 + r) * ROW + ks * 32 + kq);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+}
+__device__ __forceinline__ void mma_tile(const float* sA, const float* sB, f32x4_t (&acc)[4][4],
+                                         int wm, int wn, int lane) {
+    constexpr int ROW = Cfg<float>::ROW;
+    const int r = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int ks = 0; ks < Cfg<float>::BK / 4; ++ks) {
+        float a[4], b[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[i] = sA[(wm * 64 + i * 16 + r) * ROW + ks * 4 + kq];
+            b[i] = sB[(wn * 64 + i * 16 + r) * ROW + ks * 4 + kq];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+}
+
+template <typename TI, typename TO, bool A_KM, bool B_KM>
+__global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
+    using C_ = Cfg<TI>;
+    __shared__ __attribute__((aligned(16))) TI sA[BM * C_::ROW];
+    __shared__ __attribute__((aligned(16))) TI sB[BN * C_::ROW];
+
+    // N index fastest: consecutive blocks share the same A row panel (L2 reuse)
+    const int n_tiles = (g.N + BN - 1) / BN;
+    const int tile = blockIdx.x;
+    const int m0 = (tile / n_tiles) * BM;
+    const int n0 = (tile % n_tiles) * BN;
+    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
+
+    const TI* A = reinterpret_cast<const TI*>(g.A);
+    const TI* B = reinterpret_cast<const TI*>(g.B);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+
+    Stage<TI> ra, rb;
+    if (kbeg < kend) {
+        gload<TI, A_KM>(ra, A, g.lda, g.a_vec, m0, g.M, kbeg, kend);
+        gload<TI, B_KM>(rb, B, g.ldb, g.b_vec, n0, g.N, kbeg, kend);
+        sstore<TI, A_KM>(ra, sA);
+        sstore<TI, B_KM>(rb, sB);
+    }
+    __syncthreads();
+    for (int k0 = kbeg; k0 < kend; k0 += C_::BK) {
+        const bool more = (k0 + C_::BK) < kend;
+        if (more) {
+            gload<TI, A_KM>(ra, A, g.lda, g.a_vec, m0, g.M, k0 + C_::BK, kend);
+            gload<TI, B_KM>(rb, B, g.ldb, g.b_vec, n0, g.N, k0 + C_::BK, kend);
+        }
+        mma_tile(sA, sB, acc, wm, wn, lane);
+        __syncthreads();
+        if (more) {
+            sstore<TI, A_KM>(ra, sA);
+            sstore<TI, B_KM>(rb, sB);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: lane holds D[row = (lane>>4)*4 + r][col = lane&15] of each 16x16 tile
+    TO* C = reinterpret_cast<TO*>(g.C);
+    const bool first_split = (blockIdx.z == 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 64 + j * 16 + (lane & 15);
+        if (col >= g.N) continue;
+        float bias = 0.f;
+        if (first_split) {
+            if (g.bias1) bias += g.bias1[col];
+            if (g.bias2) bias += g.bias2[col];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 64 + i * 16 + (lane >> 4) * 4 + r;
+                if (row >= g.M) continue;
+                const float v = acc[i][j][r] + bias;
+                TO* dst = C + (long long)row * g.ldc + col;
+                if constexpr (sizeof(TO) == 4) {
+                    if (g.split_k > 1) atomicAdd(reinterpret_cast<float*>(dst), v);
+                    else if (g.accumulate) *dst = *dst + v;
+                    else *dst = v;
+                } else {
+                    if (g.accumulate) ElemIO<TO>::store(dst, ElemIO<TO>::load(dst) + v);
+                    else ElemIO<TO>::store(dst, v);
+                }
+            }
+        }
+    }
+}
+
+template <typename TI, typename TO>
+int launch(const GemmArgs& g, int a_km, int b_km, dim3 grid, hipStream_t s) {
+    if (a_km && b_km) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, true>), grid, dim3(THREADS), 0, s, g);
+    else if (a_km && !b_km) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, false>), grid, dim3(THREADS), 0, s, g);
+    else if (!a_km && b_km) hipLaunchKernelGGL((gemm_kernel<TI, TO, false, true>), grid, dim3(THREADS), 0, s, g);
+    else hipLaunchKernelGGL((gemm_kernel<TI, TO, false, false>), grid, dim3(THREADS), 0, s, g);
+    ED_CHECK_LAUNCH("gemm");
+    return ED_OK;
+}
+
+__global__ void zero_f32(float* p, long long rows, long long cols, long long ld) {
+    const long long n = rows * cols;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        p[(i / cols) * ld + (i % cols)] = 0.f;
+}
+
+}  // namespace
+
+extern "C" int edgedict_gemm(int dtype_in, int dtype_out, const void* A, long long lda, int a_kmajor,
+                             const void* B, long long ldb, int b_kmajor, void* C, long long ldc,
+                             int M, int N, int K, const float* bias1, const float* bias2,
+                             int accumulate, int split_k, void* stream_) {
+    ED_CHECK_ARG(dtype_in == ED_F32 || dtype_in == ED_BF16, "gemm: bad input dtype %d", dtype_in);
+    ED_CHECK_ARG(dtype_out == ED_F32 || dtype_out == ED_BF16, "gemm: bad output dtype %d", dtype_out);
+    ED_CHECK_ARG(!(dtype_in == ED_F32 && dtype_out == ED_BF16), "gemm: fp32 inputs with bf16 output is not supported");
+    ED_CHECK_ARG(M >= 0 && N >= 0 && K >= 0, "gemm: negative dimension");
+    ED_CHECK_ARG(split_k >= 1, "gemm: split_k must be >= 1");
+    ED_CHECK_ARG(split_k == 1 || dtype_out == ED_F32, "gemm: split_k > 1 needs an fp32 output (atomic +=)");
+    if (M == 0 || N == 0) return ED_OK;
+    ED_CHECK_ARG(A && B && C, "gemm: null operand");
+    hipStream_t stream = (hipStream_t)stream_;
+    const int esz = dtype_in == ED_F32 ? 4 : 2;
+    const int vec = 16 / esz;
+    GemmArgs g;
+    g.A = A; g.B = B; g.C = C; g.bias1 = bias1; g.bias2 = bias2;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
+    g.a_vec = ((uintptr_t)A % 16 == 0) && (lda % vec == 0);
+    g.b_vec = ((uintptr_t)B % 16 == 0) && (ldb % vec == 0);
+    g.accumulate = accumulate;
+    const int bk = dtype_in == ED_F32 ? 16 : 64;
+    int ktiles = (K + bk - 1) / bk;
+    if (split_k > ktiles) split_k = ktiles > 0 ? ktiles : 1;
+    g.split_k = split_k;
+    g.k_per_split = ((ktiles + split_k - 1) / split_k) * bk;
+    if (g.k_per_split == 0) g.k_per_split = bk;
+    if (split_k > 1 && !accumulate) {
+        // atomics need a defined starting value
+        const long long n = (long long)M * N;
+        hipLaunchKernelGGL(zero_f32, dim3(ed_grid_for(n, 256)), dim3(256), 0, stream, (float*)C,
+                           (long long)M, (long long)N, ldc);
+        ED_CHECK_LAUNCH("gemm zero");
+    }
+    const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    ED_CHECK_ARG(tiles < (1ll << 31), "gemm: too many tiles");
+    dim3 grid((unsigned)tiles, 1, split_k);
+    if (dtype_in == ED_BF16 && dtype_out == ED_BF16) return launch<bf16_t, bf16_t>(g, a_kmajor, b_kmajor, grid, stream);
+    if (dtype_in == ED_BF16 && dtype_out == ED_F32) return launch<bf16_t, float>(g, a_kmajor, b_kmajor, grid, stream);
+    return launch<float, float>(g, a_kmajor, b_kmajor, grid, stream);
+}

@@ -76,6 +76,22 @@ int edgedict_rnnt_loss_backward(const void* acts, int acts_dtype, void* grads,
  * 3 = log-likelihoods f64[B,2] (alpha-side, beta-side), 4 = lp_blank f32[B,T,U1], 5 = lp_label */
 const void* edgedict_rnnt_workspace_view(const void* workspace, int B, int T, int U1, int which);
 
+/* ------------------------------------------------------------------------------------
+ * Dense product on the matrix cores:  C[M,N] (+)= A[M,K] * B[N,K]^T + bias1[N] + bias2[N].
+ * Replaces the cuBLAS/cuDNN GEMMs behind nn.Linear / nn.LSTM input products
+ * (rnnt/models.py:45-46,65,129,135,148,156,165-167) and their autograd transposes.
+ *   x_kmajor = 1: element (row,k) at p[row*ld + k];  x_kmajor = 0: at p[k*ld + row]
+ *   dtype_in : ED_BF16 (v_mfma_f32_16x16x32_bf16) or ED_F32 (exact v_mfma_f32_16x16x4_f32)
+ *   dtype_out: ED_F32 or (bf16 inputs only) ED_BF16; accumulation is always fp32
+ *   bias1/bias2: nullable fp32 [N];  accumulate != 0: C += ...;
+ *   split_k > 1: K is partitioned over workgroups and combined with fp32 atomics
+ *                (fp32 output only; used for weight gradients whose M*N is small and K huge)
+ */
+int edgedict_gemm(int dtype_in, int dtype_out, const void* A, long long lda, int a_kmajor,
+                  const void* B, long long ldb, int b_kmajor, void* C, long long ldc, int M, int N,
+                  int K, const float* bias1, const float* bias2, int accumulate, int split_k,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,64 @@
+"""GPU: MFMA GEMM vs a plain torch fp32/fp64 reference of the same product."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(shape, dtype, seed, transposed=False):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    if transposed:
+        x = torch.randn(shape[1], shape[0], generator=g).to(dtype).cuda().t()
+    else:
+        x = torch.randn(*shape, generator=g).to(dtype).cuda()
+    return x
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (64, 16, 1024), (300, 200, 72), (1, 7, 8),
+                                   (513, 1030, 264), (129, 640, 896)])
+@pytest.mark.parametrize("ta,tb", [(False, False), (True, False), (False, True), (True, True)])
+def test_gemm_layouts(hip_lib, dtype, M, N, K, ta, tb):
+    from edgedict_amd import ops
+    a = _mk((M, K), dtype, 1, ta)
+    b = _mk((N, K), dtype, 2, tb)   # asymmetric operands: catches row/col swaps
+    bias = torch.arange(N, dtype=torch.float32).cuda() * 0.01
+    out = ops.gemm(a, b, bias=bias, out_dtype=torch.float32)
+    ref = (a.double() @ b.double().t() + bias.double()).float()
+    tol = 2e-5 * (K ** 0.5) if dtype == torch.float32 else 2e-5 * (K ** 0.5)
+    # bf16 products are exact in fp32; only the accumulation order differs in both modes
+    assert (out - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item() / 10)
+
+
+def test_gemm_bf16_output_accumulate_and_splitk(hip_lib):
+    from edgedict_amd import ops
+    M, N, K = 256, 384, 4096
+    a = _mk((M, K), torch.bfloat16, 3)
+    b = _mk((N, K), torch.bfloat16, 4)
+    ref = a.double() @ b.double().t()
+    out = ops.gemm(a, b)  # bf16 out
+    assert out.dtype == torch.bfloat16
+    assert (out.double() - ref).abs().max().item() < 0.02 * ref.abs().max().item()
+    acc = torch.ones(M, N, device="cuda")
+    ops.gemm(a, b, out=acc, accumulate=True)
+    assert (acc.double() - ref - 1).abs().max().item() < 1e-3 * ref.abs().max().item()
+    sk = torch.ones(M, N, device="cuda")
+    ops.gemm(a, b, out=sk, accumulate=True, split_k=8)
+    assert (sk.double() - ref - 1).abs().max().item() < 1e-3 * ref.abs().max().item()
+    sk2 = torch.full((M, N), 7.0, device="cuda")
+    ops.gemm(a, b, out=sk2, split_k=5)      # not accumulating: prior contents must not leak
+    assert (sk2.double() - ref).abs().max().item() < 1e-3 * ref.abs().max().item()
+
+
+def test_gemm_strided_views_and_second_bias(hip_lib):
+    from edgedict_amd import ops
+    w = _mk((640, 896), torch.float32, 5)
+    x = _mk((77, 640), torch.float32, 6)
+    b1 = torch.randn(640).cuda()
+    b2 = torch.randn(640).cuda()
+    out = ops.gemm(x, w[:, :640], bias=b1, bias2=b2)       # column slice of W (ld = 896)
+    ref = x @ w[:, :640].t() + b1 + b2
+    assert (out - ref).abs().max().item() < 1e-3
+    out2 = ops.gemm(x[:, :256].contiguous(), w[:, 640:])
+    ref2 = x[:, :256] @ w[:, 640:].t()
+    assert (out2 - ref2).abs().max().item() < 1e-3
