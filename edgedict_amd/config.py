@@ -1,0 +1,48 @@
+"""Engine-wide numeric mode.
+
+``fp32`` (default) is the parity mode: every product runs on the exact f32 MFMA path and all
+activations are fp32, so results track the reference's CPU fp32 PyTorch path to rounding.
+``bf16`` is the throughput mode: bf16 activations / weight copies with fp32 accumulation,
+fp32 master weights, fp32 cell state, statistics and loss lattice.
+
+Select with ``edgedict_amd.set_compute_dtype('bf16')``, the ``EDGEDICT_DTYPE`` environment
+variable, or per model via ``model.compute_dtype = torch.bfloat16``.
+"""
+import os
+
+import torch
+
+_NAMES = {"fp32": torch.float32, "float32": torch.float32, "f32": torch.float32,
+          "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}
+
+
+def _parse(x):
+    if isinstance(x, torch.dtype):
+        if x not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute dtype must be float32 or bfloat16")
+        return x
+    try:
+        return _NAMES[str(x).lower()]
+    except KeyError:
+        raise ValueError("unknown compute dtype %r (use 'fp32' or 'bf16')" % (x,))
+
+
+_state = {"dtype": _parse(os.environ.get("EDGEDICT_DTYPE", "fp32")), "epoch": 0}
+
+
+def set_compute_dtype(x):
+    _state["dtype"] = _parse(x)
+
+
+def get_compute_dtype():
+    return _state["dtype"]
+
+
+def bump_param_epoch():
+    """Called by optimisers that update parameters behind autograd's back (raw kernels) so
+    cached compute-dtype weight copies are refreshed."""
+    _state["epoch"] += 1
+
+
+def param_epoch():
+    return _state["epoch"]

@@ -1,0 +1,400 @@
+// Streaming (HBM-bound) helper kernels of the RNN-T path: dtype casts / transposes of weights,
+// bias-gradient column sums, the prediction network's embedding lookup, the joint network's
+// broadcast-add + tanh and its backward reduction, and the fused Adam update.
+//
+// Reference arithmetic:
+//   Decoder.forward   rnnt/models.py:150-157  F.pad(ys,[1,0],BOS) -> nn.Embedding(padding_idx=PAD)
+//   Joint.forward     rnnt/models.py:169-179  Linear(cat[enc;dec]) -> Tanh  (the first Linear is
+//                     split as W1e*enc + W1d*dec + b1; here: tanh(E1[b,t]+D1[b,u]))
+//   optimiser         cli/train.py:135-146,268 torch.optim.Adam (no weight decay)
+#include "common.hpp"
+
+namespace {
+
+// ---------------------------------------------------------------- cast (contiguous)
+template <typename TS, typename TD>
+__global__ void cast_kernel(const TS* __restrict__ s, TD* __restrict__ d, long long n) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        ElemIO<TD>::store(d + i, ElemIO<TS>::load(s + i));
+}
+
+// ---------------------------------------------------------------- transpose + cast
+// dst[c][r] = src[r][c];  32x32 tile through LDS, coalesced on both sides.
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void transpose_kernel(const TS* __restrict__ s,
+                                                        TD* __restrict__ d, int R, int C) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + ty + i * 8, c = c0 + tx;
+        tile[ty + i * 8][tx] = (r < R && c < C) ? ElemIO<TS>::load(s + (long long)r * C + c) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + i * 8, r = r0 + tx;
+        if (c < C && r < R) ElemIO<TD>::store(d + (long long)c * R + r, tile[tx][ty + i * 8]);
+    }
+}
+
+// ---------------------------------------------------------------- column sum: out[n] += sum_m X[m][n]
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, long long ld,
+                                                     float* __restrict__ out, long long M, int N,
+                                                     int rows_per_block) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    const long long m0 = (long long)blockIdx.y * rows_per_block;
+    const long long m1 = min(M, m0 + rows_per_block);
+    if (col >= N) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    long long m = m0;
+    for (; m + 3 < m1; m += 4) {
+        a0 += ElemIO<T>::load(x + m * ld + col);
+        a1 += ElemIO<T>::load(x + (m + 1) * ld + col);
+        a2 += ElemIO<T>::load(x + (m + 2) * ld + col);
+        a3 += ElemIO<T>::load(x + (m + 3) * ld + col);
+    }
+    for (; m < m1; ++m) a0 += ElemIO<T>::load(x + m * ld + col);
+    atomicAdd(out + col, (a0 + a1) + (a2 + a3));
+}
+
+// ---------------------------------------------------------------- embedding
+// out[b, u, :] = emb[tok(b,u), :], tok(b,0) = bos when prepend_bos else labels[b,u]
+template <typename T, typename TW>
+__global__ void embedding_fwd(const int32_t* __restrict__ tokens, int tok_stride,
+                              const TW* __restrict__ emb, T* __restrict__ out, int B, int Uout,
+                              int E, int prepend_bos, int bos, int V) {
+    const long long n = (long long)B * Uout * E;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(i % E);
+        const long long bu = i / E;
+        const int u = (int)(bu % Uout), b = (int)(bu / Uout);
+        int tok;
+        if (prepend_bos) tok = (u == 0) ? bos : tokens[(long long)b * tok_stride + u - 1];
+        else tok = tokens[(long long)b * tok_stride + u];
+        tok = min(max(tok, 0), V - 1);
+        ElemIO<T>::store(out + i, ElemIO<TW>::load(emb + (long long)tok * E + e));
+    }
+}
+// demb[tok] += dout rows (fp32 atomics); the padding row receives nothing (padding_idx)
+template <typename T>
+__global__ void embedding_bwd(const int32_t* __restrict__ tokens, int tok_stride,
+                              const T* __restrict__ dout, float* __restrict__ demb, int B, int Uout,
+                              int E, int prepend_bos, int bos, int pad, int V) {
+    const long long n = (long long)B * Uout * E;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(i % E);
+        const long long bu = i / E;
+        const int u = (int)(bu % Uout), b = (int)(bu / Uout);
+        int tok;
+        if (prepend_bos) tok = (u == 0) ? bos : tokens[(long long)b * tok_stride + u - 1];
+        else tok = tokens[(long long)b * tok_stride + u];
+        if (tok == pad || tok < 0 || tok >= V) continue;
+        atomicAdd(demb + (long long)tok * E + e, ElemIO<T>::load(dout + i));
+    }
+}
+
+// ---------------------------------------------------------------- joint: hid = tanh(E1[b,t] + D1[b,u])
+template <typename T>
+__global__ __launch_bounds__(256) void joint_hidden_fwd(const T* __restrict__ E1,
+                                                        const T* __restrict__ D1,
+                                                        T* __restrict__ hid, int B, int Tn, int U1,
+                                                        int J) {
+    constexpr int VEC = ElemIO<T>::VEC;
+    const int chunks = J / VEC;  // J % VEC == 0 checked on the host
+    const long long n = (long long)B * Tn * U1 * chunks;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % chunks);
+        const long long btu = i / chunks;
+        const int u = (int)(btu % U1);
+        const long long bt = btu / U1;
+        const int b = (int)(bt / Tn);
+        float e[VEC], d[VEC], o[VEC];
+        ElemIO<T>::load_vec(E1 + bt * J + c * VEC, e);
+        ElemIO<T>::load_vec(D1 + ((long long)b * U1 + u) * J + c * VEC, d);
+#pragma unroll
+        for (int k = 0; k < VEC; ++k) o[k] = tanhf(e[k] + d[k]);
+        ElemIO<T>::store_vec(hid + btu * J + c * VEC, o);
+    }
+}
+
+// backward of the broadcast-add + tanh:  dpre = dhid * (1 - hid^2)
+//   dE1[b,t,j] = sum_u dpre[b,t,u,j]        dD1[b,u,j] = sum_t dpre[b,t,u,j]
+// One workgroup per (b, 256-wide j block, t slab); one thread per j.  The per-u running sums live
+// in LDS ([64][256] floats, each column owned by its thread: no conflicts, no atomics inside the
+// block); label positions are processed in chunks of 64 so any U+1 fits; t slabs combine with
+// global atomics.
+constexpr int JB_UCHUNK = 64;
+template <typename T>
+__global__ __launch_bounds__(256) void joint_hidden_bwd(const T* __restrict__ dhid,
+                                                        const T* __restrict__ hid,
+                                                        float* __restrict__ dE1,
+                                                        float* __restrict__ dD1, int B, int Tn,
+                                                        int U1, int J, int t_per_block) {
+    __shared__ float usum[JB_UCHUNK * 256];
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    const int t0 = blockIdx.z * t_per_block, t1 = min(Tn, t0 + t_per_block);
+    if (j >= J) return;  // no barriers below: columns are thread-private
+    for (int uc = 0; uc < U1; uc += JB_UCHUNK) {
+        const int un = min(JB_UCHUNK, U1 - uc);
+        for (int u = 0; u < un; ++u) usum[u * 256 + threadIdx.x] = 0.f;
+        for (int t = t0; t < t1; ++t) {
+            const long long base = (((long long)b * Tn + t) * U1 + uc) * J + j;
+            float tsum = 0.f;
+            for (int u = 0; u < un; ++u) {
+                const float h = ElemIO<T>::load(hid + base + (long long)u * J);
+                const float g = ElemIO<T>::load(dhid + base + (long long)u * J);
+                const float dp = g * (1.f - h * h);
+                tsum += dp;
+                usum[u * 256 + threadIdx.x] += dp;
+            }
+            float* de = dE1 + ((long long)b * Tn + t) * J + j;
+            *de = (uc == 0) ? tsum : *de + tsum;
+        }
+        for (int u = 0; u < un; ++u)
+            atomicAdd(dD1 + ((long long)b * U1 + uc + u) * J + j, usum[u * 256 + threadIdx.x]);
+    }
+}
+
+// ---------------------------------------------------------------- Adam (torch.optim.Adam semantics)
+// m = b1*m + (1-b1)*g;  v = b2*v + (1-b2)*g*g;  p -= step_size * m / (sqrt(v)/sqrt(bc2) + eps)
+// grad_scale is read from device memory (gradient clipping coefficient) when given.
+__global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                            float* __restrict__ m, float* __restrict__ v, long long n, float lr,
+                            float b1, float b2, float eps, float bc1, float bc2,
+                            float weight_decay, const float* __restrict__ grad_scale,
+                            bf16_t* __restrict__ p_bf16) {
+    const float gs = grad_scale ? *grad_scale : 1.f;
+    const float step = lr / bc1;
+    const float inv_sqrt_bc2 = rsqrtf(bc2);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float gi = g[i] * gs;
+        float pi = p[i];
+        if (weight_decay != 0.f) gi += weight_decay * pi;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        pi -= step * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+        p[i] = pi;
+        if (p_bf16) p_bf16[i] = f32_to_bf16(pi);
+    }
+}
+
+// sum of squares -> out[0] (atomic); used for the global gradient norm
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x, long long n,
+                                                    float* __restrict__ out) {
+    __shared__ float part[4];
+    float a = 0.f;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        a += x[i] * x[i];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+// coef[0] = min(1, max_norm / (sqrt(sumsq) + 1e-6))   (torch.nn.utils.clip_grad_norm_)
+__global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* coef, float* norm_out) {
+    const float nrm = sqrtf(*sumsq);
+    if (norm_out) *norm_out = nrm;
+    *coef = fminf(1.f, max_norm / (nrm + 1e-6f));
+}
+
+}  // namespace
+
+extern "C" int edgedict_cast(int src_dtype, const void* src, int dst_dtype, void* dst,
+                             long long n, void* stream_) {
+    ED_CHECK_ARG(n >= 0, "cast: negative size");
+    if (n == 0) return ED_OK;
+    ED_CHECK_ARG(src && dst, "cast: null pointer");
+    hipStream_t s = (hipStream_t)stream_;
+    const int grid = ed_grid_for(n, 256 * 4, 256 * 8);
+    if (src_dtype == ED_F32 && dst_dtype == ED_BF16)
+        hipLaunchKernelGGL((cast_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, s, (const float*)src, (bf16_t*)dst, n);
+    else if (src_dtype == ED_BF16 && dst_dtype == ED_F32)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, (float*)dst, n);
+    else if (src_dtype == ED_F32 && dst_dtype == ED_F32)
+        hipLaunchKernelGGL((cast_kernel<float, float>), dim3(grid), dim3(256), 0, s, (const float*)src, (float*)dst, n);
+    else if (src_dtype == ED_BF16 && dst_dtype == ED_BF16)
+        hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, n);
+    else {
+        ed_set_error("cast: unsupported dtype pair %d -> %d", src_dtype, dst_dtype);
+        return ED_ERR_INVALID;
+    }
+    ED_CHECK_LAUNCH("cast");
+    return ED_OK;
+}
+
+extern "C" int edgedict_transpose(int src_dtype, const void* src, int dst_dtype, void* dst, int R,
+                                  int C, void* stream_) {
+    ED_CHECK_ARG(R >= 0 && C >= 0, "transpose: negative size");
+    if (R == 0 || C == 0) return ED_OK;
+    ED_CHECK_ARG(src && dst, "transpose: null pointer");
+    hipStream_t s = (hipStream_t)stream_;
+    dim3 grid((C + 31) / 32, (R + 31) / 32);
+    if (src_dtype == ED_F32 && dst_dtype == ED_BF16)
+        hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, dim3(256), 0, s, (const float*)src, (bf16_t*)dst, R, C);
+    else if (src_dtype == ED_F32 && dst_dtype == ED_F32)
+        hipLaunchKernelGGL((transpose_kernel<float, float>), grid, dim3(256), 0, s, (const float*)src, (float*)dst, R, C);
+    else if (src_dtype == ED_BF16 && dst_dtype == ED_BF16)
+        hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, R, C);
+    else if (src_dtype == ED_BF16 && dst_dtype == ED_F32)
+        hipLaunchKernelGGL((transpose_kernel<bf16_t, float>), grid, dim3(256), 0, s, (const bf16_t*)src, (float*)dst, R, C);
+    else {
+        ed_set_error("transpose: unsupported dtype pair %d -> %d", src_dtype, dst_dtype);
+        return ED_ERR_INVALID;
+    }
+    ED_CHECK_LAUNCH("transpose");
+    return ED_OK;
+}
+
+extern "C" int edgedict_colsum(int dtype, const void* x, long long ld, float* out, long long M,
+                               int N, void* stream_) {
+    ED_CHECK_ARG(dtype == ED_F32 || dtype == ED_BF16, "colsum: bad dtype");
+    ED_CHECK_ARG(M >= 0 && N >= 0, "colsum: negative size");
+    if (M == 0 || N == 0) return ED_OK;
+    ED_CHECK_ARG(x && out, "colsum: null pointer");
+    hipStream_t s = (hipStream_t)stream_;
+    const int colblocks = (N + 255) / 256;
+    long long want_rowblocks = (2048 + colblocks - 1) / colblocks;  // ~2k workgroups in total
+    long long rpb = (M + want_rowblocks - 1) / want_rowblocks;
+    if (rpb < 64) rpb = 64;
+    const long long rowblocks = (M + rpb - 1) / rpb;
+    ED_CHECK_ARG(rowblocks <= 65535, "colsum: too many row blocks");
+    dim3 grid(colblocks, (unsigned)rowblocks);
+    if (dtype == ED_F32)
+        hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, s, (const float*)x, ld, out, M, N, (int)rpb);
+    else
+        hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)x, ld, out, M, N, (int)rpb);
+    ED_CHECK_LAUNCH("colsum");
+    return ED_OK;
+}
+
+extern "C" int edgedict_embedding_fwd(int out_dtype, int emb_dtype, const int32_t* tokens,
+                                      int tok_stride, const void* emb, void* out, int B, int Uout,
+                                      int E, int V, int prepend_bos, int bos, void* stream_) {
+    ED_CHECK_ARG(B >= 0 && Uout >= 0 && E > 0 && V > 0, "embedding_fwd: bad shape");
+    if (B == 0 || Uout == 0) return ED_OK;
+    ED_CHECK_ARG(emb && out && (tokens || (prepend_bos && Uout == 1)), "embedding_fwd: null pointer");
+    hipStream_t s = (hipStream_t)stream_;
+    const long long n = (long long)B * Uout * E;
+    const int grid = ed_grid_for(n, 256, 2048);
+#define ED_EMB(TO, TW) hipLaunchKernelGGL((embedding_fwd<TO, TW>), dim3(grid), dim3(256), 0, s, tokens, tok_stride, (const TW*)emb, (TO*)out, B, Uout, E, prepend_bos, bos, V)
+    if (out_dtype == ED_F32 && emb_dtype == ED_F32) ED_EMB(float, float);
+    else if (out_dtype == ED_BF16 && emb_dtype == ED_F32) ED_EMB(bf16_t, float);
+    else if (out_dtype == ED_BF16 && emb_dtype == ED_BF16) ED_EMB(bf16_t, bf16_t);
+    else {
+        ed_set_error("embedding_fwd: unsupported dtype pair");
+        return ED_ERR_INVALID;
+    }
+#undef ED_EMB
+    ED_CHECK_LAUNCH("embedding_fwd");
+    return ED_OK;
+}
+
+extern "C" int edgedict_embedding_bwd(int dtype, const int32_t* tokens, int tok_stride,
+                                      const void* dout, float* demb, int B, int Uout, int E, int V,
+                                      int prepend_bos, int bos, int pad, void* stream_) {
+    ED_CHECK_ARG(B >= 0 && Uout >= 0 && E > 0 && V > 0, "embedding_bwd: bad shape");
+    if (B == 0 || Uout == 0) return ED_OK;
+    ED_CHECK_ARG(dout && demb && (tokens || (prepend_bos && Uout == 1)), "embedding_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream_;
+    const long long n = (long long)B * Uout * E;
+    const int grid = ed_grid_for(n, 256, 2048);
+    if (dtype == ED_F32)
+        hipLaunchKernelGGL(embedding_bwd<float>, dim3(grid), dim3(256), 0, s, tokens, tok_stride, (const float*)dout, demb, B, Uout, E, prepend_bos, bos, pad, V);
+    else if (dtype == ED_BF16)
+        hipLaunchKernelGGL(embedding_bwd<bf16_t>, dim3(grid), dim3(256), 0, s, tokens, tok_stride, (const bf16_t*)dout, demb, B, Uout, E, prepend_bos, bos, pad, V);
+    else {
+        ed_set_error("embedding_bwd: bad dtype");
+        return ED_ERR_INVALID;
+    }
+    ED_CHECK_LAUNCH("embedding_bwd");
+    return ED_OK;
+}
+
+extern "C" int edgedict_joint_hidden_fwd(int dtype, const void* E1, const void* D1, void* hid,
+                                         int B, int T, int U1, int J, void* stream_) {
+    ED_CHECK_ARG(dtype == ED_F32 || dtype == ED_BF16, "joint_hidden_fwd: bad dtype");
+    ED_CHECK_ARG(B > 0 && T > 0 && U1 > 0 && J > 0, "joint_hidden_fwd: bad shape");
+    const int vec = dtype == ED_F32 ? 4 : 8;
+    ED_CHECK_ARG(J % vec == 0, "joint_hidden_fwd: joint size %d must be a multiple of %d", J, vec);
+    ED_CHECK_ARG(E1 && D1 && hid, "joint_hidden_fwd: null pointer");
+    hipStream_t s = (hipStream_t)stream_;
+    const long long n = (long long)B * T * U1 * (J / vec);
+    const int grid = ed_grid_for(n, 256, 256 * 16);
+    if (dtype == ED_F32)
+        hipLaunchKernelGGL(joint_hidden_fwd<float>, dim3(grid), dim3(256), 0, s, (const float*)E1, (const float*)D1, (float*)hid, B, T, U1, J);
+    else
+        hipLaunchKernelGGL(joint_hidden_fwd<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)E1, (const bf16_t*)D1, (bf16_t*)hid, B, T, U1, J);
+    ED_CHECK_LAUNCH("joint_hidden_fwd");
+    return ED_OK;
+}
+
+extern "C" int edgedict_joint_hidden_bwd(int dtype, const void* dhid, const void* hid, float* dE1,
+                                         float* dD1, int B, int T, int U1, int J, void* stream_) {
+    ED_CHECK_ARG(dtype == ED_F32 || dtype == ED_BF16, "joint_hidden_bwd: bad dtype");
+    ED_CHECK_ARG(B > 0 && T > 0 && U1 > 0 && J > 0, "joint_hidden_bwd: bad shape");
+    ED_CHECK_ARG(dhid && hid && dE1 && dD1, "joint_hidden_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream_;
+    // dD1 is accumulated with atomics across t slabs: zero it first
+    hipError_t e = hipMemsetAsync(dD1, 0, (size_t)B * U1 * J * sizeof(float), s);
+    if (e != hipSuccess) {
+        ed_set_error("joint_hidden_bwd: memset failed: %s", hipGetErrorString(e));
+        return ED_ERR_LAUNCH;
+    }
+    const int jblocks = (J + 255) / 256;
+    int tslabs = (1024 + B * jblocks - 1) / (B * jblocks);  // aim at ~1k workgroups
+    if (tslabs > T) tslabs = T;
+    if (tslabs < 1) tslabs = 1;
+    const int tpb = (T + tslabs - 1) / tslabs;
+    tslabs = (T + tpb - 1) / tpb;
+    dim3 grid(jblocks, B, tslabs);
+    if (dtype == ED_F32)
+        hipLaunchKernelGGL(joint_hidden_bwd<float>, grid, dim3(256), 0, s, (const float*)dhid, (const float*)hid, dE1, dD1, B, T, U1, J, tpb);
+    else
+        hipLaunchKernelGGL(joint_hidden_bwd<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dhid, (const bf16_t*)hid, dE1, dD1, B, T, U1, J, tpb);
+    ED_CHECK_LAUNCH("joint_hidden_bwd");
+    return ED_OK;
+}
+
+extern "C" int edgedict_adam_step(float* p, const float* g, float* m, float* v, long long n,
+                                  float lr, float beta1, float beta2, float eps, int step,
+                                  float weight_decay, const float* grad_scale, void* p_bf16,
+                                  void* stream_) {
+    ED_CHECK_ARG(n >= 0 && step >= 1, "adam_step: bad size/step");
+    if (n == 0) return ED_OK;
+    ED_CHECK_ARG(p && g && m && v, "adam_step: null pointer");
+    const float bc1 = 1.f - powf(beta1, (float)step);
+    const float bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(ed_grid_for(n, 256 * 4, 256 * 8)), dim3(256), 0,
+                       (hipStream_t)stream_, p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2,
+                       weight_decay, grad_scale, (bf16_t*)p_bf16);
+    ED_CHECK_LAUNCH("adam_step");
+    return ED_OK;
+}
+
+extern "C" int edgedict_grad_clip_coef(const float* g, long long n, float max_norm, float* sumsq_ws,
+                                       float* coef, float* norm_out, void* stream_) {
+    ED_CHECK_ARG(n >= 0 && g && sumsq_ws && coef, "grad_clip_coef: bad arguments");
+    hipStream_t s = (hipStream_t)stream_;
+    hipError_t e = hipMemsetAsync(sumsq_ws, 0, sizeof(float), s);
+    if (e != hipSuccess) {
+        ed_set_error("grad_clip_coef: memset failed: %s", hipGetErrorString(e));
+        return ED_ERR_LAUNCH;
+    }
+    if (n > 0)
+        hipLaunchKernelGGL(sumsq_kernel, dim3(ed_grid_for(n, 256 * 8, 1024)), dim3(256), 0, s, g, n, sumsq_ws);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, s, sumsq_ws, max_norm, coef, norm_out);
+    ED_CHECK_LAUNCH("grad_clip_coef");
+    return ED_OK;
+}

@@ -1,0 +1,276 @@
+// LSTM time recurrence (forward and BPTT) for gfx950.
+//
+// Replaces the cuDNN/MIOpen RNN behind nn.LSTM as the reference uses it:
+//   encoder  rnnt/models.py:45-46,65   six 1-layer batch_first LSTMs, state (hs[i], cs[i])
+//   decoder  rnnt/models.py:145-147,155 one multi-layer LSTM
+// PyTorch cell semantics: gate order i,f,g,o in the 4H rows of weight_ih / weight_hh,
+//   i,f,o = sigmoid, g = tanh,  c' = f*c + i*g,  h' = o*tanh(c').
+//
+// Division of labour: the input product X*W_ih^T + b_ih + b_hh for ALL timesteps
+// is one big MFMA GEMM (gemm.hip) that leaves pre-activations in G[B,T,4H].  What remains is the
+// strictly serial part, h_{t-1}*W_hh^T, handled here as ONE SMALL KERNEL PER TIMESTEP:
+// a dependent kernel boundary costs ~1.5 us on MI355X, less than any software grid barrier
+// (MI355X_MICROARCH.md price list: boundary 1.45 us vs barrier-xcd 4-5 us), and needs no
+// co-residency assumptions.
+//
+// Forward step t, workgroup (unit block j0..j0+3, batch block of 64 rows), 4 waves:
+//   each wave owns a quarter of K = H and multiplies Hprev[:, t, kslice] (64 x K/4) by the
+//   16 W_hh rows {gate*H + j0 + u} with v_mfma 16x16 tiles, operands loaded straight from
+//   L2 into VGPRs (no LDS staging: nothing is reused inside the workgroup);
+//   the four partial 64x16 tiles are reduced through LDS, then one thread per (row, unit)
+//   applies the cell update and writes, in place, the post-activation gates over G[:, t],
+//   c_t, h_t -> Y[:, t] and h_t -> Hprev[:, t+1].
+// Backward step t, workgroup (16 units, 16 batch rows): dh = dY[:, t] + dG[:, t+1] * W_hh
+//   (K = 4H, one gate per wave, operand W_hh^T), then the cell backward, writing the
+//   pre-activation gradients in place over G[:, t] and carrying dc in a [B,H] fp32 buffer.
+// After the sweep G holds dG for every t, and dX / dW_ih / dW_hh / db are plain GEMMs / column sums.
+#include "common.hpp"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
+
+// ---- fragment loads straight from global memory (row-major, K contiguous) -------------
+// bf16: lane holds 8 consecutive k (16 B) of row (lane & 15), k offset (lane >> 4) * 8
+__device__ __forceinline__ bf16x8_t load_frag(const bf16_t* row_ptr, int k, int kmax, bool row_ok) {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row_ok && k + 8 <= kmax) v = *reinterpret_cast<const uint4*>(row_ptr + k);
+    return *reinterpret_cast<bf16x8_t*>(&v);
+}
+__device__ __forceinline__ float load_frag(const float* row_ptr, int k, int kmax, bool row_ok) {
+    return (row_ok && k < kmax) ? row_ptr[k] : 0.f;
+}
+__device__ __forceinline__ f32x4_t mma(bf16x8_t a, bf16x8_t b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4_t mma(float a, float b, f32x4_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+template <typename T> struct MK;
+template <> struct MK<bf16_t> { static constexpr int K = 32, LANE_K = 8; };
+template <> struct MK<float> { static constexpr int K = 4, LANE_K = 1; };
+
+constexpr int UNITS = 4;  // hidden units per forward workgroup (x 4 gates = one 16-wide N tile)
+
+template <typename T>
+__global__ __launch_bounds__(256) void lstm_step_fwd(
+    T* __restrict__ G, T* __restrict__ Hprev, T* __restrict__ Y, float* __restrict__ Cst,
+    const T* __restrict__ Whh, const float* __restrict__ c0, float* __restrict__ hN,
+    float* __restrict__ cN, int B, int Tn, int H, int t) {
+    __shared__ float red[4][64][17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j0 = blockIdx.x * UNITS;
+    const int b0 = blockIdx.y * 64;
+    constexpr int MKK = MK<T>::K, LK = MK<T>::LANE_K;
+
+    // K slice of this wave, rounded to whole MFMA steps
+    const int steps_total = (H + MKK - 1) / MKK;
+    const int steps_per_wave = (steps_total + 3) / 4;
+    const int kbeg = wave * steps_per_wave * MKK;
+    const int kend = min(H, kbeg + steps_per_wave * MKK);
+
+    // B operand rows: n = gate*UNITS + unit  ->  W_hh row gate*H + j0 + unit
+    const int n = lane & 15;
+    const int wrow = (n / UNITS) * H + j0 + (n % UNITS);
+    const bool w_ok = (j0 + (n % UNITS)) < H;
+    const T* wptr = Whh + (long long)wrow * H;
+    const int koff = (lane >> 4) * LK;
+
+    f32x4_t acc[4];
+    const T* aptr[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const int b = b0 + m * 16 + (lane & 15);
+        a_ok[m] = b < B;
+        aptr[m] = Hprev + ((long long)min(b, B - 1) * Tn + t) * H;
+    }
+    for (int k = kbeg; k < kend; k += MKK) {
+        const auto bf = load_frag(wptr, k + koff, H, w_ok);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            const auto af = load_frag(aptr[m], k + koff, H, a_ok[m]);
+            acc[m] = mma(af, bf, acc[m]);
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            red[wave][m * 16 + (lane >> 4) * 4 + r][lane & 15] = acc[m][r];
+    __syncthreads();
+
+    const int bl = threadIdx.x / UNITS, u = threadIdx.x % UNITS;
+    const int b = b0 + bl, j = j0 + u;
+    if (b >= B || j >= H) return;
+    float pre[4];
+    T* grow = G + ((long long)b * Tn + t) * 4 * H;
+#pragma unroll
+    for (int gate = 0; gate < 4; ++gate) {
+        const int col = gate * UNITS + u;
+        pre[gate] = red[0][bl][col] + red[1][bl][col] + red[2][bl][col] + red[3][bl][col] +
+                    ElemIO<T>::load(grow + gate * H + j);
+    }
+    const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]),
+                og = sigmoidf_(pre[3]);
+    const float cprev = (t > 0) ? Cst[((long long)b * Tn + t - 1) * H + j] : (c0 ? c0[(long long)b * H + j] : 0.f);
+    const float c = fg * cprev + ig * gg;
+    const float h = og * tanhf(c);
+    ElemIO<T>::store(grow + 0 * H + j, ig);
+    ElemIO<T>::store(grow + 1 * H + j, fg);
+    ElemIO<T>::store(grow + 2 * H + j, gg);
+    ElemIO<T>::store(grow + 3 * H + j, og);
+    Cst[((long long)b * Tn + t) * H + j] = c;
+    ElemIO<T>::store(Y + ((long long)b * Tn + t) * H + j, h);
+    if (t + 1 < Tn) {
+        ElemIO<T>::store(Hprev + ((long long)b * Tn + t + 1) * H + j, h);
+    } else {
+        if (hN) hN[(long long)b * H + j] = h;
+        if (cN) cN[(long long)b * H + j] = c;
+    }
+}
+
+// Hprev[:, 0, :] <- h0 (or zeros)
+template <typename T>
+__global__ void lstm_init_hprev(T* __restrict__ Hprev, const float* __restrict__ h0, int B, int Tn,
+                                int H) {
+    const long long n = (long long)B * H;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const long long b = i / H, j = i % H;
+        ElemIO<T>::store(Hprev + (b * Tn) * H + j, h0 ? h0[i] : 0.f);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void lstm_step_bwd(
+    T* __restrict__ G, const T* __restrict__ dY, const float* __restrict__ Cst,
+    const float* __restrict__ c0, const T* __restrict__ WhhT, float* __restrict__ dC, int B,
+    int Tn, int H, int t) {
+    __shared__ float red[4][16][17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j0 = blockIdx.x * 16;
+    const int b0 = blockIdx.y * 16;
+    constexpr int MKK = MK<T>::K, LK = MK<T>::LANE_K;
+    const int K = 4 * H;
+
+    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (t + 1 < Tn) {
+        const int steps_total = (K + MKK - 1) / MKK;
+        const int steps_per_wave = (steps_total + 3) / 4;
+        const int kbeg = wave * steps_per_wave * MKK;
+        const int kend = min(K, kbeg + steps_per_wave * MKK);
+        const int rb = b0 + (lane & 15);
+        const bool a_ok = rb < B;
+        const T* aptr = G + ((long long)min(rb, B - 1) * Tn + t + 1) * K;
+        const int jn = j0 + (lane & 15);
+        const bool w_ok = jn < H;
+        const T* wptr = WhhT + (long long)min(jn, H - 1) * K;
+        const int koff = (lane >> 4) * LK;
+        f32x4_t acc2 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        int k = kbeg;
+        for (; k + MKK < kend; k += 2 * MKK) {  // two independent accumulation chains
+            const auto a0 = load_frag(aptr, k + koff, K, a_ok);
+            const auto w0 = load_frag(wptr, k + koff, K, w_ok);
+            const auto a1 = load_frag(aptr, k + MKK + koff, K, a_ok);
+            const auto w1 = load_frag(wptr, k + MKK + koff, K, w_ok);
+            acc = mma(a0, w0, acc);
+            acc2 = mma(a1, w1, acc2);
+        }
+        for (; k < kend; k += MKK) {
+            const auto a0 = load_frag(aptr, k + koff, K, a_ok);
+            const auto w0 = load_frag(wptr, k + koff, K, w_ok);
+            acc = mma(a0, w0, acc);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][(lane >> 4) * 4 + r][lane & 15] = acc[r];
+    __syncthreads();
+
+    const int bl = threadIdx.x >> 4, nl = threadIdx.x & 15;
+    const int b = b0 + bl, j = j0 + nl;
+    if (b >= B || j >= H) return;
+    const long long row = (long long)b * Tn + t;
+    float dh = red[0][bl][nl] + red[1][bl][nl] + red[2][bl][nl] + red[3][bl][nl];
+    if (dY) dh += ElemIO<T>::load(dY + row * H + j);
+    T* grow = G + row * 4 * H;
+    const float ig = ElemIO<T>::load(grow + j), fg = ElemIO<T>::load(grow + H + j),
+                gg = ElemIO<T>::load(grow + 2 * H + j), og = ElemIO<T>::load(grow + 3 * H + j);
+    const float c = Cst[row * H + j];
+    const float cprev = (t > 0) ? Cst[(row - 1) * H + j] : (c0 ? c0[(long long)b * H + j] : 0.f);
+    const float tc = tanhf(c);
+    const float dct = dC[(long long)b * H + j] + dh * og * (1.f - tc * tc);
+    ElemIO<T>::store(grow + j, dct * gg * ig * (1.f - ig));
+    ElemIO<T>::store(grow + H + j, dct * cprev * fg * (1.f - fg));
+    ElemIO<T>::store(grow + 2 * H + j, dct * ig * (1.f - gg * gg));
+    ElemIO<T>::store(grow + 3 * H + j, dh * tc * og * (1.f - og));
+    dC[(long long)b * H + j] = dct * fg;
+}
+
+__global__ void fill_f32(float* p, long long n, float v) {
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x)
+        p[i] = v;
+}
+
+template <typename T>
+int run_fwd(void* G, void* Hprev, void* Y, float* Cst, const void* Whh, const float* h0,
+            const float* c0, float* hN, float* cN, int B, int Tn, int H, hipStream_t s) {
+    hipLaunchKernelGGL(lstm_init_hprev<T>, dim3(ed_grid_for((long long)B * H, 256)), dim3(256), 0,
+                       s, (T*)Hprev, h0, B, Tn, H);
+    ED_CHECK_LAUNCH("lstm_init_hprev");
+    dim3 grid((H + UNITS - 1) / UNITS, (B + 63) / 64);
+    for (int t = 0; t < Tn; ++t) {
+        hipLaunchKernelGGL(lstm_step_fwd<T>, grid, dim3(256), 0, s, (T*)G, (T*)Hprev, (T*)Y, Cst,
+                           (const T*)Whh, c0, hN, cN, B, Tn, H, t);
+    }
+    ED_CHECK_LAUNCH("lstm_step_fwd");
+    return ED_OK;
+}
+
+template <typename T>
+int run_bwd(void* G, const void* dY, const float* Cst, const float* c0, const void* WhhT,
+            float* dC, int B, int Tn, int H, hipStream_t s) {
+    hipLaunchKernelGGL(fill_f32, dim3(ed_grid_for((long long)B * H, 256)), dim3(256), 0, s, dC,
+                       (long long)B * H, 0.f);
+    ED_CHECK_LAUNCH("lstm dC init");
+    dim3 grid((H + 15) / 16, (B + 15) / 16);
+    for (int t = Tn - 1; t >= 0; --t) {
+        hipLaunchKernelGGL(lstm_step_bwd<T>, grid, dim3(256), 0, s, (T*)G, (const T*)dY, Cst, c0,
+                           (const T*)WhhT, dC, B, Tn, H, t);
+    }
+    ED_CHECK_LAUNCH("lstm_step_bwd");
+    return ED_OK;
+}
+
+}  // namespace
+
+extern "C" int edgedict_lstm_forward(int dtype, void* G, void* Hprev, void* Y, float* Cst,
+                                     const void* Whh, const float* h0, const float* c0, float* hN,
+                                     float* cN, int B, int T, int H, void* stream) {
+    ED_CHECK_ARG(dtype == ED_F32 || dtype == ED_BF16, "lstm_forward: bad dtype %d", dtype);
+    ED_CHECK_ARG(B > 0 && T > 0 && H > 0, "lstm_forward: B,T,H must be positive (got %d,%d,%d)", B, T, H);
+    ED_CHECK_ARG(H % 8 == 0, "lstm_forward: hidden size %d must be a multiple of 8", H);
+    ED_CHECK_ARG(G && Hprev && Y && Cst && Whh, "lstm_forward: null pointer");
+    if (dtype == ED_F32)
+        return run_fwd<float>(G, Hprev, Y, Cst, Whh, h0, c0, hN, cN, B, T, H, (hipStream_t)stream);
+    return run_fwd<bf16_t>(G, Hprev, Y, Cst, Whh, h0, c0, hN, cN, B, T, H, (hipStream_t)stream);
+}
+
+extern "C" int edgedict_lstm_backward(int dtype, void* G, const void* dY, const float* Cst,
+                                      const float* c0, const void* WhhT, float* dC_ws, int B,
+                                      int T, int H, void* stream) {
+    ED_CHECK_ARG(dtype == ED_F32 || dtype == ED_BF16, "lstm_backward: bad dtype %d", dtype);
+    ED_CHECK_ARG(B > 0 && T > 0 && H > 0, "lstm_backward: B,T,H must be positive");
+    ED_CHECK_ARG(H % 8 == 0, "lstm_backward: hidden size %d must be a multiple of 8", H);
+    ED_CHECK_ARG(G && Cst && WhhT && dC_ws, "lstm_backward: null pointer");
+    if (dtype == ED_F32)
+        return run_bwd<float>(G, dY, Cst, c0, WhhT, dC_ws, B, T, H, (hipStream_t)stream);
+    return run_bwd<bf16_t>(G, dY, Cst, c0, WhhT, dC_ws, B, T, H, (hipStream_t)stream);
+}

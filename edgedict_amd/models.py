@@ -1,0 +1,536 @@
+"""MI355X-native RNN-Transducer with the class surface of the reference's ``rnnt/models.py``.
+
+Same constructor arguments, sub-module call signatures, state-dict keys/shapes and return types
+as the reference, so ``cli/train.py`` / ``cli/baseline.py`` / ``rnnt/stream.py``
+style callers run unchanged — but every piece of arithmetic on the path is a hand-written
+gfx950 kernel reached through the C ABI in ``include/edgedict_hip.h``:
+
+=====================  =====================================  ==============================
+reference (file:line)  what                                   here
+=====================  =====================================  ==============================
+rnnt/models.py:131-136 Encoder.forward                        ``Encoder.forward``
+rnnt/models.py:55-75   ResLayerNormLSTM.forward               ``_LSTMBlockFn`` per layer
+rnnt/models.py:21-29   TimeReduction                          fused in ``layernorm_fwd``
+rnnt/models.py:150-157 Decoder.forward                        ``Decoder.forward``
+rnnt/models.py:169-179 Joint.forward                          ``_JointFn``
+rnnt/models.py:223-241 Transducer.scale_length / forward      ``Transducer``
+rnnt/models.py:243-269 Transducer.greedy_decode               ``Transducer.greedy_decode``
+=====================  =====================================  ==============================
+
+PyTorch is the container/plumbing layer only: ``nn.Parameter`` holds the fp32 master weights,
+``torch.autograd.Function`` routes gradients into ``.grad``, the caching allocator owns memory.
+There is no CPU or eager-PyTorch fallback: tensors must live on an MI355X.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import config, ops
+from ._lib import require_cuda
+from .loss import _RNNTLossFn
+from .tokenizer import BOS, NUL, PAD
+
+F32 = torch.float32
+
+
+# ----------------------------------------------------------------------------------------
+# compute-dtype weight copies (fp32 master -> bf16 / transposed), refreshed when the
+# parameter's version counter or the engine's parameter epoch changes
+class _WeightCache:
+    def __init__(self):
+        self._store = {}
+
+    def get(self, p, dtype, transposed=False):
+        key = (id(p), dtype, transposed)
+        ver = (p.data_ptr(), p._version, config.param_epoch())
+        hit = self._store.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1]
+        src = p.detach()
+        if not src.is_contiguous():
+            src = src.contiguous()
+        if transposed:
+            t = ops.transpose(src, dtype)
+        elif dtype == src.dtype:
+            t = src
+        else:
+            t = ops.cast(src, dtype)
+        self._store[key] = (ver, t)
+        return t
+
+    def clear(self):
+        self._store.clear()
+
+
+WEIGHTS = _WeightCache()
+
+
+def _to_cd(x, cd):
+    """Bring an activation into the compute dtype (device cast kernel, no-op if already there)."""
+    if x.dtype == cd:
+        return x.contiguous()
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        x = x.float()
+    return ops.cast(x.contiguous(), cd)
+
+
+def _state(t):
+    """Recurrent state slice -> contiguous fp32 [B,H] (or None)."""
+    if t is None:
+        return None
+    t = t.detach()
+    if t.dtype != F32:
+        t = ops.cast(t.contiguous(), F32)
+    return t.contiguous()
+
+
+# ----------------------------------------------------------------------------------------
+# autograd plumbing around the kernels
+class _InputNormFn(torch.autograd.Function):
+    """LayerNorm(input_size) on the stacked log-mel input (rnnt/models.py:124,132)."""
+
+    @staticmethod
+    def forward(ctx, xs, gamma, beta, cd):
+        x = _to_cd(xs, cd)
+        y, mean, rstd = ops.layernorm_fwd(x, None, gamma.detach(), beta.detach(), 1)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.in_dtype = xs.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        ds, dgamma, dbeta = ops.layernorm_bwd(dy, x, None, gamma.detach(), mean, rstd, 1)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ds if ds.dtype == ctx.in_dtype else ops.cast(ds, ctx.in_dtype)
+        return dx, dgamma, dbeta, None
+
+
+class _LSTMBlockFn(torch.autograd.Function):
+    """One 1-layer LSTM over the whole sequence, optionally followed by the encoder's
+    residual add + LayerNorm (+ TimeReduction).
+
+    forward : G = x W_ih^T + b_ih + b_hh (one MFMA GEMM) -> T step kernels -> fused LN epilogue
+    backward: LN backward -> T BPTT step kernels (G becomes dG in place) -> dX, dW_ih, dW_hh as
+              GEMMs reading dG / x / h_{t-1} transposed in place, db as a column sum.
+    """
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, ln_w, ln_b, h0, c0, residual, reduce, cd):
+        B, T, I = x.shape
+        H = w_hh.shape[1]
+        wih = WEIGHTS.get(w_ih, cd)
+        whh = WEIGHTS.get(w_hh, cd)
+        G = ops.gemm(x.view(B * T, I), wih, bias=b_ih.detach(), bias2=b_hh.detach())
+        G = G.view(B, T, 4 * H)
+        Y, Hprev, Cst, hN, cN = ops.lstm_forward(G, whh, h0, c0)
+        if ln_w is not None:
+            out, mean, rstd = ops.layernorm_fwd(Y, x if residual else None, ln_w.detach(),
+                                                ln_b.detach(), reduce)
+        else:
+            out, mean, rstd = Y, None, None
+        ctx.save_for_backward(x, w_ih, w_hh, ln_w, c0)
+        ctx.inter = (G, Y, Hprev, Cst, mean, rstd)
+        ctx.cfg = (residual, reduce, cd, ln_w is not None)
+        ctx.mark_non_differentiable(hN, cN)
+        return out, hN, cN
+
+    @staticmethod
+    def backward(ctx, dout, _dh, _dc):
+        if ctx.inter is None:
+            raise RuntimeError("edgedict_amd: this LSTM block's saved gates were consumed by a "
+                               "previous backward (retain_graph is not supported)")
+        x, w_ih, w_hh, ln_w, c0 = ctx.saved_tensors
+        G, Y, Hprev, Cst, mean, rstd = ctx.inter
+        ctx.inter = None
+        residual, reduce, cd, has_ln = ctx.cfg
+        B, T, I = x.shape
+        H = w_hh.shape[1]
+        dgamma = dbeta = None
+        if has_ln:
+            ds, dgamma, dbeta = ops.layernorm_bwd(dout, Y, x if residual else None,
+                                                  ln_w.detach(), mean, rstd, reduce)
+        else:
+            ds = dout.contiguous()
+        ops.lstm_backward(G, ds, Cst, c0, WEIGHTS.get(w_hh, cd, transposed=True))
+        dG = G.view(B * T, 4 * H)
+        x2 = x.view(B * T, I)
+        M = B * T
+        dw_ih = ops.gemm(dG.t(), x2.t(), out_dtype=F32, split_k=ops.pick_split_k(4 * H, I, M))
+        dw_hh = ops.gemm(dG.t(), Hprev.view(M, H).t(), out_dtype=F32,
+                         split_k=ops.pick_split_k(4 * H, H, M))
+        db = ops.colsum(dG)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wih = WEIGHTS.get(w_ih, cd)
+            if residual and has_ln:
+                dx = ds  # d(residual) + dG W_ih, accumulated in place by the GEMM epilogue
+                ops.gemm(dG, wih.t(), out=ds.view(M, I), accumulate=True)
+            else:
+                dx = ops.gemm(dG, wih.t()).view(B, T, I)
+        return (dx, dw_ih, dw_hh, db, db.clone(), dgamma, dbeta, None, None, None, None, None)
+
+
+class _LinearFn(torch.autograd.Function):
+    """y = x W^T + b on the last dimension (nn.Linear: rnnt/models.py:129,135,148,156)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, cd):
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        wc = WEIGHTS.get(w, cd)
+        y = ops.gemm(x2, wc, bias=b.detach() if b is not None else None)
+        ctx.save_for_backward(x2, w)
+        ctx.cfg = (cd, shp, b is not None)
+        return y.view(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        cd, shp, has_b = ctx.cfg
+        dy2 = dy.reshape(-1, w.shape[0])
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        M = x2.shape[0]
+        dw = ops.gemm(dy2.t(), x2.t(), out_dtype=F32,
+                      split_k=ops.pick_split_k(w.shape[0], w.shape[1], M))
+        db = ops.colsum(dy2) if has_b else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dy2, WEIGHTS.get(w, cd).t()).view(*shp)
+        return dx, dw, db, None
+
+
+class _EmbeddingFn(torch.autograd.Function):
+    """BOS left-pad + nn.Embedding(padding_idx=PAD) (rnnt/models.py:150-153)."""
+
+    @staticmethod
+    def forward(ctx, tokens, weight, prepend_bos, cd):
+        out = ops.embedding_fwd(tokens, weight.detach(), cd, prepend_bos, BOS)
+        ctx.save_for_backward(tokens)
+        ctx.cfg = (weight.shape[0], prepend_bos)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (tokens,) = ctx.saved_tensors
+        V, prepend_bos = ctx.cfg
+        return None, ops.embedding_bwd(tokens, dout, V, prepend_bos, BOS, PAD), None, None
+
+
+class _JointFn(torch.autograd.Function):
+    """logits[b,t,u,:] = W2 tanh(W1 [enc[b,t]; dec[b,u]] + b1) + b2 (rnnt/models.py:169-179).
+
+    W1 is applied as two small GEMMs (W1[:, :P_enc] on enc, W1[:, P_enc:] on dec) followed by a
+    broadcast-add+tanh kernel, so the reference's [B,T,U+1,P_enc+P_dec] concat is never built.
+    """
+
+    @staticmethod
+    def forward(ctx, enc, dec, w1, b1, w2, b2, cd):
+        B, T, P = enc.shape
+        U1, P2 = dec.shape[1], dec.shape[2]
+        J, V = w1.shape[0], w2.shape[0]
+        w1c = WEIGHTS.get(w1, cd)
+        w2c = WEIGHTS.get(w2, cd)
+        enc2 = enc.reshape(B * T, P)
+        dec2 = dec.reshape(B * U1, P2)
+        E1 = ops.gemm(enc2, w1c[:, :P])
+        D1 = ops.gemm(dec2, w1c[:, P:], bias=b1.detach())
+        hid = ops.joint_hidden_fwd(E1.view(B, T, J), D1.view(B, U1, J))
+        logits = ops.gemm(hid.view(B * T * U1, J), w2c, bias=b2.detach())
+        ctx.save_for_backward(enc2, dec2, w1, w2, hid)
+        ctx.cfg = (cd, B, T, U1, P, P2, J, V)
+        return logits.view(B, T, U1, V)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        enc2, dec2, w1, w2, hid = ctx.saved_tensors
+        cd, B, T, U1, P, P2, J, V = ctx.cfg
+        M = B * T * U1
+        dl = dlogits.reshape(M, V)
+        if not dl.is_contiguous():
+            dl = dl.contiguous()
+        hid2 = hid.view(M, J)
+        w1c = WEIGHTS.get(w1, cd)
+        w2c = WEIGHTS.get(w2, cd)
+        dhid = ops.gemm(dl, w2c.t())
+        dw2 = ops.gemm(dl.t(), hid2.t(), out_dtype=F32, split_k=ops.pick_split_k(V, J, M))
+        db2 = ops.colsum(dl)
+        dE1, dD1 = ops.joint_hidden_bwd(dhid.view(B, T, U1, J), hid)
+        del dhid
+        dE1c = ops.cast(dE1, cd).view(B * T, J)
+        dD1c = ops.cast(dD1, cd).view(B * U1, J)
+        denc = ops.gemm(dE1c, w1c[:, :P].t()).view(B, T, P)
+        ddec = ops.gemm(dD1c, w1c[:, P:].t()).view(B, U1, P2)
+        dw1 = torch.empty(J, P + P2, dtype=F32, device=dl.device)
+        ops.gemm(dE1c.t(), enc2.t(), out=dw1[:, :P], split_k=ops.pick_split_k(J, P, B * T))
+        ops.gemm(dD1c.t(), dec2.t(), out=dw1[:, P:], split_k=ops.pick_split_k(J, P2, B * U1))
+        db1 = ops.colsum(dD1.view(B * U1, J))
+        return denc, ddec, dw1, db1, dw2, db2, None
+
+
+# ----------------------------------------------------------------------------------------
+# parameter containers with the reference's names, shapes and default initialisation
+class TimeReduction(nn.Module):
+    """Marker for the 2x time reduction of rnnt/models.py:16-29; the arithmetic (zero-pad to an
+    even length after the LayerNorm, mean of frame pairs) is fused into the LayerNorm kernel."""
+
+    def __init__(self, reduction_factor=2):
+        super().__init__()
+        self.reduction_factor = reduction_factor
+
+
+class _LayerNormParams(nn.Module):
+    def __init__(self, size, eps=1e-5):
+        super().__init__()
+        self.normalized_shape = (size,)
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(size))
+        self.bias = nn.Parameter(torch.zeros(size))
+
+
+class _LinearParams(nn.Module):
+    def __init__(self, in_features, out_features):
+        super().__init__()
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features))
+        # nn.Linear default init
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        bound = 1.0 / math.sqrt(in_features)
+        nn.init.uniform_(self.bias, -bound, bound)
+
+
+class _LSTMParams(nn.Module):
+    """nn.LSTM-compatible parameter set: weight_ih_l{k} [4H,I], weight_hh_l{k} [4H,H],
+    bias_ih_l{k}, bias_hh_l{k} [4H]; gate order i,f,g,o; uniform(-1/sqrt(H), 1/sqrt(H))."""
+
+    def __init__(self, input_size, hidden_size, num_layers=1, dropout=0.0):
+        super().__init__()
+        self.input_size, self.hidden_size = input_size, hidden_size
+        self.num_layers, self.dropout = num_layers, dropout
+        k = 1.0 / math.sqrt(hidden_size)
+        for layer in range(num_layers):
+            i = input_size if layer == 0 else hidden_size
+            for name, shape in (("weight_ih", (4 * hidden_size, i)),
+                                ("weight_hh", (4 * hidden_size, hidden_size)),
+                                ("bias_ih", (4 * hidden_size,)),
+                                ("bias_hh", (4 * hidden_size,))):
+                p = nn.Parameter(torch.empty(*shape).uniform_(-k, k))
+                setattr(self, "%s_l%d" % (name, layer), p)
+
+    def layer(self, k):
+        return tuple(getattr(self, "%s_l%d" % (n, k))
+                     for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+
+    def flatten_parameters(self):  # API compatibility (cuDNN concept; nothing to do here)
+        pass
+
+
+class ResLayerNormLSTM(nn.Module):
+    """Stack of 1-layer LSTMs with residual connections, LayerNorm and optional time reduction
+    (reference rnnt/models.py:32-75).  Padded frames are NOT masked, as in the reference."""
+
+    def __init__(self, input_size, hidden_size, num_layers, dropout=0,
+                 time_reductions=[1], reduction_factor=2):
+        super().__init__()
+        if reduction_factor != 2:
+            raise ValueError("only reduction_factor=2 is implemented (the reference default)")
+        if dropout > 0:
+            raise NotImplementedError("encoder dropout > 0 is not implemented on the HIP path")
+        self.hidden_size = hidden_size
+        self.lstms = nn.ModuleList()
+        self.projs = nn.ModuleList()
+        self.reductions = []
+        for i in range(num_layers):
+            self.lstms.append(_LSTMParams(input_size, hidden_size, 1))
+            proj = [_LayerNormParams(hidden_size)]
+            if i in time_reductions:
+                proj.append(TimeReduction(reduction_factor))
+            self.reductions.append(2 if i in time_reductions else 1)
+            input_size = hidden_size
+            self.projs.append(nn.Sequential(*proj))
+
+    def forward(self, xs, hiddens=None, cd=None):
+        cd = cd or config.get_compute_dtype()
+        xs = _to_cd(xs, cd) if xs.dtype != cd else xs
+        new_hs, new_cs = [], []
+        for i, (lstm, proj) in enumerate(zip(self.lstms, self.projs)):
+            h0 = c0 = None
+            if hiddens is not None:
+                h0, c0 = _state(hiddens[0][i]), _state(hiddens[1][i])
+            w_ih, w_hh, b_ih, b_hh = lstm.layer(0)
+            xs, h, c = _LSTMBlockFn.apply(xs.contiguous(), w_ih, w_hh, b_ih, b_hh,
+                                          proj[0].weight, proj[0].bias, h0, c0, i != 0,
+                                          self.reductions[i], cd)
+            new_hs.append(h)
+            new_cs.append(c)
+        return xs, (torch.stack(new_hs, 0), torch.stack(new_cs, 0))
+
+
+class Encoder(nn.Module):
+    """LayerNorm -> ResLayerNormLSTM -> Linear (reference rnnt/models.py:119-136)."""
+
+    def __init__(self, input_size, hidden_size, num_layers, dropout, proj_size,
+                 module=ResLayerNormLSTM, time_reductions=[1], has_proj=True):
+        super().__init__()
+        self.norm = _LayerNormParams(input_size)
+        self.lstm = module(input_size, hidden_size, num_layers, dropout=dropout,
+                           time_reductions=time_reductions)
+        self.has_proj = has_proj
+        if has_proj:
+            self.proj = _LinearParams(hidden_size, proj_size)
+
+    def forward(self, xs, hiddens=None):
+        require_cuda(xs)
+        cd = getattr(self, "compute_dtype", None) or config.get_compute_dtype()
+        xs = _InputNormFn.apply(xs, self.norm.weight, self.norm.bias, cd)
+        xs, hiddens = self.lstm(xs, hiddens, cd)
+        if self.has_proj:
+            xs = _LinearFn.apply(xs, self.proj.weight, self.proj.bias, cd)
+        return xs, hiddens
+
+
+class Decoder(nn.Module):
+    """Prediction network: Embedding -> multi-layer LSTM -> Linear (rnnt/models.py:139-157)."""
+
+    def __init__(self, vocab_embed_size, vocab_size, hidden_size, num_layers,
+                 dropout=0, proj_size=None):
+        super().__init__()
+        self.embed = nn.Embedding(vocab_size, vocab_embed_size, padding_idx=PAD)  # container
+        self.lstm = _LSTMParams(vocab_embed_size, hidden_size, num_layers, dropout)
+        self.proj = _LinearParams(hidden_size, proj_size)
+        self.dropout = dropout
+
+    def forward(self, ys, hidden=None):
+        require_cuda(self.embed.weight)
+        cd = getattr(self, "compute_dtype", None) or config.get_compute_dtype()
+        prepend = hidden is None
+        tokens = ys.to(device=self.embed.weight.device, dtype=torch.int32)
+        if tokens.dim() != 2:
+            raise ValueError("decoder expects token ids of shape [B, U]")
+        if not tokens.is_contiguous():
+            tokens = tokens.contiguous()
+        x = _EmbeddingFn.apply(tokens, self.embed.weight, prepend, cd)
+        hs, cs = [], []
+        for k in range(self.lstm.num_layers):
+            h0 = c0 = None
+            if hidden is not None:
+                h0, c0 = _state(hidden[0][k]), _state(hidden[1][k])
+            w_ih, w_hh, b_ih, b_hh = self.lstm.layer(k)
+            x, h, c = _LSTMBlockFn.apply(x, w_ih, w_hh, b_ih, b_hh, None, None, h0, c0,
+                                         False, 1, cd)
+            if self.dropout > 0 and self.training and k + 1 < self.lstm.num_layers:
+                raise NotImplementedError("prediction-network dropout is not implemented yet")
+            hs.append(h)
+            cs.append(c)
+        y = _LinearFn.apply(x, self.proj.weight, self.proj.bias, cd)
+        return y, (torch.stack(hs, 0), torch.stack(cs, 0))
+
+
+class Joint(nn.Module):
+    """Linear(P_enc+P_dec, J) -> Tanh -> Linear(J, V) on every (t, u) pair
+    (rnnt/models.py:160-179).  Returns raw logits."""
+
+    def __init__(self, input_size, hidden_size, vocab_size):
+        super().__init__()
+        self.joint = nn.Sequential(_LinearParams(input_size, hidden_size), nn.Tanh(),
+                                   _LinearParams(hidden_size, vocab_size))
+
+    def forward(self, h_enc, h_dec):
+        require_cuda(h_enc, h_dec)
+        cd = getattr(self, "compute_dtype", None) or config.get_compute_dtype()
+        l1, l2 = self.joint[0], self.joint[2]
+        if h_enc.dim() == 3 and h_dec.dim() == 3:
+            e, d = _to_cd(h_enc, cd), _to_cd(h_dec, cd)
+            return _JointFn.apply(e, d, l1.weight, l1.bias, l2.weight, l2.bias, cd)
+        if h_enc.dim() != h_dec.dim() or h_enc.dim() != 2:
+            raise ValueError("joint expects two 3-D or two 2-D inputs")
+        e, d = _to_cd(h_enc, cd)[:, None], _to_cd(h_dec, cd)[:, None]
+        out = _JointFn.apply(e, d, l1.weight, l1.bias, l2.weight, l2.bias, cd)
+        return out[:, 0, 0]
+
+
+class Transducer(nn.Module):
+    """RNN-Transducer with the reference's constructor and methods (rnnt/models.py:182-269)."""
+
+    def __init__(self,
+                 vocab_embed_size, vocab_size, input_size,
+                 enc_hidden_size, enc_layers, enc_dropout, enc_proj_size,
+                 dec_hidden_size, dec_layers, dec_dropout, dec_proj_size,
+                 joint_size, enc_time_reductions=[1],
+                 blank=NUL, module_type='LSTM', output_loss=True):
+        super().__init__()
+        self.blank = blank
+        if module_type not in ['GRU', 'LSTM']:
+            raise ValueError('Unsupported module type')
+        if module_type == 'GRU':
+            raise NotImplementedError(
+                "the GRU encoder variant is outside the MI355X hot path (SURVEY.md 8f)")
+        self.encoder = Encoder(input_size=input_size, hidden_size=enc_hidden_size,
+                               num_layers=enc_layers, dropout=enc_dropout,
+                               proj_size=enc_proj_size, time_reductions=enc_time_reductions,
+                               module=ResLayerNormLSTM)
+        self.decoder = Decoder(vocab_embed_size=vocab_embed_size, vocab_size=vocab_size,
+                               hidden_size=dec_hidden_size, num_layers=dec_layers,
+                               dropout=dec_dropout, proj_size=dec_proj_size)
+        self.joint = Joint(input_size=enc_proj_size + dec_proj_size, hidden_size=joint_size,
+                           vocab_size=vocab_size)
+        self.output_loss = output_loss
+
+    # compute dtype shared with the sub-modules -----------------------------------------
+    @property
+    def compute_dtype(self):
+        return getattr(self.encoder, "compute_dtype", None) or config.get_compute_dtype()
+
+    @compute_dtype.setter
+    def compute_dtype(self, value):
+        value = config._parse(value)
+        for m in (self.encoder, self.decoder, self.joint):
+            m.compute_dtype = value
+
+    def scale_length(self, logits, xlen):
+        # rnnt/models.py:223-226 (host-side integer logic on a [B] tensor)
+        scale = (xlen.max().float() / logits.shape[1]).ceil()
+        xlen = (xlen / scale).ceil().int()
+        return xlen
+
+    def forward(self, xs, ys, xlen, ylen):
+        xs = xs[:, :xlen.max()].contiguous()
+        ys = ys[:, :ylen.max()].contiguous()
+        h_enc, _ = self.encoder(xs)
+        h_dec, _ = self.decoder(ys)
+        logits = self.joint(h_enc, h_dec)
+        if self.output_loss:
+            xlen = self.scale_length(logits, xlen)
+            labels = ys.to(torch.int32).contiguous()
+            loss = _RNNTLossFn.apply(logits, labels, xlen.to(torch.int32).contiguous(),
+                                     ylen.to(torch.int32).contiguous(), self.blank, "mean")
+            return loss
+        return logits
+
+    @torch.no_grad()
+    def greedy_decode(self, xs, xlen):
+        """Batched one-symbol-per-frame greedy search (rnnt/models.py:243-269): returns
+        (list of int64 numpy arrays INCLUDING blanks, truncated to the un-scaled xlen,
+        -sum_t max log p as a [B] tensor)."""
+        from .decode import greedy_decode_batch
+        return greedy_decode_batch(self, xs, xlen)
+
+
+def convert_lightning2normal(checkpoint):
+    """Lightning checkpoint -> ``{'model': state_dict}`` (same contract as the reference's
+    rnnt/models.py:366-380): when the file has a ``state_dict`` whose keys carry the Lightning
+    ``model.`` prefix, the prefix is removed everywhere and the result is wrapped under
+    ``'model'``; a ``state_dict`` without the prefix is returned bare; anything else is
+    passed through untouched."""
+    if 'state_dict' not in checkpoint:
+        return checkpoint
+    inner = checkpoint['state_dict']
+    names = list(inner.keys())
+    if names and 'model.' in names[0]:
+        return {'model': {name.replace('model.', ''): t for name, t in inner.items()}}
+    return inner

@@ -51,3 +51,143 @@ def gemm(a, b, out=None, bias=None, bias2=None, accumulate=False, split_k=1,
          out, _ll(out.stride(0) if M > 1 else max(out.stride(0), N)), M, N, K, bias, bias2,
          int(bool(accumulate)), int(split_k))
     return out
+
+
+def cast(x, dtype):
+    """Contiguous dtype conversion (fp32 <-> bf16) on the device."""
+    require_cuda(x)
+    if x.dtype == dtype:
+        return x
+    x = x.contiguous()
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    call("cast", dtype_code(x.dtype), x, dtype_code(dtype), out, _ll(x.numel()))
+    return out
+
+
+def transpose(x, dtype=None):
+    """out[c, r] = x[r, c] (optionally converting dtype). x must be a contiguous 2-D tensor."""
+    require_cuda(x)
+    assert x.dim() == 2 and x.is_contiguous()
+    dtype = dtype or x.dtype
+    out = torch.empty(x.shape[1], x.shape[0], dtype=dtype, device=x.device)
+    call("transpose", dtype_code(x.dtype), x, dtype_code(dtype), out, x.shape[0], x.shape[1])
+    return out
+
+
+def colsum(x2d, out=None):
+    """fp32 column sums of a row-major [M,N] matrix (atomically accumulated into ``out``)."""
+    require_cuda(x2d)
+    M, N = x2d.shape
+    assert x2d.stride(1) == 1
+    if out is None:
+        out = torch.zeros(N, dtype=torch.float32, device=x2d.device)
+    call("colsum", dtype_code(x2d.dtype), x2d, _ll(x2d.stride(0) if M > 1 else N), out, _ll(M), N)
+    return out
+
+
+def layernorm_fwd(x, res, gamma, beta, reduce=1, eps=1e-5):
+    """y = pairmean_reduce(LN(x + res)); x,res [B,T,D] in the compute dtype."""
+    require_cuda(x, gamma, beta)
+    B, T, D = x.shape
+    assert x.is_contiguous() and (res is None or (res.is_contiguous() and res.shape == x.shape))
+    Tout = (T + reduce - 1) // reduce
+    y = torch.empty(B, Tout, D, dtype=x.dtype, device=x.device)
+    mean = torch.empty(B * T, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(B * T, dtype=torch.float32, device=x.device)
+    call("layernorm_fwd", dtype_code(x.dtype), x, res, gamma, beta, y, mean, rstd, B, T, D,
+         int(reduce), float(eps))
+    return y, mean, rstd
+
+
+def layernorm_bwd(dout, x, res, gamma, mean, rstd, reduce=1, dgamma=None, dbeta=None):
+    require_cuda(dout, x)
+    B, T, D = x.shape
+    dout = dout.contiguous()
+    ds = torch.empty_like(x)
+    if dgamma is None:
+        dgamma = torch.zeros(D, dtype=torch.float32, device=x.device)
+    if dbeta is None:
+        dbeta = torch.zeros(D, dtype=torch.float32, device=x.device)
+    call("layernorm_bwd", dtype_code(x.dtype), dout, x, res, gamma, mean, rstd, ds, dgamma, dbeta,
+         B, T, D, int(reduce))
+    return ds, dgamma, dbeta
+
+
+def lstm_forward(G, Whh, h0=None, c0=None):
+    """Run the recurrence over G[B,T,4H] (input pre-activations, overwritten with the gates).
+    Returns (Y, Hprev, Cst, hN, cN)."""
+    require_cuda(G, Whh)
+    B, T, H4 = G.shape
+    H = H4 // 4
+    assert G.is_contiguous() and Whh.is_contiguous() and Whh.shape == (H4, H)
+    dev = G.device
+    Hprev = torch.empty(B, T, H, dtype=G.dtype, device=dev)
+    Y = torch.empty(B, T, H, dtype=G.dtype, device=dev)
+    Cst = torch.empty(B, T, H, dtype=torch.float32, device=dev)
+    hN = torch.empty(B, H, dtype=torch.float32, device=dev)
+    cN = torch.empty(B, H, dtype=torch.float32, device=dev)
+    for s in (h0, c0):
+        if s is not None:
+            assert s.dtype == torch.float32 and s.is_contiguous() and s.shape == (B, H)
+    call("lstm_forward", dtype_code(G.dtype), G, Hprev, Y, Cst, Whh, h0, c0, hN, cN, B, T, H)
+    return Y, Hprev, Cst, hN, cN
+
+
+def lstm_backward(G, dY, Cst, c0, WhhT):
+    """BPTT sweep: G (saved gates) is overwritten with dL/d(pre-activation) for every step."""
+    B, T, H4 = G.shape
+    H = H4 // 4
+    assert WhhT.shape == (H, H4) and WhhT.is_contiguous()
+    if dY is not None:
+        assert dY.is_contiguous() and dY.dtype == G.dtype and dY.shape == (B, T, H)
+    dC = torch.empty(B, H, dtype=torch.float32, device=G.device)
+    call("lstm_backward", dtype_code(G.dtype), G, dY, Cst, c0, WhhT, dC, B, T, H)
+    return G
+
+
+def embedding_fwd(tokens, weight, out_dtype, prepend_bos, bos):
+    """tokens int32 [B,U] -> [B, U(+1), E] in out_dtype; weight may be the fp32 master."""
+    require_cuda(weight)
+    B, U = tokens.shape
+    V, E = weight.shape
+    Uout = U + (1 if prepend_bos else 0)
+    out = torch.empty(B, Uout, E, dtype=out_dtype, device=weight.device)
+    tok = tokens if U > 0 else None
+    call("embedding_fwd", dtype_code(out_dtype), dtype_code(weight.dtype), tok,
+         int(tokens.stride(0)) if U > 0 else 0, weight, out, B, Uout, E, V, int(prepend_bos),
+         int(bos))
+    return out
+
+
+def embedding_bwd(tokens, dout, V, prepend_bos, bos, pad):
+    B, Uout, E = dout.shape
+    U = tokens.shape[1]
+    demb = torch.zeros(V, E, dtype=torch.float32, device=dout.device)
+    dout = dout.contiguous()
+    tok = tokens if U > 0 else None
+    call("embedding_bwd", dtype_code(dout.dtype), tok, int(tokens.stride(0)) if U > 0 else 0,
+         dout, demb, B, Uout, E, V, int(prepend_bos), int(bos), int(pad))
+    return demb
+
+
+def joint_hidden_fwd(E1, D1):
+    B, T, J = E1.shape
+    U1 = D1.shape[1]
+    hid = torch.empty(B, T, U1, J, dtype=E1.dtype, device=E1.device)
+    call("joint_hidden_fwd", dtype_code(E1.dtype), E1, D1, hid, B, T, U1, J)
+    return hid
+
+
+def joint_hidden_bwd(dhid, hid):
+    B, T, U1, J = hid.shape
+    dE1 = torch.empty(B, T, J, dtype=torch.float32, device=hid.device)
+    dD1 = torch.empty(B, U1, J, dtype=torch.float32, device=hid.device)
+    call("joint_hidden_bwd", dtype_code(hid.dtype), dhid, hid, dE1, dD1, B, T, U1, J)
+    return dE1, dD1
+
+
+def pick_split_k(M, N, K, bk=64):
+    """Split-K factor for weight-gradient GEMMs (small M*N, huge K): aim at >= ~512 workgroups."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    want = max(1, 768 // max(tiles, 1))
+    return int(max(1, min(want, K // (4 * bk) if K >= 8 * bk else 1)))

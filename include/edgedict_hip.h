@@ -92,6 +92,88 @@ int edgedict_gemm(int dtype_in, int dtype_out, const void* A, long long lda, int
                   int K, const float* bias1, const float* bias2, int accumulate, int split_k,
                   void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * LayerNorm fused with the residual add and the encoder's TimeReduction.
+ * Replaces nn.LayerNorm at rnnt/models.py:124,132 and the per-layer
+ * `xs = xs + lstm(xs); xs = Sequential(LayerNorm[, TimeReduction])(xs)` at rnnt/models.py:47-53,
+ * 66-70 with TimeReduction.forward rnnt/models.py:21-29 (zero-pad AFTER the norm, pair mean).
+ *   x, res (nullable)  [B,T,D] dtype;  s = x + res is what gets normalised
+ *   y                  [B, ceil(T/reduce), D] dtype;  reduce in {1,2}
+ *   mean, rstd         fp32 [B*T] saved for backward
+ * backward: ds [B,T,D] dtype (gradient wrt x AND wrt res), dgamma/dbeta fp32 [D] are ACCUMULATED
+ * (atomic +=), pass NULL to skip.
+ */
+int edgedict_layernorm_fwd(int dtype, const void* x, const void* res, const float* gamma,
+                           const float* beta, void* y, float* mean, float* rstd, int B, int T,
+                           int D, int reduce, float eps, void* stream);
+int edgedict_layernorm_bwd(int dtype, const void* dout, const void* x, const void* res,
+                           const float* gamma, const float* mean, const float* rstd, void* ds,
+                           float* dgamma, float* dbeta, int B, int T, int D, int reduce,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * LSTM time recurrence.  Replaces the cuDNN RNN behind nn.LSTM (rnnt/models.py:45-46,65 encoder
+ * layers; rnnt/models.py:145-147,155 prediction network).  PyTorch gate order i,f,g,o.
+ * forward:
+ *   G      [B,T,4H] dtype  in : X*W_ih^T + b_ih + b_hh (from edgedict_gemm)
+ *                          out: post-activation gates i,f,g,o (saved for backward, in place)
+ *   Hprev  [B,T,H]  dtype  out: h_{t-1} per step (row t=0 <- h0); operand of dW_hh later
+ *   Y      [B,T,H]  dtype  out: h_t
+ *   Cst    [B,T,H]  fp32   out: c_t
+ *   Whh    [4H,H]   dtype;  h0,c0 fp32 [B,H] nullable (= zeros);  hN,cN fp32 [B,H] nullable
+ * backward (after forward, same buffers):
+ *   dY     [B,T,H]  dtype  gradient wrt h_t (nullable = zeros)
+ *   G                     in : saved gates;  out: dL/d(pre-activations) for every t (in place)
+ *   WhhT   [H,4H]   dtype  (edgedict_transpose of Whh);  dC_ws fp32 [B,H] scratch
+ * One kernel launch per timestep (kernel boundary ~1.5us < any grid barrier on MI355X).
+ * Limits: H % 8 == 0.  Gradients wrt (h0,c0) are not produced.
+ */
+int edgedict_lstm_forward(int dtype, void* G, void* Hprev, void* Y, float* Cst, const void* Whh,
+                          const float* h0, const float* c0, float* hN, float* cN, int B, int T,
+                          int H, void* stream);
+int edgedict_lstm_backward(int dtype, void* G, const void* dY, const float* Cst, const float* c0,
+                           const void* WhhT, float* dC_ws, int B, int T, int H, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Streaming helpers.
+ * cast / transpose: weight copies in the compute dtype (fp32 master -> bf16), dst[c][r]=src[r][c].
+ * colsum: out[n] += sum_m x[m*ld+n]  (bias gradients; ATOMIC accumulate into fp32 out).
+ * embedding: nn.Embedding(V,E,padding_idx=PAD) lookup with the BOS left-pad of
+ *            Decoder.forward (rnnt/models.py:150-153) folded in; backward scatters with atomics
+ *            and skips the padding row.
+ * joint_hidden: hid[b,t,u,:] = tanh(E1[b,t,:] + D1[b,u,:])  (Joint.forward rnnt/models.py:169-179
+ *            with the first Linear split over [enc;dec]); backward returns fp32
+ *            dE1[B,T,J] = sum_u dpre, dD1[B,U1,J] = sum_t dpre with dpre = dhid*(1-hid^2).
+ */
+int edgedict_cast(int src_dtype, const void* src, int dst_dtype, void* dst, long long n,
+                  void* stream);
+int edgedict_transpose(int src_dtype, const void* src, int dst_dtype, void* dst, int R, int C,
+                       void* stream);
+int edgedict_colsum(int dtype, const void* x, long long ld, float* out, long long M, int N,
+                    void* stream);
+int edgedict_embedding_fwd(int out_dtype, int emb_dtype, const int32_t* tokens, int tok_stride,
+                           const void* emb, void* out, int B, int Uout, int E, int V,
+                           int prepend_bos, int bos, void* stream);
+int edgedict_embedding_bwd(int dtype, const int32_t* tokens, int tok_stride, const void* dout,
+                           float* demb, int B, int Uout, int E, int V, int prepend_bos, int bos,
+                           int pad, void* stream);
+int edgedict_joint_hidden_fwd(int dtype, const void* E1, const void* D1, void* hid, int B, int T,
+                              int U1, int J, void* stream);
+int edgedict_joint_hidden_bwd(int dtype, const void* dhid, const void* hid, float* dE1,
+                              float* dD1, int B, int T, int U1, int J, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Optimiser step on flat fp32 buffers (torch.optim.Adam semantics, cli/train.py:135-146,268)
+ * and the global-norm clip coefficient of clip_grad_norm_ (cli/train.py:262-267).
+ *   grad_scale: nullable device scalar multiplied into every gradient (the clip coefficient)
+ *   p_bf16    : nullable; receives the bf16 copy of the updated parameters
+ */
+int edgedict_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr,
+                       float beta1, float beta2, float eps, int step, float weight_decay,
+                       const float* grad_scale, void* p_bf16, void* stream);
+int edgedict_grad_clip_coef(const float* g, long long n, float max_norm, float* sumsq_ws,
+                            float* coef, float* norm_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
