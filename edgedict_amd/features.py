@@ -1,0 +1,179 @@
+"""Log-mel filterbank features on the GPU (mirror of the reference's ``rnnt/features.py``).
+
+``FilterbankFeatures`` keeps the reference's constructor arguments, buffer names (``fb``,
+``window``) and output layout ``[B, n_filt, frames]`` (rnnt/features.py:33-152).
+``StackedLogFbank`` is the fused form the engine's trainer uses: filterbank + the frame
+stacking of ``Downsample`` (rnnt/transforms.py:30-51) written directly as ``[B, T0, n_filt*k]``.
+All arithmetic runs in csrc/fbank.hip; numpy is used only to build the constant tables
+(window, FFT twiddles, mel weights) exactly as librosa 0.7.2's ``filters.mel`` defines them.
+"""
+import math
+
+import numpy as np
+import torch
+from torch import nn
+
+from . import _lib
+from ._lib import call, dtype_code, require_cuda
+from .ops import _ll
+
+
+def _hz_to_mel_slaney(f):
+    f = np.asarray(f, dtype=np.float64)
+    f_sp = 200.0 / 3
+    mel = f / f_sp
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    return np.where(f >= min_log_hz, min_log_mel + np.log(np.maximum(f, 1e-10) / min_log_hz) / logstep, mel)
+
+
+def _mel_to_hz_slaney(m):
+    m = np.asarray(m, dtype=np.float64)
+    f_sp = 200.0 / 3
+    min_log_hz = 1000.0
+    min_log_mel = min_log_hz / f_sp
+    logstep = np.log(6.4) / 27.0
+    return np.where(m >= min_log_mel, min_log_hz * np.exp(logstep * (m - min_log_mel)), f_sp * m)
+
+
+def mel_filterbank(sr, n_fft, n_mels, fmin=0.0, fmax=None):
+    """librosa.filters.mel(sr, n_fft, n_mels, fmin, fmax) with its 0.7.2 defaults
+    (Slaney scale, ``htk=False``, area normalisation), float32 ``[n_mels, 1+n_fft//2]``."""
+    fmax = float(sr) / 2 if fmax is None else fmax
+    nbins = 1 + n_fft // 2
+    fftfreqs = np.linspace(0, float(sr) / 2, nbins, endpoint=True)
+    mel_pts = np.linspace(_hz_to_mel_slaney(fmin), _hz_to_mel_slaney(fmax), n_mels + 2)
+    mel_f = _mel_to_hz_slaney(mel_pts)
+    fdiff = np.diff(mel_f)
+    ramps = np.subtract.outer(mel_f, fftfreqs)
+    weights = np.zeros((n_mels, nbins), dtype=np.float32)
+    for i in range(n_mels):
+        lower = -ramps[i] / fdiff[i]
+        upper = ramps[i + 2] / fdiff[i + 1]
+        weights[i] = np.maximum(0, np.minimum(lower, upper))
+    enorm = 2.0 / (mel_f[2:n_mels + 2] - mel_f[:n_mels])
+    weights *= enorm[:, np.newaxis]
+    return weights
+
+
+def _window_tensor(name, win_length):
+    fns = {'hann': torch.hann_window, 'hamming': torch.hamming_window,
+           'blackman': torch.blackman_window, 'bartlett': torch.bartlett_window}
+    if name not in fns:
+        return None
+    return fns[name](win_length, periodic=False, dtype=torch.float32)
+
+
+class FilterbankFeatures(nn.Module):
+    """Drop-in for rnnt.features.FilterbankFeatures (normalize='none', pad_to=0 path)."""
+
+    def __init__(self, sample_rate=16000, win_length=320, hop_length=160, n_fft=512,
+                 window="hann", normalize="none", log=True, dither=1e-5, pad_to=0,
+                 max_duration=16.7, preemph=0.97, n_filt=64, f_min=0, f_max=None):
+        super().__init__()
+        if normalize not in ("none", None):
+            raise NotImplementedError("only normalize='none' (what build_transform uses) is implemented")
+        if pad_to != 0:
+            raise NotImplementedError("pad_to != 0 is not implemented (the reference never sets it)")
+        self.win_length = win_length
+        self.hop_length = hop_length
+        self.n_fft = n_fft or 2 ** math.ceil(math.log2(win_length))
+        self.normalize = normalize
+        self.log = log
+        self.dither = dither
+        self.n_filt = n_filt
+        self.preemph = preemph
+        self.pad_to = pad_to
+        f_max = f_max or sample_rate / 2
+        win = _window_tensor(window, win_length)
+        if win is None:
+            win = torch.ones(win_length)
+        fb = mel_filterbank(sample_rate, self.n_fft, n_filt, f_min, f_max)
+        self.register_buffer("fb", torch.from_numpy(fb).unsqueeze(0))
+        self.register_buffer("window", win)
+        # kernel-side constant tables
+        lo = (self.n_fft - win_length) // 2
+        full = torch.zeros(self.n_fft)
+        full[lo:lo + win_length] = win
+        k = np.arange(self.n_fft // 2, dtype=np.float64)
+        tw = np.stack([np.cos(2 * np.pi * k / self.n_fft), np.sin(2 * np.pi * k / self.n_fft)], 1)
+        rng = np.zeros((n_filt, 2), dtype=np.int32)
+        for m in range(n_filt):
+            nz = np.nonzero(fb[m])[0]
+            rng[m] = (nz[0], nz[-1] + 1) if len(nz) else (0, 0)
+        self.register_buffer("_window_full", full, persistent=False)
+        self.register_buffer("_twiddle", torch.from_numpy(tw.astype(np.float32)), persistent=False)
+        self.register_buffer("_fb_range", torch.from_numpy(rng), persistent=False)
+        self._win_support = (lo, lo + win_length)
+        self._seed = 0
+        max_length = 1 + math.ceil((max_duration * sample_rate - win_length) / hop_length)
+        self.max_length = max_length + (16 - (max_length % 16))
+
+    def get_seq_len(self, seq_len):
+        return torch.ceil(seq_len.float() / self.hop_length).int()
+
+    def n_frames(self, n_samples):
+        return 1 + n_samples // self.hop_length
+
+    def _run(self, x, lengths, out, o_b, o_group, o_k, o_m, stack, frames_out):
+        require_cuda(x, self.fb)
+        if x.dim() != 2 or x.dtype != torch.float32 or x.stride(1) != 1:
+            raise ValueError("waveform must be a float32 [B, N] tensor with unit sample stride")
+        B, N = x.shape
+        if self.dither > 0:
+            # in place on the caller's tensor, as the reference does (rnnt/features.py:111-112)
+            self._seed = (self._seed * 1664525 + 1013904223) & 0xFFFFFFFF
+            import ctypes
+            call("dither", x, _ll(x.stride(0)), B, N, lengths, float(self.dither),
+                 ctypes.c_uint(self._seed))
+        lo, hi = self._win_support
+        call("fbank_forward", x, _ll(x.stride(0)), B, N, lengths, self._window_full, self._twiddle,
+             self.fb, self._fb_range, self.n_fft, lo, hi, self.hop_length, self.n_filt,
+             float(self.preemph if self.preemph is not None else 0.0), int(bool(self.log)), out,
+             dtype_code(out.dtype), _ll(o_b), _ll(o_group), _ll(o_k), _ll(o_m), int(stack),
+             int(frames_out))
+        return out
+
+    @torch.no_grad()
+    def forward(self, x):
+        """x: float32 [B, N] -> float32 [B, n_filt, 1 + N // hop] (reference layout)."""
+        B, N = x.shape
+        F_ = self.n_frames(N)
+        out = torch.empty(B, self.n_filt, F_, dtype=torch.float32, device=x.device)
+        return self._run(x, None, out, self.n_filt * F_, 1, 0, F_, 1, F_)
+
+
+class StackedLogFbank(nn.Module):
+    """FilterbankFeatures + Downsample(n_frame) + transpose in one kernel:
+    waveforms ``[B, N]`` (+ optional per-utterance sample counts) -> ``xs [B, T0, n_filt*k]``
+    and ``xlen [B]`` in stacked frames, i.e. exactly what ``seq_collate`` hands to the model
+    (rnnt/dataset.py:225-240) when the test transform is logfbank + Downsample."""
+
+    def __init__(self, n_frame=3, pad_to_divisible=True, out_dtype=torch.float32, **fbank_args):
+        super().__init__()
+        self.fbank = FilterbankFeatures(**fbank_args)
+        self.n_frame = n_frame
+        self.pad_to_divisible = pad_to_divisible
+        self.out_dtype = out_dtype
+
+    def output_frames(self, n_samples):
+        F_ = self.fbank.n_frames(n_samples)
+        k = self.n_frame
+        return (F_ + k - 1) // k if self.pad_to_divisible else F_ // k
+
+    @torch.no_grad()
+    def forward(self, x, lengths=None):
+        B, N = x.shape
+        k, M = self.n_frame, self.fbank.n_filt
+        T0 = self.output_frames(N)
+        out = torch.empty(B, T0, M * k, dtype=self.out_dtype, device=x.device)
+        if lengths is not None:
+            lengths = lengths.to(device=x.device, dtype=torch.int32).contiguous()
+        self.fbank._run(x, lengths, out, T0 * M * k, M * k, M, 1, k, T0 * k)
+        if lengths is None:
+            xlen = torch.full((B,), T0, dtype=torch.int32, device=x.device)
+        else:
+            F_b = 1 + lengths // self.fbank.hop_length
+            xlen = ((F_b + k - 1) // k if self.pad_to_divisible else F_b // k).to(torch.int32)
+        return out, xlen

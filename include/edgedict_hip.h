@@ -174,6 +174,53 @@ int edgedict_adam_step(float* p, const float* g, float* m, float* v, long long n
 int edgedict_grad_clip_coef(const float* g, long long n, float max_norm, float* sumsq_ws,
                             float* coef, float* norm_out, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Log-mel filterbank front-end.  Replaces FilterbankFeatures.forward (rnnt/features.py:106-152,
+ * twin parts/features.py:298-347) + Downsample.forward (rnnt/transforms.py:38-51) in one kernel;
+ * the STFT spectrum never reaches HBM.
+ *   wave      fp32 [B, N] (row stride wave_stride); lengths nullable int32 [B] valid samples
+ *   window    fp32 [n_fft]  hann(win_length, periodic=False) centred in n_fft, zeros outside
+ *             [win_lo, win_hi);  twiddle fp32 [n_fft/2][2] = cos,sin(2*pi*k/n_fft)
+ *   fb        fp32 [n_mels, n_fft/2+1] mel weights; fb_range int32 [n_mels][2] non-zero support
+ *   out[b*o_b + (f/stack)*o_group + (f%stack)*o_k + m*o_m], f < frames_out (multiple of stack):
+ *             frames f >= 1+N_b/hop (no such STFT frame) and f >= ceil(N_b/hop) (the reference's
+ *             seq_len mask) are written as zeros.
+ * dither: wave[b,n] += amplitude * N(0,1) in place (rnnt/features.py:111-112), counter-based RNG.
+ */
+int edgedict_dither(float* wave, long long wave_stride, int B, int N, const int32_t* lengths,
+                    float amplitude, unsigned seed, void* stream);
+int edgedict_fbank_forward(const float* wave, long long wave_stride, int B, int N,
+                           const int32_t* lengths, const float* window, const float* twiddle,
+                           const float* fb, const int32_t* fb_range, int n_fft, int win_lo,
+                           int win_hi, int hop, int n_mels, float preemph, int do_log, void* out,
+                           int out_dtype, long long o_b, long long o_group, long long o_k,
+                           long long o_m, int stack, int frames_out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Batched greedy / streaming search: the whole per-frame loop of Transducer.greedy_decode
+ * (rnnt/models.py:243-269) or PytorchStreamDecoder.decode (rnnt/stream.py:102-119) in one call.
+ *   E1        dtype, frame t of row b at E1[b*e_row_stride + t*e_frame_stride + j]: the encoder
+ *             half of the joint's first Linear, enc_out * W1[:, :P_enc]^T, for all T frames
+ *   W1d       dtype [J, P2] view (leading dimension ldw1) = W1[:, P_enc:];  b1 fp32 [J]
+ *   W2        dtype [V, J]; b2 fp32 [V];  emb [V, E] (emb_dtype);  Wp dtype [P2, H]; bp fp32 [P2]
+ *   w_ih/w_hh/b_ih/b_hh  HOST arrays of L device pointers (prediction-network LSTM layers)
+ *   h_state, c_state fp32 [L,B,H] and dec_out dtype [B,P2]: prediction-network state, in/out
+ *   unk < 0 : greedy mode  (log-softmax max; score[b] += -max log p; nullable score)
+ *   unk >= 0: stream mode  (raw-logit arg-max with the reference's <unk> rule)
+ *   tokens_out int32, token of row b at frame t stored at tokens_out[b*tok_stride + t] (nullable)
+ *   workspace: edgedict_greedy_workspace_bytes(...) bytes, 256-byte aligned
+ */
+size_t edgedict_greedy_workspace_bytes(int dtype, int B, int J, int V, int E, int L, int H, int P2);
+int edgedict_greedy_decode(int dtype, const void* E1, long long e_row_stride,
+                           long long e_frame_stride, int B, int T, int J, const void* W1d,
+                           long long ldw1, const float* b1, int P2, const void* W2,
+                           const float* b2, int V, const void* emb, int emb_dtype, int E, int L,
+                           const void* const* w_ih, const void* const* w_hh,
+                           const float* const* b_ih, const float* const* b_hh, int H,
+                           const void* Wp, const float* bp, float* h_state, float* c_state,
+                           void* dec_out, int blank, int unk, int32_t* tokens_out, int tok_stride,
+                           float* score, void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -134,3 +134,15 @@ def test_bf16_mode_tracks_fp32_loss(hip_lib):
     assert rel < 2e-2, rel          # bf16 throughput mode: reported, not the parity bar
     for name, p in m.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), name
+
+
+@pytest.mark.parametrize("name", ["tiny", "E4D1"])
+def test_greedy_tokens_bit_exact_vs_reference_golden(hip_lib, name):
+    cfg, sd, (xs, ys, xlen, ylen), g = _load(name)
+    m = _engine(cfg, sd, output_loss=False).eval()
+    tokens, score = m.greedy_decode(xs.cuda(), xlen.cuda())
+    assert len(tokens) == xs.shape[0]
+    for b, t in enumerate(tokens):
+        assert t.dtype == np.int64
+        assert np.array_equal(t, g["greedy_tokens"][b][:len(t)]), b     # blanks included
+    np.testing.assert_allclose(score.cpu().numpy(), g["greedy_score"], rtol=1e-4)
