@@ -1,0 +1,205 @@
+#!/usr/bin/env python
+"""Headline benchmark: utterances/s of a full RNN-T training step on E6D2, 15 s audio.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the whole hot path over one synthetic batch that is already resident in
+HBM: dither + fused log-mel/stack-3 front-end -> LayerNorm + 6x1024 LSTM encoder with 2x time
+reduction -> 2x256 LSTM prediction network -> joint (640) over the T'xU lattice -> RNN-T loss ->
+full backward -> bucketed RCCL all-reduce (N > 1) -> clip-free Adam update.  Per-GPU batch is fixed
+at 64 utterances (weak scaling).  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (not the 2:1 sparse figure)
+MFMA_F32_PEAK_TF = 157.3
+
+
+def synth_batch(flags, B, seconds, U, seed, device):
+    """16 kHz 0.1*randn audio clipped to [-1,1], ids in [4,V),
+    ragged xlen ~ U{300..401} stacked frames and ylen ~ U{32..64}, one full-length row."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    N = int(seconds * 16000)
+    wave = (0.1 * torch.randn(B, N, generator=g)).clamp_(-1, 1)
+    frames_full = (1 + N // flags.hop_length + flags.downsample - 1) // flags.downsample
+    lo = max(1, (frames_full * 3) // 4)
+    t0 = torch.randint(lo, frames_full + 1, (B,), generator=g)
+    wave_len = ((t0 * flags.downsample - 1) * flags.hop_length).clamp_(max=N).to(torch.int32)
+    wave_len[0] = N
+    ys = torch.randint(4, flags.bpe_size, (B, U), generator=g, dtype=torch.int32)
+    ylen = torch.randint(U // 2, U + 1, (B,), generator=g, dtype=torch.int32)
+    ylen[0] = U
+    for b in range(B):
+        wave[b, wave_len[b]:] = 0
+        ys[b, ylen[b]:] = 1
+    return wave.to(device), wave_len.to(device), ys.to(device), ylen.to(device)
+
+
+def cpu_baseline(flags, seconds, U, budget_s=25.0):
+    """Oracle ('port') timed on the host cores: restated log-mel + reference-equivalent torch
+    CPU encoder/prediction/joint + vectorised RNN-T DP loss, forward + backward (no optimiser),
+    on a bounded sample of the same workload."""
+    from oracle import features_ref as Fr
+    from oracle import models_ref as M
+    from oracle import rnnt_loss_ref as R
+    from edgedict_amd.flags import model_kwargs
+    cfg = {k: v for k, v in model_kwargs(flags).items() if not k.endswith("dropout")}
+    B = 4
+    threads = torch.get_num_threads()
+    sd = {k: v.requires_grad_(True) for k, v in M.make_state_dict(cfg, 0).items()}
+    g = torch.Generator(device="cpu").manual_seed(1)
+    wave = (0.1 * torch.randn(B, int(seconds * 16000), generator=g)).clamp_(-1, 1)
+    ys = torch.randint(4, cfg["vocab_size"], (B, U), generator=g, dtype=torch.int32)
+    ylen = torch.full((B,), U, dtype=torch.int32)
+
+    def one():
+        xs = Fr.stacked_features(wave, flags.downsample, True, win_length=flags.win_length,
+                                 hop_length=flags.hop_length, n_fft=flags.n_fft,
+                                 n_filt=flags.feature_size)
+        xlen = torch.full((B,), xs.shape[1], dtype=torch.int32)
+        logits, act_lens = M.transducer_logits(sd, xs, ys, xlen, ylen)
+        with torch.no_grad():
+            costs, dl = R.rnnt_loss_torch_fast(logits.detach(), ys, act_lens, ylen)
+        logits.backward(dl / B)
+        for v in sd.values():
+            v.grad = None
+        return float(costs.mean())
+
+    one()  # warm-up
+    t0 = time.time()
+    iters = 0
+    while iters < 2 or (time.time() - t0 < budget_s and iters < 8):
+        one()
+        iters += 1
+    dt = time.time() - t0
+    return {"value": B * iters / dt, "unit": "utterances/s", "cores": threads, "kind": "port",
+            "sample": "%d iterations of %d x %.0f s utterances (U=%d), E6D2, fp32 fwd+bwd incl. "
+                      "log-mel and RNN-T loss, no optimiser step; torch CPU with %d threads"
+                      % (iters, B, seconds, U, threads)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="utterances per GPU")
+    ap.add_argument("--seconds", type=float, default=15.0)
+    ap.add_argument("--labels", type=int, default=64)
+    ap.add_argument("--preset", default="E6D2")
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    from edgedict_amd import ops
+    from edgedict_amd.flags import make_flags
+    from edgedict_amd.trainer import TrainEngine
+
+    flags = make_flags(args.preset, gradclip=None, dither=1e-5)
+    flags.sub_batch_size = args.batch          # one slice: the lattice fits in 288 GB of HBM
+    torch.manual_seed(0)
+    engine = TrainEngine(flags, device=device, compute_dtype=args.dtype)
+    batch = synth_batch(flags, args.batch, args.seconds, args.labels, 1000 + rank, device)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        loss = engine.train_step(*batch)
+    barrier()
+    ops.TIMERS = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = engine.train_step(*batch)
+    barrier()
+    dt = time.perf_counter() - t0
+    timers = ops.timer_summary()
+    ops.TIMERS = None
+    tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    loss_val = float(loss.item())
+
+    if rank == 0:
+        # dominant kernel: the joint's second Linear, logits = hid[B*T'*U1, J] x W2[V, J]^T
+        xs_frames = engine.features.output_frames(batch[0].shape[1])
+        Tp = (xs_frames + 1) // 2
+        U1 = args.labels + 1
+        J, V = flags.joint_size, flags.bpe_size
+        flop = 2.0 * args.batch * Tp * U1 * J * V
+        n, ms = timers.get("joint_logits_gemm", (0, float("nan")))
+        peak = MFMA_BF16_PEAK_TF if args.dtype == "bf16" else MFMA_F32_PEAK_TF
+        achieved = flop / (ms * 1e-3) / 1e12 if n else float("nan")
+        out = {
+            "metric": "utterances/sec (E6D2, 15 s audio)",
+            "value": args.batch * world * args.steps / dt,
+            "unit": "utterances/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": "%s full training step (dither+log-mel+stack3 -> %dx%d LSTM encoder, 2x "
+                            "time reduction -> %dx%d LSTM prediction net -> joint %d -> RNN-T loss "
+                            "-> backward -> grad all-reduce -> Adam); %d x %.0f s utterances per GPU, "
+                            "U=%d, V=%d, ragged lengths; lattice [%d,%d,%d,%d]"
+                            % (args.preset, flags.enc_layers, flags.enc_hidden_size,
+                               flags.dec_layers, flags.dec_hidden_size, flags.joint_size,
+                               args.batch, args.seconds, args.labels, V, args.batch, Tp, U1, V),
+                "global_batch": args.batch * world,
+                "parallelism": "dp%d" % world,
+                "final_loss": loss_val,
+            },
+            "roofline": {
+                "kernel": "gemm_kernel<bf16,bf16,NT> joint logits [%d x %d x %d]"
+                          % (args.batch * Tp * U1, V, J),
+                "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved / peak, "traffic": None,
+                "launch_ms": ms, "launches_timed": n,
+            },
+            "kernel_ms": {k: round(v[1], 4) for k, v in sorted(timers.items())},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(flags, args.seconds, args.labels)
+            out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -169,9 +169,10 @@ __global__ __launch_bounds__(256) void joint_hidden_bwd(const T* __restrict__ dh
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                             float* __restrict__ m, float* __restrict__ v, long long n, float lr,
                             float b1, float b2, float eps, float bc1, float bc2,
-                            float weight_decay, const float* __restrict__ grad_scale,
+                            float weight_decay, float grad_scale_host,
+                            const float* __restrict__ grad_scale,
                             bf16_t* __restrict__ p_bf16) {
-    const float gs = grad_scale ? *grad_scale : 1.f;
+    const float gs = grad_scale_host * (grad_scale ? *grad_scale : 1.f);
     const float step = lr / bc1;
     const float inv_sqrt_bc2 = rsqrtf(bc2);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -203,8 +204,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
     if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 // coef[0] = min(1, max_norm / (sqrt(sumsq) + 1e-6))   (torch.nn.utils.clip_grad_norm_)
-__global__ void clip_coef_kernel(const float* sumsq, float max_norm, float* coef, float* norm_out) {
-    const float nrm = sqrtf(*sumsq);
+__global__ void clip_coef_kernel(const float* sumsq, float max_norm, float pre_scale, float* coef,
+                                 float* norm_out) {
+    const float nrm = sqrtf(*sumsq) * pre_scale;
     if (norm_out) *norm_out = nrm;
     *coef = fminf(1.f, max_norm / (nrm + 1e-6f));
 }
@@ -369,8 +371,8 @@ extern "C" int edgedict_joint_hidden_bwd(int dtype, const void* dhid, const void
 
 extern "C" int edgedict_adam_step(float* p, const float* g, float* m, float* v, long long n,
                                   float lr, float beta1, float beta2, float eps, int step,
-                                  float weight_decay, const float* grad_scale, void* p_bf16,
-                                  void* stream_) {
+                                  float weight_decay, float grad_scale_host,
+                                  const float* grad_scale, void* p_bf16, void* stream_) {
     ED_CHECK_ARG(n >= 0 && step >= 1, "adam_step: bad size/step");
     if (n == 0) return ED_OK;
     ED_CHECK_ARG(p && g && m && v, "adam_step: null pointer");
@@ -378,13 +380,14 @@ extern "C" int edgedict_adam_step(float* p, const float* g, float* m, float* v, 
     const float bc2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adam_kernel, dim3(ed_grid_for(n, 256 * 4, 256 * 8)), dim3(256), 0,
                        (hipStream_t)stream_, p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2,
-                       weight_decay, grad_scale, (bf16_t*)p_bf16);
+                       weight_decay, grad_scale_host, grad_scale, (bf16_t*)p_bf16);
     ED_CHECK_LAUNCH("adam_step");
     return ED_OK;
 }
 
-extern "C" int edgedict_grad_clip_coef(const float* g, long long n, float max_norm, float* sumsq_ws,
-                                       float* coef, float* norm_out, void* stream_) {
+extern "C" int edgedict_grad_clip_coef(const float* g, long long n, float max_norm,
+                                       float pre_scale, float* sumsq_ws, float* coef,
+                                       float* norm_out, void* stream_) {
     ED_CHECK_ARG(n >= 0 && g && sumsq_ws && coef, "grad_clip_coef: bad arguments");
     hipStream_t s = (hipStream_t)stream_;
     hipError_t e = hipMemsetAsync(sumsq_ws, 0, sizeof(float), s);
@@ -394,7 +397,8 @@ extern "C" int edgedict_grad_clip_coef(const float* g, long long n, float max_no
     }
     if (n > 0)
         hipLaunchKernelGGL(sumsq_kernel, dim3(ed_grid_for(n, 256 * 8, 1024)), dim3(256), 0, s, g, n, sumsq_ws);
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, s, sumsq_ws, max_norm, coef, norm_out);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, s, sumsq_ws, max_norm, pre_scale, coef,
+                       norm_out);
     ED_CHECK_LAUNCH("grad_clip_coef");
     return ED_OK;
 }

@@ -126,7 +126,8 @@ class _LSTMBlockFn(torch.autograd.Function):
         whh = WEIGHTS.get(w_hh, cd)
         G = ops.gemm(x.view(B * T, I), wih, bias=b_ih.detach(), bias2=b_hh.detach())
         G = G.view(B, T, 4 * H)
-        Y, Hprev, Cst, hN, cN = ops.lstm_forward(G, whh, h0, c0)
+        with ops.timed("lstm_fwd_T%d_H%d" % (T, H)):
+            Y, Hprev, Cst, hN, cN = ops.lstm_forward(G, whh, h0, c0)
         if ln_w is not None:
             out, mean, rstd = ops.layernorm_fwd(Y, x if residual else None, ln_w.detach(),
                                                 ln_b.detach(), reduce)
@@ -155,7 +156,8 @@ class _LSTMBlockFn(torch.autograd.Function):
                                                   ln_w.detach(), mean, rstd, reduce)
         else:
             ds = dout.contiguous()
-        ops.lstm_backward(G, ds, Cst, c0, WEIGHTS.get(w_hh, cd, transposed=True))
+        with ops.timed("lstm_bwd_T%d_H%d" % (T, H)):
+            ops.lstm_backward(G, ds, Cst, c0, WEIGHTS.get(w_hh, cd, transposed=True))
         dG = G.view(B * T, 4 * H)
         x2 = x.view(B * T, I)
         M = B * T
@@ -240,7 +242,8 @@ class _JointFn(torch.autograd.Function):
         E1 = ops.gemm(enc2, w1c[:, :P])
         D1 = ops.gemm(dec2, w1c[:, P:], bias=b1.detach())
         hid = ops.joint_hidden_fwd(E1.view(B, T, J), D1.view(B, U1, J))
-        logits = ops.gemm(hid.view(B * T * U1, J), w2c, bias=b2.detach())
+        with ops.timed("joint_logits_gemm"):
+            logits = ops.gemm(hid.view(B * T * U1, J), w2c, bias=b2.detach())
         ctx.save_for_backward(enc2, dec2, w1, w2, hid)
         ctx.cfg = (cd, B, T, U1, P, P2, J, V)
         return logits.view(B, T, U1, V)
@@ -256,8 +259,10 @@ class _JointFn(torch.autograd.Function):
         hid2 = hid.view(M, J)
         w1c = WEIGHTS.get(w1, cd)
         w2c = WEIGHTS.get(w2, cd)
-        dhid = ops.gemm(dl, w2c.t())
-        dw2 = ops.gemm(dl.t(), hid2.t(), out_dtype=F32, split_k=ops.pick_split_k(V, J, M))
+        with ops.timed("joint_dhid_gemm"):
+            dhid = ops.gemm(dl, w2c.t())
+        with ops.timed("joint_dw2_gemm"):
+            dw2 = ops.gemm(dl.t(), hid2.t(), out_dtype=F32, split_k=ops.pick_split_k(V, J, M))
         db2 = ops.colsum(dl)
         dE1, dD1 = ops.joint_hidden_bwd(dhid.view(B, T, U1, J), hid)
         del dhid

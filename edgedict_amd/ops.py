@@ -15,6 +15,40 @@ def _ll(x):
     return ctypes.c_longlong(int(x))
 
 
+# ---- optional per-kernel timing with HIP events on the launch stream (used by bench.py) -------
+TIMERS = None   # set to {} to enable: tag -> list of (start_event, end_event)
+
+
+class timed:
+    """``with timed("tag"):`` brackets the enclosed launches with events on the current stream
+    when ``ops.TIMERS`` is a dict; otherwise it costs nothing."""
+
+    def __init__(self, tag):
+        self.tag = tag
+
+    def __enter__(self):
+        if TIMERS is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.end = torch.cuda.Event(enable_timing=True)
+            self.start.record()
+        return self
+
+    def __exit__(self, *exc):
+        if TIMERS is not None:
+            self.end.record()
+            TIMERS.setdefault(self.tag, []).append((self.start, self.end))
+        return False
+
+
+def timer_summary():
+    """tag -> (count, mean milliseconds); call after a device synchronise."""
+    out = {}
+    for tag, evs in (TIMERS or {}).items():
+        ms = [a.elapsed_time(b) for a, b in evs]
+        out[tag] = (len(ms), sum(ms) / max(1, len(ms)))
+    return out
+
+
 def _operand(t):
     """(tensor, ld, k_major) for a 2-D operand that is either row-major or a transposed view."""
     assert t.dim() == 2

@@ -1,0 +1,69 @@
+"""Training step of the engine: features -> Transducer -> loss -> backward -> gradient exchange
+-> Adam, all on the device.
+
+Mirrors ``Trainer.train_step`` of the reference's log-mel trainer (cli/baseline.py:214-248;
+cli/train.py:223-271 is the same loop around the FrontEnd variant): the batch is processed in
+``sub_batch_size`` slices, each slice's mean loss is divided by the number of slices and
+back-propagated, then gradients are optionally clipped and the optimiser steps.  Differences, all
+MI355X-motivated: the log-mel front-end runs on the GPU inside the step (the reference computes
+it in DataLoader workers on the CPU), gradients live in one flat buffer, data parallelism is one
+process per GPU with bucketed RCCL all-reduce overlapped with the backward pass, and Adam is a
+single kernel.
+"""
+import torch
+import torch.distributed as dist
+
+from . import config
+from .dp import BucketedAllReduce
+from .features import StackedLogFbank
+from .flags import model_kwargs
+from .models import Transducer
+from .optim import FlatParams, FusedAdam
+
+
+class TrainEngine:
+    def __init__(self, flags, vocab_size=None, device="cuda", compute_dtype=None,
+                 process_group=None, state_dict=None):
+        self.flags = flags
+        self.device = torch.device(device)
+        cd = config._parse(compute_dtype) if compute_dtype is not None else config.get_compute_dtype()
+        self.compute_dtype = cd
+        self.features = StackedLogFbank(
+            n_frame=flags.downsample, pad_to_divisible=True, out_dtype=torch.float32,
+            sample_rate=getattr(flags, "sample_rate", 16000), win_length=flags.win_length,
+            hop_length=flags.hop_length, n_fft=flags.n_fft, n_filt=flags.feature_size,
+            dither=getattr(flags, "dither", 1e-5)).to(self.device)
+        self.model = Transducer(**model_kwargs(flags, vocab_size=vocab_size))
+        if state_dict is not None:
+            self.model.load_state_dict(state_dict)
+        self.model.to(self.device)
+        self.model.compute_dtype = cd
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        if self.world > 1:  # identical initial weights on every rank
+            for p in self.model.parameters():
+                dist.broadcast(p.data, src=0, group=process_group)
+        self.flat = FlatParams(self.model)
+        self.optim = FusedAdam(self.flat, lr=flags.lr, max_grad_norm=getattr(flags, "gradclip", None))
+        self.reducer = BucketedAllReduce(self.flat, process_group)
+        self.sub_batch_size = getattr(flags, "sub_batch_size", None)
+
+    def train_step(self, wave, wave_len, ys, ylen):
+        """wave f32[B,N] (device), wave_len i32[B] samples (or None), ys i32[B,U], ylen i32[B].
+        Returns the mean loss of the local batch as a device tensor (no host sync)."""
+        self.model.train()
+        self.optim.zero_grad()
+        B = wave.shape[0]
+        sub = self.sub_batch_size or B
+        starts = list(range(0, B, sub))
+        total = None
+        for s in starts:
+            e = min(B, s + sub)
+            self.reducer.armed = (s == starts[-1])   # exchange once, after the last accumulation
+            xs, xlen = self.features(wave[s:e], None if wave_len is None else wave_len[s:e])
+            loss = self.model(xs, ys[s:e], xlen, ylen[s:e])
+            loss = loss / len(starts)
+            loss.backward()
+            total = loss.detach() if total is None else total + loss.detach()
+        scale = self.reducer.finish()
+        self.optim.step(grad_scale=scale)
+        return total

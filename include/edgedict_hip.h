@@ -165,14 +165,16 @@ int edgedict_joint_hidden_bwd(int dtype, const void* dhid, const void* hid, floa
 /* ------------------------------------------------------------------------------------
  * Optimiser step on flat fp32 buffers (torch.optim.Adam semantics, cli/train.py:135-146,268)
  * and the global-norm clip coefficient of clip_grad_norm_ (cli/train.py:262-267).
- *   grad_scale: nullable device scalar multiplied into every gradient (the clip coefficient)
- *   p_bf16    : nullable; receives the bf16 copy of the updated parameters
+ *   effective gradient = g * grad_scale_host * (grad_scale ? *grad_scale : 1): the host factor
+ *               carries 1/world_size of the data-parallel mean, the nullable device scalar the
+ *               clip coefficient (no host sync);  p_bf16: nullable bf16 copy of the new params
+ *   grad_clip_coef: coef = min(1, max_norm / (pre_scale*||g||_2 + 1e-6)), norm_out nullable
  */
 int edgedict_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr,
                        float beta1, float beta2, float eps, int step, float weight_decay,
-                       const float* grad_scale, void* p_bf16, void* stream);
-int edgedict_grad_clip_coef(const float* g, long long n, float max_norm, float* sumsq_ws,
-                            float* coef, float* norm_out, void* stream);
+                       float grad_scale_host, const float* grad_scale, void* p_bf16, void* stream);
+int edgedict_grad_clip_coef(const float* g, long long n, float max_norm, float pre_scale,
+                            float* sumsq_ws, float* coef, float* norm_out, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Log-mel filterbank front-end.  Replaces FilterbankFeatures.forward (rnnt/features.py:106-152,
