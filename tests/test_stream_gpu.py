@@ -1,0 +1,77 @@
+"""GPU: streaming decode (single-stream API and batched) vs the CPU stream oracle, bit-exact ids."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import models_ref as M
+from oracle.stream_ref import StreamOracle
+
+pytestmark = pytest.mark.gpu
+
+CFG = dict(vocab_embed_size=16, vocab_size=64, input_size=240, enc_hidden_size=64, enc_layers=3,
+           enc_proj_size=48, dec_hidden_size=32, dec_layers=2, dec_proj_size=32, joint_size=64)
+
+
+def _setup():
+    from edgedict_amd.flags import make_flags
+    from edgedict_amd.models import Transducer
+    flags = make_flags("E6D2")     # framing: win 320, hop 200, stack 3 -> chunk 1320 / 1200
+    sd = M.make_state_dict(CFG, 5)
+    # bias the joint so that non-blank symbols (and sometimes <unk>=3) are emitted
+    sd["joint.joint.2.bias"][0] -= 0.3
+    sd["joint.joint.2.bias"][3] += 0.4
+    m = Transducer(enc_dropout=0.0, dec_dropout=0.0, output_loss=False, **CFG)
+    m.load_state_dict(sd)
+    return flags, sd, m.cuda()
+
+
+class _Tok:
+    def id_to_token(self, i):
+        return {0: "<nul>", 1: "<pad>", 2: "<bos>", 3: "<unk>"}.get(i, "t%d</w>" % i)
+
+
+def test_single_stream_api_matches_oracle_tokens(hip_lib):
+    from edgedict_amd.stream import PytorchStreamDecoder, chunk_geometry
+    flags, sd, m = _setup()
+    win, hop = chunk_geometry(flags, 2)
+    assert (win, hop) == (1320, 1200)
+    g = torch.Generator(device="cpu").manual_seed(0)
+    wave = 0.1 * torch.randn(1, win + 11 * hop, generator=g)
+    dec = PytorchStreamDecoder(flags, transducer=m, tokenizer=_Tok(), dither=0)
+    ora = StreamOracle(sd, flags)
+    text, ids = "", []
+    for start in range(0, wave.shape[1] - win, hop):
+        chunk = wave[:, start:start + win]
+        want = ora.decode(chunk.clone())
+        got = dec.decode(chunk.clone())
+        exp = "".join(_Tok().id_to_token(t).replace("</w>", " ") for t in want if t != 0)
+        assert got == exp
+        ids += want
+    assert any(t != 0 for t in ids), "test vector never left blank"
+    assert len(dec.encoder_elapsed) == 11 and len(dec.joint_elapsed) == 11
+    dec.reset()
+    ora.reset()
+    assert dec.decode(wave[:, :win].clone()) == "".join(
+        _Tok().id_to_token(t).replace("</w>", " ") for t in ora.decode(wave[:, :win].clone()) if t != 0)
+
+
+def test_batched_streams_equal_independent_streams_and_masked_reset(hip_lib):
+    from edgedict_amd.stream import BatchedStreamDecoder, chunk_geometry
+    flags, sd, m = _setup()
+    win, hop = chunk_geometry(flags, 2)
+    S, n_chunks = 5, 6
+    g = torch.Generator(device="cpu").manual_seed(1)
+    wave = 0.1 * torch.randn(S, win + n_chunks * hop, generator=g)
+    dec = BatchedStreamDecoder(m, flags, S, dither=0)
+    oracles = [StreamOracle(sd, flags) for _ in range(S)]
+    for c in range(n_chunks):
+        chunk = wave[:, c * hop:c * hop + win]
+        if c == 3:   # reset streams 1 and 4 mid-way
+            mask = torch.tensor([False, True, False, False, True])
+            dec.reset(mask)
+            oracles[1].reset()
+            oracles[4].reset()
+        got = dec.decode(chunk.cuda().contiguous()).cpu().numpy()
+        for s in range(S):
+            want = oracles[s].decode(chunk[s:s + 1].clone())
+            assert got[s].tolist() == want, (c, s)
