@@ -27,6 +27,9 @@ def _parse(x):
         raise ValueError("unknown compute dtype %r (use 'fp32' or 'bf16')" % (x,))
 
 
+# test hook: route bf16 recurrences through the generic step kernels instead of lstm_fast.hip
+FORCE_GENERIC_LSTM = False
+
 _state = {"dtype": _parse(os.environ.get("EDGEDICT_DTYPE", "fp32")), "epoch": 0}
 
 

@@ -197,10 +197,10 @@ extern "C" int edgedict_greedy_decode(
             if ((rc = edgedict_gemm(dtype, dtype, xin, xin_dim, 1, w_ih[k], xin_dim, 1, G, 4 * H, B,
                                     4 * H, xin_dim, b_ih[k], b_hh[k], 0, 1, s)))
                 return rc;
-            if ((rc = edgedict_lstm_forward(dtype, G, Hprev, Y[k & 1], Cst, w_hh[k],
+            if ((rc = edgedict_lstm_forward(dtype, G, Hprev, Y[k & 1], Cst, w_hh[k], nullptr,
                                             h_state + (size_t)k * B * H, c_state + (size_t)k * B * H,
                                             h_new + (size_t)k * B * H, c_new + (size_t)k * B * H, B,
-                                            1, H, s)))
+                                            1, H, nullptr, s)))
                 return rc;
             xin = Y[k & 1];
             xin_dim = H;

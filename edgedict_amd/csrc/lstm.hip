@@ -25,6 +25,7 @@
 //   pre-activation gradients in place over G[:, t] and carrying dc in a [B,H] fp32 buffer.
 // After the sweep G holds dG for every t, and dX / dW_ih / dW_hh / db are plain GEMMs / column sums.
 #include "common.hpp"
+#include "lstm_fast.hpp"
 
 namespace {
 
@@ -251,25 +252,47 @@ int run_bwd(void* G, const void* dY, const float* Cst, const float* c0, const vo
 
 }  // namespace
 
+extern "C" size_t edgedict_lstm_workspace_bytes(int dtype, int B, int H) {
+    if (B <= 0 || H <= 0 || !ed_lstm_fast_ok(dtype, H)) return 0;
+    return ed_lstm_fast_ws_bytes(B, H);
+}
+
+extern "C" int edgedict_lstm_pack_weights(int src_dtype, const void* Whh, void* packed_fwd,
+                                          void* packed_bwd, int H, void* stream) {
+    ED_CHECK_ARG(src_dtype == ED_F32 || src_dtype == ED_BF16, "lstm_pack_weights: bad dtype");
+    ED_CHECK_ARG(H > 0 && H % 32 == 0, "lstm_pack_weights: hidden size %d must be a multiple of 32", H);
+    ED_CHECK_ARG(Whh && (packed_fwd || packed_bwd), "lstm_pack_weights: null pointer");
+    return ed_lstm_pack(src_dtype, Whh, packed_fwd, packed_bwd, H, (hipStream_t)stream);
+}
+
 extern "C" int edgedict_lstm_forward(int dtype, void* G, void* Hprev, void* Y, float* Cst,
-                                     const void* Whh, const float* h0, const float* c0, float* hN,
-                                     float* cN, int B, int T, int H, void* stream) {
+                                     const void* Whh, const void* Whh_packed, const float* h0,
+                                     const float* c0, float* hN, float* cN, int B, int T, int H,
+                                     void* ws, void* stream) {
     ED_CHECK_ARG(dtype == ED_F32 || dtype == ED_BF16, "lstm_forward: bad dtype %d", dtype);
     ED_CHECK_ARG(B > 0 && T > 0 && H > 0, "lstm_forward: B,T,H must be positive (got %d,%d,%d)", B, T, H);
     ED_CHECK_ARG(H % 8 == 0, "lstm_forward: hidden size %d must be a multiple of 8", H);
-    ED_CHECK_ARG(G && Hprev && Y && Cst && Whh, "lstm_forward: null pointer");
+    ED_CHECK_ARG(G && Hprev && Y && Cst && (Whh || Whh_packed), "lstm_forward: null pointer");
+    if (Whh_packed && ws && ed_lstm_fast_ok(dtype, H))
+        return ed_lstm_fwd_fast(G, Hprev, Y, Cst, Whh_packed, h0, c0, hN, cN, B, T, H, ws,
+                                (hipStream_t)stream);
+    ED_CHECK_ARG(Whh, "lstm_forward: the generic path needs the plain W_hh");
     if (dtype == ED_F32)
         return run_fwd<float>(G, Hprev, Y, Cst, Whh, h0, c0, hN, cN, B, T, H, (hipStream_t)stream);
     return run_fwd<bf16_t>(G, Hprev, Y, Cst, Whh, h0, c0, hN, cN, B, T, H, (hipStream_t)stream);
 }
 
 extern "C" int edgedict_lstm_backward(int dtype, void* G, const void* dY, const float* Cst,
-                                      const float* c0, const void* WhhT, float* dC_ws, int B,
-                                      int T, int H, void* stream) {
+                                      const float* c0, const void* WhhT, const void* WhhT_packed,
+                                      float* dC_ws, int B, int T, int H, void* ws, void* stream) {
     ED_CHECK_ARG(dtype == ED_F32 || dtype == ED_BF16, "lstm_backward: bad dtype %d", dtype);
     ED_CHECK_ARG(B > 0 && T > 0 && H > 0, "lstm_backward: B,T,H must be positive");
     ED_CHECK_ARG(H % 8 == 0, "lstm_backward: hidden size %d must be a multiple of 8", H);
-    ED_CHECK_ARG(G && Cst && WhhT && dC_ws, "lstm_backward: null pointer");
+    ED_CHECK_ARG(G && Cst && (WhhT || WhhT_packed) && dC_ws, "lstm_backward: null pointer");
+    if (WhhT_packed && ws && ed_lstm_fast_ok(dtype, H))
+        return ed_lstm_bwd_fast(G, dY, Cst, c0, WhhT_packed, dC_ws, B, T, H, ws,
+                                (hipStream_t)stream);
+    ED_CHECK_ARG(WhhT, "lstm_backward: the generic path needs the plain W_hh^T");
     if (dtype == ED_F32)
         return run_bwd<float>(G, dY, Cst, c0, WhhT, dC_ws, B, T, H, (hipStream_t)stream);
     return run_bwd<bf16_t>(G, dY, Cst, c0, WhhT, dC_ws, B, T, H, (hipStream_t)stream);

@@ -51,7 +51,11 @@ class _WeightCache:
         src = p.detach()
         if not src.is_contiguous():
             src = src.contiguous()
-        if transposed:
+        if transposed == "lstm_fwd":
+            t = ops.lstm_pack_weights(src, True, False)[0]
+        elif transposed == "lstm_bwd":
+            t = ops.lstm_pack_weights(src, False, True)[1]
+        elif transposed:
             t = ops.transpose(src, dtype)
         elif dtype == src.dtype:
             t = src
@@ -65,6 +69,11 @@ class _WeightCache:
 
 
 WEIGHTS = _WeightCache()
+
+
+def _lstm_fast(cd, H):
+    """bf16 fragment-order recurrence kernels (csrc/lstm_fast.hip) apply?"""
+    return cd == torch.bfloat16 and H % 32 == 0 and not config.FORCE_GENERIC_LSTM
 
 
 def _to_cd(x, cd):
@@ -123,11 +132,13 @@ class _LSTMBlockFn(torch.autograd.Function):
         B, T, I = x.shape
         H = w_hh.shape[1]
         wih = WEIGHTS.get(w_ih, cd)
-        whh = WEIGHTS.get(w_hh, cd)
+        fast = _lstm_fast(cd, H)
+        whh = None if fast else WEIGHTS.get(w_hh, cd)
+        whh_p = WEIGHTS.get(w_hh, cd, "lstm_fwd") if fast else None
         G = ops.gemm(x.view(B * T, I), wih, bias=b_ih.detach(), bias2=b_hh.detach())
         G = G.view(B, T, 4 * H)
         with ops.timed("lstm_fwd_T%d_H%d" % (T, H)):
-            Y, Hprev, Cst, hN, cN = ops.lstm_forward(G, whh, h0, c0)
+            Y, Hprev, Cst, hN, cN = ops.lstm_forward(G, whh, h0, c0, whh_p)
         if ln_w is not None:
             out, mean, rstd = ops.layernorm_fwd(Y, x if residual else None, ln_w.detach(),
                                                 ln_b.detach(), reduce)
@@ -157,7 +168,10 @@ class _LSTMBlockFn(torch.autograd.Function):
         else:
             ds = dout.contiguous()
         with ops.timed("lstm_bwd_T%d_H%d" % (T, H)):
-            ops.lstm_backward(G, ds, Cst, c0, WEIGHTS.get(w_hh, cd, transposed=True))
+            if _lstm_fast(cd, H):
+                ops.lstm_backward(G, ds, Cst, c0, None, WEIGHTS.get(w_hh, cd, "lstm_bwd"))
+            else:
+                ops.lstm_backward(G, ds, Cst, c0, WEIGHTS.get(w_hh, cd, transposed=True))
         dG = G.view(B * T, 4 * H)
         x2 = x.view(B * T, I)
         M = B * T

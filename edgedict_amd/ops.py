@@ -147,13 +147,32 @@ def layernorm_bwd(dout, x, res, gamma, mean, rstd, reduce=1, dgamma=None, dbeta=
     return ds, dgamma, dbeta
 
 
-def lstm_forward(G, Whh, h0=None, c0=None):
+def lstm_pack_weights(Whh, want_fwd=True, want_bwd=True):
+    """Fragment-order bf16 images of W_hh [4H,H] for the fast recurrence kernels."""
+    require_cuda(Whh)
+    H4, H = Whh.shape
+    assert H4 == 4 * H and Whh.is_contiguous()
+    dev = Whh.device
+    fwd = torch.empty(H4 * H, dtype=torch.bfloat16, device=dev) if want_fwd else None
+    bwd = torch.empty(H4 * H, dtype=torch.bfloat16, device=dev) if want_bwd else None
+    call("lstm_pack_weights", dtype_code(Whh.dtype), Whh, fwd, bwd, H)
+    return fwd, bwd
+
+
+def _lstm_ws(dtype, B, H, device):
+    n = _lib.load().edgedict_lstm_workspace_bytes(dtype_code(dtype), B, H)
+    return torch.empty(n, dtype=torch.uint8, device=device) if n else None
+
+
+def lstm_forward(G, Whh, h0=None, c0=None, Whh_packed=None):
     """Run the recurrence over G[B,T,4H] (input pre-activations, overwritten with the gates).
+    ``Whh_packed`` (from lstm_pack_weights) selects the bf16 fragment-order fast path.
     Returns (Y, Hprev, Cst, hN, cN)."""
-    require_cuda(G, Whh)
+    require_cuda(G)
     B, T, H4 = G.shape
     H = H4 // 4
-    assert G.is_contiguous() and Whh.is_contiguous() and Whh.shape == (H4, H)
+    assert G.is_contiguous()
+    assert Whh is None or (Whh.is_contiguous() and Whh.shape == (H4, H))
     dev = G.device
     Hprev = torch.empty(B, T, H, dtype=G.dtype, device=dev)
     Y = torch.empty(B, T, H, dtype=G.dtype, device=dev)
@@ -163,19 +182,22 @@ def lstm_forward(G, Whh, h0=None, c0=None):
     for s in (h0, c0):
         if s is not None:
             assert s.dtype == torch.float32 and s.is_contiguous() and s.shape == (B, H)
-    call("lstm_forward", dtype_code(G.dtype), G, Hprev, Y, Cst, Whh, h0, c0, hN, cN, B, T, H)
+    ws = _lstm_ws(G.dtype, B, H, dev) if Whh_packed is not None else None
+    call("lstm_forward", dtype_code(G.dtype), G, Hprev, Y, Cst, Whh, Whh_packed, h0, c0, hN, cN,
+         B, T, H, ws)
     return Y, Hprev, Cst, hN, cN
 
 
-def lstm_backward(G, dY, Cst, c0, WhhT):
+def lstm_backward(G, dY, Cst, c0, WhhT, WhhT_packed=None):
     """BPTT sweep: G (saved gates) is overwritten with dL/d(pre-activation) for every step."""
     B, T, H4 = G.shape
     H = H4 // 4
-    assert WhhT.shape == (H, H4) and WhhT.is_contiguous()
+    assert WhhT is None or (WhhT.shape == (H, H4) and WhhT.is_contiguous())
     if dY is not None:
         assert dY.is_contiguous() and dY.dtype == G.dtype and dY.shape == (B, T, H)
     dC = torch.empty(B, H, dtype=torch.float32, device=G.device)
-    call("lstm_backward", dtype_code(G.dtype), G, dY, Cst, c0, WhhT, dC, B, T, H)
+    ws = _lstm_ws(G.dtype, B, H, G.device) if WhhT_packed is not None else None
+    call("lstm_backward", dtype_code(G.dtype), G, dY, Cst, c0, WhhT, WhhT_packed, dC, B, T, H, ws)
     return G
 
 

@@ -127,12 +127,22 @@ int edgedict_layernorm_bwd(int dtype, const void* dout, const void* x, const voi
  *   WhhT   [H,4H]   dtype  (edgedict_transpose of Whh);  dC_ws fp32 [B,H] scratch
  * One kernel launch per timestep (kernel boundary ~1.5us < any grid barrier on MI355X).
  * Limits: H % 8 == 0.  Gradients wrt (h0,c0) are not produced.
+ *
+ * bf16 fast path (H % 32 == 0): pass the fragment-order weight image built by
+ * edgedict_lstm_pack_weights (packed_fwd for forward, packed_bwd for backward; each 4H*H bf16,
+ * rebuilt whenever W_hh changes) and a workspace of edgedict_lstm_workspace_bytes(dtype,B,H)
+ * bytes (ping-pong fragment images of h_t / dG_t); the plain Whh / WhhT may then be NULL.
+ * With NULL packed weights or workspace the generic path runs (any dtype).
  */
+size_t edgedict_lstm_workspace_bytes(int dtype, int B, int H);
+int edgedict_lstm_pack_weights(int src_dtype, const void* Whh, void* packed_fwd, void* packed_bwd,
+                               int H, void* stream);
 int edgedict_lstm_forward(int dtype, void* G, void* Hprev, void* Y, float* Cst, const void* Whh,
-                          const float* h0, const float* c0, float* hN, float* cN, int B, int T,
-                          int H, void* stream);
+                          const void* Whh_packed, const float* h0, const float* c0, float* hN,
+                          float* cN, int B, int T, int H, void* ws, void* stream);
 int edgedict_lstm_backward(int dtype, void* G, const void* dY, const float* Cst, const float* c0,
-                           const void* WhhT, float* dC_ws, int B, int T, int H, void* stream);
+                           const void* WhhT, const void* WhhT_packed, float* dC_ws, int B, int T,
+                           int H, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Streaming helpers.

@@ -1,0 +1,83 @@
+"""GPU: LSTM recurrence kernels (generic fp32/bf16 and the bf16 fragment-order fast path) vs a
+plain torch fp32 reference of the same cell, forward and backward."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref_lstm(x, w_ih, w_hh, b_ih, b_hh, h0, c0):
+    B, T, _ = x.shape
+    H = w_hh.shape[1]
+    h, c = h0, c0
+    ys = []
+    for t in range(T):
+        pre = x[:, t] @ w_ih.t() + b_ih + h @ w_hh.t() + b_hh
+        i, f, g, o = pre.split(H, 1)
+        i, f, g, o = i.sigmoid(), f.sigmoid(), g.tanh(), o.sigmoid()
+        c = f * c + i * g
+        h = o * c.tanh()
+        ys.append(h)
+    return torch.stack(ys, 1), h, c
+
+
+def _run(cd, B, T, I, H, force_generic, seed=0):
+    from edgedict_amd import config
+    from edgedict_amd.models import _LSTMBlockFn
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    k = 1.0 / H ** 0.5
+    w_ih = ((torch.rand(4 * H, I, generator=g) * 2 - 1) * k).cuda().requires_grad_(True)
+    w_hh = ((torch.rand(4 * H, H, generator=g) * 2 - 1) * k).cuda().requires_grad_(True)
+    b_ih = ((torch.rand(4 * H, generator=g) * 2 - 1) * k).cuda().requires_grad_(True)
+    b_hh = ((torch.rand(4 * H, generator=g) * 2 - 1) * k).cuda().requires_grad_(True)
+    x = torch.randn(B, T, I, generator=g).cuda()
+    h0 = (0.5 * torch.randn(B, H, generator=g)).cuda()
+    c0 = (0.5 * torch.randn(B, H, generator=g)).cuda()
+    dy = torch.randn(B, T, H, generator=g).cuda()
+    # reference in fp64 on the (possibly bf16-rounded) operands
+    xr = x.to(cd).double().requires_grad_(True)
+    params = [p.detach().to(cd).double().requires_grad_(True) if p.dim() == 2
+              else p.detach().double().requires_grad_(True) for p in (w_ih, w_hh, b_ih, b_hh)]
+    yr, hr, cr = _ref_lstm(xr, *params, h0.double(), c0.double())
+    (yr * dy.double()).sum().backward()
+    config.FORCE_GENERIC_LSTM = force_generic
+    try:
+        xin = x.to(cd).requires_grad_(True)
+        y, hN, cN = _LSTMBlockFn.apply(xin, w_ih, w_hh, b_ih, b_hh, None, None, h0, c0, False, 1, cd)
+        (y.float() * dy).sum().backward()
+    finally:
+        config.FORCE_GENERIC_LSTM = False
+    return (y, hN, cN, xin.grad, w_ih.grad, w_hh.grad, b_ih.grad), \
+           (yr, hr, cr, xr.grad, params[0].grad, params[1].grad, params[2].grad)
+
+
+def _close(got, ref, tol):
+    ref = ref.float().cuda()
+    err = (got.float() - ref).abs().max().item()
+    scale = max(ref.abs().max().item(), 1e-3)
+    assert err <= tol * scale, (err, scale)
+
+
+@pytest.mark.parametrize("B,T,I,H", [(3, 5, 24, 32), (16, 7, 64, 64), (64, 4, 256, 256),
+                                     (20, 3, 48, 96)])
+def test_fp32_generic_path(hip_lib, B, T, I, H):
+    got, ref = _run(torch.float32, B, T, I, H, True)
+    for a, b in zip(got, ref):
+        _close(a, b, 2e-4)
+
+
+@pytest.mark.parametrize("force_generic", [True, False])
+@pytest.mark.parametrize("B,T,I,H", [(3, 5, 32, 32), (64, 6, 240, 256), (70, 3, 64, 160),
+                                     (16, 4, 1024, 1024)])
+def test_bf16_paths(hip_lib, force_generic, B, T, I, H):
+    got, ref = _run(torch.bfloat16, B, T, I, H, force_generic)
+    tols = [2e-2, 2e-2, 2e-2, 4e-2, 4e-2, 4e-2, 4e-2]
+    for a, b, tol in zip(got, ref, tols):
+        _close(a, b, tol)
+
+
+def test_bf16_fast_equals_generic_closely(hip_lib):
+    fast, _ = _run(torch.bfloat16, 64, 9, 256, 512, False, seed=3)
+    gen, _ = _run(torch.bfloat16, 64, 9, 256, 512, True, seed=3)
+    for a, b in zip(fast, gen):
+        _close(a, b, 1.5e-2)      # same arithmetic, different accumulation split
