@@ -46,6 +46,7 @@ struct GemmArgs {
     long long lda, ldb, ldc;
     int M, N, K;
     int a_vec, b_vec;  // 16-byte vector path usable for the operand
+    int c_vec;         // bf16 output rows are 16-byte addressable (ldc % 8 == 0, N % 8 == 0)
     int accumulate;
     int split_k;
     int k_per_split;  // multiple of BK
@@ -54,13 +55,24 @@ struct GemmArgs {
 // ---- staging registers: the 16-byte chunks one thread moves per operand tile
 template <typename TI> struct Stage { uint4 v[Cfg<TI>::BK * BM / Cfg<TI>::VEC / THREADS]; };
 
-template <typename TI>
+template <typename TI, bool FAST>
 __device__ __forceinline__ uint4 load_chunk_guarded(const TI* p, long long ld, int vec_ok,
                                                     int r0, int rmax, int c0, int cmax,
                                                     bool along_row) {
     // Loads VEC elements starting at logical (r0, c0) walking along the contiguous dimension.
     // along_row: contiguous index is c (k_major: r = row, c = k); else contiguous index is r.
     constexpr int VEC = Cfg<TI>::VEC;
+    if constexpr (FAST) {
+        // host guarantees 16-byte alignment and that the contiguous extent is a multiple of VEC,
+        // so a chunk is either wholly inside or wholly outside: one unconditional load from a
+        // clamped address + select.  No branches, no waits: every load of a tile is in flight
+        // together.
+        const bool ok = (r0 < rmax) && (c0 < cmax);
+        const long long off = along_row ? (long long)r0 * ld + c0 : (long long)c0 * ld + r0;
+        uint4 v = *reinterpret_cast<const uint4*>(p + (ok ? off : 0));
+        if (!ok) v = make_uint4(0, 0, 0, 0);
+        return v;
+    }
     uint4 out = make_uint4(0, 0, 0, 0);
     TI* o = reinterpret_cast<TI*>(&out);
     if (along_row) {
@@ -82,7 +94,7 @@ __device__ __forceinline__ uint4 load_chunk_guarded(const TI* p, long long ld, i
 }
 
 // K-major operand: chunk c -> (row = c / (BK/VEC), kc = c % (BK/VEC))
-template <typename TI>
+template <typename TI, bool FAST>
 __device__ __forceinline__ void gload_kmajor(Stage<TI>& st, const TI* p, long long ld, int vec_ok,
                                              int row0, int rows, int k0, int kend) {
     constexpr int CPR = Cfg<TI>::BK / Cfg<TI>::VEC;
@@ -91,10 +103,16 @@ __device__ __forceinline__ void gload_kmajor(Stage<TI>& st, const TI* p, long lo
     for (int i = 0; i < N; ++i) {
         const int c = threadIdx.x + i * THREADS;
         const int r = c / CPR, kc = c % CPR;
-        st.v[i] = load_chunk_guarded<TI>(p, ld, vec_ok, row0 + r, rows, k0 + kc * Cfg<TI>::VEC,
-                                         kend, true);
+        st.v[i] = load_chunk_guarded<TI, FAST>(p, ld, vec_ok, row0 + r, rows,
+                                               k0 + kc * Cfg<TI>::VEC, kend, true);
     }
 }
+// bf16 tiles: the 16-byte chunk kc of row r lives at chunk position kc ^ ((r >> 3) & 7).  Rows that
+// are 8 apart start on the same LDS bank (8 * 144 B = 9 * 128 B), which is exactly the stride of
+// the transposing store below; the XOR spreads them over the 8 chunk positions.
+template <typename TI> __device__ __forceinline__ int swz(int r, int kc) { return kc; }
+template <> __device__ __forceinline__ int swz<bf16_t>(int r, int kc) { return kc ^ ((r >> 3) & 7); }
+
 template <typename TI>
 __device__ __forceinline__ void sstore_kmajor(const Stage<TI>& st, TI* lds) {
     constexpr int CPR = Cfg<TI>::BK / Cfg<TI>::VEC;
@@ -103,11 +121,12 @@ __device__ __forceinline__ void sstore_kmajor(const Stage<TI>& st, TI* lds) {
     for (int i = 0; i < N; ++i) {
         const int c = threadIdx.x + i * THREADS;
         const int r = c / CPR, kc = c % CPR;
-        *reinterpret_cast<uint4*>(lds + r * Cfg<TI>::ROW + kc * Cfg<TI>::VEC) = st.v[i];
+        *reinterpret_cast<uint4*>(lds + r * Cfg<TI>::ROW + swz<TI>(r, kc) * Cfg<TI>::VEC) = st.v[i];
     }
 }
 
 // Row-major-in-k ("transposed") operand.  fp32: item = (k, 4 rows); bf16: item = (k pair, 8 rows)
+template <bool FAST>
 __device__ __forceinline__ void gload_tr(Stage<float>& st, const float* p, long long ld,
                                          int vec_ok, int row0, int rows, int k0, int kend) {
     constexpr int CPK = BM / 4;  // chunks per k line
@@ -115,7 +134,8 @@ __device__ __forceinline__ void gload_tr(Stage<float>& st, const float* p, long 
     for (int i = 0; i < 2; ++i) {
         const int c = threadIdx.x + i * THREADS;
         const int k = c / CPK, rc = c % CPK;
-        st.v[i] = load_chunk_guarded<float>(p, ld, vec_ok, row0 + rc * 4, rows, k0 + k, kend, false);
+        st.v[i] = load_chunk_guarded<float, FAST>(p, ld, vec_ok, row0 + rc * 4, rows, k0 + k, kend,
+                                                  false);
     }
 }
 __device__ __forceinline__ void sstore_tr(const Stage<float>& st, float* lds) {
@@ -129,6 +149,7 @@ __device__ __forceinline__ void sstore_tr(const Stage<float>& st, float* lds) {
         for (int j = 0; j < 4; ++j) lds[(rc * 4 + j) * Cfg<float>::ROW + k] = f[j];
     }
 }
+template <bool FAST>
 __device__ __forceinline__ void gload_tr(Stage<bf16_t>& st, const bf16_t* p, long long ld,
                                          int vec_ok, int row0, int rows, int k0, int kend) {
     constexpr int CPK = BM / 8;  // 16 chunks per k line
@@ -136,10 +157,10 @@ __device__ __forceinline__ void gload_tr(Stage<bf16_t>& st, const bf16_t* p, lon
     for (int i = 0; i < 2; ++i) {
         const int item = threadIdx.x + i * THREADS;  // 512 items = 32 k-pairs x 16 chunks
         const int kp = item / CPK, rc = item % CPK;
-        st.v[2 * i] = load_chunk_guarded<bf16_t>(p, ld, vec_ok, row0 + rc * 8, rows,
-                                                 k0 + 2 * kp, kend, false);
-        st.v[2 * i + 1] = load_chunk_guarded<bf16_t>(p, ld, vec_ok, row0 + rc * 8, rows,
-                                                     k0 + 2 * kp + 1, kend, false);
+        st.v[2 * i] = load_chunk_guarded<bf16_t, FAST>(p, ld, vec_ok, row0 + rc * 8, rows,
+                                                       k0 + 2 * kp, kend, false);
+        st.v[2 * i + 1] = load_chunk_guarded<bf16_t, FAST>(p, ld, vec_ok, row0 + rc * 8, rows,
+                                                           k0 + 2 * kp + 1, kend, false);
     }
 }
 __device__ __forceinline__ void sstore_tr(const Stage<bf16_t>& st, bf16_t* lds) {
@@ -155,19 +176,21 @@ __device__ __forceinline__ void sstore_tr(const Stage<bf16_t>& st, bf16_t* lds) 
             // rows 2j, 2j+1 of this chunk; pack (k, k+1) for each row into one dword
             const unsigned lo = (a[j] & 0xffffu) | (b[j] << 16);
             const unsigned hi = (a[j] >> 16) | (b[j] & 0xffff0000u);
-            unsigned* d0 = reinterpret_cast<unsigned*>(lds + (rc * 8 + 2 * j) * Cfg<bf16_t>::ROW + 2 * kp);
-            unsigned* d1 = reinterpret_cast<unsigned*>(lds + (rc * 8 + 2 * j + 1) * Cfg<bf16_t>::ROW + 2 * kp);
+            // all 8 rows of this chunk share (row >> 3) = rc, hence one swizzled chunk position
+            const int pos = (((kp >> 2) ^ (rc & 7)) << 3) + ((2 * kp) & 7);
+            unsigned* d0 = reinterpret_cast<unsigned*>(lds + (rc * 8 + 2 * j) * Cfg<bf16_t>::ROW + pos);
+            unsigned* d1 = reinterpret_cast<unsigned*>(lds + (rc * 8 + 2 * j + 1) * Cfg<bf16_t>::ROW + pos);
             *d0 = lo;
             *d1 = hi;
         }
     }
 }
 
-template <typename TI, bool KMAJOR>
+template <typename TI, bool KMAJOR, bool FAST>
 __device__ __forceinline__ void gload(Stage<TI>& st, const TI* p, long long ld, int vec_ok,
                                       int row0, int rows, int k0, int kend) {
-    if constexpr (KMAJOR) gload_kmajor<TI>(st, p, ld, vec_ok, row0, rows, k0, kend);
-    else gload_tr(st, p, ld, vec_ok, row0, rows, k0, kend);
+    if constexpr (KMAJOR) gload_kmajor<TI, FAST>(st, p, ld, vec_ok, row0, rows, k0, kend);
+    else gload_tr<FAST>(st, p, ld, vec_ok, row0, rows, k0, kend);
 }
 template <typename TI, bool KMAJOR>
 __device__ __forceinline__ void sstore(const Stage<TI>& st, TI* lds) {
@@ -179,14 +202,15 @@ __device__ __forceinline__ void sstore(const Stage<TI>& st, TI* lds) {
 __device__ __forceinline__ void mma_tile(const bf16_t* sA, const bf16_t* sB, f32x4_t (&acc)[4][4],
                                          int wm, int wn, int lane) {
     constexpr int ROW = Cfg<bf16_t>::ROW;
-    const int r = lane & 15, kq = (lane >> 4) * 8;
+    const int r = lane & 15, kq = lane >> 4;
 #pragma unroll
     for (int ks = 0; ks < Cfg<bf16_t>::BK / 32; ++ks) {
         bf16x8_t a[4], b[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            a[i] = *reinterpret_cast<const bf16x8_t*>(sA + (wm * 64 + i * 16 + r) * ROW + ks * 32 + kq);
-            b[i] = *reinterpret_cast<const bf16x8_t*>(sB + (wn * 64 + i * 16 + r) * ROW + ks * 32 + kq);
+            const int ra = wm * 64 + i * 16 + r, rb = wn * 64 + i * 16 + r;
+            a[i] = *reinterpret_cast<const bf16x8_t*>(sA + ra * ROW + swz<bf16_t>(ra, ks * 4 + kq) * 8);
+            b[i] = *reinterpret_cast<const bf16x8_t*>(sB + rb * ROW + swz<bf16_t>(rb, ks * 4 + kq) * 8);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -215,11 +239,12 @@ __device__ __forceinline__ void mma_tile(const float* sA, const float* sB, f32x4
     }
 }
 
-template <typename TI, typename TO, bool A_KM, bool B_KM>
+template <typename TI, typename TO, bool A_KM, bool B_KM, bool FAST>
 __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
     using C_ = Cfg<TI>;
-    __shared__ __attribute__((aligned(16))) TI sA[BM * C_::ROW];
-    __shared__ __attribute__((aligned(16))) TI sB[BN * C_::ROW];
+    __shared__ __attribute__((aligned(16))) TI smem[(BM + BN) * C_::ROW];
+    TI* sA = smem;
+    TI* sB = smem + BM * C_::ROW;
 
     // N index fastest: consecutive blocks share the same A row panel (L2 reuse)
     const int n_tiles = (g.N + BN - 1) / BN;
@@ -242,8 +267,8 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
 
     Stage<TI> ra, rb;
     if (kbeg < kend) {
-        gload<TI, A_KM>(ra, A, g.lda, g.a_vec, m0, g.M, kbeg, kend);
-        gload<TI, B_KM>(rb, B, g.ldb, g.b_vec, n0, g.N, kbeg, kend);
+        gload<TI, A_KM, FAST>(ra, A, g.lda, g.a_vec, m0, g.M, kbeg, kend);
+        gload<TI, B_KM, FAST>(rb, B, g.ldb, g.b_vec, n0, g.N, kbeg, kend);
         sstore<TI, A_KM>(ra, sA);
         sstore<TI, B_KM>(rb, sB);
     }
@@ -251,8 +276,8 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
     for (int k0 = kbeg; k0 < kend; k0 += C_::BK) {
         const bool more = (k0 + C_::BK) < kend;
         if (more) {
-            gload<TI, A_KM>(ra, A, g.lda, g.a_vec, m0, g.M, k0 + C_::BK, kend);
-            gload<TI, B_KM>(rb, B, g.ldb, g.b_vec, n0, g.N, k0 + C_::BK, kend);
+            gload<TI, A_KM, FAST>(ra, A, g.lda, g.a_vec, m0, g.M, k0 + C_::BK, kend);
+            gload<TI, B_KM, FAST>(rb, B, g.ldb, g.b_vec, n0, g.N, k0 + C_::BK, kend);
         }
         mma_tile(sA, sB, acc, wm, wn, lane);
         __syncthreads();
@@ -266,6 +291,51 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
     // epilogue: lane holds D[row = (lane>>4)*4 + r][col = lane&15] of each 16x16 tile
     TO* C = reinterpret_cast<TO*>(g.C);
     const bool first_split = (blockIdx.z == 0);
+    if constexpr (sizeof(TO) == 2 && sizeof(TI) == 2) {
+        if (g.c_vec) {
+            // bf16 output: round in registers, stage the 128x128 tile in LDS (the operand tiles
+            // are dead after the last barrier) and leave the CU as full 16-byte row segments
+            constexpr int CROW = BN + 8;
+            bf16_t* sC = reinterpret_cast<bf16_t*>(smem);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int cl = wn * 64 + j * 16 + (lane & 15);
+                const int col = n0 + cl;
+                float bias = 0.f;
+                if (col < g.N) {
+                    if (g.bias1) bias += g.bias1[col];
+                    if (g.bias2) bias += g.bias2[col];
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        sC[(wm * 64 + i * 16 + (lane >> 4) * 4 + r) * CROW + cl] =
+                            f32_to_bf16(acc[i][j][r] + bias);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < BM * BN / 8 / THREADS; ++it) {
+                const int c = threadIdx.x + it * THREADS;
+                const int rl = c / (BN / 8), ch = c % (BN / 8);
+                const int row = m0 + rl, col = n0 + ch * 8;
+                if (row >= g.M || col >= g.N) continue;
+                uint4 v = *reinterpret_cast<const uint4*>(sC + rl * CROW + ch * 8);
+                bf16_t* dst = reinterpret_cast<bf16_t*>(C) + (long long)row * g.ldc + col;
+                if (g.accumulate) {
+                    float x[8], y[8];
+                    ElemIO<bf16_t>::load_vec(dst, x);
+                    ElemIO<bf16_t>::load_vec(reinterpret_cast<const bf16_t*>(&v), y);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) x[e] += y[e];
+                    ElemIO<bf16_t>::store_vec(dst, x);
+                } else {
+                    *reinterpret_cast<uint4*>(dst) = v;
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int col = n0 + wn * 64 + j * 16 + (lane & 15);
@@ -296,14 +366,24 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
     }
 }
 
-template <typename TI, typename TO>
-int launch(const GemmArgs& g, int a_km, int b_km, dim3 grid, hipStream_t s) {
-    if (a_km && b_km) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, true>), grid, dim3(THREADS), 0, s, g);
-    else if (a_km && !b_km) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, false>), grid, dim3(THREADS), 0, s, g);
-    else if (!a_km && b_km) hipLaunchKernelGGL((gemm_kernel<TI, TO, false, true>), grid, dim3(THREADS), 0, s, g);
-    else hipLaunchKernelGGL((gemm_kernel<TI, TO, false, false>), grid, dim3(THREADS), 0, s, g);
+template <typename TI, typename TO, bool FAST>
+int launch2(const GemmArgs& g, int a_km, int b_km, dim3 grid, hipStream_t s) {
+    if (a_km && b_km) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, true, FAST>), grid, dim3(THREADS), 0, s, g);
+    else if (a_km && !b_km) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, false, FAST>), grid, dim3(THREADS), 0, s, g);
+    else if (!a_km && b_km) hipLaunchKernelGGL((gemm_kernel<TI, TO, false, true, FAST>), grid, dim3(THREADS), 0, s, g);
+    else hipLaunchKernelGGL((gemm_kernel<TI, TO, false, false, FAST>), grid, dim3(THREADS), 0, s, g);
     ED_CHECK_LAUNCH("gemm");
     return ED_OK;
+}
+template <typename TI, typename TO>
+int launch(const GemmArgs& g, int a_km, int b_km, dim3 grid, hipStream_t s) {
+    // FAST: both operands 16-byte aligned with a leading dimension that is a multiple of the
+    // vector width, and the contiguous extent of each operand a multiple of it as well
+    constexpr int VEC = Cfg<TI>::VEC;
+    const bool a_ext = a_km ? (g.K % VEC == 0) : (g.M % VEC == 0);
+    const bool b_ext = b_km ? (g.K % VEC == 0) : (g.N % VEC == 0);
+    if (g.a_vec && g.b_vec && a_ext && b_ext) return launch2<TI, TO, true>(g, a_km, b_km, grid, s);
+    return launch2<TI, TO, false>(g, a_km, b_km, grid, s);
 }
 
 __global__ void zero_f32(float* p, long long rows, long long cols, long long ld) {
@@ -335,6 +415,7 @@ extern "C" int edgedict_gemm(int dtype_in, int dtype_out, const void* A, long lo
     g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K;
     g.a_vec = ((uintptr_t)A % 16 == 0) && (lda % vec == 0);
     g.b_vec = ((uintptr_t)B % 16 == 0) && (ldb % vec == 0);
+    g.c_vec = (dtype_out == ED_BF16) && ((uintptr_t)C % 16 == 0) && (ldc % 8 == 0) && (N % 8 == 0);
     g.accumulate = accumulate;
     const int bk = dtype_in == ED_F32 ? 16 : 64;
     int ktiles = (K + bk - 1) / bk;
