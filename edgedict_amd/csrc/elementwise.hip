@@ -126,40 +126,123 @@ __global__ __launch_bounds__(256) void joint_hidden_fwd(const T* __restrict__ E1
 
 // backward of the broadcast-add + tanh:  dpre = dhid * (1 - hid^2)
 //   dE1[b,t,j] = sum_u dpre[b,t,u,j]        dD1[b,u,j] = sum_t dpre[b,t,u,j]
-// One workgroup per (b, 256-wide j block, t slab); one thread per j.  The per-u running sums live
-// in LDS ([64][256] floats, each column owned by its thread: no conflicts, no atomics inside the
-// block); label positions are processed in chunks of 64 so any U+1 fits; t slabs combine with
-// global atomics.
-constexpr int JB_UCHUNK = 64;
+// HBM-bound (reads 2 x B*T*U1*J elements once).  One workgroup per (64-wide j block, b, t slab);
+// a wave is 8 j-vectors (8 elements = 16 B bf16 / 32 B f32 per lane, so one (b,t,u) row segment
+// is a full 128-byte line) x 8 label lanes; lane (jv, ug) owns label positions u = ug + 8 i.
+// The four waves take alternating frames.  Sums over u: registers + three xor-shuffles; sums
+// over t: per-thread registers (JB_NU x 8 accumulators), combined across the waves through LDS
+// once per slab and across slabs with fp32 atomics.
+constexpr int JB_NU = 9;              // label positions per lane and pass (8 * 9 = 72 >= U+1 = 65)
+constexpr int JB_UCHUNK = 8 * JB_NU;
+template <typename T> struct Load8;
+template <> struct Load8<bf16_t> {
+    __device__ static __forceinline__ void ld(const bf16_t* p, float (&o)[8]) {
+        ElemIO<bf16_t>::load_vec(p, o);
+    }
+};
+template <> struct Load8<float> {
+    __device__ static __forceinline__ void ld(const float* p, float (&o)[8]) {
+        const float4 a = *reinterpret_cast<const float4*>(p);
+        const float4 b = *reinterpret_cast<const float4*>(p + 4);
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w;
+        o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    }
+};
 template <typename T>
 __global__ __launch_bounds__(256) void joint_hidden_bwd(const T* __restrict__ dhid,
                                                         const T* __restrict__ hid,
                                                         float* __restrict__ dE1,
                                                         float* __restrict__ dD1, int B, int Tn,
                                                         int U1, int J, int t_per_block) {
-    __shared__ float usum[JB_UCHUNK * 256];
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float4 red[2][JB_NU][2][64];   // lane-wise hand-off of partial label sums (36 KB)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int jv = lane & 7, ug = lane >> 3;
+    const int j0 = blockIdx.x * 64 + jv * 8;
     const int b = blockIdx.y;
     const int t0 = blockIdx.z * t_per_block, t1 = min(Tn, t0 + t_per_block);
-    if (j >= J) return;  // no barriers below: columns are thread-private
+    const bool jlive = j0 < J;   // J % 8 == 0 checked on the host
     for (int uc = 0; uc < U1; uc += JB_UCHUNK) {
-        const int un = min(JB_UCHUNK, U1 - uc);
-        for (int u = 0; u < un; ++u) usum[u * 256 + threadIdx.x] = 0.f;
-        for (int t = t0; t < t1; ++t) {
-            const long long base = (((long long)b * Tn + t) * U1 + uc) * J + j;
-            float tsum = 0.f;
-            for (int u = 0; u < un; ++u) {
-                const float h = ElemIO<T>::load(hid + base + (long long)u * J);
-                const float g = ElemIO<T>::load(dhid + base + (long long)u * J);
-                const float dp = g * (1.f - h * h);
-                tsum += dp;
-                usum[u * 256 + threadIdx.x] += dp;
+        float usum[JB_NU][8];
+#pragma unroll
+        for (int i = 0; i < JB_NU; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) usum[i][e] = 0.f;
+        for (int t = t0 + wave; t < t1; t += 4) {
+            const long long base = (((long long)b * Tn + t) * U1) * J + j0;
+            float tsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < JB_NU; ++i) {
+                const int u = uc + ug + 8 * i;
+                if (u < U1 && jlive) {
+                    float h[8], g[8];
+                    Load8<T>::ld(hid + base + (long long)u * J, h);
+                    Load8<T>::ld(dhid + base + (long long)u * J, g);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float dp = g[e] * (1.f - h[e] * h[e]);
+                        tsum[e] += dp;
+                        usum[i][e] += dp;
+                    }
+                }
             }
-            float* de = dE1 + ((long long)b * Tn + t) * J + j;
-            *de = (uc == 0) ? tsum : *de + tsum;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                tsum[e] += __shfl_xor(tsum[e], 8, 64);
+                tsum[e] += __shfl_xor(tsum[e], 16, 64);
+                tsum[e] += __shfl_xor(tsum[e], 32, 64);
+            }
+            if (ug == 0 && jlive) {
+                float* de = dE1 + ((long long)b * Tn + t) * J + j0;
+                if (uc == 0) {
+                    *reinterpret_cast<float4*>(de) = make_float4(tsum[0], tsum[1], tsum[2], tsum[3]);
+                    *reinterpret_cast<float4*>(de + 4) = make_float4(tsum[4], tsum[5], tsum[6], tsum[7]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) de[e] += tsum[e];
+                }
+            }
         }
-        for (int u = 0; u < un; ++u)
-            atomicAdd(dD1 + ((long long)b * U1 + uc + u) * J + j, usum[u * 256 + threadIdx.x]);
+        // combine the four waves' label sums lane-wise (lane l of every wave owns the same (u, j)
+        // set): waves 2,3 -> waves 0,1, then wave 1 -> wave 0; one atomic per (u, j) and slab
+        if (uc > 0) __syncthreads();
+        if (wave >= 2) {
+#pragma unroll
+            for (int i = 0; i < JB_NU; ++i) {
+                red[wave - 2][i][0][lane] = make_float4(usum[i][0], usum[i][1], usum[i][2], usum[i][3]);
+                red[wave - 2][i][1][lane] = make_float4(usum[i][4], usum[i][5], usum[i][6], usum[i][7]);
+            }
+        }
+        __syncthreads();
+        if (wave < 2) {
+#pragma unroll
+            for (int i = 0; i < JB_NU; ++i) {
+                const float4 p = red[wave][i][0][lane], q = red[wave][i][1][lane];
+                usum[i][0] += p.x; usum[i][1] += p.y; usum[i][2] += p.z; usum[i][3] += p.w;
+                usum[i][4] += q.x; usum[i][5] += q.y; usum[i][6] += q.z; usum[i][7] += q.w;
+            }
+        }
+        __syncthreads();
+        if (wave == 1) {
+#pragma unroll
+            for (int i = 0; i < JB_NU; ++i) {
+                red[0][i][0][lane] = make_float4(usum[i][0], usum[i][1], usum[i][2], usum[i][3]);
+                red[0][i][1][lane] = make_float4(usum[i][4], usum[i][5], usum[i][6], usum[i][7]);
+            }
+        }
+        __syncthreads();
+        if (wave == 0 && jlive) {
+#pragma unroll
+            for (int i = 0; i < JB_NU; ++i) {
+                const int u = uc + ug + 8 * i;
+                if (u >= U1) continue;
+                const float4 p = red[0][i][0][lane], q = red[0][i][1][lane];
+                float* dd = dD1 + ((long long)b * U1 + u) * J + j0;
+                atomicAdd(dd + 0, usum[i][0] + p.x); atomicAdd(dd + 1, usum[i][1] + p.y);
+                atomicAdd(dd + 2, usum[i][2] + p.z); atomicAdd(dd + 3, usum[i][3] + p.w);
+                atomicAdd(dd + 4, usum[i][4] + q.x); atomicAdd(dd + 5, usum[i][5] + q.y);
+                atomicAdd(dd + 6, usum[i][6] + q.z); atomicAdd(dd + 7, usum[i][7] + q.w);
+            }
+        }
     }
 }
 
@@ -354,9 +437,10 @@ extern "C" int edgedict_joint_hidden_bwd(int dtype, const void* dhid, const void
         ed_set_error("joint_hidden_bwd: memset failed: %s", hipGetErrorString(e));
         return ED_ERR_LAUNCH;
     }
-    const int jblocks = (J + 255) / 256;
-    int tslabs = (1024 + B * jblocks - 1) / (B * jblocks);  // aim at ~1k workgroups
-    if (tslabs > T) tslabs = T;
+    ED_CHECK_ARG(J % 8 == 0, "joint_hidden_bwd: joint size %d must be a multiple of 8", J);
+    const int jblocks = (J + 63) / 64;
+    int tslabs = (2048 + B * jblocks - 1) / (B * jblocks);  // aim at >= ~2k workgroups
+    if (tslabs > (T + 7) / 8) tslabs = (T + 7) / 8;         // at least two frames per wave
     if (tslabs < 1) tslabs = 1;
     const int tpb = (T + tslabs - 1) / tslabs;
     tslabs = (T + tpb - 1) / tpb;
