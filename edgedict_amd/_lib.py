@@ -57,6 +57,8 @@ def load():
         lib.edgedict_rnnt_workspace_view.restype = ctypes.c_void_p
         lib.edgedict_greedy_workspace_bytes.restype = ctypes.c_size_t
         lib.edgedict_lstm_workspace_bytes.restype = ctypes.c_size_t
+        lib.edgedict_stack_workspace_bytes.restype = ctypes.c_size_t
+        lib.edgedict_stack_struct_bytes.restype = ctypes.c_size_t
         for name in declared_symbols():
             if not hasattr(lib, name):
                 raise RuntimeError("edgedict_amd: %s lacks symbol %s declared in the header"

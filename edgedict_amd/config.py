@@ -30,6 +30,10 @@ def _parse(x):
 # test hook: route bf16 recurrences through the generic step kernels instead of lstm_fast.hip
 FORCE_GENERIC_LSTM = False
 
+# bf16 encoders run as the layer-pipelined stack (csrc/encoder_stack.hip); False routes them
+# through the per-layer kernels (test hook / A-B comparison)
+USE_ENCODER_STACK = os.environ.get("EDGEDICT_ENCODER_STACK", "1") != "0"
+
 _state = {"dtype": _parse(os.environ.get("EDGEDICT_DTYPE", "fp32")), "epoch": 0}
 
 

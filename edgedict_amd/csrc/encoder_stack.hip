@@ -1,0 +1,541 @@
+// Layer-pipelined LSTM encoder stack: stream scheduler + C ABI (bf16 throughput mode).
+//
+// Replaces the per-layer loop of ResLayerNormLSTM.forward (rnnt/models.py:55-75) plus the input
+// LayerNorm of Encoder.forward (rnnt/models.py:124,132) and their autograd with ONE native call
+// per direction.  The arithmetic per layer is unchanged (input product as a GEMM, recurrence,
+// residual + LayerNorm + TimeReduction); what changes is the ORDER of the work:
+//
+//   * the recurrences of different layers are independent once their inputs exist, so layer l
+//     runs `lag` launches behind layer l-1 and ONE launch of stack_fwd_kernel carries a time step
+//     of every runnable layer (layers behind a 2x time reduction step every other launch) plus
+//     the LayerNorms of the frames the previous launch finished: ~T0 + (L-1) lag launches
+//     instead of sum_l T_l, each doing 4x the work of a per-layer step at the same latency;
+//   * the input products X_l W_ih^T are GEMMs over CHUNKS of frames (time-major rows, so a chunk
+//     is a contiguous operand) on a side stream, ordered against the recurrence stream with
+//     events: chunk k of layer l+1 is multiplied while layer l works on chunk k+1;
+//   * backward mirrors this top-down and in reverse time (BPTT launches; per chunk dX GEMM and
+//     LayerNorm backward on the side stream); weight gradients run on a third, low-priority
+//     stream as soon as a layer's BPTT is complete, under the BPTT of the layers below.
+//
+// The caller's stream is forked into the internal streams at entry and joined at exit, so the
+// call is an ordinary stream-ordered operation for the caller (and for the caching allocator).
+#include <mutex>
+#include <vector>
+
+#include "stack_kernels.hpp"
+
+namespace {
+
+// ---------------------------------------------------------------- weight images
+// wih_p[kappa(g,j)][k] = W_ih[g*H + j][k] (bf16);  bias_p[kappa] = b_ih + b_hh (fp32)
+__global__ void pack_wih_kernel(const float* __restrict__ W, const float* __restrict__ b_ih,
+                                const float* __restrict__ b_hh, bf16_t* __restrict__ Wp,
+                                float* __restrict__ bp, int H, int I) {
+    const long long n = 4ll * H * I;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / I), k = (int)(i % I);
+        const int g = row / H, j = row % H;
+        const int kap = ed_gate_col(g, j);
+        Wp[(long long)kap * I + k] = f32_to_bf16(W[i]);
+        if (k == 0) bp[kap] = b_ih[row] + b_hh[row];
+    }
+}
+// backward image of W_hh: frag[nt16][ks][lane][8], n = lane & 15 -> hidden unit nt16*16 + n,
+// k = interleaved gate column ks*32 + (lane >> 4)*8 + e
+__global__ void pack_whh_bwd_kernel(const float* __restrict__ W, bf16_t* __restrict__ out, int H) {
+    const long long n = 4ll * H * H;
+    const int KS = H >> 3;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const long long blk = i >> 9;
+        const int ks = (int)(blk % KS), nt = (int)(blk / KS);
+        const int unit = nt * 16 + (lane & 15);
+        const int kap = ks * 32 + (lane >> 4) * 8 + e;
+        const int ub = kap >> 6, g = (kap >> 4) & 3, u = kap & 15;
+        out[i] = f32_to_bf16(W[((long long)g * H + ub * 16 + u) * H + unit]);
+    }
+}
+// dst[g*H + j][k] = src[kappa(g,j)][k]
+__global__ void unpermute_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int H,
+                                      int K) {
+    const long long n = 4ll * H * K;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(i / K), k = (int)(i % K);
+        dst[i] = src[(long long)ed_gate_col(row / H, row % H) * K + k];
+    }
+}
+
+// ---------------------------------------------------------------- per-device runtime
+struct Runtime {
+    hipStream_t R = nullptr, S = nullptr, W = nullptr;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    hipEvent_t get() {
+        if (used == pool.size()) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+            pool.push_back(e);
+        }
+        return pool[used++];
+    }
+};
+std::mutex g_mu;
+std::vector<Runtime*> g_rt;   // indexed by device ordinal
+
+Runtime* runtime_for_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if ((int)g_rt.size() <= dev) g_rt.resize(dev + 1, nullptr);
+    if (!g_rt[dev]) {
+        Runtime* r = new Runtime();
+        int lo = 0, hi = 0;
+        hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least, hi = greatest priority
+        if (hipStreamCreateWithPriority(&r->R, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipStreamCreateWithPriority(&r->S, hipStreamNonBlocking, hi) != hipSuccess ||
+            hipStreamCreateWithPriority(&r->W, hipStreamNonBlocking, lo) != hipSuccess) {
+            delete r;
+            return nullptr;
+        }
+        g_rt[dev] = r;
+    }
+    g_rt[dev]->used = 0;
+    return g_rt[dev];
+}
+
+struct Geom {
+    int T, f, m, cf, off, nchunks;
+};
+
+size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+struct WsLayout {
+    std::vector<size_t> frag0, frag1, dC;   // per layer
+    size_t tmpW = 0, tmpB = 0, dX0 = 0, total = 0;
+};
+
+WsLayout ws_layout(const edgedict_stack_desc_t* d) {
+    WsLayout w;
+    const size_t B16 = (size_t)(d->B + 15) / 16 * 16;
+    size_t off = 0;
+    size_t maxK = d->H;
+    for (int l = 0; l < d->L; ++l) {
+        // ping-pong fragment images: h (forward, B16 x H) or dG (backward, B16 x 4H)
+        const size_t fb = align256(B16 * 4 * d->H * sizeof(bf16_t));
+        w.frag0.push_back(off); off += fb;
+        w.frag1.push_back(off); off += fb;
+        w.dC.push_back(off); off += align256((size_t)d->B * d->H * sizeof(float));
+        if ((size_t)d->layers[l].I > maxK) maxK = d->layers[l].I;
+    }
+    w.tmpW = off; off += align256((size_t)4 * d->H * maxK * sizeof(float));
+    w.tmpB = off; off += align256((size_t)4 * d->H * sizeof(float));
+    w.dX0 = off; off += align256((size_t)d->T0 * d->B * d->I0 * sizeof(bf16_t));
+    w.total = off;
+    return w;
+}
+
+int validate(const edgedict_stack_desc_t* d, std::vector<Geom>& g, bool backward) {
+    ED_CHECK_ARG(d && d->layers, "encoder_stack: null descriptor");
+    ED_CHECK_ARG(d->L >= 1 && d->L <= ED_STACK_MAX_SLOTS, "encoder_stack: 1..%d layers supported (got %d)", ED_STACK_MAX_SLOTS, d->L);
+    ED_CHECK_ARG(d->B >= 1 && d->H >= 32 && d->H % 32 == 0 && d->H <= 2048, "encoder_stack: need B >= 1, H %% 32 == 0, H <= 2048 (B=%d H=%d)", d->B, d->H);
+    ED_CHECK_ARG(d->chunk >= 1, "encoder_stack: chunk must be >= 1");
+    ED_CHECK_ARG(d->T0 >= 1 && d->I0 >= 8 && d->I0 % 8 == 0 && d->I0 <= 1024, "encoder_stack: bad input geometry (T0=%d I0=%d)", d->T0, d->I0);
+    ED_CHECK_ARG(d->x && d->in_gamma && d->in_beta && d->in_mean && d->in_rstd && d->out && d->ws, "encoder_stack: null pointer in descriptor");
+    g.resize(d->L);
+    int f = 1;
+    for (int l = d->L - 1; l >= 0; --l) {
+        const edgedict_stack_layer_t& y = d->layers[l];
+        ED_CHECK_ARG(y.reduce == 1 || y.reduce == 2, "encoder_stack: layer %d: time reduction must be 1 or 2", l);
+        f *= y.reduce;
+        g[l].f = f;
+        g[l].T = y.T;
+    }
+    int T = d->T0, I = d->I0;
+    for (int l = 0; l < d->L; ++l) {
+        const edgedict_stack_layer_t& y = d->layers[l];
+        ED_CHECK_ARG(y.T == T && y.I == I, "encoder_stack: layer %d geometry (T=%d I=%d) does not follow from the layers above (T=%d I=%d)", l, y.T, y.I, T, I);
+        ED_CHECK_ARG(!y.residual || y.I == d->H, "encoder_stack: layer %d: residual needs I == H", l);
+        ED_CHECK_ARG(y.wih_p && y.bias_p && y.whh_f && y.ln_gamma && y.ln_beta && y.X && y.G && y.Yx && y.Cx && y.mean && y.rstd, "encoder_stack: layer %d: null pointer", l);
+        if (backward)
+            ED_CHECK_ARG(y.whh_b && y.dZ && (l == 0 || y.dX) && y.dW_ih && y.dW_hh && y.db && y.dgamma && y.dbeta, "encoder_stack: layer %d: null backward pointer", l);
+        g[l].m = g[0].f / g[l].f;
+        g[l].cf = d->chunk * g[l].f;
+        g[l].nchunks = (y.T + g[l].cf - 1) / g[l].cf;
+        T = (T + y.reduce - 1) / y.reduce;
+        I = d->H;
+    }
+    ED_CHECK_ARG(d->ws_bytes >= ws_layout(d).total, "encoder_stack: workspace too small");
+    return ED_OK;
+}
+
+int default_lag(const edgedict_stack_desc_t* d, const std::vector<Geom>& g) {
+    // a layer may start chunk k only after the layer feeding it has finished that chunk and the
+    // chunk's GEMM has been ENQUEUED (P launches per chunk, +2 for the norm / enqueue order)
+    const int P = d->chunk * g[0].f;
+    int lag = d->lag > 0 ? d->lag : P + 8;
+    if (lag < P + 2) lag = P + 2;
+    return lag | 1;   // odd: half-rate layers alternate between even and odd launches
+}
+
+#define ED_TRY(expr)            \
+    do {                        \
+        int st__ = (expr);      \
+        if (st__ != ED_OK) return st__; \
+    } while (0)
+
+struct Streams {
+    hipStream_t C, R, S, W;
+    bool serial;
+    Runtime* rt;
+    // order `waiter` after everything enqueued so far on `src`
+    int chain(hipStream_t src, hipStream_t waiter) {
+        if (serial || src == waiter) return ED_OK;
+        hipEvent_t e = rt->get();
+        ED_CHECK_ARG(e != nullptr, "encoder_stack: event creation failed");
+        ED_CHECK_HIP(hipEventRecord(e, src));
+        ED_CHECK_HIP(hipStreamWaitEvent(waiter, e, 0));
+        return ED_OK;
+    }
+    int record(hipEvent_t& e, hipStream_t src) {
+        if (serial) return ED_OK;
+        e = rt->get();
+        ED_CHECK_ARG(e != nullptr, "encoder_stack: event creation failed");
+        ED_CHECK_HIP(hipEventRecord(e, src));
+        return ED_OK;
+    }
+    int wait(hipStream_t waiter, hipEvent_t e) {
+        if (serial || !e) return ED_OK;
+        ED_CHECK_HIP(hipStreamWaitEvent(waiter, e, 0));
+        return ED_OK;
+    }
+};
+
+int open_streams(const edgedict_stack_desc_t* d, void* stream_, Streams& st) {
+    st.C = (hipStream_t)stream_;
+    st.serial = (d->flags & EDGEDICT_STACK_SERIAL) != 0;
+    st.rt = nullptr;
+    if (st.serial) {
+        st.R = st.S = st.W = st.C;
+        return ED_OK;
+    }
+    st.rt = runtime_for_current_device();
+    ED_CHECK_ARG(st.rt != nullptr, "encoder_stack: could not create the internal streams");
+    st.R = st.rt->R;
+    st.S = st.rt->S;
+    st.W = st.rt->W;
+    return ED_OK;
+}
+
+inline bf16_t* bptr(void* p) { return reinterpret_cast<bf16_t*>(p); }
+inline const bf16_t* bptr(const void* p) { return reinterpret_cast<const bf16_t*>(p); }
+
+// G_l[chunk k] = X_l[chunk k] W_ih^T + b on stream s
+int input_gemm(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, int l, int k, hipStream_t s) {
+    const edgedict_stack_layer_t& y = d->layers[l];
+    const int t0 = k * g[l].cf, t1 = min(y.T, t0 + g[l].cf);
+    const long long r0 = (long long)t0 * d->B;
+    return edgedict_gemm(ED_BF16, ED_BF16, bptr(y.X) + r0 * y.I, y.I, 1, y.wih_p, y.I, 1,
+                         bptr(y.G) + r0 * 4 * d->H, 4ll * d->H, (t1 - t0) * d->B, 4 * d->H, y.I,
+                         y.bias_p, nullptr, 0, 1, s);
+}
+
+}  // namespace
+
+extern "C" size_t edgedict_stack_struct_bytes(int which) {
+    return which == 0 ? sizeof(edgedict_stack_layer_t) : sizeof(edgedict_stack_desc_t);
+}
+
+extern "C" size_t edgedict_stack_workspace_bytes(const edgedict_stack_desc_t* d) {
+    if (!d || !d->layers || d->L < 1) return 0;
+    return ws_layout(d).total;
+}
+
+extern "C" int edgedict_stack_pack_weights(const float* w_ih, const float* w_hh, const float* b_ih,
+                                           const float* b_hh, int H, int I, void* wih_p,
+                                           float* bias_p, void* whh_f, void* whh_b, void* stream_) {
+    ED_CHECK_ARG(H >= 32 && H % 32 == 0 && I >= 1, "stack_pack_weights: need H %% 32 == 0 (H=%d I=%d)", H, I);
+    ED_CHECK_ARG(w_ih && w_hh && b_ih && b_hh && wih_p && bias_p && whh_f, "stack_pack_weights: null pointer");
+    hipStream_t s = (hipStream_t)stream_;
+    hipLaunchKernelGGL(pack_wih_kernel, dim3(ed_grid_for(4ll * H * I, 256, 4096)), dim3(256), 0, s,
+                       w_ih, b_ih, b_hh, (bf16_t*)wih_p, bias_p, H, I);
+    ED_CHECK_LAUNCH("pack_wih_kernel");
+    ED_TRY(edgedict_lstm_pack_weights(ED_F32, w_hh, whh_f, nullptr, H, stream_));
+    if (whh_b) {
+        hipLaunchKernelGGL(pack_whh_bwd_kernel, dim3(ed_grid_for(4ll * H * H, 256, 4096)), dim3(256),
+                           0, s, w_hh, (bf16_t*)whh_b, H);
+        ED_CHECK_LAUNCH("pack_whh_bwd_kernel");
+    }
+    return ED_OK;
+}
+
+extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stream_) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    std::vector<Geom> g;
+    ED_TRY(validate(d, g, false));
+    const int B = d->B, H = d->H, L = d->L;
+    const long long BH = (long long)B * H;
+    const WsLayout wl = ws_layout(d);
+    char* ws = (char*)d->ws;
+    Streams st;
+    ED_TRY(open_streams(d, stream_, st));
+    const int lag = default_lag(d, g);
+    for (int l = 0; l < L; ++l) g[l].off = l * lag;
+
+    // ---- prologue on the caller's stream: input LayerNorm (-> X_0, time-major), initial states
+    ED_TRY(ed_stack_input_norm(d->x_dtype, d->x, d->in_gamma, d->in_beta, bptr(d->layers[0].X),
+                               d->in_mean, d->in_rstd, B, d->T0, d->I0, d->eps, st.C));
+    for (int l = 0; l < L; ++l) {
+        const edgedict_stack_layer_t& y = d->layers[l];
+        ED_TRY(ed_stack_init_state(d->h0 ? d->h0 + l * BH : nullptr, d->c0 ? d->c0 + l * BH : nullptr,
+                                   bptr(y.Yx), y.Cx, bptr(ws + wl.frag0[l]), B, H, st.C));
+    }
+    ED_TRY(st.chain(st.C, st.R));
+    ED_TRY(st.chain(st.C, st.S));
+
+    std::vector<std::vector<hipEvent_t>> Eg(L);
+    std::vector<std::vector<char>> queued(L);   // schedule self-check: producer enqueued before consumer
+    for (int l = 0; l < L; ++l) {
+        Eg[l].assign(g[l].nchunks, nullptr);
+        queued[l].assign(g[l].nchunks, 0);
+    }
+    int next_g0 = 0;   // next chunk of layer 0 whose input product has not been enqueued
+    auto feed_layer0 = [&](int upto) -> int {
+        for (; next_g0 < g[0].nchunks && next_g0 <= upto; ++next_g0) {
+            ED_TRY(input_gemm(d, g, 0, next_g0, st.S));
+            ED_TRY(st.record(Eg[0][next_g0], st.S));
+            queued[0][next_g0] = 1;
+        }
+        return ED_OK;
+    };
+    ED_TRY(feed_layer0(1));
+
+    int Wtot = 0;
+    for (int l = 0; l < L; ++l) Wtot = max(Wtot, g[l].off + (g[l].T - 1) * g[l].m + 2);
+    const int T_out = (g[L - 1].T + d->layers[L - 1].reduce - 1) / d->layers[L - 1].reduce;
+    struct Done { int l, k; };
+    for (int w = 0; w < Wtot; ++w) {
+        EdFwdLaunch Lc;
+        Lc.nstep = Lc.nnorm = 0;
+        Lc.B = B; Lc.H = H; Lc.eps = d->eps;
+        Done done[ED_STACK_MAX_SLOTS];
+        int ndone = 0;
+        for (int l = 0; l < L; ++l) {
+            const edgedict_stack_layer_t& y = d->layers[l];
+            // ---- time step of layer l
+            int dw = w - g[l].off;
+            if (dw >= 0 && dw % g[l].m == 0 && dw / g[l].m < g[l].T) {
+                const int t = dw / g[l].m;
+                if (t % g[l].cf == 0) {
+                    const int k = t / g[l].cf;
+                    if (l == 0) ED_TRY(feed_layer0(k + 2));
+                    ED_CHECK_ARG(queued[l][k], "encoder_stack: schedule violated (layer %d chunk %d)", l, k);
+                    ED_TRY(st.wait(st.R, Eg[l][k]));
+                }
+                EdFwdStep& s = Lc.step[Lc.nstep++];
+                bf16_t* f0 = bptr(ws + wl.frag0[l]);
+                bf16_t* f1 = bptr(ws + wl.frag1[l]);
+                s.G_t = bptr(y.G) + (long long)t * B * 4 * H;
+                s.hfrag_in = (t & 1) ? f1 : f0;
+                s.hfrag_out = (t & 1) ? f0 : f1;
+                s.Y_t = bptr(y.Yx) + (long long)(t + 1) * BH;
+                s.C_prev = y.Cx + (long long)t * BH;
+                s.C_t = y.Cx + (long long)(t + 1) * BH;
+                s.Wfrag = bptr(y.whh_f);
+            }
+            // ---- LayerNorm of the frame(s) the previous launch finished
+            dw = w - 1 - g[l].off;
+            if (dw >= 0 && dw % g[l].m == 0 && dw / g[l].m < g[l].T) {
+                const int t = dw / g[l].m;
+                int ta = -1, tb = -1;
+                if (y.reduce == 1) ta = t;
+                else if (t & 1) { ta = t - 1; tb = t; }
+                else if (t == g[l].T - 1) ta = t;
+                if (ta >= 0) {
+                    const int tau = ta / y.reduce;
+                    EdFwdNorm& n = Lc.norm[Lc.nnorm++];
+                    n.y0 = bptr(y.Yx) + (long long)(ta + 1) * BH;
+                    n.r0 = y.residual ? bptr(y.X) + (long long)ta * BH : nullptr;
+                    n.y1 = tb >= 0 ? bptr(y.Yx) + (long long)(tb + 1) * BH : nullptr;
+                    n.r1 = (tb >= 0 && y.residual) ? bptr(y.X) + (long long)tb * BH : nullptr;
+                    n.gamma = y.ln_gamma;
+                    n.beta = y.ln_beta;
+                    if (l + 1 < L) {
+                        n.out = bptr(d->layers[l + 1].X) + (long long)tau * BH;
+                        n.out_stride = H;
+                    } else {
+                        n.out = bptr(d->out) + (long long)tau * H;
+                        n.out_stride = (long long)T_out * H;
+                    }
+                    n.mean0 = y.mean + (long long)ta * B;
+                    n.rstd0 = y.rstd + (long long)ta * B;
+                    n.mean1 = tb >= 0 ? y.mean + (long long)tb * B : nullptr;
+                    n.rstd1 = tb >= 0 ? y.rstd + (long long)tb * B : nullptr;
+                    n.scale = y.reduce == 1 ? 1.f : 0.5f;
+                }
+                // last frame of a chunk: the next layer's input rows of this chunk are complete
+                const int k = t / g[l].cf;
+                if (l + 1 < L && t == min(g[l].T, (k + 1) * g[l].cf) - 1) {
+                    done[ndone].l = l;
+                    done[ndone].k = k;
+                    ++ndone;
+                }
+            }
+        }
+        ED_TRY(ed_stack_launch_fwd(Lc, st.R));
+        for (int i = 0; i < ndone; ++i) {
+            const int l = done[i].l + 1, k = done[i].k;
+            ED_TRY(st.chain(st.R, st.S));
+            ED_TRY(input_gemm(d, g, l, k, st.S));
+            ED_TRY(st.record(Eg[l][k], st.S));
+            queued[l][k] = 1;
+        }
+    }
+    ED_TRY(st.chain(st.R, st.C));
+    ED_TRY(st.chain(st.S, st.C));
+    return ED_OK;
+}
+
+extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* stream_) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    std::vector<Geom> g;
+    ED_TRY(validate(d, g, true));
+    ED_CHECK_ARG(d->dout && d->d_in_gamma && d->d_in_beta, "encoder_stack: null backward pointer in descriptor");
+    const int B = d->B, H = d->H, L = d->L;
+    const long long BH = (long long)B * H;
+    const WsLayout wl = ws_layout(d);
+    char* ws = (char*)d->ws;
+    Streams st;
+    ED_TRY(open_streams(d, stream_, st));
+    const int lag = default_lag(d, g);
+    for (int l = 0; l < L; ++l) g[l].off = (L - 1 - l) * lag;
+    const int T_out = (g[L - 1].T + d->layers[L - 1].reduce - 1) / d->layers[L - 1].reduce;
+
+    // ---- prologue: running dL/dc = 0, LayerNorm backward of the top layer (all frames)
+    for (int l = 0; l < L; ++l) ED_TRY(ed_stack_zero(ws + wl.dC[l], (size_t)BH * sizeof(float), st.C));
+    {
+        const edgedict_stack_layer_t& y = d->layers[L - 1];
+        ED_TRY(ed_stack_ln_bwd(bptr(d->dout), H, (long long)T_out * H, bptr(y.Yx) + BH,
+                               y.residual ? bptr(y.X) : nullptr, y.ln_gamma, y.mean, y.rstd,
+                               bptr(y.dZ), y.dgamma, y.dbeta, B, H, 0, y.T, y.reduce, st.C));
+    }
+    ED_TRY(st.chain(st.C, st.R));
+    ED_TRY(st.chain(st.C, st.S));
+    if (st.W != st.S) ED_TRY(st.chain(st.C, st.W));
+
+    std::vector<std::vector<hipEvent_t>> Eb(L);
+    std::vector<std::vector<char>> queued(L);
+    for (int l = 0; l < L; ++l) {
+        Eb[l].assign(g[l].nchunks, nullptr);
+        queued[l].assign(g[l].nchunks, l == L - 1 ? 1 : 0);
+    }
+    std::vector<int> deferred;   // layers whose weight gradients run after the BPTT (DW_AT_END)
+
+    auto weight_grads = [&](int l) -> int {
+        const edgedict_stack_layer_t& y = d->layers[l];
+        const int M = y.T * B;
+        float* tmpW = (float*)(ws + wl.tmpW);
+        float* tmpB = (float*)(ws + wl.tmpB);
+        const int sk = d->split_k > 0 ? d->split_k : max(1, min(16, M / 2048));
+        // dW_ih = dG^T X,  dW_hh = dG^T H_prev (rows come out in interleaved gate order)
+        ED_TRY(edgedict_gemm(ED_BF16, ED_F32, y.G, 4ll * H, 0, y.X, y.I, 0, tmpW, y.I, 4 * H, y.I, M,
+                             nullptr, nullptr, 0, sk, st.W));
+        hipLaunchKernelGGL(unpermute_rows_kernel, dim3(ed_grid_for(4ll * H * y.I, 256, 4096)),
+                           dim3(256), 0, st.W, tmpW, y.dW_ih, H, y.I);
+        ED_TRY(edgedict_gemm(ED_BF16, ED_F32, y.G, 4ll * H, 0, y.Yx, H, 0, tmpW, H, 4 * H, H, M,
+                             nullptr, nullptr, 0, sk, st.W));
+        hipLaunchKernelGGL(unpermute_rows_kernel, dim3(ed_grid_for(4ll * H * H, 256, 4096)),
+                           dim3(256), 0, st.W, tmpW, y.dW_hh, H, H);
+        ED_TRY(ed_stack_zero(tmpB, (size_t)4 * H * sizeof(float), st.W));
+        ED_TRY(edgedict_colsum(ED_BF16, y.G, 4ll * H, tmpB, M, 4 * H, st.W));
+        hipLaunchKernelGGL(unpermute_rows_kernel, dim3(ed_grid_for(4ll * H, 256, 4096)), dim3(256),
+                           0, st.W, tmpB, y.db, H, 1);
+        ED_CHECK_LAUNCH("unpermute_rows_kernel");
+        return ED_OK;
+    };
+
+    int Wtot = 0;
+    for (int l = 0; l < L; ++l) Wtot = max(Wtot, g[l].off + (g[l].T - 1) * g[l].m + 1);
+    struct Done { int l, k, t; };
+    for (int w = 0; w < Wtot; ++w) {
+        EdBwdLaunch Lc;
+        Lc.nstep = 0;
+        Lc.B = B; Lc.H = H;
+        Done done[ED_STACK_MAX_SLOTS];
+        int ndone = 0;
+        for (int l = L - 1; l >= 0; --l) {
+            const edgedict_stack_layer_t& y = d->layers[l];
+            const int dw = w - g[l].off;
+            if (dw < 0 || dw % g[l].m != 0 || dw / g[l].m >= g[l].T) continue;
+            const int t = g[l].T - 1 - dw / g[l].m;
+            const int k = t / g[l].cf;
+            if (t == min(g[l].T, (k + 1) * g[l].cf) - 1) {
+                ED_CHECK_ARG(queued[l][k], "encoder_stack: backward schedule violated (layer %d chunk %d)", l, k);
+                ED_TRY(st.wait(st.R, Eb[l][k]));
+            }
+            EdBwdStep& s = Lc.step[Lc.nstep++];
+            bf16_t* f0 = bptr(ws + wl.frag0[l]);
+            bf16_t* f1 = bptr(ws + wl.frag1[l]);
+            s.G_t = bptr(y.G) + (long long)t * B * 4 * H;
+            s.gfrag_in = (t == g[l].T - 1) ? nullptr : (((t + 1) & 1) ? f1 : f0);
+            s.gfrag_out = (t == 0) ? nullptr : ((t & 1) ? f1 : f0);
+            s.dY_t = bptr(y.dZ) + (long long)t * BH;
+            s.C_t = y.Cx + (long long)(t + 1) * BH;
+            s.C_prev = y.Cx + (long long)t * BH;
+            s.dC = (float*)(ws + wl.dC[l]);
+            s.WTfrag = bptr(y.whh_b);
+            if (t == k * g[l].cf) {
+                done[ndone].l = l; done[ndone].k = k; done[ndone].t = t;
+                ++ndone;
+            }
+        }
+        ED_TRY(ed_stack_launch_bwd(Lc, st.R));
+        for (int i = 0; i < ndone; ++i) {
+            const int l = done[i].l, k = done[i].k;
+            const edgedict_stack_layer_t& y = d->layers[l];
+            if (l > 0) {
+                // dX_l[chunk] (+)= dG_l[chunk] W_ih, then LayerNorm backward into layer l-1
+                const edgedict_stack_layer_t& z = d->layers[l - 1];
+                const int t0 = k * g[l].cf, t1 = min(y.T, t0 + g[l].cf);
+                const long long r0 = (long long)t0 * B;
+                ED_TRY(st.chain(st.R, st.S));
+                ED_TRY(edgedict_gemm(ED_BF16, ED_BF16, bptr(y.G) + r0 * 4 * H, 4ll * H, 1, y.wih_p,
+                                     y.I, 0, bptr(y.dX) + r0 * y.I, y.I, (t1 - t0) * B, y.I, 4 * H,
+                                     nullptr, nullptr, y.dX == y.dZ ? 1 : 0, 1, st.S));
+                const int u0 = k * g[l - 1].cf, u1 = min(z.T, u0 + g[l - 1].cf);
+                ED_TRY(ed_stack_ln_bwd(bptr(y.dX), (long long)B * y.I, y.I, bptr(z.Yx) + BH,
+                                       z.residual ? bptr(z.X) : nullptr, z.ln_gamma, z.mean, z.rstd,
+                                       bptr(z.dZ), z.dgamma, z.dbeta, B, H, u0, u1, z.reduce, st.S));
+                ED_TRY(st.record(Eb[l - 1][k], st.S));
+                queued[l - 1][k] = 1;
+            }
+            if (done[i].t == 0) {   // the layer's BPTT is complete: weight gradients
+                if (d->flags & EDGEDICT_STACK_DW_AT_END) {
+                    deferred.push_back(l);
+                } else {
+                    ED_TRY(st.chain(st.R, st.W));
+                    ED_TRY(weight_grads(l));
+                }
+            }
+        }
+    }
+    // ---- input LayerNorm parameters: dX_0 = dG_0 W_ih (all frames), then the two column sums
+    {
+        const edgedict_stack_layer_t& y = d->layers[0];
+        bf16_t* dX0 = bptr(ws + wl.dX0);
+        ED_TRY(st.chain(st.R, st.S));
+        ED_TRY(edgedict_gemm(ED_BF16, ED_BF16, y.G, 4ll * H, 1, y.wih_p, y.I, 0, dX0, y.I, y.T * B,
+                             y.I, 4 * H, nullptr, nullptr, 0, 1, st.S));
+        ED_TRY(ed_stack_input_norm_bwd(d->x_dtype, d->x, dX0, d->in_mean, d->in_rstd, d->d_in_gamma,
+                                       d->d_in_beta, B, d->T0, d->I0, st.S));
+    }
+    if (!deferred.empty()) {
+        ED_TRY(st.chain(st.R, st.W));
+        for (int l : deferred) ED_TRY(weight_grads(l));
+    }
+    ED_TRY(st.chain(st.R, st.C));
+    ED_TRY(st.chain(st.S, st.C));
+    if (st.W != st.S) ED_TRY(st.chain(st.W, st.C));
+    return ED_OK;
+}

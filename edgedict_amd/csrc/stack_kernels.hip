@@ -1,0 +1,728 @@
+// Kernels of the layer-pipelined encoder stack (bf16 throughput mode).
+//
+// Reference arithmetic: ResLayerNormLSTM.forward rnnt/models.py:55-75 (nn.LSTM per layer, residual
+// add for layers > 0, LayerNorm, TimeReduction rnnt/models.py:21-29) and its autograd.  PyTorch
+// gate order i,f,g,o; c_t = f*c_{t-1} + i*g; h_t = o*tanh(c_t).
+//
+// Why these kernels exist next to lstm_fast.hip: a dependent kernel boundary costs ~1.7 us on
+// MI355X and one LSTM step of ONE layer cannot use more than ~64 CUs' worth of L2 bandwidth, so a
+// kernel-per-step recurrence leaves the chip idle (7 us/step, 1606 steps).  Here ONE launch carries
+// one time step of EVERY layer that is currently runnable (the layers run as a skewed wavefront,
+// see encoder_stack.hip) plus the LayerNorms of the frames finished by the previous launch:
+//
+//   forward step tile : 64 batch rows x 16 hidden units x 4 gates, K = H split over the 4 waves
+//                       -> 64 workgroups per layer-step, 256 KB of L2 reads each (W_hh slice 128 KB
+//                       + all of h_{t-1} 128 KB), operands in MFMA fragment order (lstm_fast.hip)
+//   backward step tile: 32 rows x 32 units, K = 4H split over the waves -> 64 workgroups, 512 KB
+//   norm              : one wave per output row (pair mean of two frames under time reduction)
+//
+// All activations are TIME-MAJOR ([T, B, *]) so one step touches contiguous rows and a chunk of
+// frames is a contiguous GEMM operand; gate columns are interleaved (ed_gate_col) so the 4 gates
+// of 16 units are one 128-byte line.  Partial sums of the K split are handed to the wave that
+// owns the tile through LDS lane-wise (conflict-free 16-byte accesses); every global access of
+// the epilogue is a 16-byte vector staged through LDS.
+#include "stack_kernels.hpp"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ bf16x8_t ldfrag(const bf16_t* p) {
+    uint4 v = *reinterpret_cast<const uint4*>(p);
+    return *reinterpret_cast<bf16x8_t*>(&v);
+}
+__device__ __forceinline__ bf16x8_t zfrag() {
+    uint4 v = make_uint4(0, 0, 0, 0);
+    return *reinterpret_cast<bf16x8_t*>(&v);
+}
+// v_exp/v_rcp based activations (abs. error ~1e-7; the results are rounded to bf16 anyway)
+__device__ __forceinline__ float fsigmoid(float x) { return __fdividef(1.f, 1.f + __expf(-x)); }
+__device__ __forceinline__ float ftanh(float x) {
+    const float xc = fminf(fmaxf(x, -15.f), 15.f);
+    return 1.f - __fdividef(2.f, 1.f + __expf(2.f * xc));
+}
+
+// =====================================================================================
+// forward
+// =====================================================================================
+constexpr int FCH = 4;   // k-steps in flight per batch: 4 x (4 A + 4 W) x 16 B = 512 B / lane
+
+struct __attribute__((aligned(16))) FwdShared {
+    float4 hand[4][3][4][64];   // [source wave][destination slot][gate][lane]   48 KB
+    bf16_t g[64][72];           // pre-activations in, gates out (64 cols + 8 pad)  9 KB
+    float c[64][20];            // c_{t-1} in, c_t out (16 + 4 pad)                 5 KB
+    bf16_t h[64][24];           // h_t (16 + 8 pad)                                 3 KB
+};
+
+__device__ __forceinline__ void fwd_step_role(const EdFwdStep& p, int ub, int rg, int B, int H,
+                                              FwdShared& sh) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int KS = H >> 5;
+    const int per = (KS + 3) >> 2;
+    const int ks_beg = wave * per, ks_end = min(KS, ks_beg + per);
+    const int MT = (B + 15) >> 4, mt0 = rg * 4, row0 = rg * 64;
+    const long long H4 = 4ll * H;
+
+    // ---- epilogue operands: requested first, parked in registers until the MFMAs are done
+    uint4 gin[2];
+    float4 cin;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + 256 * i, r = id >> 3, part = id & 7, b = row0 + r;
+        gin[i] = make_uint4(0, 0, 0, 0);
+        if (b < B) gin[i] = *reinterpret_cast<const uint4*>(p.G_t + b * H4 + ub * 64 + part * 8);
+    }
+    {
+        const int r = tid >> 2, part = tid & 3, b = row0 + r;
+        cin = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < B) cin = *reinterpret_cast<const float4*>(p.C_prev + (long long)b * H + ub * 16 + part * 4);
+    }
+
+    // ---- W_hh h_{t-1}: this wave's K quarter, all 4 row tiles x 4 gates
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[m][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const bf16_t* abase = p.hfrag_in + lane * 8;
+    const bf16_t* wbase = p.Wfrag + ((long long)ub * 4 * KS * 64 + lane) * 8;
+    for (int ks0 = ks_beg; ks0 < ks_end; ks0 += FCH) {
+        bf16x8_t a[FCH][4], w[FCH][4];
+#pragma unroll
+        for (int i = 0; i < FCH; ++i) {
+            const int ks = min(ks0 + i, ks_end - 1);   // clamp: duplicates are masked below
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+                a[i][m] = (mt0 + m < MT) ? ldfrag(abase + ((long long)(mt0 + m) * KS + ks) * 512) : zfrag();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) w[i][g] = ldfrag(wbase + ((long long)g * KS + ks) * 512);
+        }
+#pragma unroll
+        for (int i = 0; i < FCH; ++i) {
+            if (ks0 + i < ks_end) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], w[i][g], acc[m][g], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- hand the partial tiles to their owners (wave m owns row tile m), park the operands
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        if (m != wave) {
+            const int slot = m < wave ? m : m - 1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                sh.hand[wave][slot][g][lane] = make_float4(acc[m][g][0], acc[m][g][1], acc[m][g][2], acc[m][g][3]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + 256 * i, r = id >> 3, part = id & 7;
+        *reinterpret_cast<uint4*>(&sh.g[r][part * 8]) = gin[i];
+    }
+    *reinterpret_cast<float4*>(&sh.c[tid >> 2][(tid & 3) * 4]) = cin;
+    __syncthreads();
+
+    f32x4_t mine[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        mine[g] = wave == 0 ? acc[0][g] : wave == 1 ? acc[1][g] : wave == 2 ? acc[2][g] : acc[3][g];
+#pragma unroll
+    for (int src = 0; src < 4; ++src) {
+        if (src != wave) {
+            const int slot = wave < src ? wave : wave - 1;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 v = sh.hand[src][slot][g][lane];
+                mine[g][0] += v.x; mine[g][1] += v.y; mine[g][2] += v.z; mine[g][3] += v.w;
+            }
+        }
+    }
+
+    // ---- cell update: lane owns unit u of rows wave*16 + (lane>>4)*4 + q
+    const int u = lane & 15, rbase = wave * 16 + (lane >> 4) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rl = rbase + q;
+        const float ig = fsigmoid(bf16_to_f32(sh.g[rl][u]) + mine[0][q]);
+        const float fg = fsigmoid(bf16_to_f32(sh.g[rl][16 + u]) + mine[1][q]);
+        const float gg = ftanh(bf16_to_f32(sh.g[rl][32 + u]) + mine[2][q]);
+        const float og = fsigmoid(bf16_to_f32(sh.g[rl][48 + u]) + mine[3][q]);
+        const float c = fg * sh.c[rl][u] + ig * gg;
+        const float h = og * ftanh(c);
+        sh.g[rl][u] = f32_to_bf16(ig);
+        sh.g[rl][16 + u] = f32_to_bf16(fg);
+        sh.g[rl][32 + u] = f32_to_bf16(gg);
+        sh.g[rl][48 + u] = f32_to_bf16(og);
+        sh.c[rl][u] = c;
+        sh.h[rl][u] = f32_to_bf16(h);
+    }
+    __syncthreads();
+
+    // ---- 1024 16-byte stores: gates 512, Y 128, fragment image 128, c 256
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int task = tid + 256 * i;
+        if (task < 512) {
+            const int r = task >> 3, part = task & 7, b = row0 + r;
+            if (b < B)
+                *reinterpret_cast<uint4*>(p.G_t + b * H4 + ub * 64 + part * 8) =
+                    *reinterpret_cast<const uint4*>(&sh.g[r][part * 8]);
+        } else if (task < 640) {
+            const int id = task - 512, r = id >> 1, hf = id & 1, b = row0 + r;
+            if (b < B)
+                *reinterpret_cast<uint4*>(p.Y_t + (long long)b * H + ub * 16 + hf * 8) =
+                    *reinterpret_cast<const uint4*>(&sh.h[r][hf * 8]);
+        } else if (task < 768) {
+            const int id = task - 640, m = id >> 5, kg2 = (id >> 4) & 1, r16 = id & 15;
+            const int mt = mt0 + m;
+            if (mt < MT && p.hfrag_out) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (mt * 16 + r16 < B) v = *reinterpret_cast<const uint4*>(&sh.h[m * 16 + r16][kg2 * 8]);
+                const int ks = ub >> 1, kg = (ub & 1) * 2 + kg2;
+                *reinterpret_cast<uint4*>(p.hfrag_out + (((long long)mt * KS + ks) * 64 + kg * 16 + r16) * 8) = v;
+            }
+        } else {
+            const int id = task - 768, r = id >> 2, part = id & 3, b = row0 + r;
+            if (b < B)
+                *reinterpret_cast<float4*>(p.C_t + (long long)b * H + ub * 16 + part * 4) =
+                    *reinterpret_cast<const float4*>(&sh.c[r][part * 4]);
+        }
+    }
+}
+
+// sum / centred sum of squares of one row of (y + r), 16-byte loads; rows are re-read from L1
+__device__ __forceinline__ float nrow_sum(const bf16_t* y, const bf16_t* r, int H, int lane) {
+    float s = 0.f;
+    for (int c = lane * 8; c < H; c += 512) {
+        float a[8];
+        ElemIO<bf16_t>::load_vec(y + c, a);
+        if (r) {
+            float b[8];
+            ElemIO<bf16_t>::load_vec(r + c, b);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] += b[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += a[i];
+    }
+    return wave_sum(s);
+}
+__device__ __forceinline__ float nrow_sqdev(const bf16_t* y, const bf16_t* r, float mean, int H,
+                                            int lane) {
+    float s = 0.f;
+    for (int c = lane * 8; c < H; c += 512) {
+        float a[8];
+        ElemIO<bf16_t>::load_vec(y + c, a);
+        if (r) {
+            float b[8];
+            ElemIO<bf16_t>::load_vec(r + c, b);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] += b[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float d = a[i] - mean;
+            s += d * d;
+        }
+    }
+    return wave_sum(s);
+}
+
+__device__ __forceinline__ void fwd_norm_role(const EdFwdNorm& p, int rb, int B, int H, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int b = rb * 4 + wave;
+    if (b >= B) return;
+    const bf16_t* y[2] = {p.y0 + (long long)b * H, p.y1 ? p.y1 + (long long)b * H : nullptr};
+    const bf16_t* r[2] = {p.r0 ? p.r0 + (long long)b * H : nullptr,
+                          p.r1 ? p.r1 + (long long)b * H : nullptr};
+    float mean[2] = {0.f, 0.f}, rstd[2] = {0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (!y[k]) continue;
+        const float m = nrow_sum(y[k], r[k], H, lane) / (float)H;
+        const float var = nrow_sqdev(y[k], r[k], m, H, lane) / (float)H;
+        mean[k] = m;
+        rstd[k] = rsqrtf(var + eps);
+    }
+    if (lane == 0) {
+        p.mean0[b] = mean[0];
+        p.rstd0[b] = rstd[0];
+        if (y[1]) {
+            p.mean1[b] = mean[1];
+            p.rstd1[b] = rstd[1];
+        }
+    }
+    bf16_t* out = p.out + (long long)b * p.out_stride;
+    for (int c = lane * 8; c < H; c += 512) {
+        float o[8], gm[8], bt[8];
+        const float4 g0 = *reinterpret_cast<const float4*>(p.gamma + c);
+        const float4 g1 = *reinterpret_cast<const float4*>(p.gamma + c + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(p.beta + c);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.beta + c + 4);
+        gm[0] = g0.x; gm[1] = g0.y; gm[2] = g0.z; gm[3] = g0.w;
+        gm[4] = g1.x; gm[5] = g1.y; gm[6] = g1.z; gm[7] = g1.w;
+        bt[0] = b0.x; bt[1] = b0.y; bt[2] = b0.z; bt[3] = b0.w;
+        bt[4] = b1.x; bt[5] = b1.y; bt[6] = b1.z; bt[7] = b1.w;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (!y[k]) continue;
+            float a[8];
+            ElemIO<bf16_t>::load_vec(y[k] + c, a);
+            if (r[k]) {
+                float rr[8];
+                ElemIO<bf16_t>::load_vec(r[k] + c, rr);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) a[i] += rr[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] += (a[i] - mean[k]) * rstd[k] * gm[i] + bt[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] *= p.scale;
+        ElemIO<bf16_t>::store_vec(out + c, o);
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void stack_fwd_kernel(EdFwdLaunch L) {
+    __shared__ FwdShared sh;
+    const int UB = L.H >> 4, RG = (L.B + 63) >> 6;
+    const int nsb = L.nstep * UB * RG;
+    int bid = blockIdx.x;
+    if (bid < nsb) {
+        const int slot = bid / (UB * RG), rem = bid - slot * UB * RG;
+        fwd_step_role(L.step[slot], rem % UB, rem / UB, L.B, L.H, sh);
+    } else {
+        bid -= nsb;
+        const int RB = (L.B + 3) >> 2;
+        fwd_norm_role(L.norm[bid / RB], bid % RB, L.B, L.H, L.eps);
+    }
+}
+
+// =====================================================================================
+// backward (BPTT step)
+// =====================================================================================
+constexpr int BCH = 8;   // k-steps in flight per batch: 8 x (2 A + 2 W) x 16 B = 512 B / lane
+
+struct __attribute__((aligned(16))) BwdShared {
+    float4 hand[4][3][64];   // [source wave][destination slot][lane]   12 KB
+    bf16_t g[32][136];       // gates in, dG out (128 cols + 8 pad)
+    float ct[32][36];        // c_t
+    float cp[32][36];        // c_{t-1}
+    float dc[32][36];        // dL/dc running, in/out
+    bf16_t dy[32][40];       // dL/dh_t from above
+};
+
+__device__ __forceinline__ void bwd_step_role(const EdBwdStep& p, int nb, int rg, int B, int H,
+                                              BwdShared& sh) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int KS = H >> 3;   // 4H / 32
+    const int per = (KS + 3) >> 2;
+    const int ks_beg = wave * per, ks_end = min(KS, ks_beg + per);
+    const int MT = (B + 15) >> 4, mt0 = rg * 2, row0 = rg * 32;
+    const long long H4 = 4ll * H;
+
+    uint4 gin[2], dyin = make_uint4(0, 0, 0, 0);
+    float4 ctin, cpin, dcin;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + 256 * i, r = id >> 4, part = id & 15, b = row0 + r;
+        gin[i] = make_uint4(0, 0, 0, 0);
+        if (b < B) gin[i] = *reinterpret_cast<const uint4*>(p.G_t + b * H4 + nb * 128 + part * 8);
+    }
+    {
+        const int r = tid >> 3, part = tid & 7, b = row0 + r;
+        ctin = cpin = dcin = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < B) {
+            const long long o = (long long)b * H + nb * 32 + part * 4;
+            ctin = *reinterpret_cast<const float4*>(p.C_t + o);
+            cpin = *reinterpret_cast<const float4*>(p.C_prev + o);
+            dcin = *reinterpret_cast<const float4*>(p.dC + o);
+        }
+        if (tid < 128) {
+            const int r2 = tid >> 2, part2 = tid & 3, b2 = row0 + r2;
+            if (p.dY_t && b2 < B)
+                dyin = *reinterpret_cast<const uint4*>(p.dY_t + (long long)b2 * H + nb * 32 + part2 * 8);
+        }
+    }
+
+    f32x4_t acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (p.gfrag_in) {
+        const bf16_t* abase = p.gfrag_in + lane * 8;
+        const bf16_t* wbase = p.WTfrag + ((long long)nb * 2 * KS * 64 + lane) * 8;
+        for (int ks0 = ks_beg; ks0 < ks_end; ks0 += BCH) {
+            bf16x8_t a[BCH][2], w[BCH][2];
+#pragma unroll
+            for (int i = 0; i < BCH; ++i) {
+                const int ks = min(ks0 + i, ks_end - 1);
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    a[i][m] = (mt0 + m < MT) ? ldfrag(abase + ((long long)(mt0 + m) * KS + ks) * 512) : zfrag();
+#pragma unroll
+                for (int n = 0; n < 2; ++n) w[i][n] = ldfrag(wbase + ((long long)n * KS + ks) * 512);
+            }
+#pragma unroll
+            for (int i = 0; i < BCH; ++i) {
+                if (ks0 + i < ks_end) {
+#pragma unroll
+                    for (int m = 0; m < 2; ++m)
+#pragma unroll
+                        for (int n = 0; n < 2; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], w[i][n], acc[m][n], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // wave w owns tile (m = w >> 1, n = w & 1)
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        if (tt != wave) {
+            const int slot = tt < wave ? tt : tt - 1;
+            const f32x4_t v = acc[tt >> 1][tt & 1];
+            sh.hand[wave][slot][lane] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + 256 * i, r = id >> 4, part = id & 15;
+        *reinterpret_cast<uint4*>(&sh.g[r][part * 8]) = gin[i];
+    }
+    {
+        const int r = tid >> 3, part = tid & 7;
+        *reinterpret_cast<float4*>(&sh.ct[r][part * 4]) = ctin;
+        *reinterpret_cast<float4*>(&sh.cp[r][part * 4]) = cpin;
+        *reinterpret_cast<float4*>(&sh.dc[r][part * 4]) = dcin;
+        if (tid < 128) *reinterpret_cast<uint4*>(&sh.dy[tid >> 2][(tid & 3) * 8]) = dyin;
+    }
+    __syncthreads();
+
+    f32x4_t mine = wave == 0 ? acc[0][0] : wave == 1 ? acc[0][1] : wave == 2 ? acc[1][0] : acc[1][1];
+#pragma unroll
+    for (int src = 0; src < 4; ++src) {
+        if (src != wave) {
+            const int slot = wave < src ? wave : wave - 1;
+            const float4 v = sh.hand[src][slot][lane];
+            mine[0] += v.x; mine[1] += v.y; mine[2] += v.z; mine[3] += v.w;
+        }
+    }
+
+    const int m = wave >> 1, n = wave & 1;
+    const int u = lane & 15, ul = n * 16 + u, cb = n * 64 + u, rbase = m * 16 + (lane >> 4) * 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int rl = rbase + q;
+        const float ig = bf16_to_f32(sh.g[rl][cb]), fg = bf16_to_f32(sh.g[rl][cb + 16]);
+        const float gg = bf16_to_f32(sh.g[rl][cb + 32]), og = bf16_to_f32(sh.g[rl][cb + 48]);
+        const float dh = bf16_to_f32(sh.dy[rl][ul]) + mine[q];
+        const float tc = ftanh(sh.ct[rl][ul]);
+        const float dct = sh.dc[rl][ul] + dh * og * (1.f - tc * tc);
+        sh.g[rl][cb] = f32_to_bf16(dct * gg * ig * (1.f - ig));
+        sh.g[rl][cb + 16] = f32_to_bf16(dct * sh.cp[rl][ul] * fg * (1.f - fg));
+        sh.g[rl][cb + 32] = f32_to_bf16(dct * ig * (1.f - gg * gg));
+        sh.g[rl][cb + 48] = f32_to_bf16(dh * tc * og * (1.f - og));
+        sh.dc[rl][ul] = dct * fg;
+    }
+    __syncthreads();
+
+    // 1280 16-byte stores: dG plain 512, dG fragment image 512, dC 256
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int task = tid + 256 * i;
+        if (task < 512) {
+            const int r = task >> 4, part = task & 15, b = row0 + r;
+            if (b < B)
+                *reinterpret_cast<uint4*>(p.G_t + b * H4 + nb * 128 + part * 8) =
+                    *reinterpret_cast<const uint4*>(&sh.g[r][part * 8]);
+        } else if (task < 1024) {
+            const int id = task - 512, mm = id >> 8, ksl = (id >> 6) & 3, kg = (id >> 4) & 3, r16 = id & 15;
+            const int mt = mt0 + mm;
+            if (mt < MT && p.gfrag_out) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (mt * 16 + r16 < B)
+                    v = *reinterpret_cast<const uint4*>(&sh.g[mm * 16 + r16][ksl * 32 + kg * 8]);
+                *reinterpret_cast<uint4*>(p.gfrag_out + (((long long)mt * KS + nb * 4 + ksl) * 64 + kg * 16 + r16) * 8) = v;
+            }
+        } else {
+            const int id = task - 1024, r = id >> 3, part = id & 7, b = row0 + r;
+            if (b < B)
+                *reinterpret_cast<float4*>(p.dC + (long long)b * H + nb * 32 + part * 4) =
+                    *reinterpret_cast<const float4*>(&sh.dc[r][part * 4]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void stack_bwd_kernel(EdBwdLaunch L) {
+    __shared__ BwdShared sh;
+    const int NB = L.H >> 5, RG = (L.B + 31) >> 5;
+    const int bid = blockIdx.x;
+    const int slot = bid / (NB * RG), rem = bid - slot * NB * RG;
+    bwd_step_role(L.step[slot], rem % NB, rem / NB, L.B, L.H, sh);
+}
+
+// =====================================================================================
+// LayerNorm backward, time-major, frames [t0, t1) of one layer.  One wave per input row (t, b):
+//   z = y (+ res), xhat = (z - mean) rstd, dy = dout[t / reduce, b] / reduce, g = dy gamma
+//   dz = rstd (g - mean_H(g) - xhat mean_H(g xhat));  dgamma += dy xhat;  dbeta += dy
+// Lane owns columns lane*8 + 512 i (i < 4, H <= 2048): one pass over the row in registers,
+// dgamma / dbeta accumulated per lane over the wave's rows, combined through LDS + atomics.
+// =====================================================================================
+constexpr int LNB_NB = 4;
+__global__ __launch_bounds__(256) void stack_ln_bwd_kernel(
+    const bf16_t* __restrict__ dout, long long dout_st, long long dout_sb,
+    const bf16_t* __restrict__ y, const bf16_t* __restrict__ res, const float* __restrict__ gamma,
+    const float* __restrict__ mean_in, const float* __restrict__ rstd_in, bf16_t* __restrict__ dz,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int H, int t0, int t1, int reduce) {
+    __shared__ float red[2][3][LNB_NB * 8][64];   // waves 1..3 -> wave 0, 48 KB
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float scale = 1.f / (float)reduce;
+    float ag[LNB_NB][8], ab[LNB_NB][8], gm[LNB_NB][8];
+#pragma unroll
+    for (int i = 0; i < LNB_NB; ++i) {
+        const int c = lane * 8 + 512 * i;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ag[i][e] = 0.f;
+            ab[i][e] = 0.f;
+            gm[i][e] = (c < H) ? gamma[c + e] : 0.f;
+        }
+    }
+    const long long rows = (long long)(t1 - t0) * B;
+    for (long long rr = (long long)blockIdx.x * 4 + wave; rr < rows; rr += (long long)gridDim.x * 4) {
+        const int t = t0 + (int)(rr / B), b = (int)(rr % B);
+        const long long row = (long long)t * B + b;
+        const bf16_t* dyr = dout + (long long)(t / reduce) * dout_st + (long long)b * dout_sb;
+        const bf16_t* yr = y + row * H;
+        const bf16_t* rsr = res ? res + row * H : nullptr;
+        const float m = mean_in[row], rs = rstd_in[row];
+        float dy[LNB_NB][8], xh[LNB_NB][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LNB_NB; ++i) {
+            const int c = lane * 8 + 512 * i;
+            if (c < H) {
+                float z[8];
+                ElemIO<bf16_t>::load_vec(dyr + c, dy[i]);
+                ElemIO<bf16_t>::load_vec(yr + c, z);
+                if (rsr) {
+                    float r2[8];
+                    ElemIO<bf16_t>::load_vec(rsr + c, r2);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) z[e] += r2[e];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    dy[i][e] *= scale;
+                    xh[i][e] = (z[e] - m) * rs;
+                    const float g = dy[i][e] * gm[i][e];
+                    s1 += g;
+                    s2 += g * xh[i][e];
+                    ag[i][e] += dy[i][e] * xh[i][e];
+                    ab[i][e] += dy[i][e];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)H;
+        s2 = wave_sum(s2) / (float)H;
+        bf16_t* dr = dz + row * H;
+#pragma unroll
+        for (int i = 0; i < LNB_NB; ++i) {
+            const int c = lane * 8 + 512 * i;
+            if (c < H) {
+                float o[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = rs * (dy[i][e] * gm[i][e] - s1 - xh[i][e] * s2);
+                ElemIO<bf16_t>::store_vec(dr + c, o);
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int i = 0; i < LNB_NB; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                red[0][wave - 1][i * 8 + e][lane] = ag[i][e];
+                red[1][wave - 1][i * 8 + e][lane] = ab[i][e];
+            }
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < LNB_NB; ++i) {
+            const int c = lane * 8 + 512 * i;
+            if (c < H) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int k = i * 8 + e;
+                    if (dgamma) atomicAdd(dgamma + c + e, ag[i][e] + red[0][0][k][lane] + red[0][1][k][lane] + red[0][2][k][lane]);
+                    if (dbeta) atomicAdd(dbeta + c + e, ab[i][e] + red[1][0][k][lane] + red[1][1][k][lane] + red[1][2][k][lane]);
+                }
+            }
+        }
+    }
+}
+
+// =====================================================================================
+// input LayerNorm (rnnt/models.py:124,132): x [B, T, D] batch-first (fp32 or bf16) ->
+// out [T, B, D] time-major bf16.  One wave per row; D is small (240), scalar loads.
+// =====================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void stack_input_norm_kernel(
+    const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta,
+    bf16_t* __restrict__ out, float* __restrict__ mean_out, float* __restrict__ rstd_out, int B,
+    int Tn, int D, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long rows = (long long)B * Tn;
+    for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
+        const int b = (int)(row / Tn), t = (int)(row % Tn);
+        const T* xr = x + row * D;
+        float s = 0.f;
+        for (int c = lane; c < D; c += 64) s += ElemIO<T>::load(xr + c);
+        const float m = wave_sum(s) / (float)D;
+        float v = 0.f;
+        for (int c = lane; c < D; c += 64) {
+            const float d = ElemIO<T>::load(xr + c) - m;
+            v += d * d;
+        }
+        const float rs = rsqrtf(wave_sum(v) / (float)D + eps);
+        if (lane == 0) {
+            mean_out[row] = m;
+            rstd_out[row] = rs;
+        }
+        bf16_t* o = out + ((long long)t * B + b) * D;
+        for (int c = lane; c < D; c += 64)
+            o[c] = f32_to_bf16((ElemIO<T>::load(xr + c) - m) * rs * gamma[c] + beta[c]);
+    }
+}
+
+// dgamma[c] += sum_rows dX[t,b,c] * xhat[b,t,c];  dbeta[c] += sum_rows dX[t,b,c]
+template <typename T>
+__global__ __launch_bounds__(256) void stack_input_norm_bwd_kernel(
+    const T* __restrict__ x, const bf16_t* __restrict__ dX, const float* __restrict__ mean_in,
+    const float* __restrict__ rstd_in, float* __restrict__ dgamma, float* __restrict__ dbeta, int B,
+    int Tn, int D, int rows_per_block) {
+    const int c = threadIdx.x;
+    if (c >= D) return;
+    const long long rows = (long long)B * Tn;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    const long long r1 = min(rows, r0 + rows_per_block);
+    float ag = 0.f, ab = 0.f;
+    for (long long row = r0; row < r1; ++row) {   // row enumerates time-major (t, b)
+        const int t = (int)(row / B), b = (int)(row % B);
+        const long long xrow = (long long)b * Tn + t;
+        const float dy = bf16_to_f32(dX[row * D + c]);
+        const float xh = (ElemIO<T>::load(x + xrow * D + c) - mean_in[xrow]) * rstd_in[xrow];
+        ag += dy * xh;
+        ab += dy;
+    }
+    atomicAdd(dgamma + c, ag);
+    atomicAdd(dbeta + c, ab);
+}
+
+// Yx[0] <- bf16(h0), Cx[0] <- c0, fragment image of h0 (zeros when the states are null)
+__global__ void stack_init_state_kernel(const float* __restrict__ h0, const float* __restrict__ c0,
+                                        bf16_t* __restrict__ Yx0, float* __restrict__ Cx0,
+                                        bf16_t* __restrict__ hfrag, int B, int H) {
+    const int KS = H >> 5, B16 = (B + 15) / 16 * 16;
+    const long long n = (long long)B16 * H;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / H), j = (int)(i % H);
+        const bool live = b < B;
+        const bf16_t hv = f32_to_bf16((live && h0) ? h0[i] : 0.f);
+        if (live) {
+            Yx0[i] = hv;
+            Cx0[i] = c0 ? c0[i] : 0.f;
+        }
+        hfrag[((((long long)(b >> 4) * KS + (j >> 5)) * 64) + ((j & 31) >> 3) * 16 + (b & 15)) * 8 + (j & 7)] = hv;
+    }
+}
+
+}  // namespace
+
+int ed_stack_launch_fwd(const EdFwdLaunch& L, hipStream_t s) {
+    const int UB = L.H >> 4, RG = (L.B + 63) >> 6, RB = (L.B + 3) >> 2;
+    const int grid = L.nstep * UB * RG + L.nnorm * RB;
+    if (grid == 0) return ED_OK;
+    hipLaunchKernelGGL(stack_fwd_kernel, dim3(grid), dim3(256), 0, s, L);
+    ED_CHECK_LAUNCH("stack_fwd_kernel");
+    return ED_OK;
+}
+
+int ed_stack_launch_bwd(const EdBwdLaunch& L, hipStream_t s) {
+    const int NB = L.H >> 5, RG = (L.B + 31) >> 5;
+    const int grid = L.nstep * NB * RG;
+    if (grid == 0) return ED_OK;
+    hipLaunchKernelGGL(stack_bwd_kernel, dim3(grid), dim3(256), 0, s, L);
+    ED_CHECK_LAUNCH("stack_bwd_kernel");
+    return ED_OK;
+}
+
+int ed_stack_ln_bwd(const bf16_t* dout, long long dout_st, long long dout_sb, const bf16_t* y,
+                    const bf16_t* res, const float* gamma, const float* mean, const float* rstd,
+                    bf16_t* dz, float* dgamma, float* dbeta, int B, int H, int t0, int t1,
+                    int reduce, hipStream_t s) {
+    if (t1 <= t0) return ED_OK;
+    const long long rows = (long long)(t1 - t0) * B;
+    const int grid = ed_grid_for(rows, 4 * 4, 512);   // >= 4 rows per wave: amortise the atomics
+    hipLaunchKernelGGL(stack_ln_bwd_kernel, dim3(grid), dim3(256), 0, s, dout, dout_st, dout_sb, y,
+                       res, gamma, mean, rstd, dz, dgamma, dbeta, B, H, t0, t1, reduce);
+    ED_CHECK_LAUNCH("stack_ln_bwd_kernel");
+    return ED_OK;
+}
+
+int ed_stack_input_norm(int x_dtype, const void* x, const float* gamma, const float* beta,
+                        bf16_t* out, float* mean, float* rstd, int B, int T, int D, float eps,
+                        hipStream_t s) {
+    const int grid = ed_grid_for((long long)B * T, 4, 256 * 16);
+    if (x_dtype == ED_F32)
+        hipLaunchKernelGGL(stack_input_norm_kernel<float>, dim3(grid), dim3(256), 0, s,
+                           (const float*)x, gamma, beta, out, mean, rstd, B, T, D, eps);
+    else
+        hipLaunchKernelGGL(stack_input_norm_kernel<bf16_t>, dim3(grid), dim3(256), 0, s,
+                           (const bf16_t*)x, gamma, beta, out, mean, rstd, B, T, D, eps);
+    ED_CHECK_LAUNCH("stack_input_norm_kernel");
+    return ED_OK;
+}
+
+int ed_stack_input_norm_bwd(int x_dtype, const void* x, const bf16_t* dX, const float* mean,
+                            const float* rstd, float* dgamma, float* dbeta, int B, int T, int D,
+                            hipStream_t s) {
+    const long long rows = (long long)B * T;
+    const int rpb = 64;
+    const int grid = (int)((rows + rpb - 1) / rpb);
+    const int threads = (D + 63) / 64 * 64;
+    if (x_dtype == ED_F32)
+        hipLaunchKernelGGL(stack_input_norm_bwd_kernel<float>, dim3(grid), dim3(threads), 0, s,
+                           (const float*)x, dX, mean, rstd, dgamma, dbeta, B, T, D, rpb);
+    else
+        hipLaunchKernelGGL(stack_input_norm_bwd_kernel<bf16_t>, dim3(grid), dim3(threads), 0, s,
+                           (const bf16_t*)x, dX, mean, rstd, dgamma, dbeta, B, T, D, rpb);
+    ED_CHECK_LAUNCH("stack_input_norm_bwd_kernel");
+    return ED_OK;
+}
+
+int ed_stack_init_state(const float* h0, const float* c0, bf16_t* Yx0, float* Cx0, bf16_t* hfrag,
+                        int B, int H, hipStream_t s) {
+    const long long n = (long long)((B + 15) / 16 * 16) * H;
+    hipLaunchKernelGGL(stack_init_state_kernel, dim3(ed_grid_for(n, 256)), dim3(256), 0, s, h0, c0,
+                       Yx0, Cx0, hfrag, B, H);
+    ED_CHECK_LAUNCH("stack_init_state_kernel");
+    return ED_OK;
+}
+
+int ed_stack_zero(void* p, size_t bytes, hipStream_t s) {
+    ED_CHECK_HIP(hipMemsetAsync(p, 0, bytes, s));
+    return ED_OK;
+}

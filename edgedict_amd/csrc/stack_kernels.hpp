@@ -1,0 +1,79 @@
+// Launch descriptors shared by the encoder-stack kernels (stack_kernels.hip) and the stream
+// scheduler (encoder_stack.hip).  See encoder_stack.hip for the schedule these describe.
+#pragma once
+#include "common.hpp"
+
+constexpr int ED_STACK_MAX_SLOTS = 8;   // layer-steps (and norms) that ride in one launch
+
+// interleaved gate-column order of the stack's G / dG matrices: 64-column groups
+// [16 units x (i,f,g,o)], so the 4 gates of 16 consecutive units are one 128-byte line
+__host__ __device__ inline int ed_gate_col(int gate, int j) {
+    return (j >> 4) * 64 + gate * 16 + (j & 15);
+}
+
+struct EdFwdStep {             // one LSTM time step of one layer, all batch rows
+    bf16_t* G_t;               // [B, 4H] interleaved: in pre-activations, out gates i,f,g,o
+    const bf16_t* hfrag_in;    // h_{t-1} as MFMA A-fragment image [B16/16][H/32][64][8]
+    bf16_t* hfrag_out;         // h_t, same layout (ping-pong partner)
+    bf16_t* Y_t;               // [B, H] plain h_t
+    const float* C_prev;       // [B, H] c_{t-1}
+    float* C_t;                // [B, H] c_t
+    const bf16_t* Wfrag;       // W_hh B-fragment image [H/16][4][H/32][64][8]
+};
+
+struct EdFwdNorm {             // LayerNorm(y + r) of one frame, or the pair mean of two frames
+    const bf16_t* y0;          // [B, H]
+    const bf16_t* r0;          // [B, H] residual or null
+    const bf16_t* y1;          // second frame of a time-reduction pair, or null
+    const bf16_t* r1;
+    const float* gamma;
+    const float* beta;
+    bf16_t* out;               // row b at out + b * out_stride
+    long long out_stride;
+    float* mean0; float* rstd0;   // [B] saved statistics of frame 0 / frame 1
+    float* mean1; float* rstd1;
+    float scale;               // 1 (no reduction) or 0.5 (pair mean; a missing partner counts as 0)
+};
+
+struct EdFwdLaunch {
+    EdFwdStep step[ED_STACK_MAX_SLOTS];
+    EdFwdNorm norm[ED_STACK_MAX_SLOTS];
+    int nstep, nnorm;
+    int B, H;
+    float eps;
+};
+
+struct EdBwdStep {             // one BPTT step of one layer, all batch rows
+    bf16_t* G_t;               // [B, 4H] interleaved: in gates, out dL/d(pre-activation)
+    const bf16_t* gfrag_in;    // dG_{t+1} A-fragment image [B16/16][4H/32][64][8]; null at t = T-1
+    bf16_t* gfrag_out;         // dG_t image; null at t = 0
+    const bf16_t* dY_t;        // [B, H] dL/dh_t from above (null = zeros)
+    const float* C_t;          // [B, H]
+    const float* C_prev;       // [B, H]
+    float* dC;                 // [B, H] running dL/dc, in/out
+    const bf16_t* WTfrag;      // W_hh^T B-fragment image [H/16][4H/32][64][8], K interleaved
+};
+
+struct EdBwdLaunch {
+    EdBwdStep step[ED_STACK_MAX_SLOTS];
+    int nstep;
+    int B, H;
+};
+
+// kernels / launchers implemented in stack_kernels.hip
+int ed_stack_launch_fwd(const EdFwdLaunch& L, hipStream_t s);
+int ed_stack_launch_bwd(const EdBwdLaunch& L, hipStream_t s);
+// time-major LayerNorm backward over frames [t0, t1) of one layer
+int ed_stack_ln_bwd(const bf16_t* dout, long long dout_st, long long dout_sb, const bf16_t* y,
+                    const bf16_t* res, const float* gamma, const float* mean, const float* rstd,
+                    bf16_t* dz, float* dgamma, float* dbeta, int B, int H, int t0, int t1,
+                    int reduce, hipStream_t s);
+int ed_stack_input_norm(int x_dtype, const void* x, const float* gamma, const float* beta,
+                        bf16_t* out, float* mean, float* rstd, int B, int T, int D, float eps,
+                        hipStream_t s);
+int ed_stack_input_norm_bwd(int x_dtype, const void* x, const bf16_t* dX, const float* mean,
+                            const float* rstd, float* dgamma, float* dbeta, int B, int T, int D,
+                            hipStream_t s);
+int ed_stack_init_state(const float* h0, const float* c0, bf16_t* Yx0, float* Cx0, bf16_t* hfrag,
+                        int B, int H, hipStream_t s);
+int ed_stack_zero(void* p, size_t bytes, hipStream_t s);

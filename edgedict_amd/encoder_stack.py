@@ -1,0 +1,234 @@
+"""Host side of the layer-pipelined encoder stack (csrc/encoder_stack.hip).
+
+``EncoderStackFn`` is the autograd node that stands in for the reference's
+``Encoder.forward`` body up to (not including) the output projection — input LayerNorm and the
+``ResLayerNormLSTM`` loop, rnnt/models.py:55-75,124,131-134 — when the compute dtype is bf16.
+It allocates every buffer with the caching allocator, fills the C descriptors
+(``edgedict_stack_desc_t`` / ``edgedict_stack_layer_t`` in include/edgedict_hip.h) and makes ONE
+native call per direction; the stream scheduling lives in the library.
+"""
+import ctypes
+import os
+import weakref
+
+import torch
+
+from . import _lib, config, ops
+from ._lib import check, dtype_code, ptr, stream_ptr
+
+F32 = torch.float32
+BF16 = torch.bfloat16
+_vp, _fp = ctypes.c_void_p, ctypes.c_void_p
+
+
+class StackLayer(ctypes.Structure):
+    _fields_ = [("T", ctypes.c_int), ("I", ctypes.c_int), ("reduce", ctypes.c_int),
+                ("residual", ctypes.c_int),
+                ("wih_p", _vp), ("bias_p", _fp), ("whh_f", _vp), ("whh_b", _vp),
+                ("ln_gamma", _fp), ("ln_beta", _fp),
+                ("X", _vp), ("G", _vp), ("Yx", _vp), ("Cx", _fp), ("mean", _fp), ("rstd", _fp),
+                ("dZ", _vp), ("dX", _vp), ("dW_ih", _fp), ("dW_hh", _fp), ("db", _fp),
+                ("dgamma", _fp), ("dbeta", _fp)]
+
+
+class StackDesc(ctypes.Structure):
+    _fields_ = [("B", ctypes.c_int), ("H", ctypes.c_int), ("L", ctypes.c_int),
+                ("chunk", ctypes.c_int), ("lag", ctypes.c_int), ("split_k", ctypes.c_int),
+                ("flags", ctypes.c_int), ("eps", ctypes.c_float),
+                ("layers", ctypes.POINTER(StackLayer)),
+                ("x", _vp), ("x_dtype", ctypes.c_int), ("T0", ctypes.c_int), ("I0", ctypes.c_int),
+                ("in_gamma", _fp), ("in_beta", _fp), ("in_mean", _fp), ("in_rstd", _fp),
+                ("h0", _fp), ("c0", _fp), ("out", _vp), ("dout", _vp),
+                ("d_in_gamma", _fp), ("d_in_beta", _fp), ("ws", _vp), ("ws_bytes", ctypes.c_size_t)]
+
+
+SERIAL = 1
+DW_AT_END = 2
+
+# schedule knobs (env overrides are for tuning runs; the defaults are what bench.py measures)
+CHUNK = int(os.environ.get("EDGEDICT_STACK_CHUNK", "8"))
+LAG = int(os.environ.get("EDGEDICT_STACK_LAG", "0"))
+SPLIT_K = int(os.environ.get("EDGEDICT_STACK_SPLITK", "0"))
+FLAGS = int(os.environ.get("EDGEDICT_STACK_FLAGS", "0"))
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def supported(cd, H, I0, L, reductions):
+    return (cd == BF16 and H % 32 == 0 and 32 <= H <= 2048 and I0 % 8 == 0 and 8 <= I0 <= 1024
+            and 1 <= L <= 8 and all(r in (1, 2) for r in reductions) and config.USE_ENCODER_STACK)
+
+
+class _PackedLayer:
+    """bf16 weight images of one LSTM layer, rebuilt when the fp32 masters change."""
+    __slots__ = ("key", "ref", "wih_p", "bias_p", "whh_f", "whh_b")
+
+    def __init__(self, owner):
+        self.key = None
+        self.ref = weakref.ref(owner)
+
+
+_PACKED = {}
+
+
+def packed_weights(w_ih, w_hh, b_ih, b_hh):
+    ent = _PACKED.get(id(w_hh))
+    if ent is None or ent.ref() is not w_hh:     # ids are recycled: the entry must be this tensor's
+        ent = _PACKED[id(w_hh)] = _PackedLayer(w_hh)
+    key = (w_ih.data_ptr(), w_hh.data_ptr(), w_ih._version, w_hh._version, b_ih._version,
+           b_hh._version, config.param_epoch())
+    if ent.key != key:
+        H4, I = w_ih.shape
+        H = H4 // 4
+        dev = w_ih.device
+        ent.wih_p = torch.empty(H4, I, dtype=BF16, device=dev)
+        ent.bias_p = torch.empty(H4, dtype=F32, device=dev)
+        ent.whh_f = torch.empty(H4 * H, dtype=BF16, device=dev)
+        ent.whh_b = torch.empty(H4 * H, dtype=BF16, device=dev)
+        srcs = [t.detach().contiguous() for t in (w_ih, w_hh, b_ih, b_hh)]
+        for t in srcs:
+            if t.dtype != F32:
+                raise TypeError("encoder stack: master weights must be fp32")
+        lib = _lib.load()
+        check(lib.edgedict_stack_pack_weights(ptr(srcs[0]), ptr(srcs[1]), ptr(srcs[2]), ptr(srcs[3]),
+                                              H, I, ptr(ent.wih_p), ptr(ent.bias_p), ptr(ent.whh_f),
+                                              ptr(ent.whh_b), stream_ptr()), "stack_pack_weights")
+        ent.key = key
+    return ent
+
+
+def clear_cache():
+    _PACKED.clear()
+
+
+class _Plan:
+    """Buffers + descriptors of one forward/backward pair."""
+
+    def __init__(self, x, in_norm, layers, reductions, h0, c0, flags):
+        self.keep = []          # tensors referenced by raw pointer from the descriptors
+        B, T0, I0 = x.shape
+        dev = x.device
+        L = len(layers)
+        H = layers[0][1].shape[1]
+        self.B, self.H, self.L, self.T0, self.I0 = B, H, L, T0, I0
+        self.x = x
+        self.in_mean = torch.empty(B * T0, dtype=F32, device=dev)
+        self.in_rstd = torch.empty(B * T0, dtype=F32, device=dev)
+        self.larr = (StackLayer * L)()
+        self.layer_bufs = []
+        T, I = T0, I0
+        for l, (w_ih, w_hh, b_ih, b_hh, ln_w, ln_b) in enumerate(layers):
+            pk = packed_weights(w_ih, w_hh, b_ih, b_hh)
+            bufs = dict(
+                X=torch.empty(T, B, I, dtype=BF16, device=dev),
+                G=torch.empty(T, B, 4 * H, dtype=BF16, device=dev),
+                Yx=torch.empty(T + 1, B, H, dtype=BF16, device=dev),
+                Cx=torch.empty(T + 1, B, H, dtype=F32, device=dev),
+                mean=torch.empty(T, B, dtype=F32, device=dev),
+                rstd=torch.empty(T, B, dtype=F32, device=dev))
+            self.layer_bufs.append(bufs)
+            y = self.larr[l]
+            y.T, y.I, y.reduce, y.residual = T, I, reductions[l], int(l != 0)
+            y.wih_p, y.bias_p, y.whh_f, y.whh_b = map(_p, (pk.wih_p, pk.bias_p, pk.whh_f, pk.whh_b))
+            g, b = ln_w.detach(), ln_b.detach()
+            y.ln_gamma, y.ln_beta = _p(g), _p(b)
+            self.keep += [pk.wih_p, pk.bias_p, pk.whh_f, pk.whh_b, g, b]
+            for k, v in bufs.items():
+                setattr(y, k, _p(v))
+            T = (T + reductions[l] - 1) // reductions[l]
+            I = H
+        self.T_out = T
+        self.out = torch.empty(B, T, H, dtype=BF16, device=dev)
+        d = self.desc = StackDesc()
+        d.B, d.H, d.L = B, H, L
+        d.chunk, d.lag, d.split_k, d.flags, d.eps = CHUNK, LAG, SPLIT_K, flags, 1e-5
+        d.layers = ctypes.cast(self.larr, ctypes.POINTER(StackLayer))
+        d.x, d.x_dtype, d.T0, d.I0 = _p(x), dtype_code(x.dtype), T0, I0
+        ig, ib = in_norm[0].detach(), in_norm[1].detach()
+        self.keep += [ig, ib, h0, c0]
+        d.in_gamma, d.in_beta = _p(ig), _p(ib)
+        d.in_mean, d.in_rstd = _p(self.in_mean), _p(self.in_rstd)
+        d.h0, d.c0 = _p(h0), _p(c0)
+        d.out = _p(self.out)
+        lib = _lib.load()
+        d.ws, d.ws_bytes = None, 0
+        n = lib.edgedict_stack_workspace_bytes(ctypes.byref(d))
+        self.ws = torch.empty(n, dtype=torch.uint8, device=dev)
+        d.ws, d.ws_bytes = _p(self.ws), n
+
+    def forward(self):
+        lib = _lib.load()
+        check(lib.edgedict_stack_forward(ctypes.byref(self.desc), stream_ptr()), "stack_forward")
+
+    def final_states(self):
+        hN = torch.stack([b["Yx"][-1] for b in self.layer_bufs], 0).float()
+        cN = torch.stack([b["Cx"][-1] for b in self.layer_bufs], 0).clone()
+        return hN, cN
+
+    def backward(self, dout):
+        dev = dout.device
+        B, H = self.B, self.H
+        grads = []
+        d = self.desc
+        for l in range(self.L):
+            y = self.larr[l]
+            T, I = y.T, y.I
+            dZ = torch.empty(T, B, H, dtype=BF16, device=dev)
+            gb = dict(dZ=dZ, dX=dZ if y.residual else (torch.empty(T, B, I, dtype=BF16, device=dev)
+                                                       if l > 0 else None),
+                      dW_ih=torch.empty(4 * H, I, dtype=F32, device=dev),
+                      dW_hh=torch.empty(4 * H, H, dtype=F32, device=dev),
+                      db=torch.empty(4 * H, dtype=F32, device=dev),
+                      dgamma=torch.zeros(H, dtype=F32, device=dev),
+                      dbeta=torch.zeros(H, dtype=F32, device=dev))
+            for k, v in gb.items():
+                setattr(y, k, _p(v))
+            grads.append(gb)
+        dig = torch.zeros(self.I0, dtype=F32, device=dev)
+        dib = torch.zeros(self.I0, dtype=F32, device=dev)
+        dout = dout.contiguous()
+        d.dout, d.d_in_gamma, d.d_in_beta = _p(dout), _p(dig), _p(dib)
+        lib = _lib.load()
+        check(lib.edgedict_stack_backward(ctypes.byref(d), stream_ptr()), "stack_backward")
+        return dig, dib, grads
+
+
+class EncoderStackFn(torch.autograd.Function):
+    """(xs [B,T0,I0], in_gamma, in_beta, 6 tensors per layer..., h0, c0, reductions, flags)
+    -> (out [B,T',H] bf16, hN [L,B,H] f32, cN [L,B,H] f32)"""
+
+    @staticmethod
+    def forward(ctx, xs, in_g, in_b, h0, c0, reductions, flags, *params):
+        assert len(params) % 6 == 0
+        layers = [params[i:i + 6] for i in range(0, len(params), 6)]
+        x = xs.contiguous()
+        if x.dtype not in (F32, BF16):
+            x = x.float()
+        plan = _Plan(x, (in_g, in_b), layers, list(reductions), h0, c0,
+                     FLAGS if flags is None else flags)
+        with ops.timed("enc_stack_fwd_T%d_L%d" % (x.shape[1], len(layers))):
+            plan.forward()
+        hN, cN = plan.final_states()
+        out, plan.out = plan.out, None     # the descriptor keeps the raw pointer; no ctx <-> output cycle
+        ctx.plan = plan
+        ctx.nparams = len(params)
+        ctx.mark_non_differentiable(hN, cN)
+        return out, hN, cN
+
+    @staticmethod
+    def backward(ctx, dout, _dh, _dc):
+        plan = ctx.plan
+        if plan is None:
+            raise RuntimeError("edgedict_amd: the encoder stack's saved activations were consumed "
+                               "by a previous backward (retain_graph is not supported)")
+        ctx.plan = None
+        if dout.dtype != BF16:
+            dout = dout.to(BF16)
+        with ops.timed("enc_stack_bwd_T%d_L%d" % (plan.T0, plan.L)):
+            dig, dib, grads = plan.backward(dout)
+        out = [None, dig, dib, None, None, None, None]
+        for gb in grads:
+            out += [gb["dW_ih"], gb["dW_hh"], gb["db"], gb["db"].clone(), gb["dgamma"], gb["dbeta"]]
+        return tuple(out)

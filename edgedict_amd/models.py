@@ -27,7 +27,7 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import config, ops
+from . import config, encoder_stack, ops
 from ._lib import require_cuda
 from .loss import _RNNTLossFn
 from .tokenizer import BOS, NUL, PAD
@@ -406,8 +406,24 @@ class Encoder(nn.Module):
     def forward(self, xs, hiddens=None):
         require_cuda(xs)
         cd = getattr(self, "compute_dtype", None) or config.get_compute_dtype()
-        xs = _InputNormFn.apply(xs, self.norm.weight, self.norm.bias, cd)
-        xs, hiddens = self.lstm(xs, hiddens, cd)
+        lstm = self.lstm
+        if (isinstance(lstm, ResLayerNormLSTM) and xs.dim() == 3 and xs.shape[1] > 0
+                and encoder_stack.supported(cd, lstm.hidden_size, xs.shape[2], len(lstm.lstms),
+                                            lstm.reductions)):
+            # bf16: input LayerNorm + all layers as one layer-pipelined native call per direction
+            h0 = c0 = None
+            if hiddens is not None:
+                h0 = _state(hiddens[0]).contiguous()
+                c0 = _state(hiddens[1]).contiguous()
+            params = []
+            for m, proj in zip(lstm.lstms, lstm.projs):
+                params += list(m.layer(0)) + [proj[0].weight, proj[0].bias]
+            xs, h, c = encoder_stack.EncoderStackFn.apply(
+                xs, self.norm.weight, self.norm.bias, h0, c0, tuple(lstm.reductions), None, *params)
+            hiddens = (h, c)
+        else:
+            xs = _InputNormFn.apply(xs, self.norm.weight, self.norm.bias, cd)
+            xs, hiddens = self.lstm(xs, hiddens, cd)
         if self.has_proj:
             xs = _LinearFn.apply(xs, self.proj.weight, self.proj.bias, cd)
         return xs, hiddens

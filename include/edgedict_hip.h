@@ -145,6 +145,87 @@ int edgedict_lstm_backward(int dtype, void* G, const void* dY, const float* Cst,
                            int H, void* ws, void* stream);
 
 /* ------------------------------------------------------------------------------------
+ * Layer-pipelined LSTM encoder stack (bf16).  One call per direction replaces the whole of
+ * Encoder.forward's LayerNorm + ResLayerNormLSTM.forward (rnnt/models.py:55-75,124,131-134:
+ * per layer nn.LSTM, residual add for layers > 0, LayerNorm, optional TimeReduction
+ * rnnt/models.py:21-29) and its autograd.  The layers run as a skewed wavefront: one launch
+ * carries a time step of every runnable layer, the input products are chunked GEMMs on an
+ * internal side stream, weight gradients overlap the BPTT of the layers below
+ * (csrc/encoder_stack.hip).  The caller's stream is forked at entry and joined at exit.
+ *
+ * Layouts (all device memory, owned by the caller, kept from forward to backward):
+ *   activations are TIME-MAJOR;  gate columns of G are interleaved: column of (gate g, unit j)
+ *   = (j/16)*64 + g*16 + j%16  (gate order i,f,g,o);  weight images come from
+ *   edgedict_stack_pack_weights (rebuilt whenever the fp32 master weights change).
+ * Limits: H % 32 == 0, H <= 2048, L <= 8, reduce in {1,2}, residual layers need I == H.
+ * The library keeps three internal streams and an event pool per device (created on first use).
+ */
+typedef struct edgedict_stack_layer {
+    int T;                 /* time steps of this layer */
+    int I;                 /* input width */
+    int reduce;            /* time reduction after this layer's LayerNorm: 1 or 2 */
+    int residual;          /* LayerNorm(y + x) instead of LayerNorm(y) */
+    const void* wih_p;     /* bf16 [4H, I]  rows in interleaved gate order */
+    const float* bias_p;   /* f32  [4H]     b_ih + b_hh, interleaved */
+    const void* whh_f;     /* bf16 forward fragment image of W_hh (4H*H) */
+    const void* whh_b;     /* bf16 backward fragment image of W_hh (4H*H); backward only */
+    const float* ln_gamma; /* f32 [H] */
+    const float* ln_beta;  /* f32 [H] */
+    void* X;               /* bf16 [T, B, I]    layer input (layer 0: written by the input LayerNorm) */
+    void* G;               /* bf16 [T, B, 4H]   gates after forward, dL/d(pre-activation) after backward */
+    void* Yx;              /* bf16 [T+1, B, H]  row 0 = h0, row t+1 = h_t */
+    float* Cx;             /* f32  [T+1, B, H]  row 0 = c0, row t+1 = c_t */
+    float* mean;           /* f32  [T, B] LayerNorm statistics */
+    float* rstd;
+    /* backward only */
+    void* dZ;              /* bf16 [T, B, H] dL/d(LayerNorm input) = dL/dh_t from above */
+    void* dX;              /* bf16 [T, B, I] dL/d(layer input); pass dZ itself for residual layers
+                              (the product is accumulated in place); unused for layer 0 */
+    float* dW_ih;          /* f32 [4H, I] out, natural gate order */
+    float* dW_hh;          /* f32 [4H, H] out */
+    float* db;             /* f32 [4H] out (gradient of b_ih and of b_hh) */
+    float* dgamma;         /* f32 [H] ACCUMULATED (+=): zero before the call */
+    float* dbeta;
+} edgedict_stack_layer_t;
+
+#define EDGEDICT_STACK_SERIAL 1     /* run everything on the caller's stream (debug / bit-exact check) */
+#define EDGEDICT_STACK_DW_AT_END 2  /* weight gradients after the BPTT instead of under it */
+
+typedef struct edgedict_stack_desc {
+    int B, H, L;
+    int chunk;             /* frames (at the stack's output rate) per input-product chunk */
+    int lag;               /* launches between consecutive layers; 0 = chunk*f0 + 8 */
+    int split_k;           /* split-K of the weight-gradient GEMMs; 0 = automatic */
+    int flags;
+    float eps;
+    const edgedict_stack_layer_t* layers;   /* HOST array [L] */
+    const void* x;         /* [B, T0, I0] batch-first encoder input, x_dtype (ED_F32 / ED_BF16) */
+    int x_dtype, T0, I0;
+    const float* in_gamma; /* f32 [I0] input LayerNorm */
+    const float* in_beta;
+    float* in_mean;        /* f32 [B*T0] */
+    float* in_rstd;
+    const float* h0;       /* f32 [L, B, H] nullable (= zeros) */
+    const float* c0;
+    void* out;             /* bf16 [B, T_out, H] batch-first stack output */
+    const void* dout;      /* backward: bf16 [B, T_out, H] */
+    float* d_in_gamma;     /* backward: f32 [I0] ACCUMULATED */
+    float* d_in_beta;
+    void* ws;              /* edgedict_stack_workspace_bytes(desc) bytes, 256-byte aligned */
+    size_t ws_bytes;
+} edgedict_stack_desc_t;
+
+/* sizeof(edgedict_stack_layer_t) (which = 0) / sizeof(edgedict_stack_desc_t) (which = 1): lets a
+ * foreign-language binding verify its struct mirror */
+size_t edgedict_stack_struct_bytes(int which);
+size_t edgedict_stack_workspace_bytes(const edgedict_stack_desc_t* desc);
+int edgedict_stack_pack_weights(const float* w_ih, const float* w_hh, const float* b_ih,
+                                const float* b_hh, int H, int I, void* wih_p, float* bias_p,
+                                void* whh_f, void* whh_b, void* stream);
+int edgedict_stack_forward(const edgedict_stack_desc_t* desc, void* stream);
+int edgedict_stack_backward(const edgedict_stack_desc_t* desc, void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Streaming helpers.
  * cast / transpose: weight copies in the compute dtype (fp32 master -> bf16), dst[c][r]=src[r][c].
  * colsum: out[n] += sum_m x[m*ld+n]  (bias gradients; ATOMIC accumulate into fp32 out).

@@ -1,0 +1,121 @@
+"""GPU parity of the layer-pipelined bf16 encoder stack (csrc/encoder_stack.hip, reference
+arithmetic rnnt/models.py:55-75,124,131-134).
+
+Three checkers, from strict to loose:
+  1. the multi-stream wavefront schedule against the SAME kernels run serially on one stream:
+     bit-exact outputs, states and weight gradients (split_k = 1 makes the GEMMs deterministic);
+  2. against the per-layer bf16 path (lstm_fast.hip + norm.hip), which differs only in
+     activation-function rounding;
+  3. against the fp32 parity mode of the engine (itself pinned to the reference goldens in
+     test_models_gpu.py) at bf16 tolerance, forward and every parameter gradient.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# (B, T0, I0, H, L, time_reductions, chunk, lag)
+CASES = [
+    (2, 9, 16, 32, 1, [], 2, 0),
+    (3, 14, 24, 32, 3, [1], 1, 0),
+    (5, 23, 240, 64, 4, [1], 2, 0),
+    (18, 17, 40, 96, 3, [0, 1], 2, 7),
+    (70, 12, 16, 32, 2, [0], 3, 0),
+    (4, 50, 32, 64, 6, [1], 4, 0),
+]
+
+
+def _encoder(case, seed=0):
+    from edgedict_amd.models import Encoder
+    B, T0, I0, H, L, red, chunk, lag = case
+    torch.manual_seed(seed)
+    enc = Encoder(input_size=I0, hidden_size=H, num_layers=L, dropout=0.0, proj_size=24,
+                  time_reductions=red)
+    with torch.no_grad():   # non-trivial LayerNorm affine parameters
+        for p in enc.parameters():
+            if p.dim() == 1 and p.numel() in (I0, H):
+                p.add_(0.3 * torch.randn_like(p))
+    enc = enc.cuda()
+    g = torch.Generator(device="cpu").manual_seed(seed + 1)
+    xs = torch.randn(B, T0, I0, generator=g).cuda()
+    return enc, xs
+
+
+def _run(enc, xs, dtype, use_stack=True, flags=None, chunk=8, lag=0, hiddens=None, seed=5):
+    from edgedict_amd import config, encoder_stack
+    old = (config.USE_ENCODER_STACK, encoder_stack.CHUNK, encoder_stack.LAG, encoder_stack.FLAGS,
+           encoder_stack.SPLIT_K)
+    config.USE_ENCODER_STACK = use_stack
+    encoder_stack.CHUNK, encoder_stack.LAG, encoder_stack.SPLIT_K = chunk, lag, 1
+    encoder_stack.FLAGS = 0 if flags is None else flags
+    try:
+        enc.compute_dtype = dtype
+        enc.zero_grad(set_to_none=True)
+        out, (h, c) = enc(xs, hiddens)
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        w = torch.randn(out.shape, generator=g).cuda()
+        (out.float() * w).sum().backward()
+        torch.cuda.synchronize()
+        grads = {n: p.grad.detach().clone() for n, p in enc.named_parameters()}
+        return out.detach().float(), h.detach(), c.detach(), grads
+    finally:
+        (config.USE_ENCODER_STACK, encoder_stack.CHUNK, encoder_stack.LAG, encoder_stack.FLAGS,
+         encoder_stack.SPLIT_K) = old
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_wavefront_schedule_is_bit_exact_vs_serial(hip_lib, case):
+    from edgedict_amd import encoder_stack
+    enc, xs = _encoder(case)
+    a = _run(enc, xs, torch.bfloat16, flags=0, chunk=case[6], lag=case[7])
+    b = _run(enc, xs, torch.bfloat16, flags=encoder_stack.SERIAL, chunk=case[6], lag=case[7])
+    c = _run(enc, xs, torch.bfloat16, flags=encoder_stack.DW_AT_END, chunk=case[6] + 1, lag=case[7])
+    for other in (b, c):
+        assert torch.equal(a[0], other[0]) and torch.equal(a[1], other[1]) and torch.equal(a[2], other[2])
+        for n in a[3]:
+            if "norm" in n or "projs" in n:   # LayerNorm parameter gradients use fp32 atomics
+                scale = max(a[3][n].abs().max().item(), 1e-6)
+                assert (a[3][n] - other[3][n]).abs().max().item() <= 1e-4 * scale, n
+            else:
+                assert torch.equal(a[3][n], other[3][n]), n
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_stack_tracks_fp32_parity_mode(hip_lib, case):
+    enc, xs = _encoder(case)
+    ref = _run(enc, xs, torch.float32)
+    got = _run(enc, xs, torch.bfloat16, chunk=case[6], lag=case[7])
+    old = _run(enc, xs, torch.bfloat16, use_stack=False)
+    assert got[0].shape == ref[0].shape and got[1].shape == ref[1].shape
+
+    def rel(a, b):
+        return (a.double() - b.double()).norm().item() / max(b.double().norm().item(), 1e-12)
+
+    # forward: bf16 activations through up to 6 layers; the per-layer bf16 path is the yardstick
+    assert rel(got[0], ref[0]) < 3e-2, rel(got[0], ref[0])
+    assert rel(got[0], ref[0]) < 2.0 * rel(old[0], ref[0]) + 5e-3
+    assert rel(got[1], ref[1]) < 3e-2 and rel(got[2], ref[2]) < 3e-2
+    for n in ref[3]:
+        r_new, r_old = rel(got[3][n], ref[3][n]), rel(old[3][n], ref[3][n])
+        assert r_new < 6e-2 and r_new < 2.0 * r_old + 2e-2, (n, r_new, r_old)
+
+
+def test_stack_initial_states_and_chunked_streaming(hip_lib):
+    """Encoder(x, (h, c)) with carried state (rnnt/stream.py:90-91 usage) through the stack."""
+    case = (3, 12, 16, 32, 3, [1], 2, 0)
+    enc, xs = _encoder(case)
+    enc.compute_dtype = torch.bfloat16
+    with torch.no_grad():
+        full, (hf, cf) = enc(xs)
+        y1, (h1, c1) = enc(xs[:, :6])
+        y2, (h2, c2) = enc(xs[:, 6:], (h1, c1))
+    # h is carried as fp32(bf16(h)) and c as fp32, exactly what the kernels keep: bit-exact
+    assert torch.equal(torch.cat([y1, y2], 1), full)
+    assert torch.equal(h2, hf) and torch.equal(c2, cf)
+
+
+def test_stack_rejects_bad_geometry(hip_lib):
+    from edgedict_amd import encoder_stack
+    assert not encoder_stack.supported(torch.bfloat16, 48, 16, 2, [1, 1])     # H % 32
+    assert not encoder_stack.supported(torch.float32, 64, 16, 2, [1, 1])      # fp32 -> per-layer path
+    assert encoder_stack.supported(torch.bfloat16, 64, 16, 2, [1, 2])

@@ -34,3 +34,24 @@ def test_product_path_refuses_cpu_tensors(hip_lib):
     lens = torch.tensor([2], dtype=torch.int32)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         RNNTLoss(check_lengths=False)(acts, labels, lens, lens)
+
+
+def test_encoder_stack_struct_mirrors_match_the_header(hip_lib):
+    """The ctypes mirrors in edgedict_amd/encoder_stack.py must have the C structs' sizes."""
+    from edgedict_amd import encoder_stack as es
+    assert ctypes.sizeof(es.StackLayer) == hip_lib.edgedict_stack_struct_bytes(0)
+    assert ctypes.sizeof(es.StackDesc) == hip_lib.edgedict_stack_struct_bytes(1)
+
+
+def test_encoder_stack_validates_before_launching(hip_lib):
+    from edgedict_amd import encoder_stack as es
+    layers = (es.StackLayer * 1)()
+    d = es.StackDesc()
+    d.B, d.H, d.L, d.chunk, d.T0, d.I0 = 4, 48, 1, 8, 10, 16     # H % 32 != 0
+    d.layers = ctypes.cast(layers, ctypes.POINTER(es.StackLayer))
+    assert hip_lib.edgedict_stack_forward(ctypes.byref(d), None) == -1
+    assert b"H % 32" in hip_lib.edgedict_last_error()
+    assert hip_lib.edgedict_stack_workspace_bytes(ctypes.byref(d)) > 0
+    rc = hip_lib.edgedict_stack_pack_weights(None, None, None, None, 64, 16, None, None, None,
+                                             None, None)
+    assert rc == -1
