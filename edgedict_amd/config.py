@@ -34,6 +34,14 @@ FORCE_GENERIC_LSTM = False
 # through the per-layer kernels (test hook / A-B comparison)
 USE_ENCODER_STACK = os.environ.get("EDGEDICT_ENCODER_STACK", "1") != "0"
 
+# weight gradients that feed nothing downstream are accumulated straight into existing .grad
+# buffers on the auxiliary stream, concurrently with the rest of the backward pass (side.py)
+DEFER_WEIGHT_GRADS = os.environ.get("EDGEDICT_DEFER_DW", "1") != "0"
+
+# Transducer.forward runs the prediction network on the auxiliary stream, concurrently with the
+# encoder (and, through autograd's stream replay, its backward concurrently with the encoder's)
+DECODER_ON_AUX_STREAM = os.environ.get("EDGEDICT_DECODER_AUX", "1") != "0"
+
 _state = {"dtype": _parse(os.environ.get("EDGEDICT_DTYPE", "fp32")), "epoch": 0}
 
 

@@ -41,8 +41,26 @@ __global__ void pack_wih_kernel(const float* __restrict__ W, const float* __rest
         if (k == 0) bp[kap] = b_ih[row] + b_hh[row];
     }
 }
-// backward image of W_hh: frag[nt16][ks][lane][8], n = lane & 15 -> hidden unit nt16*16 + n,
-// k = interleaved gate column ks*32 + (lane >> 4)*8 + e
+// Fragment images of W_hh.  A wave's loads walk each image front to back (k-step major, the
+// operands of one k-step adjacent), so a workgroup's slice is ONE sequential stream instead of
+// several streams a power-of-two apart (which would camp on the same L2 channel).
+// forward: frag[ub][ks][gate][lane][8]: n = lane & 15 -> W_hh row gate*H + ub*16 + n,
+//          k = ks*32 + (lane >> 4)*8 + e
+__global__ void pack_whh_fwd_kernel(const float* __restrict__ W, bf16_t* __restrict__ out, int H) {
+    const long long n = 4ll * H * H;
+    const int KS = H >> 5;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const long long blk = i >> 9;
+        const int g = (int)(blk & 3), ks = (int)((blk >> 2) % KS), ub = (int)((blk >> 2) / KS);
+        const int row = g * H + ub * 16 + (lane & 15);
+        const int k = ks * 32 + (lane >> 4) * 8 + e;
+        out[i] = f32_to_bf16(W[(long long)row * H + k]);
+    }
+}
+// backward: frag[nb32][ks][n2][lane][8]: n = lane & 15 -> hidden unit (nb32*2 + n2)*16 + n,
+//           k = interleaved gate column ks*32 + (lane >> 4)*8 + e
 __global__ void pack_whh_bwd_kernel(const float* __restrict__ W, bf16_t* __restrict__ out, int H) {
     const long long n = 4ll * H * H;
     const int KS = H >> 3;
@@ -50,8 +68,8 @@ __global__ void pack_whh_bwd_kernel(const float* __restrict__ W, bf16_t* __restr
          i += (long long)gridDim.x * blockDim.x) {
         const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
         const long long blk = i >> 9;
-        const int ks = (int)(blk % KS), nt = (int)(blk / KS);
-        const int unit = nt * 16 + (lane & 15);
+        const int n2 = (int)(blk & 1), ks = (int)((blk >> 1) % KS), nb = (int)((blk >> 1) / KS);
+        const int unit = (nb * 2 + n2) * 16 + (lane & 15);
         const int kap = ks * 32 + (lane >> 4) * 8 + e;
         const int ub = kap >> 6, g = (kap >> 4) & 3, u = kap & 15;
         out[i] = f32_to_bf16(W[((long long)g * H + ub * 16 + u) * H + unit]);
@@ -70,7 +88,8 @@ __global__ void unpermute_rows_kernel(const float* __restrict__ src, float* __re
 
 // ---------------------------------------------------------------- per-device runtime
 struct Runtime {
-    hipStream_t R = nullptr, S = nullptr, W = nullptr;
+    hipStream_t R = nullptr, W = nullptr;
+    hipStream_t S[ED_STACK_MAX_SLOTS] = {};   // one side stream per layer (chunk GEMMs / LayerNorm backward)
     std::vector<hipEvent_t> pool;
     size_t used = 0;
     hipEvent_t get() {
@@ -93,15 +112,16 @@ Runtime* runtime_for_current_device() {
         Runtime* r = new Runtime();
         int lo = 0, hi = 0;
         hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least, hi = greatest priority
-        if (hipStreamCreateWithPriority(&r->R, hipStreamNonBlocking, hi) != hipSuccess ||
-            hipStreamCreateWithPriority(&r->S, hipStreamNonBlocking, hi) != hipSuccess ||
-            hipStreamCreateWithPriority(&r->W, hipStreamNonBlocking, lo) != hipSuccess) {
+        bool ok = hipStreamCreateWithPriority(&r->R, hipStreamNonBlocking, hi) == hipSuccess &&
+                  hipStreamCreateWithPriority(&r->W, hipStreamNonBlocking, lo) == hipSuccess;
+        for (int i = 0; ok && i < ED_STACK_MAX_SLOTS; ++i)
+            ok = hipStreamCreateWithPriority(&r->S[i], hipStreamNonBlocking, hi) == hipSuccess;
+        if (!ok) {
             delete r;
             return nullptr;
         }
         g_rt[dev] = r;
     }
-    g_rt[dev]->used = 0;
     return g_rt[dev];
 }
 
@@ -110,9 +130,11 @@ struct Geom {
 };
 
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+constexpr int LNB_GRID = 128;       // workgroups (= partial rows) per chunk call of the LayerNorm backward
+constexpr int LNB_GRID_TOP = 512;   // ... of the top layer's all-frames call
 
 struct WsLayout {
-    std::vector<size_t> frag0, frag1, dC;   // per layer
+    std::vector<size_t> frag0, frag1, dC, lnpart;   // per layer
     size_t tmpW = 0, tmpB = 0, dX0 = 0, total = 0;
 };
 
@@ -128,6 +150,18 @@ WsLayout ws_layout(const edgedict_stack_desc_t* d) {
         w.frag1.push_back(off); off += fb;
         w.dC.push_back(off); off += align256((size_t)d->B * d->H * sizeof(float));
         if ((size_t)d->layers[l].I > maxK) maxK = d->layers[l].I;
+    }
+    // LayerNorm-backward partial sums: LNB_GRID rows per chunk call + LNB_GRID_TOP for the top layer
+    {
+        int f = 1;
+        std::vector<int> fl(d->L);
+        for (int l = d->L - 1; l >= 0; --l) { f *= max(1, d->layers[l].reduce); fl[l] = f; }
+        for (int l = 0; l < d->L; ++l) {
+            const int cf = max(1, d->chunk) * fl[l];
+            const int nch = (d->layers[l].T + cf - 1) / cf;
+            w.lnpart.push_back(off);
+            off += align256((size_t)(nch * LNB_GRID + LNB_GRID_TOP) * 2 * d->H * sizeof(float));
+        }
     }
     w.tmpW = off; off += align256((size_t)4 * d->H * maxK * sizeof(float));
     w.tmpB = off; off += align256((size_t)4 * d->H * sizeof(float));
@@ -186,7 +220,8 @@ int default_lag(const edgedict_stack_desc_t* d, const std::vector<Geom>& g) {
     } while (0)
 
 struct Streams {
-    hipStream_t C, R, S, W;
+    hipStream_t C, R, W;
+    hipStream_t S[ED_STACK_MAX_SLOTS];
     bool serial;
     Runtime* rt;
     // order `waiter` after everything enqueued so far on `src`
@@ -217,13 +252,16 @@ int open_streams(const edgedict_stack_desc_t* d, void* stream_, Streams& st) {
     st.serial = (d->flags & EDGEDICT_STACK_SERIAL) != 0;
     st.rt = nullptr;
     if (st.serial) {
-        st.R = st.S = st.W = st.C;
+        st.R = st.W = st.C;
+        for (auto& x : st.S) x = st.C;
         return ED_OK;
     }
     st.rt = runtime_for_current_device();
     ED_CHECK_ARG(st.rt != nullptr, "encoder_stack: could not create the internal streams");
+    st.rt->used = 0;   // recycle the event pool (waits capture an event's state when enqueued)
     st.R = st.rt->R;
-    st.S = st.rt->S;
+    for (int i = 0; i < ED_STACK_MAX_SLOTS; ++i)
+        st.S[i] = st.rt->S[(d->flags & EDGEDICT_STACK_SIDE_STREAM_PER_LAYER) ? i : 0];
     st.W = st.rt->W;
     return ED_OK;
 }
@@ -243,6 +281,16 @@ int input_gemm(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, int l
 
 }  // namespace
 
+extern "C" void* edgedict_aux_stream(int which) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    Runtime* r = runtime_for_current_device();
+    if (!r) {
+        ed_set_error("aux_stream: could not create the internal streams");
+        return nullptr;
+    }
+    return which == 0 ? (void*)r->R : which == 1 ? (void*)r->S[0] : (void*)r->W;
+}
+
 extern "C" size_t edgedict_stack_struct_bytes(int which) {
     return which == 0 ? sizeof(edgedict_stack_layer_t) : sizeof(edgedict_stack_desc_t);
 }
@@ -261,7 +309,9 @@ extern "C" int edgedict_stack_pack_weights(const float* w_ih, const float* w_hh,
     hipLaunchKernelGGL(pack_wih_kernel, dim3(ed_grid_for(4ll * H * I, 256, 4096)), dim3(256), 0, s,
                        w_ih, b_ih, b_hh, (bf16_t*)wih_p, bias_p, H, I);
     ED_CHECK_LAUNCH("pack_wih_kernel");
-    ED_TRY(edgedict_lstm_pack_weights(ED_F32, w_hh, whh_f, nullptr, H, stream_));
+    hipLaunchKernelGGL(pack_whh_fwd_kernel, dim3(ed_grid_for(4ll * H * H, 256, 4096)), dim3(256), 0,
+                       s, w_hh, (bf16_t*)whh_f, H);
+    ED_CHECK_LAUNCH("pack_whh_fwd_kernel");
     if (whh_b) {
         hipLaunchKernelGGL(pack_whh_bwd_kernel, dim3(ed_grid_for(4ll * H * H, 256, 4096)), dim3(256),
                            0, s, w_hh, (bf16_t*)whh_b, H);
@@ -292,7 +342,7 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
                                    bptr(y.Yx), y.Cx, bptr(ws + wl.frag0[l]), B, H, st.C));
     }
     ED_TRY(st.chain(st.C, st.R));
-    ED_TRY(st.chain(st.C, st.S));
+    for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.C, st.S[l]));
 
     std::vector<std::vector<hipEvent_t>> Eg(L);
     std::vector<std::vector<char>> queued(L);   // schedule self-check: producer enqueued before consumer
@@ -303,8 +353,8 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     int next_g0 = 0;   // next chunk of layer 0 whose input product has not been enqueued
     auto feed_layer0 = [&](int upto) -> int {
         for (; next_g0 < g[0].nchunks && next_g0 <= upto; ++next_g0) {
-            ED_TRY(input_gemm(d, g, 0, next_g0, st.S));
-            ED_TRY(st.record(Eg[0][next_g0], st.S));
+            ED_TRY(input_gemm(d, g, 0, next_g0, st.S[0]));
+            ED_TRY(st.record(Eg[0][next_g0], st.S[0]));
             queued[0][next_g0] = 1;
         }
         return ED_OK;
@@ -386,14 +436,14 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
         ED_TRY(ed_stack_launch_fwd(Lc, st.R));
         for (int i = 0; i < ndone; ++i) {
             const int l = done[i].l + 1, k = done[i].k;
-            ED_TRY(st.chain(st.R, st.S));
-            ED_TRY(input_gemm(d, g, l, k, st.S));
-            ED_TRY(st.record(Eg[l][k], st.S));
+            ED_TRY(st.chain(st.R, st.S[l]));
+            ED_TRY(input_gemm(d, g, l, k, st.S[l]));
+            ED_TRY(st.record(Eg[l][k], st.S[l]));
             queued[l][k] = 1;
         }
     }
     ED_TRY(st.chain(st.R, st.C));
-    ED_TRY(st.chain(st.S, st.C));
+    for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.S[l], st.C));
     return ED_OK;
 }
 
@@ -418,11 +468,12 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
         const edgedict_stack_layer_t& y = d->layers[L - 1];
         ED_TRY(ed_stack_ln_bwd(bptr(d->dout), H, (long long)T_out * H, bptr(y.Yx) + BH,
                                y.residual ? bptr(y.X) : nullptr, y.ln_gamma, y.mean, y.rstd,
-                               bptr(y.dZ), y.dgamma, y.dbeta, B, H, 0, y.T, y.reduce, st.C));
+                               bptr(y.dZ), (float*)(ws + wl.lnpart[L - 1]) + (size_t)g[L - 1].nchunks * LNB_GRID * 2 * H,
+                               LNB_GRID_TOP, B, H, 0, y.T, y.reduce, st.C));
     }
     ED_TRY(st.chain(st.C, st.R));
-    ED_TRY(st.chain(st.C, st.S));
-    if (st.W != st.S) ED_TRY(st.chain(st.C, st.W));
+    for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.C, st.S[l]));
+    ED_TRY(st.chain(st.C, st.W));
 
     std::vector<std::vector<hipEvent_t>> Eb(L);
     std::vector<std::vector<char>> queued(L);
@@ -439,12 +490,12 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
         float* tmpB = (float*)(ws + wl.tmpB);
         const int sk = d->split_k > 0 ? d->split_k : max(1, min(16, M / 2048));
         // dW_ih = dG^T X,  dW_hh = dG^T H_prev (rows come out in interleaved gate order)
-        ED_TRY(edgedict_gemm(ED_BF16, ED_F32, y.G, 4ll * H, 0, y.X, y.I, 0, tmpW, y.I, 4 * H, y.I, M,
-                             nullptr, nullptr, 0, sk, st.W));
+        ED_TRY(edgedict_gemm_bg(ED_BF16, ED_F32, y.G, 4ll * H, 0, y.X, y.I, 0, tmpW, y.I, 4 * H, y.I, M,
+                                nullptr, nullptr, 0, sk, 2, st.W));
         hipLaunchKernelGGL(unpermute_rows_kernel, dim3(ed_grid_for(4ll * H * y.I, 256, 4096)),
                            dim3(256), 0, st.W, tmpW, y.dW_ih, H, y.I);
-        ED_TRY(edgedict_gemm(ED_BF16, ED_F32, y.G, 4ll * H, 0, y.Yx, H, 0, tmpW, H, 4 * H, H, M,
-                             nullptr, nullptr, 0, sk, st.W));
+        ED_TRY(edgedict_gemm_bg(ED_BF16, ED_F32, y.G, 4ll * H, 0, y.Yx, H, 0, tmpW, H, 4 * H, H, M,
+                                nullptr, nullptr, 0, sk, 2, st.W));
         hipLaunchKernelGGL(unpermute_rows_kernel, dim3(ed_grid_for(4ll * H * H, 256, 4096)),
                            dim3(256), 0, st.W, tmpW, y.dW_hh, H, H);
         ED_TRY(ed_stack_zero(tmpB, (size_t)4 * H * sizeof(float), st.W));
@@ -499,15 +550,17 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                 const edgedict_stack_layer_t& z = d->layers[l - 1];
                 const int t0 = k * g[l].cf, t1 = min(y.T, t0 + g[l].cf);
                 const long long r0 = (long long)t0 * B;
-                ED_TRY(st.chain(st.R, st.S));
+                hipStream_t S = st.S[l];
+                ED_TRY(st.chain(st.R, S));
                 ED_TRY(edgedict_gemm(ED_BF16, ED_BF16, bptr(y.G) + r0 * 4 * H, 4ll * H, 1, y.wih_p,
                                      y.I, 0, bptr(y.dX) + r0 * y.I, y.I, (t1 - t0) * B, y.I, 4 * H,
-                                     nullptr, nullptr, y.dX == y.dZ ? 1 : 0, 1, st.S));
+                                     nullptr, nullptr, y.dX == y.dZ ? 1 : 0, 1, S));
                 const int u0 = k * g[l - 1].cf, u1 = min(z.T, u0 + g[l - 1].cf);
                 ED_TRY(ed_stack_ln_bwd(bptr(y.dX), (long long)B * y.I, y.I, bptr(z.Yx) + BH,
                                        z.residual ? bptr(z.X) : nullptr, z.ln_gamma, z.mean, z.rstd,
-                                       bptr(z.dZ), z.dgamma, z.dbeta, B, H, u0, u1, z.reduce, st.S));
-                ED_TRY(st.record(Eb[l - 1][k], st.S));
+                                       bptr(z.dZ), (float*)(ws + wl.lnpart[l - 1]) + (size_t)k * LNB_GRID * 2 * H,
+                                       LNB_GRID, B, H, u0, u1, z.reduce, S));
+                ED_TRY(st.record(Eb[l - 1][k], S));
                 queued[l - 1][k] = 1;
             }
             if (done[i].t == 0) {   // the layer's BPTT is complete: weight gradients
@@ -524,18 +577,28 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     {
         const edgedict_stack_layer_t& y = d->layers[0];
         bf16_t* dX0 = bptr(ws + wl.dX0);
-        ED_TRY(st.chain(st.R, st.S));
+        ED_TRY(st.chain(st.R, st.S[0]));
         ED_TRY(edgedict_gemm(ED_BF16, ED_BF16, y.G, 4ll * H, 1, y.wih_p, y.I, 0, dX0, y.I, y.T * B,
-                             y.I, 4 * H, nullptr, nullptr, 0, 1, st.S));
+                             y.I, 4 * H, nullptr, nullptr, 0, 1, st.S[0]));
         ED_TRY(ed_stack_input_norm_bwd(d->x_dtype, d->x, dX0, d->in_mean, d->in_rstd, d->d_in_gamma,
-                                       d->d_in_beta, B, d->T0, d->I0, st.S));
+                                       d->d_in_beta, B, d->T0, d->I0, st.S[0]));
+        // LayerNorm parameter gradients: sum the per-workgroup partial rows of every launch
+        for (int l = 1; l < L; ++l) ED_TRY(st.chain(st.S[l], st.S[0]));
+        for (int l = 0; l < L; ++l) {
+            const edgedict_stack_layer_t& z = d->layers[l];
+            const float* part = (const float*)(ws + wl.lnpart[l]);
+            if (l == L - 1)   // only the top layer's all-frames call (it ran on the caller's stream)
+                ED_TRY(ed_stack_sum_parts(part + (size_t)g[l].nchunks * LNB_GRID * 2 * H, LNB_GRID_TOP, H, z.dgamma, z.dbeta, st.S[0]));
+            else
+                ED_TRY(ed_stack_sum_parts(part, g[l].nchunks * LNB_GRID, H, z.dgamma, z.dbeta, st.S[0]));
+        }
     }
     if (!deferred.empty()) {
         ED_TRY(st.chain(st.R, st.W));
         for (int l : deferred) ED_TRY(weight_grads(l));
     }
     ED_TRY(st.chain(st.R, st.C));
-    ED_TRY(st.chain(st.S, st.C));
-    if (st.W != st.S) ED_TRY(st.chain(st.W, st.C));
+    for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.S[l], st.C));
+    ED_TRY(st.chain(st.W, st.C));
     return ED_OK;
 }

@@ -367,23 +367,24 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
 }
 
 template <typename TI, typename TO, bool FAST>
-int launch2(const GemmArgs& g, int a_km, int b_km, dim3 grid, hipStream_t s) {
-    if (a_km && b_km) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, true, FAST>), grid, dim3(THREADS), 0, s, g);
-    else if (a_km && !b_km) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, false, FAST>), grid, dim3(THREADS), 0, s, g);
-    else if (!a_km && b_km) hipLaunchKernelGGL((gemm_kernel<TI, TO, false, true, FAST>), grid, dim3(THREADS), 0, s, g);
-    else hipLaunchKernelGGL((gemm_kernel<TI, TO, false, false, FAST>), grid, dim3(THREADS), 0, s, g);
+int launch2(const GemmArgs& g, int a_km, int b_km, dim3 grid, hipStream_t s, int pad) {
+    // pad = extra dynamic LDS claimed per workgroup (occupancy cap of background GEMMs)
+    if (a_km && b_km) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, true, FAST>), grid, dim3(THREADS), pad, s, g);
+    else if (a_km && !b_km) hipLaunchKernelGGL((gemm_kernel<TI, TO, true, false, FAST>), grid, dim3(THREADS), pad, s, g);
+    else if (!a_km && b_km) hipLaunchKernelGGL((gemm_kernel<TI, TO, false, true, FAST>), grid, dim3(THREADS), pad, s, g);
+    else hipLaunchKernelGGL((gemm_kernel<TI, TO, false, false, FAST>), grid, dim3(THREADS), pad, s, g);
     ED_CHECK_LAUNCH("gemm");
     return ED_OK;
 }
 template <typename TI, typename TO>
-int launch(const GemmArgs& g, int a_km, int b_km, dim3 grid, hipStream_t s) {
+int launch(const GemmArgs& g, int a_km, int b_km, dim3 grid, hipStream_t s, int pad) {
     // FAST: both operands 16-byte aligned with a leading dimension that is a multiple of the
     // vector width, and the contiguous extent of each operand a multiple of it as well
     constexpr int VEC = Cfg<TI>::VEC;
     const bool a_ext = a_km ? (g.K % VEC == 0) : (g.M % VEC == 0);
     const bool b_ext = b_km ? (g.K % VEC == 0) : (g.N % VEC == 0);
-    if (g.a_vec && g.b_vec && a_ext && b_ext) return launch2<TI, TO, true>(g, a_km, b_km, grid, s);
-    return launch2<TI, TO, false>(g, a_km, b_km, grid, s);
+    if (g.a_vec && g.b_vec && a_ext && b_ext) return launch2<TI, TO, true>(g, a_km, b_km, grid, s, pad);
+    return launch2<TI, TO, false>(g, a_km, b_km, grid, s, pad);
 }
 
 __global__ void zero_f32(float* p, long long rows, long long cols, long long ld) {
@@ -395,10 +396,10 @@ __global__ void zero_f32(float* p, long long rows, long long cols, long long ld)
 
 }  // namespace
 
-extern "C" int edgedict_gemm(int dtype_in, int dtype_out, const void* A, long long lda, int a_kmajor,
-                             const void* B, long long ldb, int b_kmajor, void* C, long long ldc,
-                             int M, int N, int K, const float* bias1, const float* bias2,
-                             int accumulate, int split_k, void* stream_) {
+static int gemm_impl(int dtype_in, int dtype_out, const void* A, long long lda, int a_kmajor,
+                     const void* B, long long ldb, int b_kmajor, void* C, long long ldc, int M, int N,
+                     int K, const float* bias1, const float* bias2, int accumulate, int split_k,
+                     void* stream_, int max_wg_per_cu) {
     ED_CHECK_ARG(dtype_in == ED_F32 || dtype_in == ED_BF16, "gemm: bad input dtype %d", dtype_in);
     ED_CHECK_ARG(dtype_out == ED_F32 || dtype_out == ED_BF16, "gemm: bad output dtype %d", dtype_out);
     ED_CHECK_ARG(!(dtype_in == ED_F32 && dtype_out == ED_BF16), "gemm: fp32 inputs with bf16 output is not supported");
@@ -433,7 +434,32 @@ extern "C" int edgedict_gemm(int dtype_in, int dtype_out, const void* A, long lo
     const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     ED_CHECK_ARG(tiles < (1ll << 31), "gemm: too many tiles");
     dim3 grid((unsigned)tiles, 1, split_k);
-    if (dtype_in == ED_BF16 && dtype_out == ED_BF16) return launch<bf16_t, bf16_t>(g, a_kmajor, b_kmajor, grid, stream);
-    if (dtype_in == ED_BF16 && dtype_out == ED_F32) return launch<bf16_t, float>(g, a_kmajor, b_kmajor, grid, stream);
-    return launch<float, float>(g, a_kmajor, b_kmajor, grid, stream);
+    // occupancy cap: claim enough extra LDS that only max_wg_per_cu workgroups fit on a CU
+    int pad = 0;
+    if (max_wg_per_cu > 0) {
+        const int stat = (BM + BN) * (dtype_in == ED_F32 ? Cfg<float>::ROW * 4 : Cfg<bf16_t>::ROW * 2);
+        const int want = (160 * 1024) / (max_wg_per_cu + 1) + 1024;   // one more would not fit
+        if (want > stat) pad = (want - stat + 255) / 256 * 256;
+    }
+    if (dtype_in == ED_BF16 && dtype_out == ED_BF16) return launch<bf16_t, bf16_t>(g, a_kmajor, b_kmajor, grid, stream, pad);
+    if (dtype_in == ED_BF16 && dtype_out == ED_F32) return launch<bf16_t, float>(g, a_kmajor, b_kmajor, grid, stream, pad);
+    return launch<float, float>(g, a_kmajor, b_kmajor, grid, stream, pad);
+}
+
+extern "C" int edgedict_gemm(int dtype_in, int dtype_out, const void* A, long long lda, int a_kmajor,
+                             const void* B, long long ldb, int b_kmajor, void* C, long long ldc,
+                             int M, int N, int K, const float* bias1, const float* bias2,
+                             int accumulate, int split_k, void* stream_) {
+    return gemm_impl(dtype_in, dtype_out, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, bias1,
+                     bias2, accumulate, split_k, stream_, 0);
+}
+
+extern "C" int edgedict_gemm_bg(int dtype_in, int dtype_out, const void* A, long long lda,
+                                int a_kmajor, const void* B, long long ldb, int b_kmajor, void* C,
+                                long long ldc, int M, int N, int K, const float* bias1,
+                                const float* bias2, int accumulate, int split_k,
+                                int max_wg_per_cu, void* stream_) {
+    ED_CHECK_ARG(max_wg_per_cu >= 1 && max_wg_per_cu <= 8, "gemm_bg: max_wg_per_cu must be 1..8");
+    return gemm_impl(dtype_in, dtype_out, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, bias1,
+                     bias2, accumulate, split_k, stream_, max_wg_per_cu);
 }

@@ -23,6 +23,10 @@
 // the epilogue is a 16-byte vector staged through LDS.
 #include "stack_kernels.hpp"
 
+#ifndef ED_STACK_DBG
+#define ED_STACK_DBG 0   // tools/stack_probe.hip builds ablation variants with this mask:
+#endif                   // 1 no operand loads/MFMA, 2 no stores, 4 cheap activations, 8 no staging loads
+
 namespace {
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
@@ -46,7 +50,7 @@ __device__ __forceinline__ float ftanh(float x) {
 // =====================================================================================
 // forward
 // =====================================================================================
-constexpr int FCH = 4;   // k-steps in flight per batch: 4 x (4 A + 4 W) x 16 B = 512 B / lane
+constexpr int FCH = 2;   // k-steps per register buffer: 2 x (4 A + 4 W) x 16 B = 256 B / lane, two buffers
 
 struct __attribute__((aligned(16))) FwdShared {
     float4 hand[4][3][4][64];   // [source wave][destination slot][gate][lane]   48 KB
@@ -71,12 +75,12 @@ __device__ __forceinline__ void fwd_step_role(const EdFwdStep& p, int ub, int rg
     for (int i = 0; i < 2; ++i) {
         const int id = tid + 256 * i, r = id >> 3, part = id & 7, b = row0 + r;
         gin[i] = make_uint4(0, 0, 0, 0);
-        if (b < B) gin[i] = *reinterpret_cast<const uint4*>(p.G_t + b * H4 + ub * 64 + part * 8);
+        if (b < B && !(ED_STACK_DBG & 8)) gin[i] = *reinterpret_cast<const uint4*>(p.G_t + b * H4 + ub * 64 + part * 8);
     }
     {
         const int r = tid >> 2, part = tid & 3, b = row0 + r;
         cin = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (b < B) cin = *reinterpret_cast<const float4*>(p.C_prev + (long long)b * H + ub * 16 + part * 4);
+        if (b < B && !(ED_STACK_DBG & 8)) cin = *reinterpret_cast<const float4*>(p.C_prev + (long long)b * H + ub * 16 + part * 4);
     }
 
     // ---- W_hh h_{t-1}: this wave's K quarter, all 4 row tiles x 4 gates
@@ -87,17 +91,20 @@ __device__ __forceinline__ void fwd_step_role(const EdFwdStep& p, int ub, int rg
         for (int g = 0; g < 4; ++g) acc[m][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const bf16_t* abase = p.hfrag_in + lane * 8;
     const bf16_t* wbase = p.Wfrag + ((long long)ub * 4 * KS * 64 + lane) * 8;
-    for (int ks0 = ks_beg; ks0 < ks_end; ks0 += FCH) {
-        bf16x8_t a[FCH][4], w[FCH][4];
+    // two register buffers of FCH k-steps: the loads of one are in flight under the MFMAs of the other
+    bf16x8_t a0[FCH][4], w0[FCH][4], a1[FCH][4], w1[FCH][4];
+    auto load = [&](bf16x8_t (&a)[FCH][4], bf16x8_t (&w)[FCH][4], int ks0) {
 #pragma unroll
         for (int i = 0; i < FCH; ++i) {
-            const int ks = min(ks0 + i, ks_end - 1);   // clamp: duplicates are masked below
+            const int ks = min(ks0 + i, ks_end - 1);   // clamp: duplicates are masked in mma()
 #pragma unroll
             for (int m = 0; m < 4; ++m)
-                a[i][m] = (mt0 + m < MT) ? ldfrag(abase + ((long long)(mt0 + m) * KS + ks) * 512) : zfrag();
+                a[i][m] = (mt0 + m < MT) ? ldfrag(abase + ((long long)ks * MT + mt0 + m) * 512) : zfrag();
 #pragma unroll
-            for (int g = 0; g < 4; ++g) w[i][g] = ldfrag(wbase + ((long long)g * KS + ks) * 512);
+            for (int g = 0; g < 4; ++g) w[i][g] = ldfrag(wbase + ((long long)ks * 4 + g) * 512);
         }
+    };
+    auto mma = [&](bf16x8_t (&a)[FCH][4], bf16x8_t (&w)[FCH][4], int ks0) {
 #pragma unroll
         for (int i = 0; i < FCH; ++i) {
             if (ks0 + i < ks_end) {
@@ -107,6 +114,15 @@ __device__ __forceinline__ void fwd_step_role(const EdFwdStep& p, int ub, int rg
                     for (int g = 0; g < 4; ++g)
                         acc[m][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], w[i][g], acc[m][g], 0, 0, 0);
             }
+        }
+    };
+    if (ks_beg < ks_end && !(ED_STACK_DBG & 1)) {
+        load(a0, w0, ks_beg);
+        for (int ks0 = ks_beg; ks0 < ks_end; ks0 += 2 * FCH) {
+            if (ks0 + FCH < ks_end) load(a1, w1, ks0 + FCH);
+            mma(a0, w0, ks0);
+            if (ks0 + 2 * FCH < ks_end) load(a0, w0, ks0 + 2 * FCH);
+            if (ks0 + FCH < ks_end) mma(a1, w1, ks0 + FCH);
         }
     }
 
@@ -149,12 +165,20 @@ __device__ __forceinline__ void fwd_step_role(const EdFwdStep& p, int ub, int rg
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int rl = rbase + q;
-        const float ig = fsigmoid(bf16_to_f32(sh.g[rl][u]) + mine[0][q]);
-        const float fg = fsigmoid(bf16_to_f32(sh.g[rl][16 + u]) + mine[1][q]);
-        const float gg = ftanh(bf16_to_f32(sh.g[rl][32 + u]) + mine[2][q]);
-        const float og = fsigmoid(bf16_to_f32(sh.g[rl][48 + u]) + mine[3][q]);
-        const float c = fg * sh.c[rl][u] + ig * gg;
-        const float h = og * ftanh(c);
+        float ig, fg, gg, og, c, h;
+        if (ED_STACK_DBG & 4) {
+            ig = bf16_to_f32(sh.g[rl][u]) + mine[0][q]; fg = bf16_to_f32(sh.g[rl][16 + u]) + mine[1][q];
+            gg = bf16_to_f32(sh.g[rl][32 + u]) + mine[2][q]; og = bf16_to_f32(sh.g[rl][48 + u]) + mine[3][q];
+            c = fg * sh.c[rl][u] + ig * gg;
+            h = og * c;
+        } else {
+            ig = fsigmoid(bf16_to_f32(sh.g[rl][u]) + mine[0][q]);
+            fg = fsigmoid(bf16_to_f32(sh.g[rl][16 + u]) + mine[1][q]);
+            gg = ftanh(bf16_to_f32(sh.g[rl][32 + u]) + mine[2][q]);
+            og = fsigmoid(bf16_to_f32(sh.g[rl][48 + u]) + mine[3][q]);
+            c = fg * sh.c[rl][u] + ig * gg;
+            h = og * ftanh(c);
+        }
         sh.g[rl][u] = f32_to_bf16(ig);
         sh.g[rl][16 + u] = f32_to_bf16(fg);
         sh.g[rl][32 + u] = f32_to_bf16(gg);
@@ -166,7 +190,7 @@ __device__ __forceinline__ void fwd_step_role(const EdFwdStep& p, int ub, int rg
 
     // ---- 1024 16-byte stores: gates 512, Y 128, fragment image 128, c 256
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < ((ED_STACK_DBG & 2) ? 0 : 4); ++i) {
         const int task = tid + 256 * i;
         if (task < 512) {
             const int r = task >> 3, part = task & 7, b = row0 + r;
@@ -185,7 +209,7 @@ __device__ __forceinline__ void fwd_step_role(const EdFwdStep& p, int ub, int rg
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (mt * 16 + r16 < B) v = *reinterpret_cast<const uint4*>(&sh.h[m * 16 + r16][kg2 * 8]);
                 const int ks = ub >> 1, kg = (ub & 1) * 2 + kg2;
-                *reinterpret_cast<uint4*>(p.hfrag_out + (((long long)mt * KS + ks) * 64 + kg * 16 + r16) * 8) = v;
+                *reinterpret_cast<uint4*>(p.hfrag_out + (((long long)ks * MT + mt) * 64 + kg * 16 + r16) * 8) = v;
             }
         } else {
             const int id = task - 768, r = id >> 2, part = id & 3, b = row0 + r;
@@ -309,7 +333,7 @@ __global__ __launch_bounds__(256, 2) void stack_fwd_kernel(EdFwdLaunch L) {
 // =====================================================================================
 // backward (BPTT step)
 // =====================================================================================
-constexpr int BCH = 8;   // k-steps in flight per batch: 8 x (2 A + 2 W) x 16 B = 512 B / lane
+constexpr int BCH = 4;   // k-steps per register buffer: 4 x (2 A + 2 W) x 16 B = 256 B / lane, two buffers
 
 struct __attribute__((aligned(16))) BwdShared {
     float4 hand[4][3][64];   // [source wave][destination slot][lane]   12 KB
@@ -361,17 +385,19 @@ __device__ __forceinline__ void bwd_step_role(const EdBwdStep& p, int nb, int rg
     if (p.gfrag_in) {
         const bf16_t* abase = p.gfrag_in + lane * 8;
         const bf16_t* wbase = p.WTfrag + ((long long)nb * 2 * KS * 64 + lane) * 8;
-        for (int ks0 = ks_beg; ks0 < ks_end; ks0 += BCH) {
-            bf16x8_t a[BCH][2], w[BCH][2];
+        bf16x8_t a0[BCH][2], w0[BCH][2], a1[BCH][2], w1[BCH][2];
+        auto load = [&](bf16x8_t (&a)[BCH][2], bf16x8_t (&w)[BCH][2], int ks0) {
 #pragma unroll
             for (int i = 0; i < BCH; ++i) {
                 const int ks = min(ks0 + i, ks_end - 1);
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
-                    a[i][m] = (mt0 + m < MT) ? ldfrag(abase + ((long long)(mt0 + m) * KS + ks) * 512) : zfrag();
+                    a[i][m] = (mt0 + m < MT) ? ldfrag(abase + ((long long)ks * MT + mt0 + m) * 512) : zfrag();
 #pragma unroll
-                for (int n = 0; n < 2; ++n) w[i][n] = ldfrag(wbase + ((long long)n * KS + ks) * 512);
+                for (int n = 0; n < 2; ++n) w[i][n] = ldfrag(wbase + ((long long)ks * 2 + n) * 512);
             }
+        };
+        auto mma = [&](bf16x8_t (&a)[BCH][2], bf16x8_t (&w)[BCH][2], int ks0) {
 #pragma unroll
             for (int i = 0; i < BCH; ++i) {
                 if (ks0 + i < ks_end) {
@@ -381,6 +407,15 @@ __device__ __forceinline__ void bwd_step_role(const EdBwdStep& p, int nb, int rg
                         for (int n = 0; n < 2; ++n)
                             acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], w[i][n], acc[m][n], 0, 0, 0);
                 }
+            }
+        };
+        if (ks_beg < ks_end) {
+            load(a0, w0, ks_beg);
+            for (int ks0 = ks_beg; ks0 < ks_end; ks0 += 2 * BCH) {
+                if (ks0 + BCH < ks_end) load(a1, w1, ks0 + BCH);
+                mma(a0, w0, ks0);
+                if (ks0 + 2 * BCH < ks_end) load(a0, w0, ks0 + 2 * BCH);
+                if (ks0 + BCH < ks_end) mma(a1, w1, ks0 + BCH);
             }
         }
     }
@@ -452,7 +487,7 @@ __device__ __forceinline__ void bwd_step_role(const EdBwdStep& p, int nb, int rg
                 uint4 v = make_uint4(0, 0, 0, 0);
                 if (mt * 16 + r16 < B)
                     v = *reinterpret_cast<const uint4*>(&sh.g[mm * 16 + r16][ksl * 32 + kg * 8]);
-                *reinterpret_cast<uint4*>(p.gfrag_out + (((long long)mt * KS + nb * 4 + ksl) * 64 + kg * 16 + r16) * 8) = v;
+                *reinterpret_cast<uint4*>(p.gfrag_out + (((long long)(nb * 4 + ksl) * MT + mt) * 64 + kg * 16 + r16) * 8) = v;
             }
         } else {
             const int id = task - 1024, r = id >> 3, part = id & 7, b = row0 + r;
@@ -476,14 +511,15 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_kernel(EdBwdLaunch L) {
 //   z = y (+ res), xhat = (z - mean) rstd, dy = dout[t / reduce, b] / reduce, g = dy gamma
 //   dz = rstd (g - mean_H(g) - xhat mean_H(g xhat));  dgamma += dy xhat;  dbeta += dy
 // Lane owns columns lane*8 + 512 i (i < 4, H <= 2048): one pass over the row in registers,
-// dgamma / dbeta accumulated per lane over the wave's rows, combined through LDS + atomics.
+// dgamma / dbeta accumulated per lane over the wave's rows, combined through LDS into ONE partial
+// row per workgroup (no atomics: 2H x grid contended fp32 atomics per launch cost 20 us).
 // =====================================================================================
 constexpr int LNB_NB = 4;
 __global__ __launch_bounds__(256) void stack_ln_bwd_kernel(
     const bf16_t* __restrict__ dout, long long dout_st, long long dout_sb,
     const bf16_t* __restrict__ y, const bf16_t* __restrict__ res, const float* __restrict__ gamma,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in, bf16_t* __restrict__ dz,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, int B, int H, int t0, int t1, int reduce) {
+    float* __restrict__ part, int B, int H, int t0, int t1, int reduce) {
     __shared__ float red[2][3][LNB_NB * 8][64];   // waves 1..3 -> wave 0, 48 KB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float scale = 1.f / (float)reduce;
@@ -558,19 +594,47 @@ __global__ __launch_bounds__(256) void stack_ln_bwd_kernel(
     }
     __syncthreads();
     if (wave == 0) {
+        // this workgroup's partial sums: row blockIdx.x of part[.][2][H] (plain stores; the rows of
+        // all launches of a layer are summed once at the end by stack_sum_parts_kernel)
+        float* pg = part + (long long)blockIdx.x * 2 * H;
+        float* pb = pg + H;
 #pragma unroll
         for (int i = 0; i < LNB_NB; ++i) {
             const int c = lane * 8 + 512 * i;
             if (c < H) {
+                float og[8], ob[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int k = i * 8 + e;
-                    if (dgamma) atomicAdd(dgamma + c + e, ag[i][e] + red[0][0][k][lane] + red[0][1][k][lane] + red[0][2][k][lane]);
-                    if (dbeta) atomicAdd(dbeta + c + e, ab[i][e] + red[1][0][k][lane] + red[1][1][k][lane] + red[1][2][k][lane]);
+                    og[e] = ag[i][e] + red[0][0][k][lane] + red[0][1][k][lane] + red[0][2][k][lane];
+                    ob[e] = ab[i][e] + red[1][0][k][lane] + red[1][1][k][lane] + red[1][2][k][lane];
                 }
+                *reinterpret_cast<float4*>(pg + c) = make_float4(og[0], og[1], og[2], og[3]);
+                *reinterpret_cast<float4*>(pg + c + 4) = make_float4(og[4], og[5], og[6], og[7]);
+                *reinterpret_cast<float4*>(pb + c) = make_float4(ob[0], ob[1], ob[2], ob[3]);
+                *reinterpret_cast<float4*>(pb + c + 4) = make_float4(ob[4], ob[5], ob[6], ob[7]);
             }
         }
     }
+}
+
+// dgamma[c] += sum_r part[r][0][c];  dbeta[c] += sum_r part[r][1][c]
+__global__ __launch_bounds__(256) void stack_sum_parts_kernel(const float* __restrict__ part, int rows,
+                                                             int H, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta) {
+    const int c = blockIdx.x * 256 + threadIdx.x;   // column of the [2][H] pair
+    if (c >= 2 * H) return;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int r = blockIdx.y;
+    const int stride = gridDim.y;
+    for (; r + 3 * stride < rows; r += 4 * stride) {
+        a0 += part[(long long)r * 2 * H + c];
+        a1 += part[(long long)(r + stride) * 2 * H + c];
+        a2 += part[(long long)(r + 2 * stride) * 2 * H + c];
+        a3 += part[(long long)(r + 3 * stride) * 2 * H + c];
+    }
+    for (; r < rows; r += stride) a0 += part[(long long)r * 2 * H + c];
+    atomicAdd(c < H ? dgamma + c : dbeta + (c - H), (a0 + a1) + (a2 + a3));
 }
 
 // =====================================================================================
@@ -634,7 +698,7 @@ __global__ __launch_bounds__(256) void stack_input_norm_bwd_kernel(
 __global__ void stack_init_state_kernel(const float* __restrict__ h0, const float* __restrict__ c0,
                                         bf16_t* __restrict__ Yx0, float* __restrict__ Cx0,
                                         bf16_t* __restrict__ hfrag, int B, int H) {
-    const int KS = H >> 5, B16 = (B + 15) / 16 * 16;
+    const int B16 = (B + 15) / 16 * 16;
     const long long n = (long long)B16 * H;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
@@ -645,7 +709,7 @@ __global__ void stack_init_state_kernel(const float* __restrict__ h0, const floa
             Yx0[i] = hv;
             Cx0[i] = c0 ? c0[i] : 0.f;
         }
-        hfrag[((((long long)(b >> 4) * KS + (j >> 5)) * 64) + ((j & 31) >> 3) * 16 + (b & 15)) * 8 + (j & 7)] = hv;
+        hfrag[((((long long)(j >> 5) * (B16 >> 4) + (b >> 4)) * 64) + ((j & 31) >> 3) * 16 + (b & 15)) * 8 + (j & 7)] = hv;
     }
 }
 
@@ -671,14 +735,21 @@ int ed_stack_launch_bwd(const EdBwdLaunch& L, hipStream_t s) {
 
 int ed_stack_ln_bwd(const bf16_t* dout, long long dout_st, long long dout_sb, const bf16_t* y,
                     const bf16_t* res, const float* gamma, const float* mean, const float* rstd,
-                    bf16_t* dz, float* dgamma, float* dbeta, int B, int H, int t0, int t1,
-                    int reduce, hipStream_t s) {
-    if (t1 <= t0) return ED_OK;
-    const long long rows = (long long)(t1 - t0) * B;
-    const int grid = ed_grid_for(rows, 4 * 4, 512);   // >= 4 rows per wave: amortise the atomics
+                    bf16_t* dz, float* part, int grid, int B, int H, int t0, int t1, int reduce,
+                    hipStream_t s) {
+    // fixed grid: every workgroup writes its partial row (zeros when it owns no rows)
     hipLaunchKernelGGL(stack_ln_bwd_kernel, dim3(grid), dim3(256), 0, s, dout, dout_st, dout_sb, y,
-                       res, gamma, mean, rstd, dz, dgamma, dbeta, B, H, t0, t1, reduce);
+                       res, gamma, mean, rstd, dz, part, B, H, t0, max(t0, t1), reduce);
     ED_CHECK_LAUNCH("stack_ln_bwd_kernel");
+    return ED_OK;
+}
+
+int ed_stack_sum_parts(const float* part, int rows, int H, float* dgamma, float* dbeta, hipStream_t s) {
+    if (rows <= 0) return ED_OK;
+    const int gy = rows >= 64 ? 16 : 1;
+    hipLaunchKernelGGL(stack_sum_parts_kernel, dim3((2 * H + 255) / 256, gy), dim3(256), 0, s, part,
+                       rows, H, dgamma, dbeta);
+    ED_CHECK_LAUNCH("stack_sum_parts_kernel");
     return ED_OK;
 }
 

@@ -13,12 +13,12 @@ __host__ __device__ inline int ed_gate_col(int gate, int j) {
 
 struct EdFwdStep {             // one LSTM time step of one layer, all batch rows
     bf16_t* G_t;               // [B, 4H] interleaved: in pre-activations, out gates i,f,g,o
-    const bf16_t* hfrag_in;    // h_{t-1} as MFMA A-fragment image [B16/16][H/32][64][8]
+    const bf16_t* hfrag_in;    // h_{t-1} as MFMA A-fragment image [H/32][B16/16][64][8] (k-step major)
     bf16_t* hfrag_out;         // h_t, same layout (ping-pong partner)
     bf16_t* Y_t;               // [B, H] plain h_t
     const float* C_prev;       // [B, H] c_{t-1}
     float* C_t;                // [B, H] c_t
-    const bf16_t* Wfrag;       // W_hh B-fragment image [H/16][4][H/32][64][8]
+    const bf16_t* Wfrag;       // W_hh B-fragment image [H/16][H/32][4 gates][64][8]
 };
 
 struct EdFwdNorm {             // LayerNorm(y + r) of one frame, or the pair mean of two frames
@@ -45,13 +45,13 @@ struct EdFwdLaunch {
 
 struct EdBwdStep {             // one BPTT step of one layer, all batch rows
     bf16_t* G_t;               // [B, 4H] interleaved: in gates, out dL/d(pre-activation)
-    const bf16_t* gfrag_in;    // dG_{t+1} A-fragment image [B16/16][4H/32][64][8]; null at t = T-1
+    const bf16_t* gfrag_in;    // dG_{t+1} A-fragment image [4H/32][B16/16][64][8]; null at t = T-1
     bf16_t* gfrag_out;         // dG_t image; null at t = 0
     const bf16_t* dY_t;        // [B, H] dL/dh_t from above (null = zeros)
     const float* C_t;          // [B, H]
     const float* C_prev;       // [B, H]
     float* dC;                 // [B, H] running dL/dc, in/out
-    const bf16_t* WTfrag;      // W_hh^T B-fragment image [H/16][4H/32][64][8], K interleaved
+    const bf16_t* WTfrag;      // W_hh^T B-fragment image [H/32][4H/32][2][64][8], K interleaved
 };
 
 struct EdBwdLaunch {
@@ -63,11 +63,13 @@ struct EdBwdLaunch {
 // kernels / launchers implemented in stack_kernels.hip
 int ed_stack_launch_fwd(const EdFwdLaunch& L, hipStream_t s);
 int ed_stack_launch_bwd(const EdBwdLaunch& L, hipStream_t s);
-// time-major LayerNorm backward over frames [t0, t1) of one layer
+// time-major LayerNorm backward over frames [t0, t1) of one layer; workgroup j writes its
+// dgamma/dbeta partial sums to part[j][2][H] (grid rows), summed later by ed_stack_sum_parts
 int ed_stack_ln_bwd(const bf16_t* dout, long long dout_st, long long dout_sb, const bf16_t* y,
                     const bf16_t* res, const float* gamma, const float* mean, const float* rstd,
-                    bf16_t* dz, float* dgamma, float* dbeta, int B, int H, int t0, int t1,
-                    int reduce, hipStream_t s);
+                    bf16_t* dz, float* part, int grid, int B, int H, int t0, int t1, int reduce,
+                    hipStream_t s);
+int ed_stack_sum_parts(const float* part, int rows, int H, float* dgamma, float* dbeta, hipStream_t s);
 int ed_stack_input_norm(int x_dtype, const void* x, const float* gamma, const float* beta,
                         bf16_t* out, float* mean, float* rstd, int B, int T, int D, float eps,
                         hipStream_t s);

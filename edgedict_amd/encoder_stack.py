@@ -46,7 +46,7 @@ SERIAL = 1
 DW_AT_END = 2
 
 # schedule knobs (env overrides are for tuning runs; the defaults are what bench.py measures)
-CHUNK = int(os.environ.get("EDGEDICT_STACK_CHUNK", "8"))
+CHUNK = int(os.environ.get("EDGEDICT_STACK_CHUNK", "16"))
 LAG = int(os.environ.get("EDGEDICT_STACK_LAG", "0"))
 SPLIT_K = int(os.environ.get("EDGEDICT_STACK_SPLITK", "0"))
 FLAGS = int(os.environ.get("EDGEDICT_STACK_FLAGS", "0"))

@@ -22,12 +22,13 @@ PyTorch is the container/plumbing layer only: ``nn.Parameter`` holds the fp32 ma
 There is no CPU or eager-PyTorch fallback: tensors must live on an MI355X.
 """
 import math
+import weakref
 
 import numpy as np
 import torch
 from torch import nn
 
-from . import config, encoder_stack, ops
+from . import config, encoder_stack, ops, side
 from ._lib import require_cuda
 from .loss import _RNNTLossFn
 from .tokenizer import BOS, NUL, PAD
@@ -46,7 +47,9 @@ class _WeightCache:
         key = (id(p), dtype, transposed)
         ver = (p.data_ptr(), p._version, config.param_epoch())
         hit = self._store.get(key)
-        if hit is not None and hit[0] == ver:
+        # ids (and device addresses) are recycled once a tensor dies: the entry must belong to
+        # THIS tensor object, not to a dead one that happened to share id, address and version
+        if hit is not None and hit[0] == ver and hit[2]() is p:
             return hit[1]
         src = p.detach()
         if not src.is_contiguous():
@@ -61,7 +64,7 @@ class _WeightCache:
             t = src
         else:
             t = ops.cast(src, dtype)
-        self._store[key] = (ver, t)
+        self._store[key] = (ver, t, weakref.ref(p))
         return t
 
     def clear(self):
@@ -259,6 +262,7 @@ class _JointFn(torch.autograd.Function):
         with ops.timed("joint_logits_gemm"):
             logits = ops.gemm(hid.view(B * T * U1, J), w2c, bias=b2.detach())
         ctx.save_for_backward(enc2, dec2, w1, w2, hid)
+        ctx.b1, ctx.b2 = b1, b2
         ctx.cfg = (cd, B, T, U1, P, P2, J, V)
         return logits.view(B, T, U1, V)
 
@@ -273,21 +277,43 @@ class _JointFn(torch.autograd.Function):
         hid2 = hid.view(M, J)
         w1c = WEIGHTS.get(w1, cd)
         w2c = WEIGHTS.get(w2, cd)
+        # weight gradients feed nothing downstream: when the parameters already own fp32 .grad
+        # buffers they are accumulated in place on the auxiliary stream, under the encoder's
+        # backward pass (side.py); otherwise they are returned to autograd as usual
+        defer = config.DEFER_WEIGHT_GRADS and all(
+            p.grad is not None and p.grad.dtype == F32 and p.grad.is_contiguous()
+            for p in (w1, ctx.b1, w2, ctx.b2))
+        dw1 = db1 = dw2 = db2 = None
         with ops.timed("joint_dhid_gemm"):
             dhid = ops.gemm(dl, w2c.t())
-        with ops.timed("joint_dw2_gemm"):
-            dw2 = ops.gemm(dl.t(), hid2.t(), out_dtype=F32, split_k=ops.pick_split_k(V, J, M))
-        db2 = ops.colsum(dl)
+        if not defer:
+            with ops.timed("joint_dw2_gemm"):
+                dw2 = ops.gemm(dl.t(), hid2.t(), out_dtype=F32, split_k=ops.pick_split_k(V, J, M))
+            db2 = ops.colsum(dl)
         dE1, dD1 = ops.joint_hidden_bwd(dhid.view(B, T, U1, J), hid)
         del dhid
         dE1c = ops.cast(dE1, cd).view(B * T, J)
         dD1c = ops.cast(dD1, cd).view(B * U1, J)
         denc = ops.gemm(dE1c, w1c[:, :P].t()).view(B, T, P)
         ddec = ops.gemm(dD1c, w1c[:, P:].t()).view(B, U1, P2)
-        dw1 = torch.empty(J, P + P2, dtype=F32, device=dl.device)
-        ops.gemm(dE1c.t(), enc2.t(), out=dw1[:, :P], split_k=ops.pick_split_k(J, P, B * T))
-        ops.gemm(dD1c.t(), dec2.t(), out=dw1[:, P:], split_k=ops.pick_split_k(J, P2, B * U1))
-        db1 = ops.colsum(dD1.view(B * U1, J))
+        if defer:
+            # enqueued AFTER the critical-path products above: the auxiliary stream starts when
+            # they are done and its MFMA work runs under the latency-bound recurrences that follow
+            with side.deferred(dl.device, dl, hid, dE1c, dD1c, dD1, enc2, dec2):
+                ops.gemm(dl.t(), hid2.t(), out=w2.grad, accumulate=True,
+                         split_k=ops.pick_split_k(V, J, M), max_wg_per_cu=2)
+                ops.colsum(dl, out=ctx.b2.grad)
+                g1 = w1.grad
+                ops.gemm(dE1c.t(), enc2.t(), out=g1[:, :P], accumulate=True,
+                         split_k=ops.pick_split_k(J, P, B * T))
+                ops.gemm(dD1c.t(), dec2.t(), out=g1[:, P:], accumulate=True,
+                         split_k=ops.pick_split_k(J, P2, B * U1))
+                ops.colsum(dD1.view(B * U1, J), out=ctx.b1.grad)
+        if not defer:
+            dw1 = torch.empty(J, P + P2, dtype=F32, device=dl.device)
+            ops.gemm(dE1c.t(), enc2.t(), out=dw1[:, :P], split_k=ops.pick_split_k(J, P, B * T))
+            ops.gemm(dD1c.t(), dec2.t(), out=dw1[:, P:], split_k=ops.pick_split_k(J, P2, B * U1))
+            db1 = ops.colsum(dD1.view(B * U1, J))
         return denc, ddec, dw1, db1, dw2, db2, None
 
 
@@ -536,8 +562,23 @@ class Transducer(nn.Module):
     def forward(self, xs, ys, xlen, ylen):
         xs = xs[:, :xlen.max()].contiguous()
         ys = ys[:, :ylen.max()].contiguous()
-        h_enc, _ = self.encoder(xs)
-        h_dec, _ = self.decoder(ys)
+        if config.DECODER_ON_AUX_STREAM and xs.is_cuda:
+            # the prediction network does not depend on the encoder: it runs on the auxiliary
+            # stream under the encoder's recurrences.  Autograd replays each node on its forward
+            # stream, so its backward overlaps the encoder's backward the same way.
+            main = torch.cuda.current_stream(xs.device)
+            aux = side.stream(xs.device)
+            ready = main.record_event()          # ys (and the parameters) are ready here
+            h_enc, _ = self.encoder(xs)          # enqueued first: it is the long pole
+            aux.wait_event(ready)
+            ys.record_stream(aux)
+            with torch.cuda.stream(aux):
+                h_dec, _ = self.decoder(ys)
+            main.wait_stream(aux)
+            h_dec.record_stream(main)
+        else:
+            h_enc, _ = self.encoder(xs)
+            h_dec, _ = self.decoder(ys)
         logits = self.joint(h_enc, h_dec)
         if self.output_loss:
             xlen = self.scale_length(logits, xlen)

@@ -60,7 +60,7 @@ def _operand(t):
 
 
 def gemm(a, b, out=None, bias=None, bias2=None, accumulate=False, split_k=1,
-         out_dtype=None):
+         out_dtype=None, max_wg_per_cu=0):
     """out[M,N] (+)= a[M,K] @ b[N,K]^T (+ bias).  ``a`` / ``b`` may be transposed *views*
     (``x.t()``): the kernel reads them in place, nothing is materialised."""
     require_cuda(a, b)
@@ -81,9 +81,13 @@ def gemm(a, b, out=None, bias=None, bias2=None, accumulate=False, split_k=1,
     for v in (bias, bias2):
         if v is not None and (v.dtype != torch.float32 or v.numel() != N or not v.is_contiguous()):
             raise ValueError("gemm: bias must be contiguous fp32 [N]")
-    call("gemm", dtype_code(a.dtype), dtype_code(out.dtype), a_, _ll(lda), akm, b_, _ll(ldb), bkm,
-         out, _ll(out.stride(0) if M > 1 else max(out.stride(0), N)), M, N, K, bias, bias2,
-         int(bool(accumulate)), int(split_k))
+    args = (dtype_code(a.dtype), dtype_code(out.dtype), a_, _ll(lda), akm, b_, _ll(ldb), bkm,
+            out, _ll(out.stride(0) if M > 1 else max(out.stride(0), N)), M, N, K, bias, bias2,
+            int(bool(accumulate)), int(split_k))
+    if max_wg_per_cu:     # background product on a side stream: capped CU residency
+        call("gemm_bg", *args, int(max_wg_per_cu))
+    else:
+        call("gemm", *args)
     return out
 
 

@@ -92,6 +92,15 @@ int edgedict_gemm(int dtype_in, int dtype_out, const void* A, long long lda, int
                   int K, const float* bias1, const float* bias2, int accumulate, int split_k,
                   void* stream);
 
+/* Background variant for products that are OFF the critical path (weight gradients) and run on a
+ * side stream next to latency-bound kernels: identical arithmetic, but every workgroup claims
+ * enough extra LDS that at most max_wg_per_cu of them are resident per CU, so the long-lived GEMM
+ * workgroups can never fill a CU and starve the recurrence kernels of LDS/wave slots. */
+int edgedict_gemm_bg(int dtype_in, int dtype_out, const void* A, long long lda, int a_kmajor,
+                     const void* B, long long ldb, int b_kmajor, void* C, long long ldc, int M,
+                     int N, int K, const float* bias1, const float* bias2, int accumulate,
+                     int split_k, int max_wg_per_cu, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * LayerNorm fused with the residual add and the encoder's TimeReduction.
  * Replaces nn.LayerNorm at rnnt/models.py:124,132 and the per-layer
@@ -158,7 +167,8 @@ int edgedict_lstm_backward(int dtype, void* G, const void* dY, const float* Cst,
  *   = (j/16)*64 + g*16 + j%16  (gate order i,f,g,o);  weight images come from
  *   edgedict_stack_pack_weights (rebuilt whenever the fp32 master weights change).
  * Limits: H % 32 == 0, H <= 2048, L <= 8, reduce in {1,2}, residual layers need I == H.
- * The library keeps three internal streams and an event pool per device (created on first use).
+ * The library keeps its internal streams (recurrence, chunk GEMMs, weight gradients)
+ * and an event pool per device (created on first use).
  */
 typedef struct edgedict_stack_layer {
     int T;                 /* time steps of this layer */
@@ -190,6 +200,8 @@ typedef struct edgedict_stack_layer {
 
 #define EDGEDICT_STACK_SERIAL 1     /* run everything on the caller's stream (debug / bit-exact check) */
 #define EDGEDICT_STACK_DW_AT_END 2  /* weight gradients after the BPTT instead of under it */
+#define EDGEDICT_STACK_SIDE_STREAM_PER_LAYER 4 /* experiment: chunk GEMMs on one side stream PER LAYER.
+   Measured 2x SLOWER end to end: more streams than hardware queues serialises everything. */
 
 typedef struct edgedict_stack_desc {
     int B, H, L;
@@ -218,6 +230,12 @@ typedef struct edgedict_stack_desc {
 /* sizeof(edgedict_stack_layer_t) (which = 0) / sizeof(edgedict_stack_desc_t) (which = 1): lets a
  * foreign-language binding verify its struct mirror */
 size_t edgedict_stack_struct_bytes(int which);
+/* The library's internal streams of the current device (0 = recurrence, 1 = chunk GEMMs, 2 = the
+ * low-priority weight-gradient stream), created on first use.  Host code that wants to run its
+ * own off-critical-path work (e.g. the joint network's weight gradients) concurrently should
+ * borrow stream 2 instead of creating more streams: beyond the 4 hardware queues HIP multiplexes
+ * streams and every cross-stream dependency gets slower. */
+void* edgedict_aux_stream(int which);
 size_t edgedict_stack_workspace_bytes(const edgedict_stack_desc_t* desc);
 int edgedict_stack_pack_weights(const float* w_ih, const float* w_hh, const float* b_ih,
                                 const float* b_hh, int H, int I, void* wih_p, float* bias_p,
