@@ -30,14 +30,16 @@ namespace {
 // wih_p[kappa(g,j)][k] = W_ih[g*H + j][k] (bf16);  bias_p[kappa] = b_ih + b_hh (fp32)
 __global__ void pack_wih_kernel(const float* __restrict__ W, const float* __restrict__ b_ih,
                                 const float* __restrict__ b_hh, bf16_t* __restrict__ Wp,
-                                float* __restrict__ bp, int H, int I) {
+                                bf16_t* __restrict__ Wt, float* __restrict__ bp, int H, int I) {
     const long long n = 4ll * H * I;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
         const int row = (int)(i / I), k = (int)(i % I);
         const int g = row / H, j = row % H;
         const int kap = ed_gate_col(g, j);
-        Wp[(long long)kap * I + k] = f32_to_bf16(W[i]);
+        const bf16_t v = f32_to_bf16(W[i]);
+        Wp[(long long)kap * I + k] = v;
+        if (Wt) Wt[(long long)k * 4 * H + kap] = v;
         if (k == 0) bp[kap] = b_ih[row] + b_hh[row];
     }
 }
@@ -301,13 +303,13 @@ extern "C" size_t edgedict_stack_workspace_bytes(const edgedict_stack_desc_t* d)
 }
 
 extern "C" int edgedict_stack_pack_weights(const float* w_ih, const float* w_hh, const float* b_ih,
-                                           const float* b_hh, int H, int I, void* wih_p,
+                                           const float* b_hh, int H, int I, void* wih_p, void* wih_t,
                                            float* bias_p, void* whh_f, void* whh_b, void* stream_) {
     ED_CHECK_ARG(H >= 32 && H % 32 == 0 && I >= 1, "stack_pack_weights: need H %% 32 == 0 (H=%d I=%d)", H, I);
     ED_CHECK_ARG(w_ih && w_hh && b_ih && b_hh && wih_p && bias_p && whh_f, "stack_pack_weights: null pointer");
     hipStream_t s = (hipStream_t)stream_;
     hipLaunchKernelGGL(pack_wih_kernel, dim3(ed_grid_for(4ll * H * I, 256, 4096)), dim3(256), 0, s,
-                       w_ih, b_ih, b_hh, (bf16_t*)wih_p, bias_p, H, I);
+                       w_ih, b_ih, b_hh, (bf16_t*)wih_p, (bf16_t*)wih_t, bias_p, H, I);
     ED_CHECK_LAUNCH("pack_wih_kernel");
     hipLaunchKernelGGL(pack_whh_fwd_kernel, dim3(ed_grid_for(4ll * H * H, 256, 4096)), dim3(256), 0,
                        s, w_hh, (bf16_t*)whh_f, H);
@@ -552,9 +554,10 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                 const long long r0 = (long long)t0 * B;
                 hipStream_t S = st.S[l];
                 ED_TRY(st.chain(st.R, S));
-                ED_TRY(edgedict_gemm(ED_BF16, ED_BF16, bptr(y.G) + r0 * 4 * H, 4ll * H, 1, y.wih_p,
-                                     y.I, 0, bptr(y.dX) + r0 * y.I, y.I, (t1 - t0) * B, y.I, 4 * H,
-                                     nullptr, nullptr, y.dX == y.dZ ? 1 : 0, 1, S));
+                ED_TRY(edgedict_gemm(ED_BF16, ED_BF16, bptr(y.G) + r0 * 4 * H, 4ll * H, 1,
+                                     y.wih_t ? y.wih_t : y.wih_p, y.wih_t ? 4ll * H : y.I,
+                                     y.wih_t ? 1 : 0, bptr(y.dX) + r0 * y.I, y.I, (t1 - t0) * B, y.I,
+                                     4 * H, nullptr, nullptr, y.dX == y.dZ ? 1 : 0, 1, S));
                 const int u0 = k * g[l - 1].cf, u1 = min(z.T, u0 + g[l - 1].cf);
                 ED_TRY(ed_stack_ln_bwd(bptr(y.dX), (long long)B * y.I, y.I, bptr(z.Yx) + BH,
                                        z.residual ? bptr(z.X) : nullptr, z.ln_gamma, z.mean, z.rstd,
@@ -578,8 +581,9 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
         const edgedict_stack_layer_t& y = d->layers[0];
         bf16_t* dX0 = bptr(ws + wl.dX0);
         ED_TRY(st.chain(st.R, st.S[0]));
-        ED_TRY(edgedict_gemm(ED_BF16, ED_BF16, y.G, 4ll * H, 1, y.wih_p, y.I, 0, dX0, y.I, y.T * B,
-                             y.I, 4 * H, nullptr, nullptr, 0, 1, st.S[0]));
+        ED_TRY(edgedict_gemm(ED_BF16, ED_BF16, y.G, 4ll * H, 1, y.wih_t ? y.wih_t : y.wih_p,
+                             y.wih_t ? 4ll * H : y.I, y.wih_t ? 1 : 0, dX0, y.I, y.T * B, y.I, 4 * H,
+                             nullptr, nullptr, 0, 1, st.S[0]));
         ED_TRY(ed_stack_input_norm_bwd(d->x_dtype, d->x, dX0, d->in_mean, d->in_rstd, d->d_in_gamma,
                                        d->d_in_beta, B, d->T0, d->I0, st.S[0]));
         // LayerNorm parameter gradients: sum the per-workgroup partial rows of every launch

@@ -15,7 +15,10 @@
 // global -> registers -> LDS (rows padded by 16 B against ds_read bank conflicts) with the next
 // tile's global loads issued before the current tile's MFMAs.
 // split_k > 1 partitions K over blockIdx.z and combines with fp32 atomics (gradient "+=").
+#include <stdlib.h>
+
 #include "common.hpp"
+#include "gemm_nt.hpp"
 
 namespace {
 
@@ -409,6 +412,14 @@ static int gemm_impl(int dtype_in, int dtype_out, const void* A, long long lda, 
     if (M == 0 || N == 0) return ED_OK;
     ED_CHECK_ARG(A && B && C, "gemm: null operand");
     hipStream_t stream = (hipStream_t)stream_;
+    // bf16 NT products with K % 64 == 0 take the direct-to-LDS kernel (gemm_nt.hip)
+    static const bool nt_enabled = [] {
+        const char* e = getenv("EDGEDICT_GEMM_NT");
+        return !(e && e[0] == '0');
+    }();
+    if (nt_enabled && max_wg_per_cu == 0 &&
+        ed_gemm_nt_ok(dtype_in, dtype_out, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, split_k, bias1, bias2))
+        return ed_gemm_nt_launch(A, lda, B, ldb, C, ldc, M, N, K, bias1, bias2, accumulate, 0, stream);
     const int esz = dtype_in == ED_F32 ? 4 : 2;
     const int vec = 16 / esz;
     GemmArgs g;

@@ -1,0 +1,212 @@
+// bf16 "NT" GEMM fast path:  C[M,N] (+)= A[M,K] * B[N,K]^T + bias1[N] + bias2[N]
+// (both operands K-contiguous, bf16 output).  Serves the large forward products of the path --
+// joint logits hid x W2^T (rnnt/models.py:165-167,177), the encoder input products X x W_ih^T
+// (rnnt/models.py:45-46,65) -- and, with a pre-transposed weight copy, their dX products.
+//
+// Differences from the general kernel in gemm.hip (register staging, two barriers per K step):
+//   * operand tiles go HBM -> LDS directly (global_load_lds_dwordx4, 1 KiB per wave instruction),
+//     double-buffered: the DMA of K-tile t+1 is in flight under the MFMAs of tile t; ONE barrier
+//     per K step; no staging registers, no ds_write pass;
+//   * the LDS image is lane-linear (a DMA cannot scatter), so the bank swizzle is applied on the
+//     SOURCE side: lane l of an 8-row x 128-byte piece fetches 16-byte chunk (l%8) ^ (l/8) of its
+//     row, which leaves every row a full 128-byte line in HBM and makes the ds_read_b128 fragment
+//     reads (16 rows x one chunk) conflict-free.
+// Tile 128x128x64, 4 waves (2x2), wave tile 64x64 = 4x4 MFMA 16x16x32 tiles, 64 KB LDS
+// (2 workgroups per CU: one's epilogue stores overlap the other's main loop).
+// Requirements (else gemm.hip's kernel runs): K % 64 == 0, lda/ldb % 8 == 0, 16-byte aligned
+// operands, bf16 output with ldc % 8 == 0 and N % 8 == 0, split_k == 1.
+#include <stdlib.h>
+
+#include "common.hpp"
+#include "gemm_nt.hpp"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+constexpr int BM = 128, BN = 128, BK = 64, THREADS = 256;
+constexpr int TILE_BYTES = BM * BK * 2;          // 16 KB per operand tile
+constexpr int BUF_BYTES = 2 * TILE_BYTES;        // A + B
+
+struct NtArgs {
+    const bf16_t* A;
+    const bf16_t* B;
+    bf16_t* C;
+    const float* bias1;
+    const float* bias2;
+    long long lda, ldb, ldc;
+    int M, N, K;
+    int accumulate;
+    int n_tiles, tiles;
+    int debug;   // probe only: 1 = skip the C stores, 2 = skip the K loop
+};
+
+__device__ __forceinline__ void glds16(const bf16_t* src, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// (A 3-buffer variant with counted `s_waitcnt vmcnt(8)` + raw s_barrier, 96 KB LDS and ONE workgroup
+// per CU was measured and is slower on every shape of this path: joint logits 4.6 vs 3.6 ms,
+// 4096^3 657 vs 901 TF/s.  Two co-resident workgroups hide latency better than a deeper pipeline.)
+__global__ __launch_bounds__(THREADS, 2) void gemm_nt_kernel(NtArgs g) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF_BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int KT = g.K / BK;
+
+    // XCD-aware tile order: consecutive workgroups of ONE XCD (blockIdx % 8) walk adjacent tiles,
+    // so the A row panel they share stays in that XCD's L2.  One tile per workgroup: a persistent
+    // variant (512 workgroups walking contiguous tile ranges, DMA pipeline kept full across tiles)
+    // was measured SLOWER (joint dhid 3.25 vs 2.45 ms): co-resident persistent workgroups run in
+    // phase, so their epilogues coincide instead of hiding under each other's main loops.
+    int tile = blockIdx.x;
+    {
+        const int nx = 8, q = g.tiles / nx, r = g.tiles % nx, x = tile % nx, i = tile / nx;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int m0 = (tile / g.n_tiles) * BM, n0 = (tile % g.n_tiles) * BN;
+
+    // this lane's DMA sources: piece p = i*4 + wave covers tile rows p*8 .. p*8+7; lane l fetches
+    // 16-byte chunk (l%8) ^ (l/8) of its row (source-side swizzle, LDS image stays lane-linear)
+    const int prow = lane >> 3;
+    const int chunk = (lane & 7) ^ prow;
+    const bf16_t* asrc[4];
+    const bf16_t* bsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = (i * 4 + wave) * 8 + prow;
+        asrc[i] = g.A + (long long)min(m0 + row, g.M - 1) * g.lda + chunk * 8;
+        bsrc[i] = g.B + (long long)min(n0 + row, g.N - 1) * g.ldb + chunk * 8;
+    }
+    auto issue = [&](int buf, int k0) {
+        unsigned char* base = smem + buf * BUF_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            glds16(asrc[i] + k0, base + (i * 4 + wave) * 1024);
+            glds16(bsrc[i] + k0, base + TILE_BYTES + (i * 4 + wave) * 1024);
+        }
+    };
+
+    f32x4_t acc[4][4];
+    // operands swapped (B fragment first): lane holds D[n = (lane>>4)*4 + q][m = lane & 15], i.e.
+    // FOUR CONSECUTIVE COLUMNS of one C row -> 8-byte packed stores in the epilogue
+    auto compute = [&](int buf) {
+        const unsigned char* sA = smem + buf * BUF_BYTES;
+        const unsigned char* sB = sA + TILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8_t a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ra = wm * 64 + i * 16 + r16, rb = wn * 64 + i * 16 + r16;
+                a[i] = *reinterpret_cast<const bf16x8_t*>(sA + ra * 128 + (((ks * 4 + kq) ^ (ra & 7)) << 4));
+                b[i] = *reinterpret_cast<const bf16x8_t*>(sB + rb * 128 + (((ks * 4 + kq) ^ (rb & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    issue(0, 0);
+    {
+        // biases enter through the accumulators.  They are ordinary loads, and hipcc waits vmcnt(0)
+        // at the first use of an ordinary load while a DMA is in flight: issue them here and use
+        // them right after the first __syncthreads() of the K loop, which waits vmcnt(0) anyway.
+        float4 bv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nc = n0 + wn * 64 + j * 16 + kq * 4;   // 4 consecutive columns of this lane
+            bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (nc < g.N) {   // N % 8 == 0: the 4 columns are all inside or all outside
+                if (g.bias1) bv[j] = *reinterpret_cast<const float4*>(g.bias1 + nc);
+                if (g.bias2) {
+                    const float4 v = *reinterpret_cast<const float4*>(g.bias2 + nc);
+                    bv[j].x += v.x; bv[j].y += v.y; bv[j].z += v.z; bv[j].w += v.w;
+                }
+            }
+        }
+        for (int kt = 0; kt < ((g.debug & 2) ? 1 : KT); ++kt) {
+            __syncthreads();   // vmcnt(0) + barrier: this K tile landed everywhere, the other buffer is free
+            if (kt == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){bv[j].x, bv[j].y, bv[j].z, bv[j].w};
+            }
+            if (kt + 1 < KT) issue((kt + 1) & 1, (kt + 1) * BK);
+            compute(kt & 1);
+        }
+        // ---- epilogue: the operand tiles are dead after this barrier; C is staged in LDS
+        __syncthreads();
+        unsigned char* sC = smem;   // [128 rows][16 chunks of 16 B], chunk ^= row & 15
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nl = wn * 64 + j * 16 + kq * 4;        // 4 consecutive columns nl .. nl+3
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ml = wm * 64 + i * 16 + r16;
+                uint2 pk;
+                pk.x = (unsigned)f32_to_bf16(acc[i][j][0]) | ((unsigned)f32_to_bf16(acc[i][j][1]) << 16);
+                pk.y = (unsigned)f32_to_bf16(acc[i][j][2]) | ((unsigned)f32_to_bf16(acc[i][j][3]) << 16);
+                *reinterpret_cast<uint2*>(sC + ml * 256 + ((((nl >> 3) ^ (ml & 15)) << 4) | ((nl & 4) << 1))) = pk;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < BM * BN / 8 / THREADS; ++it) {
+            const int c = threadIdx.x + it * THREADS;
+            const int rl = c >> 4, ch = c & 15;
+            const int row = m0 + rl, col = n0 + ch * 8;
+            if (row >= g.M || col >= g.N || ((g.debug & 1) && row > 0)) continue;
+            uint4 v = *reinterpret_cast<const uint4*>(sC + rl * 256 + ((ch ^ (rl & 15)) << 4));
+            bf16_t* dst = g.C + (long long)row * g.ldc + col;
+            if (g.accumulate) {
+                float x[8], y[8];
+                ElemIO<bf16_t>::load_vec(dst, x);
+                ElemIO<bf16_t>::load_vec(reinterpret_cast<const bf16_t*>(&v), y);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] += y[e];
+                ElemIO<bf16_t>::store_vec(dst, x);
+            } else {
+                *reinterpret_cast<uint4*>(dst) = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool ed_gemm_nt_ok(int dtype_in, int dtype_out, const void* A, long long lda, int a_kmajor,
+                   const void* B, long long ldb, int b_kmajor, const void* C, long long ldc, int M,
+                   int N, int K, int split_k, const float* bias1, const float* bias2) {
+    if ((uintptr_t)bias1 % 16 != 0 || (uintptr_t)bias2 % 16 != 0) return false;   // float4 bias loads
+    return dtype_in == ED_BF16 && dtype_out == ED_BF16 && a_kmajor && b_kmajor && split_k == 1 &&
+           M > 0 && N > 0 && K >= BK && K % BK == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 &&
+           N % 8 == 0 && (uintptr_t)A % 16 == 0 && (uintptr_t)B % 16 == 0 && (uintptr_t)C % 16 == 0;
+}
+
+int ed_gemm_nt_launch(const void* A, long long lda, const void* B, long long ldb, void* C,
+                      long long ldc, int M, int N, int K, const float* bias1, const float* bias2,
+                      int accumulate, int lds_pad, hipStream_t s) {
+    NtArgs g;
+    g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = (bf16_t*)C;
+    g.bias1 = bias1; g.bias2 = bias2;
+    g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.M = M; g.N = N; g.K = K;
+    g.accumulate = accumulate;
+    g.n_tiles = (N + BN - 1) / BN;
+    const long long tiles = (long long)((M + BM - 1) / BM) * g.n_tiles;
+    ED_CHECK_ARG(tiles < (1ll << 31), "gemm: too many tiles");
+    g.tiles = (int)tiles;
+    static const int dbg = [] { const char* e = getenv("EDGEDICT_GEMM_NT_DEBUG"); return e ? atoi(e) : 0; }();
+    g.debug = dbg;
+    hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)tiles), dim3(THREADS), lds_pad, s, g);
+    ED_CHECK_LAUNCH("gemm_nt");
+    return ED_OK;
+}

@@ -1,0 +1,9 @@
+// bf16 NT fast path (gemm_nt.hip): direct-to-LDS double-buffered tiles.  Internal interface.
+#pragma once
+#include <hip/hip_runtime.h>
+bool ed_gemm_nt_ok(int dtype_in, int dtype_out, const void* A, long long lda, int a_kmajor,
+                   const void* B, long long ldb, int b_kmajor, const void* C, long long ldc, int M,
+                   int N, int K, int split_k, const float* bias1, const float* bias2);
+int ed_gemm_nt_launch(const void* A, long long lda, const void* B, long long ldb, void* C,
+                      long long ldc, int M, int N, int K, const float* bias1, const float* bias2,
+                      int accumulate, int lds_pad, hipStream_t s);

@@ -24,7 +24,7 @@ _vp, _fp = ctypes.c_void_p, ctypes.c_void_p
 class StackLayer(ctypes.Structure):
     _fields_ = [("T", ctypes.c_int), ("I", ctypes.c_int), ("reduce", ctypes.c_int),
                 ("residual", ctypes.c_int),
-                ("wih_p", _vp), ("bias_p", _fp), ("whh_f", _vp), ("whh_b", _vp),
+                ("wih_p", _vp), ("wih_t", _vp), ("bias_p", _fp), ("whh_f", _vp), ("whh_b", _vp),
                 ("ln_gamma", _fp), ("ln_beta", _fp),
                 ("X", _vp), ("G", _vp), ("Yx", _vp), ("Cx", _fp), ("mean", _fp), ("rstd", _fp),
                 ("dZ", _vp), ("dX", _vp), ("dW_ih", _fp), ("dW_hh", _fp), ("db", _fp),
@@ -63,7 +63,7 @@ def supported(cd, H, I0, L, reductions):
 
 class _PackedLayer:
     """bf16 weight images of one LSTM layer, rebuilt when the fp32 masters change."""
-    __slots__ = ("key", "ref", "wih_p", "bias_p", "whh_f", "whh_b")
+    __slots__ = ("key", "ref", "wih_p", "wih_t", "bias_p", "whh_f", "whh_b")
 
     def __init__(self, owner):
         self.key = None
@@ -84,6 +84,7 @@ def packed_weights(w_ih, w_hh, b_ih, b_hh):
         H = H4 // 4
         dev = w_ih.device
         ent.wih_p = torch.empty(H4, I, dtype=BF16, device=dev)
+        ent.wih_t = torch.empty(I, H4, dtype=BF16, device=dev)
         ent.bias_p = torch.empty(H4, dtype=F32, device=dev)
         ent.whh_f = torch.empty(H4 * H, dtype=BF16, device=dev)
         ent.whh_b = torch.empty(H4 * H, dtype=BF16, device=dev)
@@ -93,7 +94,7 @@ def packed_weights(w_ih, w_hh, b_ih, b_hh):
                 raise TypeError("encoder stack: master weights must be fp32")
         lib = _lib.load()
         check(lib.edgedict_stack_pack_weights(ptr(srcs[0]), ptr(srcs[1]), ptr(srcs[2]), ptr(srcs[3]),
-                                              H, I, ptr(ent.wih_p), ptr(ent.bias_p), ptr(ent.whh_f),
+                                              H, I, ptr(ent.wih_p), ptr(ent.wih_t), ptr(ent.bias_p), ptr(ent.whh_f),
                                               ptr(ent.whh_b), stream_ptr()), "stack_pack_weights")
         ent.key = key
     return ent
@@ -131,10 +132,11 @@ class _Plan:
             self.layer_bufs.append(bufs)
             y = self.larr[l]
             y.T, y.I, y.reduce, y.residual = T, I, reductions[l], int(l != 0)
-            y.wih_p, y.bias_p, y.whh_f, y.whh_b = map(_p, (pk.wih_p, pk.bias_p, pk.whh_f, pk.whh_b))
+            y.wih_p, y.wih_t, y.bias_p, y.whh_f, y.whh_b = map(
+                _p, (pk.wih_p, pk.wih_t, pk.bias_p, pk.whh_f, pk.whh_b))
             g, b = ln_w.detach(), ln_b.detach()
             y.ln_gamma, y.ln_beta = _p(g), _p(b)
-            self.keep += [pk.wih_p, pk.bias_p, pk.whh_f, pk.whh_b, g, b]
+            self.keep += [pk.wih_p, pk.wih_t, pk.bias_p, pk.whh_f, pk.whh_b, g, b]
             for k, v in bufs.items():
                 setattr(y, k, _p(v))
             T = (T + reductions[l] - 1) // reductions[l]
@@ -160,7 +162,8 @@ class _Plan:
 
     def forward(self):
         lib = _lib.load()
-        check(lib.edgedict_stack_forward(ctypes.byref(self.desc), stream_ptr()), "stack_forward")
+        with ops.host_timed("stack_forward_call"):
+            check(lib.edgedict_stack_forward(ctypes.byref(self.desc), stream_ptr()), "stack_forward")
 
     def final_states(self):
         hN = torch.stack([b["Yx"][-1] for b in self.layer_bufs], 0).float()
@@ -191,7 +194,8 @@ class _Plan:
         dout = dout.contiguous()
         d.dout, d.d_in_gamma, d.d_in_beta = _p(dout), _p(dig), _p(dib)
         lib = _lib.load()
-        check(lib.edgedict_stack_backward(ctypes.byref(d), stream_ptr()), "stack_backward")
+        with ops.host_timed("stack_backward_call"):
+            check(lib.edgedict_stack_backward(ctypes.byref(d), stream_ptr()), "stack_backward")
         return dig, dib, grads
 
 

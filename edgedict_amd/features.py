@@ -168,12 +168,16 @@ class StackedLogFbank(nn.Module):
         k, M = self.n_frame, self.fbank.n_filt
         T0 = self.output_frames(N)
         out = torch.empty(B, T0, M * k, dtype=self.out_dtype, device=x.device)
+        host_lengths = lengths
         if lengths is not None:
-            lengths = lengths.to(device=x.device, dtype=torch.int32).contiguous()
+            lengths = lengths.to(device=x.device, dtype=torch.int32, non_blocking=True).contiguous()
         self.fbank._run(x, lengths, out, T0 * M * k, M * k, M, 1, k, T0 * k)
         if lengths is None:
             xlen = torch.full((B,), T0, dtype=torch.int32, device=x.device)
         else:
-            F_b = 1 + lengths // self.fbank.hop_length
+            # sample counts given on the HOST (what a DataLoader hands over) keep the frame counts
+            # on the host too: the model slices by xlen.max() and that must not cost a device sync
+            src = host_lengths if not host_lengths.is_cuda else lengths
+            F_b = 1 + src.to(torch.int32) // self.fbank.hop_length
             xlen = ((F_b + k - 1) // k if self.pad_to_divisible else F_b // k).to(torch.int32)
         return out, xlen

@@ -285,7 +285,9 @@ class _JointFn(torch.autograd.Function):
             for p in (w1, ctx.b1, w2, ctx.b2))
         dw1 = db1 = dw2 = db2 = None
         with ops.timed("joint_dhid_gemm"):
-            dhid = ops.gemm(dl, w2c.t())
+            # dl x W2 with W2^T materialised once per optimiser step (1.3 M elements): both
+            # operands K-contiguous -> the direct-to-LDS kernel (gemm_nt.hip)
+            dhid = ops.gemm(dl, WEIGHTS.get(w2, cd, transposed=True))
         if not defer:
             with ops.timed("joint_dw2_gemm"):
                 dw2 = ops.gemm(dl.t(), hid2.t(), out_dtype=F32, split_k=ops.pick_split_k(V, J, M))
@@ -583,8 +585,12 @@ class Transducer(nn.Module):
         if self.output_loss:
             xlen = self.scale_length(logits, xlen)
             labels = ys.to(torch.int32).contiguous()
-            loss = _RNNTLossFn.apply(logits, labels, xlen.to(torch.int32).contiguous(),
-                                     ylen.to(torch.int32).contiguous(), self.blank, "mean")
+            dev = logits.device   # lengths may live on the host (no sync for the slicing above)
+            loss = _RNNTLossFn.apply(
+                logits, labels,
+                xlen.to(device=dev, dtype=torch.int32, non_blocking=True).contiguous(),
+                ylen.to(device=dev, dtype=torch.int32, non_blocking=True).contiguous(),
+                self.blank, "mean")
             return loss
         return logits
 

@@ -4,6 +4,7 @@ Nothing here computes: each function validates shapes, allocates outputs with th
 caching allocator and forwards raw pointers to libedgedict_hip.so on the current stream.
 """
 import ctypes
+import time
 
 import torch
 
@@ -17,6 +18,28 @@ def _ll(x):
 
 # ---- optional per-kernel timing with HIP events on the launch stream (used by bench.py) -------
 TIMERS = None   # set to {} to enable: tag -> list of (start_event, end_event)
+
+
+HOST = None     # set to {} to accumulate host wall time of selected native calls (bench.py)
+
+
+class host_timed:
+    def __init__(self, tag):
+        self.tag = tag
+
+    def __enter__(self):
+        if HOST is not None:
+            self.t0 = time.perf_counter()
+        return self
+
+    def __exit__(self, *exc):
+        if HOST is not None:
+            HOST.setdefault(self.tag, []).append(time.perf_counter() - self.t0)
+        return False
+
+
+def host_summary():
+    return {k: (len(v), 1e3 * sum(v) / max(1, len(v))) for k, v in (HOST or {}).items()}
 
 
 class timed:

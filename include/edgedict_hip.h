@@ -176,6 +176,7 @@ typedef struct edgedict_stack_layer {
     int reduce;            /* time reduction after this layer's LayerNorm: 1 or 2 */
     int residual;          /* LayerNorm(y + x) instead of LayerNorm(y) */
     const void* wih_p;     /* bf16 [4H, I]  rows in interleaved gate order */
+    const void* wih_t;     /* bf16 [I, 4H]  its transpose (K-contiguous operand of the dX product); backward only */
     const float* bias_p;   /* f32  [4H]     b_ih + b_hh, interleaved */
     const void* whh_f;     /* bf16 forward fragment image of W_hh (4H*H) */
     const void* whh_b;     /* bf16 backward fragment image of W_hh (4H*H); backward only */
@@ -238,8 +239,8 @@ size_t edgedict_stack_struct_bytes(int which);
 void* edgedict_aux_stream(int which);
 size_t edgedict_stack_workspace_bytes(const edgedict_stack_desc_t* desc);
 int edgedict_stack_pack_weights(const float* w_ih, const float* w_hh, const float* b_ih,
-                                const float* b_hh, int H, int I, void* wih_p, float* bias_p,
-                                void* whh_f, void* whh_b, void* stream);
+                                const float* b_hh, int H, int I, void* wih_p, void* wih_t,
+                                float* bias_p, void* whh_f, void* whh_b, void* stream);
 int edgedict_stack_forward(const edgedict_stack_desc_t* desc, void* stream);
 int edgedict_stack_backward(const edgedict_stack_desc_t* desc, void* stream);
 

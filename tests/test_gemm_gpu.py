@@ -62,3 +62,29 @@ def test_gemm_strided_views_and_second_bias(hip_lib):
     out2 = ops.gemm(x[:, :256].contiguous(), w[:, 640:])
     ref2 = x[:, :256] @ w[:, 640:].t()
     assert (out2 - ref2).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (1, 8, 64), (300, 200, 640), (1029, 2048, 128),
+                                   (64 * 33, 4096, 1024), (130, 136, 4096)])
+def test_gemm_nt_direct_to_lds_path(hip_lib, M, N, K):
+    """bf16 x bf16 -> bf16 with K-contiguous operands and K % 64 == 0 runs gemm_nt.hip
+    (global_load_lds double buffering, source-side swizzle): ragged M/N edges, both biases,
+    strided operands, in-place accumulation."""
+    from edgedict_amd import ops
+    a_full = _mk((M, K + 64), torch.bfloat16, 11)
+    a = a_full[:, 64:]                                  # lda = K + 64, 128-byte offset
+    b = _mk((N, K), torch.bfloat16, 12)
+    b1 = torch.randn(N, generator=torch.Generator().manual_seed(1)).cuda()
+    b2 = torch.randn(N, generator=torch.Generator().manual_seed(2)).cuda()
+    ref = a.double() @ b.double().t() + b1.double() + b2.double()
+    out = ops.gemm(a, b, bias=b1, bias2=b2)
+    assert out.dtype == torch.bfloat16
+    # one bf16 rounding of an fp32-accumulated value
+    err = (out.double() - ref).abs()
+    assert (err <= 2.0 ** -8 * ref.abs() + 1e-3 * (K ** 0.5)).all()
+    base = _mk((M, N), torch.bfloat16, 13)
+    acc = base.clone()
+    ops.gemm(a, b, out=acc, accumulate=True)
+    ref2 = base.double() + (a.double() @ b.double().t())
+    err2 = (acc.double() - ref2).abs()
+    assert (err2 <= 2.0 ** -7 * ref2.abs() + 2e-3 * (K ** 0.5)).all()

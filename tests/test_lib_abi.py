@@ -53,5 +53,5 @@ def test_encoder_stack_validates_before_launching(hip_lib):
     assert b"H % 32" in hip_lib.edgedict_last_error()
     assert hip_lib.edgedict_stack_workspace_bytes(ctypes.byref(d)) > 0
     rc = hip_lib.edgedict_stack_pack_weights(None, None, None, None, 64, 16, None, None, None,
-                                             None, None)
+                                             None, None, None)
     assert rc == -1

@@ -55,3 +55,26 @@ def test_stack_and_per_layer_steps_agree_in_bf16(hip_lib):
     assert abs(la - lb) / abs(lb) < 2e-2
     cos = torch.nn.functional.cosine_similarity(ga.double(), gb.double(), dim=0).item()
     assert cos > 0.99, cos
+
+
+def test_host_side_lengths_give_the_same_step(hip_lib):
+    """Lengths handed over on the host (as a DataLoader does, rnnt/dataset.py:225-240) must give
+    the same step as device-resident lengths; they only remove the xlen.max() device sync."""
+    from edgedict_amd.trainer import TrainEngine
+    res = []
+    for host in (False, True):
+        torch.manual_seed(0)
+        eng = TrainEngine(_flags(), vocab_size=40, device="cuda", compute_dtype="fp32")
+        g = torch.Generator(device="cpu").manual_seed(1)
+        wave = (0.1 * torch.randn(4, 16000, generator=g)).cuda()
+        wlen = torch.tensor([16000, 15000, 12000, 9000], dtype=torch.int32)
+        ys = torch.randint(4, 40, (4, 7), generator=g, dtype=torch.int32).cuda()
+        ylen = torch.tensor([7, 5, 6, 3], dtype=torch.int32)
+        if not host:
+            wlen, ylen = wlen.cuda(), ylen.cuda()
+        loss = eng.train_step(wave, wlen, ys, ylen)
+        torch.cuda.synchronize()
+        res.append((loss.item(), eng.flat.grad.clone()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1]) or \
+        (res[0][1] - res[1][1]).abs().max().item() <= 2e-5 * res[0][1].abs().max().item()

@@ -24,7 +24,11 @@ M = 64 * 201 * 65
 bench("joint logits (NT)", M, 2048, 640)
 bench("joint dhid (NN)", M, 640, 2048, tb=True)
 bench("joint dW2 (TN, splitk)", 2048, 640, M, ta=True, tb=True, out_dtype=torch.float32, split_k=9)
+bench("joint dhid via W2^T copy (NT)", M, 640, 2048)
 bench("enc L1 input gemm (NT)", 64 * 401, 4096, 1024)
+bench("enc chunk input gemm (NT)", 64 * 32, 4096, 1024, iters=20)
+bench("enc chunk dX, Wih^T copy (NT)", 64 * 16, 1024, 4096, iters=20)
+bench("enc chunk dX (NN)", 64 * 16, 1024, 4096, tb=True, iters=20)
 bench("enc dX (NN)", 64 * 401, 1024, 4096, tb=True)
 bench("enc dW_ih (TN)", 4096, 1024, 64 * 401, ta=True, tb=True, out_dtype=torch.float32, split_k=3)
 bench("square 4096 (NT)", 4096, 4096, 4096)
