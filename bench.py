@@ -165,6 +165,18 @@ def main():
         n, ms = timers.get("joint_logits_gemm", (0, float("nan")))
         peak = MFMA_BF16_PEAK_TF if args.dtype == "bf16" else MFMA_F32_PEAK_TF
         achieved = flop / (ms * 1e-3) / 1e12 if n else float("nan")
+        # HBM bytes per launch of that kernel from the committed PMC passes (profiles/collect.sh:
+        # separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 FETCH correction); null if not collected
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as fh:
+                pmc = json.load(fh)["kernels"]
+            tiles = ((args.batch * Tp * U1 + 127) // 128) * ((V + 127) // 128)
+            ent = pmc.get("gemm_nt_kernel [tiles=%d]" % tiles)
+            if ent:
+                traffic = ent["hbm_bytes"]
+        except (OSError, ValueError, KeyError):
+            pass
         out = {
             "metric": "utterances/sec (E6D2, 15 s audio)",
             "value": args.batch * world * args.steps / dt,
@@ -191,10 +203,11 @@ def main():
                 "final_loss": loss_val,
             },
             "roofline": {
-                "kernel": "gemm_kernel<bf16,bf16,NT> joint logits [%d x %d x %d]"
+                "kernel": "gemm_nt_kernel (bf16 NT, direct-to-LDS) joint logits [%d x %d x %d]"
                           % (args.batch * Tp * U1, V, J),
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                "frac": achieved / peak, "traffic": None,
+                "frac": achieved / peak, "traffic": traffic,
+                "algorithmic_bytes": 2.0 * args.batch * Tp * U1 * (J + V) + 2.0 * V * J,
                 "launch_ms": ms, "launches_timed": n,
             },
             "kernel_ms": {k: round(v[1], 4) for k, v in sorted(timers.items())},

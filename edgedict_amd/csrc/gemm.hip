@@ -14,7 +14,8 @@
 // v_mfma_f32_16x16x4_f32 (BK = 16).  Accumulation is always fp32.  Operand tiles are staged
 // global -> registers -> LDS (rows padded by 16 B against ds_read bank conflicts) with the next
 // tile's global loads issued before the current tile's MFMAs.
-// split_k > 1 partitions K over blockIdx.z and combines with fp32 atomics (gradient "+=").
+// split_k > 1 partitions K over workgroups (XCD-aware: one K slice per XCD) and combines with fp32
+// atomics (gradient "+=").
 #include <stdlib.h>
 
 #include "common.hpp"
@@ -251,10 +252,15 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
 
     // N index fastest: consecutive blocks share the same A row panel (L2 reuse)
     const int n_tiles = (g.N + BN - 1) / BN;
-    const int tile = blockIdx.x;
+    // split-K launches are 1-D with the K slice FASTEST (slice = id % split_k, split_k % 8 == 0):
+    // workgroup id % 8 is the XCD, so every tile of one K slice runs on the SAME XCD and the slice's
+    // operand rows are fetched from HBM once into that XCD's L2 instead of once per XCD
+    // (measured on the joint dW2 product: 26.5 GB of HBM reads for 4.5 GB of operands before).
+    const int tile = g.split_k > 1 ? blockIdx.x / g.split_k : blockIdx.x;
+    const int slice = g.split_k > 1 ? blockIdx.x % g.split_k : 0;
     const int m0 = (tile / n_tiles) * BM;
     const int n0 = (tile % n_tiles) * BN;
-    const int kbeg = blockIdx.z * g.k_per_split;
+    const int kbeg = slice * g.k_per_split;
     const int kend = min(g.K, kbeg + g.k_per_split);
 
     const TI* A = reinterpret_cast<const TI*>(g.A);
@@ -293,7 +299,7 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
 
     // epilogue: lane holds D[row = (lane>>4)*4 + r][col = lane&15] of each 16x16 tile
     TO* C = reinterpret_cast<TO*>(g.C);
-    const bool first_split = (blockIdx.z == 0);
+    const bool first_split = (slice == 0);
     if constexpr (sizeof(TO) == 2 && sizeof(TI) == 2) {
         if (g.c_vec) {
             // bf16 output: round in registers, stage the 128x128 tile in LDS (the operand tiles
@@ -431,6 +437,7 @@ static int gemm_impl(int dtype_in, int dtype_out, const void* A, long long lda, 
     g.accumulate = accumulate;
     const int bk = dtype_in == ED_F32 ? 16 : 64;
     int ktiles = (K + bk - 1) / bk;
+    if (split_k > 1) split_k = (split_k + 7) / 8 * 8;   // whole K slices per XCD (see the kernel)
     if (split_k > ktiles) split_k = ktiles > 0 ? ktiles : 1;
     g.split_k = split_k;
     g.k_per_split = ((ktiles + split_k - 1) / split_k) * bk;
@@ -444,7 +451,8 @@ static int gemm_impl(int dtype_in, int dtype_out, const void* A, long long lda, 
     }
     const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     ED_CHECK_ARG(tiles < (1ll << 31), "gemm: too many tiles");
-    dim3 grid((unsigned)tiles, 1, split_k);
+    ED_CHECK_ARG(tiles * split_k < (1ll << 31), "gemm: too many workgroups");
+    dim3 grid((unsigned)(tiles * split_k), 1, 1);
     // occupancy cap: claim enough extra LDS that only max_wg_per_cu workgroups fit on a CU
     int pad = 0;
     if (max_wg_per_cu > 0) {
