@@ -19,10 +19,16 @@
 //
 // The caller's stream is forked into the internal streams at entry and joined at exit, so the
 // call is an ordinary stream-ordered operation for the caller (and for the caching allocator).
+#include <stdlib.h>
+
 #include <mutex>
 #include <vector>
 
 #include "stack_kernels.hpp"
+
+int ed_gemm_quiet_partials(int dtype_in, const void* A, long long lda, int a_kmajor, const void* B,
+                           long long ldb, int b_kmajor, int M, int N, int K, int split_k,
+                           int max_wg_per_cu, float* partials, int* slices, hipStream_t stream);   // gemm.hip
 
 namespace {
 
@@ -77,14 +83,20 @@ __global__ void pack_whh_bwd_kernel(const float* __restrict__ W, bf16_t* __restr
         out[i] = f32_to_bf16(W[((long long)g * H + ub * 16 + u) * H + unit]);
     }
 }
-// dst[g*H + j][k] = src[kappa(g,j)][k]
-__global__ void unpermute_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int H,
-                                      int K) {
+// dst[g*H + j][k] (+)= sum_s src[s][kappa(g,j)][k]   (slices of a quiet split-K product; dst2 gets
+// the same values: the two LSTM bias gradients are equal)
+__global__ void unpermute_rows_kernel(const float* __restrict__ src, long long slice_stride, int S,
+                                      float* __restrict__ dst, float* __restrict__ dst2, int H, int K,
+                                      int accumulate) {
     const long long n = 4ll * H * K;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
         const int row = (int)(i / K), k = (int)(i % K);
-        dst[i] = src[(long long)ed_gate_col(row / H, row % H) * K + k];
+        const long long o = (long long)ed_gate_col(row / H, row % H) * K + k;
+        float v = 0.f;
+        for (int sl = 0; sl < S; ++sl) v += src[sl * slice_stride + o];
+        dst[i] = accumulate ? dst[i] + v : v;
+        if (dst2) dst2[i] = accumulate ? dst2[i] + v : v;
     }
 }
 
@@ -114,8 +126,10 @@ Runtime* runtime_for_current_device() {
         Runtime* r = new Runtime();
         int lo = 0, hi = 0;
         hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least, hi = greatest priority
+        const char* e = getenv("EDGEDICT_AUX_PRIORITY");
+        const bool aux_high = e && e[0] == '1';
         bool ok = hipStreamCreateWithPriority(&r->R, hipStreamNonBlocking, hi) == hipSuccess &&
-                  hipStreamCreateWithPriority(&r->W, hipStreamNonBlocking, lo) == hipSuccess;
+                  hipStreamCreateWithPriority(&r->W, hipStreamNonBlocking, aux_high ? hi : lo) == hipSuccess;
         for (int i = 0; ok && i < ED_STACK_MAX_SLOTS; ++i)
             ok = hipStreamCreateWithPriority(&r->S[i], hipStreamNonBlocking, hi) == hipSuccess;
         if (!ok) {
@@ -165,7 +179,7 @@ WsLayout ws_layout(const edgedict_stack_desc_t* d) {
             off += align256((size_t)(nch * LNB_GRID + LNB_GRID_TOP) * 2 * d->H * sizeof(float));
         }
     }
-    w.tmpW = off; off += align256((size_t)4 * d->H * maxK * sizeof(float));
+    w.tmpW = off; off += align256((size_t)8 * 4 * d->H * maxK * sizeof(float));   // up to 8 K slices
     w.tmpB = off; off += align256((size_t)4 * d->H * sizeof(float));
     w.dX0 = off; off += align256((size_t)d->T0 * d->B * d->I0 * sizeof(bf16_t));
     w.total = off;
@@ -485,25 +499,27 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     }
     std::vector<int> deferred;   // layers whose weight gradients run after the BPTT (DW_AT_END)
 
+    const int acc_grads = (d->flags & EDGEDICT_STACK_ACCUM_GRADS) ? 1 : 0;
     auto weight_grads = [&](int l) -> int {
         const edgedict_stack_layer_t& y = d->layers[l];
         const int M = y.T * B;
         float* tmpW = (float*)(ws + wl.tmpW);
         float* tmpB = (float*)(ws + wl.tmpB);
-        const int sk = d->split_k > 0 ? d->split_k : max(1, min(16, M / 2048));
-        // dW_ih = dG^T X,  dW_hh = dG^T H_prev (rows come out in interleaved gate order)
-        ED_TRY(edgedict_gemm_bg(ED_BF16, ED_F32, y.G, 4ll * H, 0, y.X, y.I, 0, tmpW, y.I, 4 * H, y.I, M,
-                                nullptr, nullptr, 0, sk, 2, st.W));
+        const int sk = d->split_k > 0 ? d->split_k : 2;
+        int S = 1;
+        // dW_ih = dG^T X,  dW_hh = dG^T H_prev as QUIET products (K slices written once, no atomics:
+        // a concurrent kernel with dirty lines makes every BPTT launch boundary 3-10x dearer);
+        // rows come out in interleaved gate order and are summed + un-permuted in one pass
+        ED_TRY(ed_gemm_quiet_partials(ED_BF16, y.G, 4ll * H, 0, y.X, y.I, 0, 4 * H, y.I, M, sk, 2, tmpW, &S, st.W));
         hipLaunchKernelGGL(unpermute_rows_kernel, dim3(ed_grid_for(4ll * H * y.I, 256, 4096)),
-                           dim3(256), 0, st.W, tmpW, y.dW_ih, H, y.I);
-        ED_TRY(edgedict_gemm_bg(ED_BF16, ED_F32, y.G, 4ll * H, 0, y.Yx, H, 0, tmpW, H, 4 * H, H, M,
-                                nullptr, nullptr, 0, sk, 2, st.W));
+                           dim3(256), 0, st.W, tmpW, 4ll * H * y.I, S, y.dW_ih, nullptr, H, y.I, acc_grads);
+        ED_TRY(ed_gemm_quiet_partials(ED_BF16, y.G, 4ll * H, 0, y.Yx, H, 0, 4 * H, H, M, sk, 2, tmpW, &S, st.W));
         hipLaunchKernelGGL(unpermute_rows_kernel, dim3(ed_grid_for(4ll * H * H, 256, 4096)),
-                           dim3(256), 0, st.W, tmpW, y.dW_hh, H, H);
+                           dim3(256), 0, st.W, tmpW, 4ll * H * H, S, y.dW_hh, nullptr, H, H, acc_grads);
         ED_TRY(ed_stack_zero(tmpB, (size_t)4 * H * sizeof(float), st.W));
         ED_TRY(edgedict_colsum(ED_BF16, y.G, 4ll * H, tmpB, M, 4 * H, st.W));
         hipLaunchKernelGGL(unpermute_rows_kernel, dim3(ed_grid_for(4ll * H, 256, 4096)), dim3(256),
-                           0, st.W, tmpB, y.db, H, 1);
+                           0, st.W, tmpB, 0, 1, y.db, y.db_hh, H, 1, acc_grads);
         ED_CHECK_LAUNCH("unpermute_rows_kernel");
         return ED_OK;
     };

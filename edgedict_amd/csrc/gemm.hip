@@ -54,6 +54,9 @@ struct GemmArgs {
     int accumulate;
     int split_k;
     int k_per_split;  // multiple of BK
+    int items;        // tiles * split_k
+    float* partials;  // non-null: slice s stores its tiles to partials + s*partial_stride ([M][N] dense,
+    long long partial_stride;   // plain stores, no atomics); the caller sums the slices
 };
 
 // ---- staging registers: the 16-byte chunks one thread moves per operand tile
@@ -256,17 +259,23 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
     // workgroup id % 8 is the XCD, so every tile of one K slice runs on the SAME XCD and the slice's
     // operand rows are fetched from HBM once into that XCD's L2 instead of once per XCD
     // (measured on the joint dW2 product: 26.5 GB of HBM reads for 4.5 GB of operands before).
-    const int tile = g.split_k > 1 ? blockIdx.x / g.split_k : blockIdx.x;
-    const int slice = g.split_k > 1 ? blockIdx.x % g.split_k : 0;
-    const int m0 = (tile / n_tiles) * BM;
-    const int n0 = (tile % n_tiles) * BN;
-    const int kbeg = slice * g.k_per_split;
-    const int kend = min(g.K, kbeg + g.k_per_split);
-
+    // Work items = tiles x K slices.  A normal launch has one workgroup per item; a BACKGROUND launch
+    // (edgedict_gemm_bg) has only as many workgroups as are resident at once and each walks its
+    // items (stride gridDim.x, a multiple of split_k: the slice, hence the XCD, stays fixed).  A
+    // grid with more workgroups than fit parks its tail in the dispatcher, and on this chip that
+    // blocks the dispatch of OTHER queues' kernels (measured: 60 us per tiny kernel on the main
+    // stream while a 1280-workgroup dW GEMM ran on the auxiliary stream).
     const TI* A = reinterpret_cast<const TI*>(g.A);
     const TI* B = reinterpret_cast<const TI*>(g.B);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+  for (int item = blockIdx.x; item < g.items; item += gridDim.x) {
+    const int tile = g.split_k > 1 ? item / g.split_k : item;
+    const int slice = g.split_k > 1 ? item % g.split_k : 0;
+    const int m0 = (tile / n_tiles) * BM;
+    const int n0 = (tile % n_tiles) * BN;
+    const int kbeg = slice * g.k_per_split;
+    const int kend = min(g.K, kbeg + g.k_per_split);
 
     f32x4_t acc[4][4];
 #pragma unroll
@@ -342,7 +351,8 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
                     *reinterpret_cast<uint4*>(dst) = v;
                 }
             }
-            return;
+            __syncthreads();   // staging tile consumed before the next item's operand tiles land
+            continue;
         }
     }
 #pragma unroll
@@ -363,7 +373,8 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
                 const float v = acc[i][j][r] + bias;
                 TO* dst = C + (long long)row * g.ldc + col;
                 if constexpr (sizeof(TO) == 4) {
-                    if (g.split_k > 1) atomicAdd(reinterpret_cast<float*>(dst), v);
+                    if (g.partials) g.partials[slice * g.partial_stride + (long long)row * g.N + col] = v;
+                    else if (g.split_k > 1) atomicAdd(reinterpret_cast<float*>(dst), v);
                     else if (g.accumulate) *dst = *dst + v;
                     else *dst = v;
                 } else {
@@ -373,6 +384,7 @@ __global__ __launch_bounds__(THREADS) void gemm_kernel(GemmArgs g) {
             }
         }
     }
+  }   // items
 }
 
 template <typename TI, typename TO, bool FAST>
@@ -396,6 +408,20 @@ int launch(const GemmArgs& g, int a_km, int b_km, dim3 grid, hipStream_t s, int 
     return launch2<TI, TO, false>(g, a_km, b_km, grid, s, pad);
 }
 
+// C[m][n] (+)= sum_s part[s][m][n]
+__global__ void reduce_partials_kernel(const float* __restrict__ part, long long stride, int S,
+                                       float* __restrict__ C, long long ldc, long long M, int N,
+                                       int accumulate) {
+    const long long n = M * N;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        float a = 0.f;
+        for (int s = 0; s < S; ++s) a += part[s * stride + i];
+        float* dst = C + (i / N) * ldc + (i % N);
+        *dst = accumulate ? *dst + a : a;
+    }
+}
+
 __global__ void zero_f32(float* p, long long rows, long long cols, long long ld) {
     const long long n = rows * cols;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
@@ -408,7 +434,7 @@ __global__ void zero_f32(float* p, long long rows, long long cols, long long ld)
 static int gemm_impl(int dtype_in, int dtype_out, const void* A, long long lda, int a_kmajor,
                      const void* B, long long ldb, int b_kmajor, void* C, long long ldc, int M, int N,
                      int K, const float* bias1, const float* bias2, int accumulate, int split_k,
-                     void* stream_, int max_wg_per_cu) {
+                     void* stream_, int max_wg_per_cu, float* partials = nullptr, bool reduce = true) {
     ED_CHECK_ARG(dtype_in == ED_F32 || dtype_in == ED_BF16, "gemm: bad input dtype %d", dtype_in);
     ED_CHECK_ARG(dtype_out == ED_F32 || dtype_out == ED_BF16, "gemm: bad output dtype %d", dtype_out);
     ED_CHECK_ARG(!(dtype_in == ED_F32 && dtype_out == ED_BF16), "gemm: fp32 inputs with bf16 output is not supported");
@@ -437,12 +463,21 @@ static int gemm_impl(int dtype_in, int dtype_out, const void* A, long long lda, 
     g.accumulate = accumulate;
     const int bk = dtype_in == ED_F32 ? 16 : 64;
     int ktiles = (K + bk - 1) / bk;
-    if (split_k > 1) split_k = (split_k + 7) / 8 * 8;   // whole K slices per XCD (see the kernel)
+    if (partials) {
+        // quiet mode: few long-lived slices (power of two <= 8 keeps slice <-> XCD set fixed)
+        int p2 = 1;
+        while (p2 < split_k && p2 < 8) p2 *= 2;
+        split_k = p2;
+    } else if (split_k > 1) {
+        split_k = (split_k + 7) / 8 * 8;   // whole K slices per XCD (see the kernel)
+    }
     if (split_k > ktiles) split_k = ktiles > 0 ? ktiles : 1;
     g.split_k = split_k;
     g.k_per_split = ((ktiles + split_k - 1) / split_k) * bk;
     if (g.k_per_split == 0) g.k_per_split = bk;
-    if (split_k > 1 && !accumulate) {
+    g.partials = partials;
+    g.partial_stride = (long long)M * N;
+    if (split_k > 1 && !accumulate && !partials) {
         // atomics need a defined starting value
         const long long n = (long long)M * N;
         hipLaunchKernelGGL(zero_f32, dim3(ed_grid_for(n, 256)), dim3(256), 0, stream, (float*)C,
@@ -452,7 +487,20 @@ static int gemm_impl(int dtype_in, int dtype_out, const void* A, long long lda, 
     const long long tiles = (long long)((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     ED_CHECK_ARG(tiles < (1ll << 31), "gemm: too many tiles");
     ED_CHECK_ARG(tiles * split_k < (1ll << 31), "gemm: too many workgroups");
-    dim3 grid((unsigned)(tiles * split_k), 1, 1);
+    g.items = (int)(tiles * split_k);
+    long long nwg = g.items;
+    if (max_wg_per_cu > 0) {
+        // background: only as many workgroups as are resident at once (see the kernel)
+        static const int n_cu = [] {
+            int dev = 0, n = 256;
+            if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            return n > 0 ? n : 256;
+        }();
+        long long cap = (long long)max_wg_per_cu * n_cu;
+        if (split_k > 1) cap = cap / split_k * split_k;   // keep item % split_k fixed per workgroup
+        if (cap >= split_k && nwg > cap) nwg = cap;
+    }
+    dim3 grid((unsigned)nwg, 1, 1);
     // occupancy cap: claim enough extra LDS that only max_wg_per_cu workgroups fit on a CU
     int pad = 0;
     if (max_wg_per_cu > 0) {
@@ -460,9 +508,31 @@ static int gemm_impl(int dtype_in, int dtype_out, const void* A, long long lda, 
         const int want = (160 * 1024) / (max_wg_per_cu + 1) + 1024;   // one more would not fit
         if (want > stat) pad = (want - stat + 255) / 256 * 256;
     }
-    if (dtype_in == ED_BF16 && dtype_out == ED_BF16) return launch<bf16_t, bf16_t>(g, a_kmajor, b_kmajor, grid, stream, pad);
-    if (dtype_in == ED_BF16 && dtype_out == ED_F32) return launch<bf16_t, float>(g, a_kmajor, b_kmajor, grid, stream, pad);
-    return launch<float, float>(g, a_kmajor, b_kmajor, grid, stream, pad);
+    int rc;
+    if (dtype_in == ED_BF16 && dtype_out == ED_BF16) rc = launch<bf16_t, bf16_t>(g, a_kmajor, b_kmajor, grid, stream, pad);
+    else if (dtype_in == ED_BF16 && dtype_out == ED_F32) rc = launch<bf16_t, float>(g, a_kmajor, b_kmajor, grid, stream, pad);
+    else rc = launch<float, float>(g, a_kmajor, b_kmajor, grid, stream, pad);
+    if (rc != ED_OK || !partials || !reduce) return rc;
+    hipLaunchKernelGGL(reduce_partials_kernel, dim3(ed_grid_for((long long)M * N, 256, 2048)), dim3(256), 0,
+                       stream, partials, g.partial_stride, g.split_k, (float*)C, ldc, (long long)M, N,
+                       accumulate);
+    ED_CHECK_LAUNCH("gemm reduce_partials");
+    return ED_OK;
+}
+
+// internal (encoder_stack.hip): quiet background product that leaves the slices UNREDUCED in
+// `partials`; returns the number of slices written through *slices
+int ed_gemm_quiet_partials(int dtype_in, const void* A, long long lda, int a_kmajor, const void* B,
+                           long long ldb, int b_kmajor, int M, int N, int K, int split_k,
+                           int max_wg_per_cu, float* partials, int* slices, hipStream_t stream) {
+    int p2 = 1;
+    while (p2 < split_k && p2 < 8) p2 *= 2;
+    const int bk = dtype_in == ED_F32 ? 16 : 64;
+    const int ktiles = (K + bk - 1) / bk;
+    if (p2 > ktiles) p2 = ktiles > 0 ? ktiles : 1;
+    *slices = p2;
+    return gemm_impl(dtype_in, ED_F32, A, lda, a_kmajor, B, ldb, b_kmajor, partials, N, M, N, K, nullptr,
+                     nullptr, 0, p2, (void*)stream, max_wg_per_cu, partials, false);
 }
 
 extern "C" int edgedict_gemm(int dtype_in, int dtype_out, const void* A, long long lda, int a_kmajor,
@@ -477,8 +547,10 @@ extern "C" int edgedict_gemm_bg(int dtype_in, int dtype_out, const void* A, long
                                 int a_kmajor, const void* B, long long ldb, int b_kmajor, void* C,
                                 long long ldc, int M, int N, int K, const float* bias1,
                                 const float* bias2, int accumulate, int split_k,
-                                int max_wg_per_cu, void* stream_) {
+                                int max_wg_per_cu, float* partials, void* stream_) {
     ED_CHECK_ARG(max_wg_per_cu >= 1 && max_wg_per_cu <= 8, "gemm_bg: max_wg_per_cu must be 1..8");
+    ED_CHECK_ARG(!partials || dtype_out == ED_F32, "gemm_bg: the quiet (partials) form needs an fp32 output");
+    ED_CHECK_ARG(!partials || (!bias1 && !bias2), "gemm_bg: the quiet (partials) form takes no bias");
     return gemm_impl(dtype_in, dtype_out, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, bias1,
-                     bias2, accumulate, split_k, stream_, max_wg_per_cu);
+                     bias2, accumulate, split_k, stream_, max_wg_per_cu, partials, true);
 }

@@ -27,7 +27,7 @@ class StackLayer(ctypes.Structure):
                 ("wih_p", _vp), ("wih_t", _vp), ("bias_p", _fp), ("whh_f", _vp), ("whh_b", _vp),
                 ("ln_gamma", _fp), ("ln_beta", _fp),
                 ("X", _vp), ("G", _vp), ("Yx", _vp), ("Cx", _fp), ("mean", _fp), ("rstd", _fp),
-                ("dZ", _vp), ("dX", _vp), ("dW_ih", _fp), ("dW_hh", _fp), ("db", _fp),
+                ("dZ", _vp), ("dX", _vp), ("dW_ih", _fp), ("dW_hh", _fp), ("db", _fp), ("db_hh", _fp),
                 ("dgamma", _fp), ("dbeta", _fp)]
 
 
@@ -44,6 +44,7 @@ class StackDesc(ctypes.Structure):
 
 SERIAL = 1
 DW_AT_END = 2
+ACCUM_GRADS = 8
 
 # schedule knobs (env overrides are for tuning runs; the defaults are what bench.py measures)
 CHUNK = int(os.environ.get("EDGEDICT_STACK_CHUNK", "16"))
@@ -162,41 +163,62 @@ class _Plan:
 
     def forward(self):
         lib = _lib.load()
+        ops.mark("stack_fwd:enter")
         with ops.host_timed("stack_forward_call"):
             check(lib.edgedict_stack_forward(ctypes.byref(self.desc), stream_ptr()), "stack_forward")
+        ops.mark("stack_fwd:exit")
 
     def final_states(self):
         hN = torch.stack([b["Yx"][-1] for b in self.layer_bufs], 0).float()
         cN = torch.stack([b["Cx"][-1] for b in self.layer_bufs], 0).clone()
         return hN, cN
 
-    def backward(self, dout):
+    def backward(self, dout, params, in_norm):
+        """Returns (dig, dib, per-layer grads) or None when every gradient was accumulated straight
+        into the parameters' existing fp32 .grad buffers (flat-buffer training: no AccumulateGrad
+        adds, no temporaries)."""
         dev = dout.device
         B, H = self.B, self.H
         grads = []
         d = self.desc
+        everyone = list(params) + list(in_norm)
+        direct = config.DEFER_WEIGHT_GRADS and all(
+            p.grad is not None and p.grad.dtype == F32 and p.grad.is_contiguous() for p in everyone)
+        zeros = None if direct else torch.zeros(2 * H * self.L + 2 * self.I0, dtype=F32, device=dev)
         for l in range(self.L):
             y = self.larr[l]
             T, I = y.T, y.I
+            w_ih, w_hh, b_ih, b_hh, ln_w, ln_b = params[6 * l:6 * l + 6]
             dZ = torch.empty(T, B, H, dtype=BF16, device=dev)
             gb = dict(dZ=dZ, dX=dZ if y.residual else (torch.empty(T, B, I, dtype=BF16, device=dev)
-                                                       if l > 0 else None),
-                      dW_ih=torch.empty(4 * H, I, dtype=F32, device=dev),
-                      dW_hh=torch.empty(4 * H, H, dtype=F32, device=dev),
-                      db=torch.empty(4 * H, dtype=F32, device=dev),
-                      dgamma=torch.zeros(H, dtype=F32, device=dev),
-                      dbeta=torch.zeros(H, dtype=F32, device=dev))
+                                                       if l > 0 else None))
+            if direct:
+                gb.update(dW_ih=w_ih.grad, dW_hh=w_hh.grad, db=b_ih.grad, db_hh=b_hh.grad,
+                          dgamma=ln_w.grad, dbeta=ln_b.grad)
+            else:
+                gb.update(dW_ih=torch.empty(4 * H, I, dtype=F32, device=dev),
+                          dW_hh=torch.empty(4 * H, H, dtype=F32, device=dev),
+                          db=torch.empty(4 * H, dtype=F32, device=dev), db_hh=None,
+                          dgamma=zeros[2 * H * l:2 * H * l + H],
+                          dbeta=zeros[2 * H * l + H:2 * H * (l + 1)])
             for k, v in gb.items():
                 setattr(y, k, _p(v))
             grads.append(gb)
-        dig = torch.zeros(self.I0, dtype=F32, device=dev)
-        dib = torch.zeros(self.I0, dtype=F32, device=dev)
+        if direct:
+            dig, dib = in_norm[0].grad, in_norm[1].grad
+            d.flags |= ACCUM_GRADS
+        else:
+            dig = zeros[2 * H * self.L:2 * H * self.L + self.I0]
+            dib = zeros[2 * H * self.L + self.I0:]
+            d.flags &= ~ACCUM_GRADS
         dout = dout.contiguous()
         d.dout, d.d_in_gamma, d.d_in_beta = _p(dout), _p(dig), _p(dib)
         lib = _lib.load()
+        ops.mark("stack_bwd:enter")
         with ops.host_timed("stack_backward_call"):
             check(lib.edgedict_stack_backward(ctypes.byref(d), stream_ptr()), "stack_backward")
-        return dig, dib, grads
+        ops.mark("stack_bwd:exit")
+        return None if direct else (dig, dib, grads)
 
 
 class EncoderStackFn(torch.autograd.Function):
@@ -217,7 +239,8 @@ class EncoderStackFn(torch.autograd.Function):
         hN, cN = plan.final_states()
         out, plan.out = plan.out, None     # the descriptor keeps the raw pointer; no ctx <-> output cycle
         ctx.plan = plan
-        ctx.nparams = len(params)
+        ctx.params = params
+        ctx.in_norm = (in_g, in_b)
         ctx.mark_non_differentiable(hN, cN)
         return out, hN, cN
 
@@ -231,7 +254,10 @@ class EncoderStackFn(torch.autograd.Function):
         if dout.dtype != BF16:
             dout = dout.to(BF16)
         with ops.timed("enc_stack_bwd_T%d_L%d" % (plan.T0, plan.L)):
-            dig, dib, grads = plan.backward(dout)
+            res = plan.backward(dout, ctx.params, ctx.in_norm)
+        if res is None:        # accumulated in place
+            return (None,) * (7 + len(ctx.params))
+        dig, dib, grads = res
         out = [None, dig, dib, None, None, None, None]
         for gb in grads:
             out += [gb["dW_ih"], gb["dW_hh"], gb["db"], gb["db"].clone(), gb["dgamma"], gb["dbeta"]]

@@ -268,6 +268,7 @@ class _JointFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dlogits):
+        ops.mark("joint_bwd:enter")
         enc2, dec2, w1, w2, hid = ctx.saved_tensors
         cd, B, T, U1, P, P2, J, V = ctx.cfg
         M = B * T * U1
@@ -302,8 +303,8 @@ class _JointFn(torch.autograd.Function):
             # enqueued AFTER the critical-path products above: the auxiliary stream starts when
             # they are done and its MFMA work runs under the latency-bound recurrences that follow
             with side.deferred(dl.device, dl, hid, dE1c, dD1c, dD1, enc2, dec2):
-                ops.gemm(dl.t(), hid2.t(), out=w2.grad, accumulate=True,
-                         split_k=ops.pick_split_k(V, J, M), max_wg_per_cu=2)
+                ops.gemm(dl.t(), hid2.t(), out=w2.grad, accumulate=True, split_k=4,
+                         max_wg_per_cu=2)
                 ops.colsum(dl, out=ctx.b2.grad)
                 g1 = w1.grad
                 ops.gemm(dE1c.t(), enc2.t(), out=g1[:, :P], accumulate=True,
@@ -316,6 +317,7 @@ class _JointFn(torch.autograd.Function):
             ops.gemm(dE1c.t(), enc2.t(), out=dw1[:, :P], split_k=ops.pick_split_k(J, P, B * T))
             ops.gemm(dD1c.t(), dec2.t(), out=dw1[:, P:], split_k=ops.pick_split_k(J, P2, B * U1))
             db1 = ops.colsum(dD1.view(B * U1, J))
+        ops.mark("joint_bwd:exit")
         return denc, ddec, dw1, db1, dw2, db2, None
 
 
@@ -581,7 +583,9 @@ class Transducer(nn.Module):
         else:
             h_enc, _ = self.encoder(xs)
             h_dec, _ = self.decoder(ys)
+        ops.mark("joint:enter")
         logits = self.joint(h_enc, h_dec)
+        ops.mark("joint:exit")
         if self.output_loss:
             xlen = self.scale_length(logits, xlen)
             labels = ys.to(torch.int32).contiguous()

@@ -20,6 +20,17 @@ def _ll(x):
 TIMERS = None   # set to {} to enable: tag -> list of (start_event, end_event)
 
 
+MARKS = None    # set to [] to collect (tag, host seconds, event on the current stream) marks
+
+
+def mark(tag):
+    """Debug aid (tools/host_vs_gpu.py): where is the host, and where is the GPU, at this point?"""
+    if MARKS is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        MARKS.append((tag, time.perf_counter(), ev))
+
+
 HOST = None     # set to {} to accumulate host wall time of selected native calls (bench.py)
 
 
@@ -107,8 +118,14 @@ def gemm(a, b, out=None, bias=None, bias2=None, accumulate=False, split_k=1,
     args = (dtype_code(a.dtype), dtype_code(out.dtype), a_, _ll(lda), akm, b_, _ll(ldb), bkm,
             out, _ll(out.stride(0) if M > 1 else max(out.stride(0), N)), M, N, K, bias, bias2,
             int(bool(accumulate)), int(split_k))
-    if max_wg_per_cu:     # background product on a side stream: capped CU residency
-        call("gemm_bg", *args, int(max_wg_per_cu))
+    if max_wg_per_cu:     # background product on a side stream: capped CU residency, quiet split-K
+        part = None
+        if out.dtype == torch.float32 and bias is None and bias2 is None:
+            nslice = 1
+            while nslice < int(split_k) and nslice < 8:
+                nslice *= 2
+            part = torch.empty(nslice, M, N, dtype=torch.float32, device=out.device)
+        call("gemm_bg", *args, int(max_wg_per_cu), part)
     else:
         call("gemm", *args)
     return out

@@ -50,6 +50,8 @@ class TrainEngine:
     def train_step(self, wave, wave_len, ys, ylen):
         """wave f32[B,N] (device), wave_len i32[B] samples (or None), ys i32[B,U], ylen i32[B].
         Returns the mean loss of the local batch as a device tensor (no host sync)."""
+        from . import ops
+        ops.mark("step:enter")
         self.model.train()
         self.optim.zero_grad()
         B = wave.shape[0]
@@ -62,8 +64,11 @@ class TrainEngine:
             xs, xlen = self.features(wave[s:e], None if wave_len is None else wave_len[s:e])
             loss = self.model(xs, ys[s:e], xlen, ylen[s:e])
             loss = loss / len(starts)
+            ops.mark("backward:enter")
             loss.backward()
+            ops.mark("backward:exit")
             total = loss.detach() if total is None else total + loss.detach()
         scale = self.reducer.finish()
         self.optim.step(grad_scale=scale)
+        ops.mark("step:exit")
         return total

@@ -93,13 +93,20 @@ int edgedict_gemm(int dtype_in, int dtype_out, const void* A, long long lda, int
                   void* stream);
 
 /* Background variant for products that are OFF the critical path (weight gradients) and run on a
- * side stream next to latency-bound kernels: identical arithmetic, but every workgroup claims
- * enough extra LDS that at most max_wg_per_cu of them are resident per CU, so the long-lived GEMM
- * workgroups can never fill a CU and starve the recurrence kernels of LDS/wave slots. */
+ * side stream next to latency-bound kernels.  Identical arithmetic, three scheduling differences:
+ *   - every workgroup claims enough extra LDS that at most max_wg_per_cu are resident per CU, and
+ *     only as many workgroups are launched as are resident at once (each walks its work items): a
+ *     long-lived GEMM can neither fill a CU nor park a tail of workgroups in the dispatcher;
+ *   - with `partials` (fp32 [P][M][N], P = smallest power of two >= split_k, at most 8) the K
+ *     slices are written ONCE, at the end of each workgroup, with plain stores and summed by a
+ *     small reduce kernel - no atomics, no dirty lines while the main loop runs.  Measured on
+ *     MI355X (tools/boundary_probe.hip): a concurrent kernel that streams writes / fp32 atomics
+ *     raises every dependent kernel boundary on the other streams from 2.4 us to 10 / 8-32 us
+ *     (the end-of-kernel L2 write-back has to flush everybody's dirty lines); reads cost nothing. */
 int edgedict_gemm_bg(int dtype_in, int dtype_out, const void* A, long long lda, int a_kmajor,
                      const void* B, long long ldb, int b_kmajor, void* C, long long ldc, int M,
                      int N, int K, const float* bias1, const float* bias2, int accumulate,
-                     int split_k, int max_wg_per_cu, void* stream);
+                     int split_k, int max_wg_per_cu, float* partials, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm fused with the residual add and the encoder's TimeReduction.
@@ -195,12 +202,14 @@ typedef struct edgedict_stack_layer {
     float* dW_ih;          /* f32 [4H, I] out, natural gate order */
     float* dW_hh;          /* f32 [4H, H] out */
     float* db;             /* f32 [4H] out (gradient of b_ih and of b_hh) */
+    float* db_hh;          /* nullable second destination of the same values (b_hh.grad when accumulating) */
     float* dgamma;         /* f32 [H] ACCUMULATED (+=): zero before the call */
     float* dbeta;
 } edgedict_stack_layer_t;
 
 #define EDGEDICT_STACK_SERIAL 1     /* run everything on the caller's stream (debug / bit-exact check) */
 #define EDGEDICT_STACK_DW_AT_END 2  /* weight gradients after the BPTT instead of under it */
+#define EDGEDICT_STACK_ACCUM_GRADS 8 /* dW_ih / dW_hh / db / db_hh are existing gradient buffers: += instead of = */
 #define EDGEDICT_STACK_SIDE_STREAM_PER_LAYER 4 /* experiment: chunk GEMMs on one side stream PER LAYER.
    Measured 2x SLOWER end to end: more streams than hardware queues serialises everything. */
 
@@ -208,7 +217,7 @@ typedef struct edgedict_stack_desc {
     int B, H, L;
     int chunk;             /* frames (at the stack's output rate) per input-product chunk */
     int lag;               /* launches between consecutive layers; 0 = chunk*f0 + 8 */
-    int split_k;           /* split-K of the weight-gradient GEMMs; 0 = automatic */
+    int split_k;           /* K slices of the (quiet) weight-gradient products: 1, 2, 4 or 8; 0 = 2 */
     int flags;
     float eps;
     const edgedict_stack_layer_t* layers;   /* HOST array [L] */
