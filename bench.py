@@ -172,7 +172,7 @@ def main():
             with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as fh:
                 pmc = json.load(fh)["kernels"]
             tiles = ((args.batch * Tp * U1 + 127) // 128) * ((V + 127) // 128)
-            ent = pmc.get("gemm_nt_kernel [tiles=%d]" % tiles)
+            ent = pmc.get("gemm_nt_kernel<128> [tiles=%d]" % tiles) or pmc.get("gemm_nt_kernel [tiles=%d]" % tiles)
             if ent:
                 traffic = ent["hbm_bytes"]
         except (OSError, ValueError, KeyError):

@@ -102,7 +102,13 @@ __global__ void unpermute_rows_kernel(const float* __restrict__ src, long long s
 
 // ---------------------------------------------------------------- per-device runtime
 struct Runtime {
-    hipStream_t R = nullptr, W = nullptr;
+    hipStream_t R = nullptr, R2 = nullptr, W = nullptr;
+    int prio_hi = 0;
+    // experiment streams, created on first use (and therefore AFTER the three above)
+    hipStream_t lazy(hipStream_t& s) {
+        if (!s && hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio_hi) != hipSuccess) s = nullptr;
+        return s;
+    }
     hipStream_t S[ED_STACK_MAX_SLOTS] = {};   // one side stream per layer (chunk GEMMs / LayerNorm backward)
     std::vector<hipEvent_t> pool;
     size_t used = 0;
@@ -128,10 +134,14 @@ Runtime* runtime_for_current_device() {
         hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least, hi = greatest priority
         const char* e = getenv("EDGEDICT_AUX_PRIORITY");
         const bool aux_high = e && e[0] == '1';
+        // HIP maps streams onto 4 hardware queues round-robin in creation order: create ONLY the
+        // three streams the default schedule uses (recurrence, auxiliary, chunk GEMMs; with the
+        // caller's stream that is one queue each).  Streams sharing a queue serialise: creating
+        // one more stream before these was measured to cost 13 ms per training step.
+        r->prio_hi = hi;
         bool ok = hipStreamCreateWithPriority(&r->R, hipStreamNonBlocking, hi) == hipSuccess &&
-                  hipStreamCreateWithPriority(&r->W, hipStreamNonBlocking, aux_high ? hi : lo) == hipSuccess;
-        for (int i = 0; ok && i < ED_STACK_MAX_SLOTS; ++i)
-            ok = hipStreamCreateWithPriority(&r->S[i], hipStreamNonBlocking, hi) == hipSuccess;
+                  hipStreamCreateWithPriority(&r->W, hipStreamNonBlocking, aux_high ? hi : lo) == hipSuccess &&
+                  hipStreamCreateWithPriority(&r->S[0], hipStreamNonBlocking, hi) == hipSuccess;
         if (!ok) {
             delete r;
             return nullptr;
@@ -224,7 +234,7 @@ int default_lag(const edgedict_stack_desc_t* d, const std::vector<Geom>& g) {
     // a layer may start chunk k only after the layer feeding it has finished that chunk and the
     // chunk's GEMM has been ENQUEUED (P launches per chunk, +2 for the norm / enqueue order)
     const int P = d->chunk * g[0].f;
-    int lag = d->lag > 0 ? d->lag : P + 8;
+    int lag = d->lag > 0 ? d->lag : P + 5;
     if (lag < P + 2) lag = P + 2;
     return lag | 1;   // odd: half-rate layers alternate between even and odd launches
 }
@@ -236,7 +246,9 @@ int default_lag(const edgedict_stack_desc_t* d, const std::vector<Geom>& g) {
     } while (0)
 
 struct Streams {
-    hipStream_t C, R, W;
+    hipStream_t C, R, R2, W;
+    int split;   // layers >= split run their recurrence on R2 (experiment; L = never)
+    hipStream_t RS(int l) const { return l >= split ? R2 : R; }
     hipStream_t S[ED_STACK_MAX_SLOTS];
     bool serial;
     Runtime* rt;
@@ -268,7 +280,7 @@ int open_streams(const edgedict_stack_desc_t* d, void* stream_, Streams& st) {
     st.serial = (d->flags & EDGEDICT_STACK_SERIAL) != 0;
     st.rt = nullptr;
     if (st.serial) {
-        st.R = st.W = st.C;
+        st.R = st.R2 = st.W = st.C;
         for (auto& x : st.S) x = st.C;
         return ED_OK;
     }
@@ -276,8 +288,18 @@ int open_streams(const edgedict_stack_desc_t* d, void* stream_, Streams& st) {
     ED_CHECK_ARG(st.rt != nullptr, "encoder_stack: could not create the internal streams");
     st.rt->used = 0;   // recycle the event pool (waits capture an event's state when enqueued)
     st.R = st.rt->R;
-    for (int i = 0; i < ED_STACK_MAX_SLOTS; ++i)
-        st.S[i] = st.rt->S[(d->flags & EDGEDICT_STACK_SIDE_STREAM_PER_LAYER) ? i : 0];
+    st.R2 = st.rt->R;
+    if (d->flags & EDGEDICT_STACK_TWO_RECURRENCE_STREAMS) {
+        st.R2 = st.rt->lazy(st.rt->R2);
+        ED_CHECK_ARG(st.R2 != nullptr, "encoder_stack: stream creation failed");
+    }
+    for (int i = 0; i < ED_STACK_MAX_SLOTS; ++i) {
+        st.S[i] = st.rt->S[0];
+        if ((d->flags & EDGEDICT_STACK_SIDE_STREAM_PER_LAYER) && i > 0) {
+            st.S[i] = st.rt->lazy(st.rt->S[i]);
+            ED_CHECK_ARG(st.S[i] != nullptr, "encoder_stack: stream creation failed");
+        }
+    }
     st.W = st.rt->W;
     return ED_OK;
 }
@@ -346,6 +368,13 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     char* ws = (char*)d->ws;
     Streams st;
     ED_TRY(open_streams(d, stream_, st));
+    st.split = L;
+    if (st.R2 != st.R) {   // full-rate layers (up to the first time reduction) vs the rest
+        st.split = L / 2;
+        for (int l = 0; l < L; ++l)
+            if (d->layers[l].reduce == 2) { st.split = l + 1; break; }
+        if (st.split >= L) st.split = L / 2;
+    }
     const int lag = default_lag(d, g);
     for (int l = 0; l < L; ++l) g[l].off = l * lag;
 
@@ -358,6 +387,7 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
                                    bptr(y.Yx), y.Cx, bptr(ws + wl.frag0[l]), B, H, st.C));
     }
     ED_TRY(st.chain(st.C, st.R));
+    if (st.R2 != st.R) ED_TRY(st.chain(st.C, st.R2));
     for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.C, st.S[l]));
 
     std::vector<std::vector<hipEvent_t>> Eg(L);
@@ -382,13 +412,16 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     const int T_out = (g[L - 1].T + d->layers[L - 1].reduce - 1) / d->layers[L - 1].reduce;
     struct Done { int l, k; };
     for (int w = 0; w < Wtot; ++w) {
-        EdFwdLaunch Lc;
-        Lc.nstep = Lc.nnorm = 0;
-        Lc.B = B; Lc.H = H; Lc.eps = d->eps;
+        EdFwdLaunch Lcs[2];
+        for (auto& x : Lcs) {
+            x.nstep = x.nnorm = 0;
+            x.B = B; x.H = H; x.eps = d->eps;
+        }
         Done done[ED_STACK_MAX_SLOTS];
         int ndone = 0;
         for (int l = 0; l < L; ++l) {
             const edgedict_stack_layer_t& y = d->layers[l];
+            EdFwdLaunch& Lc = Lcs[l >= st.split ? 1 : 0];
             // ---- time step of layer l
             int dw = w - g[l].off;
             if (dw >= 0 && dw % g[l].m == 0 && dw / g[l].m < g[l].T) {
@@ -397,7 +430,7 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
                     const int k = t / g[l].cf;
                     if (l == 0) ED_TRY(feed_layer0(k + 2));
                     ED_CHECK_ARG(queued[l][k], "encoder_stack: schedule violated (layer %d chunk %d)", l, k);
-                    ED_TRY(st.wait(st.R, Eg[l][k]));
+                    ED_TRY(st.wait(st.RS(l), Eg[l][k]));
                 }
                 EdFwdStep& s = Lc.step[Lc.nstep++];
                 bf16_t* f0 = bptr(ws + wl.frag0[l]);
@@ -449,16 +482,18 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
                 }
             }
         }
-        ED_TRY(ed_stack_launch_fwd(Lc, st.R));
+        ED_TRY(ed_stack_launch_fwd(Lcs[0], st.R));
+        if (st.split < L) ED_TRY(ed_stack_launch_fwd(Lcs[1], st.R2));
         for (int i = 0; i < ndone; ++i) {
             const int l = done[i].l + 1, k = done[i].k;
-            ED_TRY(st.chain(st.R, st.S[l]));
+            ED_TRY(st.chain(st.RS(done[i].l), st.S[l]));
             ED_TRY(input_gemm(d, g, l, k, st.S[l]));
             ED_TRY(st.record(Eg[l][k], st.S[l]));
             queued[l][k] = 1;
         }
     }
     ED_TRY(st.chain(st.R, st.C));
+    if (st.R2 != st.R) ED_TRY(st.chain(st.R2, st.C));
     for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.S[l], st.C));
     return ED_OK;
 }
@@ -474,6 +509,13 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     char* ws = (char*)d->ws;
     Streams st;
     ED_TRY(open_streams(d, stream_, st));
+    st.split = L;
+    if (st.R2 != st.R) {   // full-rate layers (up to the first time reduction) vs the rest
+        st.split = L / 2;
+        for (int l = 0; l < L; ++l)
+            if (d->layers[l].reduce == 2) { st.split = l + 1; break; }
+        if (st.split >= L) st.split = L / 2;
+    }
     const int lag = default_lag(d, g);
     for (int l = 0; l < L; ++l) g[l].off = (L - 1 - l) * lag;
     const int T_out = (g[L - 1].T + d->layers[L - 1].reduce - 1) / d->layers[L - 1].reduce;
@@ -488,6 +530,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                                LNB_GRID_TOP, B, H, 0, y.T, y.reduce, st.C));
     }
     ED_TRY(st.chain(st.C, st.R));
+    if (st.R2 != st.R) ED_TRY(st.chain(st.C, st.R2));
     for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.C, st.S[l]));
     ED_TRY(st.chain(st.C, st.W));
 
@@ -528,9 +571,11 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     for (int l = 0; l < L; ++l) Wtot = max(Wtot, g[l].off + (g[l].T - 1) * g[l].m + 1);
     struct Done { int l, k, t; };
     for (int w = 0; w < Wtot; ++w) {
-        EdBwdLaunch Lc;
-        Lc.nstep = 0;
-        Lc.B = B; Lc.H = H;
+        EdBwdLaunch Lcs[2];
+        for (auto& x : Lcs) {
+            x.nstep = 0;
+            x.B = B; x.H = H;
+        }
         Done done[ED_STACK_MAX_SLOTS];
         int ndone = 0;
         for (int l = L - 1; l >= 0; --l) {
@@ -541,8 +586,9 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
             const int k = t / g[l].cf;
             if (t == min(g[l].T, (k + 1) * g[l].cf) - 1) {
                 ED_CHECK_ARG(queued[l][k], "encoder_stack: backward schedule violated (layer %d chunk %d)", l, k);
-                ED_TRY(st.wait(st.R, Eb[l][k]));
+                ED_TRY(st.wait(st.RS(l), Eb[l][k]));
             }
+            EdBwdLaunch& Lc = Lcs[l >= st.split ? 1 : 0];
             EdBwdStep& s = Lc.step[Lc.nstep++];
             bf16_t* f0 = bptr(ws + wl.frag0[l]);
             bf16_t* f1 = bptr(ws + wl.frag1[l]);
@@ -559,7 +605,8 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                 ++ndone;
             }
         }
-        ED_TRY(ed_stack_launch_bwd(Lc, st.R));
+        ED_TRY(ed_stack_launch_bwd(Lcs[0], st.R));
+        if (st.split < L) ED_TRY(ed_stack_launch_bwd(Lcs[1], st.R2));
         for (int i = 0; i < ndone; ++i) {
             const int l = done[i].l, k = done[i].k;
             const edgedict_stack_layer_t& y = d->layers[l];
@@ -569,7 +616,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                 const int t0 = k * g[l].cf, t1 = min(y.T, t0 + g[l].cf);
                 const long long r0 = (long long)t0 * B;
                 hipStream_t S = st.S[l];
-                ED_TRY(st.chain(st.R, S));
+                ED_TRY(st.chain(st.RS(l), S));
                 ED_TRY(edgedict_gemm(ED_BF16, ED_BF16, bptr(y.G) + r0 * 4 * H, 4ll * H, 1,
                                      y.wih_t ? y.wih_t : y.wih_p, y.wih_t ? 4ll * H : y.I,
                                      y.wih_t ? 1 : 0, bptr(y.dX) + r0 * y.I, y.I, (t1 - t0) * B, y.I,
@@ -586,7 +633,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                 if (d->flags & EDGEDICT_STACK_DW_AT_END) {
                     deferred.push_back(l);
                 } else {
-                    ED_TRY(st.chain(st.R, st.W));
+                    ED_TRY(st.chain(st.RS(l), st.W));
                     ED_TRY(weight_grads(l));
                 }
             }
@@ -596,7 +643,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     {
         const edgedict_stack_layer_t& y = d->layers[0];
         bf16_t* dX0 = bptr(ws + wl.dX0);
-        ED_TRY(st.chain(st.R, st.S[0]));
+        ED_TRY(st.chain(st.RS(0), st.S[0]));
         ED_TRY(edgedict_gemm(ED_BF16, ED_BF16, y.G, 4ll * H, 1, y.wih_t ? y.wih_t : y.wih_p,
                              y.wih_t ? 4ll * H : y.I, y.wih_t ? 1 : 0, dX0, y.I, y.T * B, y.I, 4 * H,
                              nullptr, nullptr, 0, 1, st.S[0]));
@@ -615,9 +662,11 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     }
     if (!deferred.empty()) {
         ED_TRY(st.chain(st.R, st.W));
+        if (st.R2 != st.R) ED_TRY(st.chain(st.R2, st.W));
         for (int l : deferred) ED_TRY(weight_grads(l));
     }
     ED_TRY(st.chain(st.R, st.C));
+    if (st.R2 != st.R) ED_TRY(st.chain(st.R2, st.C));
     for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.S[l], st.C));
     ED_TRY(st.chain(st.W, st.C));
     return ED_OK;

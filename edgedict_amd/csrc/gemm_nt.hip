@@ -25,9 +25,7 @@ namespace {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
-constexpr int BM = 128, BN = 128, BK = 64, THREADS = 256;
-constexpr int TILE_BYTES = BM * BK * 2;          // 16 KB per operand tile
-constexpr int BUF_BYTES = 2 * TILE_BYTES;        // A + B
+constexpr int BK = 64;
 
 struct NtArgs {
     const bf16_t* A;
@@ -50,10 +48,24 @@ __device__ __forceinline__ void glds16(const bf16_t* src, unsigned char* lds_wav
 // (A 3-buffer variant with counted `s_waitcnt vmcnt(8)` + raw s_barrier, 96 KB LDS and ONE workgroup
 // per CU was measured and is slower on every shape of this path: joint logits 4.6 vs 3.6 ms,
 // 4096^3 657 vs 901 TF/s.  Two co-resident workgroups hide latency better than a deeper pipeline.)
-__global__ __launch_bounds__(THREADS, 2) void gemm_nt_kernel(NtArgs g) {
+// TILE = 128: 128x128 output tile, wave tile 64x64 (grids that fill the chip).
+// TILE = 64 : 64x64 output tile, wave tile 32x32, for SMALL problems (e.g. the encoder's chunked dX
+//             products, 1024x1024x4096): the kernel is bound by the per-CU L2->LDS fetch rate
+//             (~55 GB/s per CU, measured the same at one or two workgroups and 4 or 8 waves per CU),
+//             so a problem with 64 big tiles uses a quarter of the chip's fetch bandwidth; 4x the
+//             workgroups fetch 2x the bytes at 4x the rate.
+template <int TILE>
+__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs g) {
+    constexpr int THREADS = 256, WAVES = 4;
+    constexpr int BM = TILE, BN = TILE;
+    constexpr int MI = TILE / 32, NJ = TILE / 32;   // 16x16 MFMA tiles per wave along M / N
+    constexpr int PIECES = TILE / 8 / WAVES;        // 1 KiB DMA pieces per wave, operand and K tile
+    constexpr int TILE_BYTES = TILE * BK * 2;
+    constexpr int BUF_BYTES = 2 * TILE_BYTES;
+    constexpr int CCH = TILE / 8;                   // 16-byte chunks per staged C row
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF_BYTES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;     // wave rows wm * (MI*16), wave cols wn * (NJ*16)
     const int r16 = lane & 15, kq = lane >> 4;
     const int KT = g.K / BK;
 
@@ -73,24 +85,24 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_kernel(NtArgs g) {
     // 16-byte chunk (l%8) ^ (l/8) of its row (source-side swizzle, LDS image stays lane-linear)
     const int prow = lane >> 3;
     const int chunk = (lane & 7) ^ prow;
-    const bf16_t* asrc[4];
-    const bf16_t* bsrc[4];
+    const bf16_t* asrc[PIECES];
+    const bf16_t* bsrc[PIECES];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = (i * 4 + wave) * 8 + prow;
+    for (int i = 0; i < PIECES; ++i) {
+        const int row = (i * WAVES + wave) * 8 + prow;
         asrc[i] = g.A + (long long)min(m0 + row, g.M - 1) * g.lda + chunk * 8;
         bsrc[i] = g.B + (long long)min(n0 + row, g.N - 1) * g.ldb + chunk * 8;
     }
     auto issue = [&](int buf, int k0) {
         unsigned char* base = smem + buf * BUF_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            glds16(asrc[i] + k0, base + (i * 4 + wave) * 1024);
-            glds16(bsrc[i] + k0, base + TILE_BYTES + (i * 4 + wave) * 1024);
+        for (int i = 0; i < PIECES; ++i) {
+            glds16(asrc[i] + k0, base + (i * WAVES + wave) * 1024);
+            glds16(bsrc[i] + k0, base + TILE_BYTES + (i * WAVES + wave) * 1024);
         }
     };
 
-    f32x4_t acc[4][4];
+    f32x4_t acc[MI][NJ];
     // operands swapped (B fragment first): lane holds D[n = (lane>>4)*4 + q][m = lane & 15], i.e.
     // FOUR CONSECUTIVE COLUMNS of one C row -> 8-byte packed stores in the epilogue
     auto compute = [&](int buf) {
@@ -98,17 +110,21 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_kernel(NtArgs g) {
         const unsigned char* sB = sA + TILE_BYTES;
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
-            bf16x8_t a[4], b[4];
+            bf16x8_t a[MI], b[NJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ra = wm * 64 + i * 16 + r16, rb = wn * 64 + i * 16 + r16;
+            for (int i = 0; i < MI; ++i) {
+                const int ra = wm * (MI * 16) + i * 16 + r16;
                 a[i] = *reinterpret_cast<const bf16x8_t*>(sA + ra * 128 + (((ks * 4 + kq) ^ (ra & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) {
+                const int rb = wn * (NJ * 16) + i * 16 + r16;
                 b[i] = *reinterpret_cast<const bf16x8_t*>(sB + rb * 128 + (((ks * 4 + kq) ^ (rb & 7)) << 4));
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < NJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
         }
     };
@@ -118,10 +134,10 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_kernel(NtArgs g) {
         // biases enter through the accumulators.  They are ordinary loads, and hipcc waits vmcnt(0)
         // at the first use of an ordinary load while a DMA is in flight: issue them here and use
         // them right after the first __syncthreads() of the K loop, which waits vmcnt(0) anyway.
-        float4 bv[4];
+        float4 bv[NJ];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int nc = n0 + wn * 64 + j * 16 + kq * 4;   // 4 consecutive columns of this lane
+        for (int j = 0; j < NJ; ++j) {
+            const int nc = n0 + wn * (NJ * 16) + j * 16 + kq * 4;   // 4 consecutive columns of this lane
             bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (nc < g.N) {   // N % 8 == 0: the 4 columns are all inside or all outside
                 if (g.bias1) bv[j] = *reinterpret_cast<const float4*>(g.bias1 + nc);
@@ -135,36 +151,36 @@ __global__ __launch_bounds__(THREADS, 2) void gemm_nt_kernel(NtArgs g) {
             __syncthreads();   // vmcnt(0) + barrier: this K tile landed everywhere, the other buffer is free
             if (kt == 0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){bv[j].x, bv[j].y, bv[j].z, bv[j].w};
+                    for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4_t){bv[j].x, bv[j].y, bv[j].z, bv[j].w};
             }
             if (kt + 1 < KT) issue((kt + 1) & 1, (kt + 1) * BK);
             compute(kt & 1);
         }
         // ---- epilogue: the operand tiles are dead after this barrier; C is staged in LDS
         __syncthreads();
-        unsigned char* sC = smem;   // [128 rows][16 chunks of 16 B], chunk ^= row & 15
+        unsigned char* sC = smem;   // [TILE rows][CCH chunks of 16 B], chunk ^= row & (CCH - 1)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int nl = wn * 64 + j * 16 + kq * 4;        // 4 consecutive columns nl .. nl+3
+        for (int j = 0; j < NJ; ++j) {
+            const int nl = wn * (NJ * 16) + j * 16 + kq * 4;        // 4 consecutive columns nl .. nl+3
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ml = wm * 64 + i * 16 + r16;
+            for (int i = 0; i < MI; ++i) {
+                const int ml = wm * (MI * 16) + i * 16 + r16;
                 uint2 pk;
                 pk.x = (unsigned)f32_to_bf16(acc[i][j][0]) | ((unsigned)f32_to_bf16(acc[i][j][1]) << 16);
                 pk.y = (unsigned)f32_to_bf16(acc[i][j][2]) | ((unsigned)f32_to_bf16(acc[i][j][3]) << 16);
-                *reinterpret_cast<uint2*>(sC + ml * 256 + ((((nl >> 3) ^ (ml & 15)) << 4) | ((nl & 4) << 1))) = pk;
+                *reinterpret_cast<uint2*>(sC + ml * (TILE * 2) + ((((nl >> 3) ^ (ml & (CCH - 1))) << 4) | ((nl & 4) << 1))) = pk;
             }
         }
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < BM * BN / 8 / THREADS; ++it) {
             const int c = threadIdx.x + it * THREADS;
-            const int rl = c >> 4, ch = c & 15;
+            const int rl = c / CCH, ch = c % CCH;
             const int row = m0 + rl, col = n0 + ch * 8;
             if (row >= g.M || col >= g.N || ((g.debug & 1) && row > 0)) continue;
-            uint4 v = *reinterpret_cast<const uint4*>(sC + rl * 256 + ((ch ^ (rl & 15)) << 4));
+            uint4 v = *reinterpret_cast<const uint4*>(sC + rl * (TILE * 2) + ((ch ^ (rl & (CCH - 1))) << 4));
             bf16_t* dst = g.C + (long long)row * g.ldc + col;
             if (g.accumulate) {
                 float x[8], y[8];
@@ -187,7 +203,7 @@ bool ed_gemm_nt_ok(int dtype_in, int dtype_out, const void* A, long long lda, in
                    int N, int K, int split_k, const float* bias1, const float* bias2) {
     if ((uintptr_t)bias1 % 16 != 0 || (uintptr_t)bias2 % 16 != 0) return false;   // float4 bias loads
     return dtype_in == ED_BF16 && dtype_out == ED_BF16 && a_kmajor && b_kmajor && split_k == 1 &&
-           M > 0 && N > 0 && K >= BK && K % BK == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 &&
+           M > 0 && N > 0 && K >= 64 && K % 64 == 0 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 &&
            N % 8 == 0 && (uintptr_t)A % 16 == 0 && (uintptr_t)B % 16 == 0 && (uintptr_t)C % 16 == 0;
 }
 
@@ -200,13 +216,17 @@ int ed_gemm_nt_launch(const void* A, long long lda, const void* B, long long ldb
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K;
     g.accumulate = accumulate;
-    g.n_tiles = (N + BN - 1) / BN;
-    const long long tiles = (long long)((M + BM - 1) / BM) * g.n_tiles;
-    ED_CHECK_ARG(tiles < (1ll << 31), "gemm: too many tiles");
-    g.tiles = (int)tiles;
     static const int dbg = [] { const char* e = getenv("EDGEDICT_GEMM_NT_DEBUG"); return e ? atoi(e) : 0; }();
     g.debug = dbg;
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)tiles), dim3(THREADS), lds_pad, s, g);
+    static const int force_t = [] { const char* e = getenv("EDGEDICT_GEMM_NT_TILE"); return e ? atoi(e) : 0; }();
+    const long long tiles128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
+    const int tile = force_t ? force_t : (tiles128 <= 128 ? 64 : 128);   // small problem: spread it out
+    g.n_tiles = (N + tile - 1) / tile;
+    const long long tiles = (long long)((M + tile - 1) / tile) * g.n_tiles;
+    ED_CHECK_ARG(tiles < (1ll << 31), "gemm: too many tiles");
+    g.tiles = (int)tiles;
+    if (tile == 64) hipLaunchKernelGGL(gemm_nt_kernel<64>, dim3((unsigned)tiles), dim3(256), lds_pad, s, g);
+    else hipLaunchKernelGGL(gemm_nt_kernel<128>, dim3((unsigned)tiles), dim3(256), lds_pad, s, g);
     ED_CHECK_LAUNCH("gemm_nt");
     return ED_OK;
 }

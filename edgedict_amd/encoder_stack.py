@@ -47,7 +47,7 @@ DW_AT_END = 2
 ACCUM_GRADS = 8
 
 # schedule knobs (env overrides are for tuning runs; the defaults are what bench.py measures)
-CHUNK = int(os.environ.get("EDGEDICT_STACK_CHUNK", "16"))
+CHUNK = int(os.environ.get("EDGEDICT_STACK_CHUNK", "12"))
 LAG = int(os.environ.get("EDGEDICT_STACK_LAG", "0"))
 SPLIT_K = int(os.environ.get("EDGEDICT_STACK_SPLITK", "0"))
 FLAGS = int(os.environ.get("EDGEDICT_STACK_FLAGS", "0"))

@@ -209,6 +209,9 @@ typedef struct edgedict_stack_layer {
 
 #define EDGEDICT_STACK_SERIAL 1     /* run everything on the caller's stream (debug / bit-exact check) */
 #define EDGEDICT_STACK_DW_AT_END 2  /* weight gradients after the BPTT instead of under it */
+#define EDGEDICT_STACK_TWO_RECURRENCE_STREAMS 16 /* experiment: full-rate layers and the layers behind the
+   time reduction launch on separate streams so their kernel boundaries overlap.  A 5th HIP stream
+   shares a hardware queue with a busy one: measured 66.8 vs 34.5 ms per step.  Do not use. */
 #define EDGEDICT_STACK_ACCUM_GRADS 8 /* dW_ih / dW_hh / db / db_hh are existing gradient buffers: += instead of = */
 #define EDGEDICT_STACK_SIDE_STREAM_PER_LAYER 4 /* experiment: chunk GEMMs on one side stream PER LAYER.
    Measured 2x SLOWER end to end: more streams than hardware queues serialises everything. */
@@ -216,7 +219,7 @@ typedef struct edgedict_stack_layer {
 typedef struct edgedict_stack_desc {
     int B, H, L;
     int chunk;             /* frames (at the stack's output rate) per input-product chunk */
-    int lag;               /* launches between consecutive layers; 0 = chunk*f0 + 8 */
+    int lag;               /* launches between consecutive layers; 0 = chunk*f0 + 5 */
     int split_k;           /* K slices of the (quiet) weight-gradient products: 1, 2, 4 or 8; 0 = 2 */
     int flags;
     float eps;
