@@ -191,7 +191,7 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": "%s full training step (dither+log-mel+stack3 -> %dx%d LSTM encoder, 2x "
+                "workload": "%s full training step (dither+log-mel+stack3+SpecAugment masks -> %dx%d LSTM encoder, 2x "
                             "time reduction -> %dx%d LSTM prediction net -> joint %d -> RNN-T loss "
                             "-> backward -> grad all-reduce -> Adam); %d x %.0f s utterances per GPU, "
                             "U=%d, V=%d, ragged lengths; lattice [%d,%d,%d,%d]"

@@ -99,6 +99,56 @@ __global__ void embedding_bwd(const int32_t* __restrict__ tokens, int tok_stride
     }
 }
 
+// ---------------------------------------------------------------- dropout
+// y = x * keep(i) / (1 - p), keep(i) = hash(seed, i) >= p: a counter-based mask (no state, no mask
+// tensor): the backward pass regenerates it from the same (seed, index), so dy -> dx is the SAME
+// kernel.  nn.Dropout / nn.LSTM(dropout=p) semantics (rnnt/models.py:47-53,145-147): scaling by
+// 1/(1-p) in training, identity in eval (the host simply does not call it).
+__device__ __forceinline__ unsigned drop_hash(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, float p,
+                               unsigned seed) {
+    const unsigned thresh = (unsigned)(p * 4294967296.0);   // keep iff hash >= p * 2^32
+    const float scale = 1.f / (1.f - p);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const unsigned h = drop_hash(seed ^ drop_hash((unsigned)i * 0x9e3779b9U + (unsigned)(i >> 32)));
+        ElemIO<T>::store(y + i, h >= thresh ? ElemIO<T>::load(x + i) * scale : 0.f);
+    }
+}
+
+// ---------------------------------------------------------------- SpecAugment masks
+// x[b, t, f] = 0 where t or f falls in one of the row's mask intervals (TimeMasking /
+// FrequencyMasking, rnnt/transforms.py:54-146: the reference applies them AFTER frame stacking, on
+// [B, F, T] with F = n_mels*stack, the frequency interval running over the stacked feature index).
+// The intervals are drawn on the host with Python's `random` in the reference's call order (so the
+// same seed gives the same masks) and applied here in one pass over the resident batch.
+// layout here: x [B, T, F] (the model's input layout)
+__global__ void spec_mask_kernel(float* __restrict__ x, int B, int Tn, int F,
+                                 const int32_t* __restrict__ t_iv, int n_t,   // [B][n_t][2] start,end
+                                 const int32_t* __restrict__ f_iv, int n_f) { // [B][n_f][2]
+    const long long n = (long long)B * Tn * F;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int f = (int)(i % F);
+        const long long bt = i / F;
+        const int t = (int)(bt % Tn), b = (int)(bt / Tn);
+        bool kill = false;
+        for (int k = 0; k < n_t; ++k) {
+            const int s0 = t_iv[((long long)b * n_t + k) * 2], s1 = t_iv[((long long)b * n_t + k) * 2 + 1];
+            kill |= (t >= s0 && t < s1);
+        }
+        for (int k = 0; k < n_f; ++k) {
+            const int s0 = f_iv[((long long)b * n_f + k) * 2], s1 = f_iv[((long long)b * n_f + k) * 2 + 1];
+            kill |= (f >= s0 && f < s1);
+        }
+        if (kill) x[i] = 0.f;
+    }
+}
+
 // ---------------------------------------------------------------- joint: hid = tanh(E1[b,t] + D1[b,u])
 template <typename T>
 __global__ __launch_bounds__(256) void joint_hidden_fwd(const T* __restrict__ E1,
@@ -404,6 +454,34 @@ extern "C" int edgedict_embedding_bwd(int dtype, const int32_t* tokens, int tok_
         return ED_ERR_INVALID;
     }
     ED_CHECK_LAUNCH("embedding_bwd");
+    return ED_OK;
+}
+
+extern "C" int edgedict_dropout(int dtype, const void* x, void* y, long long n, float p,
+                                unsigned seed, void* stream_) {
+    ED_CHECK_ARG(dtype == ED_F32 || dtype == ED_BF16, "dropout: bad dtype");
+    ED_CHECK_ARG(p >= 0.f && p < 1.f, "dropout: p must be in [0, 1)");
+    ED_CHECK_ARG(n >= 0, "dropout: bad size");
+    if (n == 0) return ED_OK;
+    ED_CHECK_ARG(x && y, "dropout: null pointer");
+    const int grid = ed_grid_for(n, 256 * 4, 256 * 16);
+    if (dtype == ED_F32)
+        hipLaunchKernelGGL(dropout_kernel<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream_, (const float*)x, (float*)y, n, p, seed);
+    else
+        hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream_, (const bf16_t*)x, (bf16_t*)y, n, p, seed);
+    ED_CHECK_LAUNCH("dropout");
+    return ED_OK;
+}
+
+extern "C" int edgedict_spec_mask(float* x, int B, int T, int F, const int32_t* t_iv, int n_t,
+                                  const int32_t* f_iv, int n_f, void* stream_) {
+    ED_CHECK_ARG(B >= 0 && T >= 0 && F > 0, "spec_mask: bad shape");
+    ED_CHECK_ARG(n_t >= 0 && n_f >= 0 && (n_t == 0 || t_iv) && (n_f == 0 || f_iv), "spec_mask: bad intervals");
+    if (B == 0 || T == 0 || (n_t == 0 && n_f == 0)) return ED_OK;
+    ED_CHECK_ARG(x, "spec_mask: null pointer");
+    hipLaunchKernelGGL(spec_mask_kernel, dim3(ed_grid_for((long long)B * T * F, 256 * 4, 256 * 16)),
+                       dim3(256), 0, (hipStream_t)stream_, x, B, T, F, t_iv, n_t, f_iv, n_f);
+    ED_CHECK_LAUNCH("spec_mask");
     return ED_OK;
 }
 

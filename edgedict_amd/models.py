@@ -193,6 +193,32 @@ class _LSTMBlockFn(torch.autograd.Function):
         return (dx, dw_ih, dw_hh, db, db.clone(), dgamma, dbeta, None, None, None, None, None)
 
 
+class _DropoutFn(torch.autograd.Function):
+    """Training-mode dropout with a counter-based mask (csrc/elementwise.hip): the backward pass
+    re-applies the same (p, seed) to the gradient, no mask tensor is kept."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.cfg = (float(p), int(seed))
+        return ops.dropout(x, p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        p, seed = ctx.cfg
+        return ops.dropout(dy.contiguous(), p, seed), None, None
+
+
+_dropout_calls = [0]
+
+
+def _dropout(x, p):
+    """A fresh mask per call: seed = torch's RNG stream (so torch.manual_seed governs it) mixed with
+    a call counter."""
+    _dropout_calls[0] += 1
+    seed = (torch.initial_seed() * 0x9E3779B1 + _dropout_calls[0] * 0x85EBCA6B) & 0xFFFFFFFF
+    return _DropoutFn.apply(x, p, seed)
+
+
 class _LinearFn(torch.autograd.Function):
     """y = x W^T + b on the last dimension (nn.Linear: rnnt/models.py:129,135,148,156)."""
 
@@ -388,8 +414,7 @@ class ResLayerNormLSTM(nn.Module):
         super().__init__()
         if reduction_factor != 2:
             raise ValueError("only reduction_factor=2 is implemented (the reference default)")
-        if dropout > 0:
-            raise NotImplementedError("encoder dropout > 0 is not implemented on the HIP path")
+        self.dropout = dropout      # nn.Dropout after LayerNorm(+TimeReduction), rnnt/models.py:47-53
         self.hidden_size = hidden_size
         self.lstms = nn.ModuleList()
         self.projs = nn.ModuleList()
@@ -415,6 +440,8 @@ class ResLayerNormLSTM(nn.Module):
             xs, h, c = _LSTMBlockFn.apply(xs.contiguous(), w_ih, w_hh, b_ih, b_hh,
                                           proj[0].weight, proj[0].bias, h0, c0, i != 0,
                                           self.reductions[i], cd)
+            if self.dropout > 0 and self.training:
+                xs = _dropout(xs, self.dropout)
             new_hs.append(h)
             new_cs.append(c)
         return xs, (torch.stack(new_hs, 0), torch.stack(new_cs, 0))
@@ -437,7 +464,8 @@ class Encoder(nn.Module):
         require_cuda(xs)
         cd = getattr(self, "compute_dtype", None) or config.get_compute_dtype()
         lstm = self.lstm
-        if (isinstance(lstm, ResLayerNormLSTM) and xs.dim() == 3 and xs.shape[1] > 0
+        drop = getattr(lstm, "dropout", 0) > 0 and self.training    # per-layer path applies it
+        if (isinstance(lstm, ResLayerNormLSTM) and xs.dim() == 3 and xs.shape[1] > 0 and not drop
                 and encoder_stack.supported(cd, lstm.hidden_size, xs.shape[2], len(lstm.lstms),
                                             lstm.reductions)):
             # bf16: input LayerNorm + all layers as one layer-pipelined native call per direction
@@ -488,8 +516,9 @@ class Decoder(nn.Module):
             w_ih, w_hh, b_ih, b_hh = self.lstm.layer(k)
             x, h, c = _LSTMBlockFn.apply(x, w_ih, w_hh, b_ih, b_hh, None, None, h0, c0,
                                          False, 1, cd)
+            # nn.LSTM(dropout=p): on the outputs of every layer except the last, training only
             if self.dropout > 0 and self.training and k + 1 < self.lstm.num_layers:
-                raise NotImplementedError("prediction-network dropout is not implemented yet")
+                x = _dropout(x, self.dropout)
             hs.append(h)
             cs.append(c)
         y = _LinearFn.apply(x, self.proj.weight, self.proj.bias, cd)

@@ -291,3 +291,28 @@ def pick_split_k(M, N, K, bk=64):
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     want = max(1, 768 // max(tiles, 1))
     return int(max(1, min(want, K // (4 * bk) if K >= 8 * bk else 1)))
+
+
+def dropout(x, p, seed, out=None):
+    """Counter-based dropout (training mode): ``x * keep / (1 - p)``; the same (p, seed) applied to
+    a gradient is the backward pass."""
+    require_cuda(x)
+    x = x.contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    call("dropout", dtype_code(x.dtype), x, out, _ll(x.numel()), float(p),
+         ctypes.c_uint(int(seed) & 0xFFFFFFFF))
+    return out
+
+
+def spec_mask_(x, t_intervals, f_intervals):
+    """In-place SpecAugment zero-fill on a resident fp32 feature batch [B,T,F].
+    ``t_intervals`` / ``f_intervals``: int32 device tensors [B, n, 2] of half-open intervals over
+    the frame index / the (stacked) feature index, or None."""
+    require_cuda(x)
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3
+    B, T, F_ = x.shape
+    n_t = 0 if t_intervals is None else t_intervals.shape[1]
+    n_f = 0 if f_intervals is None else f_intervals.shape[1]
+    call("spec_mask", x, B, T, F_, t_intervals, n_t, f_intervals, n_f)
+    return x

@@ -33,6 +33,14 @@ class TrainEngine:
             sample_rate=getattr(flags, "sample_rate", 16000), win_length=flags.win_length,
             hop_length=flags.hop_length, n_fft=flags.n_fft, n_filt=flags.feature_size,
             dither=getattr(flags, "dither", 1e-5)).to(self.device)
+        # the reference's train transform ends with TimeMasking + FrequencyMasking
+        # (rnnt/transforms.py:196-200); here one kernel on the resident stacked batch
+        self.spec_augment = None
+        if getattr(flags, "T_mask", 0) and getattr(flags, "T_num_mask", 0) or \
+                getattr(flags, "F_mask", 0) and getattr(flags, "F_num_mask", 0):
+            from .transforms import SpecAugment
+            self.spec_augment = SpecAugment(getattr(flags, "T_mask", 0), getattr(flags, "T_num_mask", 0),
+                                            getattr(flags, "F_mask", 0), getattr(flags, "F_num_mask", 0))
         self.model = Transducer(**model_kwargs(flags, vocab_size=vocab_size))
         if state_dict is not None:
             self.model.load_state_dict(state_dict)
@@ -62,6 +70,8 @@ class TrainEngine:
             e = min(B, s + sub)
             self.reducer.armed = (s == starts[-1])   # exchange once, after the last accumulation
             xs, xlen = self.features(wave[s:e], None if wave_len is None else wave_len[s:e])
+            if self.spec_augment is not None:
+                xs = self.spec_augment(xs)
             loss = self.model(xs, ys[s:e], xlen, ylen[s:e])
             loss = loss / len(starts)
             ops.mark("backward:enter")

@@ -3,8 +3,8 @@
 Only the log-mel path of the north-star is implemented on the GPU: ``FilterbankFeatures`` and the
 frame stacking ``Downsample`` (pure data movement).  ``build_transform`` returns the same triple
 ``(transform_train, transform_test, input_size)`` as the reference (rnnt/transforms.py:165-203);
-SpecAugment masking, deltas and CMVN are train-time augmentation outside the hot path
- and raise if requested.
+SpecAugment masking runs on the resident batch (``SpecAugment``, one kernel); deltas and CMVN
+are outside the hot path and raise if requested.
 """
 import torch
 
@@ -46,6 +46,78 @@ class _FusedFbankDownsample(torch.nn.Module):
     def forward(self, x):
         xs, _ = self.inner(x)
         return xs.transpose(1, 2)
+
+
+class SpecAugment(torch.nn.Module):
+    """``TimeMasking(T_mask, T_num_mask)`` followed by ``FrequencyMasking(F_mask, F_num_mask)``
+    (rnnt/transforms.py:54-146, zero fill) on a resident, already stacked feature batch
+    ``xs [B, T0, F]`` — the reference runs them in DataLoader workers on ``[B, F, T0]``.
+
+    The intervals are drawn with Python's ``random`` in exactly the reference's order (all time
+    masks row by row, then all frequency masks row by row; ``start = randrange(dim)``,
+    ``end = start + randrange(max_width)``), so ``random.seed(s)`` gives the reference's masks;
+    one kernel applies them in place."""
+
+    def __init__(self, T_mask=0, T_num_mask=0, F_mask=0, F_num_mask=0):
+        super().__init__()
+        self.T_mask, self.T_num_mask = T_mask, T_num_mask
+        self.F_mask, self.F_num_mask = F_mask, F_num_mask
+
+    def draw(self, B, T0, F):
+        """Half-open [start, end) intervals, int32 CPU tensors [B, n, 2] (or None)."""
+        import random
+        t_iv = f_iv = None
+        if self.T_mask > 0 and self.T_num_mask > 0:
+            rows = []
+            for _ in range(B):
+                for _ in range(self.T_num_mask):
+                    start = random.randrange(0, T0)
+                    rows.append((start, start + random.randrange(0, self.T_mask)))
+            t_iv = torch.tensor(rows, dtype=torch.int32).view(B, self.T_num_mask, 2)
+        if self.F_mask > 0 and self.F_num_mask > 0:
+            rows = []
+            for _ in range(B):
+                for _ in range(self.F_num_mask):
+                    start = random.randrange(0, F)
+                    rows.append((start, start + random.randrange(0, self.F_mask)))
+            f_iv = torch.tensor(rows, dtype=torch.int32).view(B, self.F_num_mask, 2)
+        return t_iv, f_iv
+
+    def _stage(self, cpu, dev):
+        """Host -> device through a small ring of pinned buffers (a pageable copy would make the
+        host wait for the device once per step); a slot is reused only after its copy has run."""
+        ring = self.__dict__.setdefault("_ring", [])       # [pinned buffer, event], oldest first
+        n = cpu.numel()
+        idx = None
+        for i, (buf, ev) in enumerate(ring):
+            if buf.numel() >= n and ev.query():
+                idx = i
+                break
+        if idx is None and len(ring) < 8:
+            ring.append([torch.empty(max(n, 1024), dtype=torch.int32).pin_memory(), torch.cuda.Event()])
+            idx = len(ring) - 1
+        elif idx is None:
+            idx = 0
+            ring[0][1].synchronize()
+            if ring[0][0].numel() < n:
+                ring[0][0] = torch.empty(n, dtype=torch.int32).pin_memory()
+        slot = ring.pop(idx)
+        slot[0][:n].copy_(cpu.reshape(-1))
+        out = slot[0][:n].to(dev, non_blocking=True).view(cpu.shape)
+        slot[1].record()
+        ring.append(slot)
+        return out
+
+    @torch.no_grad()
+    def forward(self, xs):
+        from . import ops
+        B, T0, F = xs.shape
+        t_iv, f_iv = self.draw(B, T0, F)
+        if t_iv is None and f_iv is None:
+            return xs
+        dev = xs.device
+        return ops.spec_mask_(xs, None if t_iv is None else self._stage(t_iv, dev),
+                              None if f_iv is None else self._stage(f_iv, dev))
 
 
 def build_transform(feature_type, feature_size, n_fft=512, win_length=400, hop_length=200,

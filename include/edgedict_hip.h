@@ -279,6 +279,17 @@ int edgedict_embedding_fwd(int out_dtype, int emb_dtype, const int32_t* tokens, 
 int edgedict_embedding_bwd(int dtype, const int32_t* tokens, int tok_stride, const void* dout,
                            float* demb, int B, int Uout, int E, int V, int prepend_bos, int bos,
                            int pad, void* stream);
+/* dropout: y[i] = x[i] * keep(seed, i) / (1-p) with a counter-based mask (nn.Dropout /
+ *          nn.LSTM(dropout=p) in training mode, rnnt/models.py:47-53,145-147); the backward pass is
+ *          the same call on the incoming gradient with the same seed.  x == y is allowed.
+ * spec_mask: zero-fill the SpecAugment time / frequency intervals (TimeMasking / FrequencyMasking,
+ *          rnnt/transforms.py:54-146, applied after frame stacking) of a resident feature batch
+ *          x fp32 [B,T,F]; t_iv int32 [B][n_t][2], f_iv int32 [B][n_f][2] = half-open [start,end)
+ *          intervals over the frame index / the stacked feature index. */
+int edgedict_dropout(int dtype, const void* x, void* y, long long n, float p, unsigned seed,
+                     void* stream);
+int edgedict_spec_mask(float* x, int B, int T, int F, const int32_t* t_iv, int n_t,
+                       const int32_t* f_iv, int n_f, void* stream);
 int edgedict_joint_hidden_fwd(int dtype, const void* E1, const void* D1, void* hid, int B, int T,
                               int U1, int J, void* stream);
 int edgedict_joint_hidden_bwd(int dtype, const void* dhid, const void* hid, float* dE1,
