@@ -13,6 +13,7 @@ import types
 _DEFAULTS = dict(
     name="rnn-t-v5", model_name="model.pt", mode="train",
     optim="adam", lr=1e-4, batch_size=8, sub_batch_size=8, eval_batch_size=4,
+    sched=False, sched_patience=1, sched_factor=0.5, sched_min_lr=1e-6, warmup_step=0,
     enc_type="LSTM", enc_hidden_size=600, enc_layers=4, enc_dropout=0.0, enc_proj_size=600,
     dec_hidden_size=150, dec_layers=2, dec_dropout=0.0, dec_proj_size=150, joint_size=512,
     audio_max_length=14, feature="mfcc", feature_size=80, n_fft=400, win_length=400,
@@ -30,17 +31,20 @@ _COMMON = dict(
 
 PRESETS = {
     # flagfiles/E4D1.txt
-    "E4D1": dict(_COMMON, lr=5e-4, batch_size=32, sub_batch_size=16, eval_batch_size=2,
+    "E4D1": dict(_COMMON, lr=5e-4, sched=True, sched_patience=1, sched_factor=0.5, sched_min_lr=1e-6,
+                 warmup_step=10000, batch_size=32, sub_batch_size=16, eval_batch_size=2,
                  enc_hidden_size=256, enc_layers=4, enc_proj_size=256,
                  dec_hidden_size=256, dec_layers=1, dec_dropout=0.0, dec_proj_size=256,
                  joint_size=256, audio_max_length=16, win_length=320, hop_length=160),
     # flagfiles/E6D2.txt
-    "E6D2": dict(_COMMON, lr=5e-4, batch_size=32, sub_batch_size=32, eval_batch_size=4,
+    "E6D2": dict(_COMMON, lr=5e-4, sched=True, sched_patience=1, sched_factor=0.5, sched_min_lr=1e-6,
+                 warmup_step=10000, batch_size=32, sub_batch_size=32, eval_batch_size=4,
                  enc_hidden_size=1024, enc_layers=6, enc_proj_size=640,
                  dec_hidden_size=256, dec_layers=2, dec_dropout=0.0, dec_proj_size=256,
                  joint_size=640, audio_max_length=16, win_length=320, hop_length=200),
     # flagfiles/E6D2_LARGE_Batch.txt
-    "E6D2_LARGE_Batch": dict(_COMMON, lr=8e-4, batch_size=128, sub_batch_size=7,
+    "E6D2_LARGE_Batch": dict(_COMMON, lr=8e-4, sched=True, sched_patience=1, sched_factor=0.7,
+                             sched_min_lr=1e-6, warmup_step=5000, batch_size=128, sub_batch_size=7,
                              eval_batch_size=4, enc_type="LSTM",
                              enc_hidden_size=1024, enc_layers=6, enc_proj_size=640,
                              dec_hidden_size=512, dec_layers=2, dec_dropout=0.1,

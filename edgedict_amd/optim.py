@@ -81,10 +81,102 @@ class FusedAdam:
         config.bump_param_epoch()
 
     def state_dict(self):
-        return {"step": self.step_count, "m": self.m, "v": self.v, "lr": self.lr}
+        """``torch.optim.Adam.state_dict()`` layout (what the reference's checkpoints hold under
+        ``'optim'``, cli/train.py:321-336): per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq``
+        (clones of the flat buffers' views) and one param group, so a checkpoint written here
+        loads into ``torch.optim.Adam`` over the same parameter list and vice versa."""
+        state = {}
+        for i, (p, off) in enumerate(zip(self.flat.params, self.flat.offsets)):
+            n = p.numel()
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": self.m[off:off + n].view_as(p).clone(),
+                        "exp_avg_sq": self.v[off:off + n].view_as(p).clone()}
+        group = {"lr": self.param_groups[0]["lr"], "betas": tuple(self.betas), "eps": self.eps,
+                 "weight_decay": self.weight_decay, "amsgrad": False,
+                 "params": list(range(len(self.flat.params)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
+        if "param_groups" in sd:           # torch.optim.Adam layout
+            g = sd["param_groups"][0]
+            self.lr = self.param_groups[0]["lr"] = float(g["lr"])
+            self.betas = tuple(g.get("betas", self.betas))
+            self.eps = float(g.get("eps", self.eps))
+            self.weight_decay = float(g.get("weight_decay", self.weight_decay))
+            steps = set()
+            for i, (p, off) in enumerate(zip(self.flat.params, self.flat.offsets)):
+                st = sd["state"].get(i, sd["state"].get(str(i)))
+                n = p.numel()
+                if st is None:             # parameter that never received a gradient
+                    self.m[off:off + n].zero_()
+                    self.v[off:off + n].zero_()
+                    continue
+                self.m[off:off + n].view_as(p).copy_(st["exp_avg"])
+                self.v[off:off + n].view_as(p).copy_(st["exp_avg_sq"])
+                steps.add(int(float(st["step"])))
+            if len(steps) > 1:
+                raise ValueError("per-parameter Adam step counts differ (%s): the flat Adam kernel "
+                                 "uses one bias correction for all parameters" % sorted(steps))
+            self.step_count = steps.pop() if steps else 0
+            return
+        self.step_count = int(sd["step"])  # round-1 flat layout
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
         self.lr = self.param_groups[0]["lr"] = float(sd["lr"])
+
+
+class WarmupLR:
+    """Linear warm-up of the reference's training loop (cli/train.py:189-191):
+    ``lr = base_lr * step / warmup_step`` for ``step <= warmup_step`` (steps count from 1)."""
+
+    def __init__(self, optimizer, base_lr, warmup_step):
+        self.optimizer, self.base_lr, self.warmup_step = optimizer, float(base_lr), int(warmup_step)
+
+    def step(self, step):
+        if self.warmup_step > 0 and step <= self.warmup_step:
+            self.optimizer.param_groups[0]["lr"] = self.base_lr * step / self.warmup_step
+        return self.optimizer.param_groups[0]["lr"]
+
+
+class ReduceLROnPlateau:
+    """``torch.optim.lr_scheduler.ReduceLROnPlateau(optim, patience, factor, min_lr)`` as the
+    reference configures it (cli/train.py:142-146: mode 'min', relative threshold 1e-4, no
+    cooldown, eps 1e-8), for any object with ``param_groups`` (FusedAdam is not a
+    ``torch.optim.Optimizer``).  ``state_dict`` uses torch's key names."""
+
+    def __init__(self, optimizer, patience=10, factor=0.1, min_lr=0.0, threshold=1e-4, eps=1e-8):
+        if factor >= 1.0:
+            raise ValueError("Factor should be < 1.0.")
+        self.optimizer = optimizer
+        self.patience, self.factor, self.min_lr = patience, factor, min_lr
+        self.threshold, self.eps = threshold, eps
+        self.best = float("inf")
+        self.num_bad_epochs = 0
+        self.last_epoch = 0
+
+    def step(self, metric):
+        current = float(metric)
+        self.last_epoch += 1
+        if current < self.best * (1.0 - self.threshold):
+            self.best = current
+            self.num_bad_epochs = 0
+        else:
+            self.num_bad_epochs += 1
+        if self.num_bad_epochs > self.patience:
+            for g in self.optimizer.param_groups:
+                old = float(g["lr"])
+                new = max(old * self.factor, self.min_lr)
+                if old - new > self.eps:
+                    g["lr"] = new
+            self.num_bad_epochs = 0
+
+    def state_dict(self):
+        return {"best": self.best, "num_bad_epochs": self.num_bad_epochs,
+                "last_epoch": self.last_epoch, "patience": self.patience, "factor": self.factor,
+                "min_lrs": [self.min_lr], "threshold": self.threshold, "eps": self.eps,
+                "mode": "min", "threshold_mode": "rel", "cooldown": 0, "cooldown_counter": 0}
+
+    def load_state_dict(self, sd):
+        self.best = float(sd["best"])
+        self.num_bad_epochs = int(sd["num_bad_epochs"])
+        self.last_epoch = int(sd.get("last_epoch", 0))

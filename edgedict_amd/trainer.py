@@ -18,7 +18,7 @@ from .dp import BucketedAllReduce
 from .features import StackedLogFbank
 from .flags import model_kwargs
 from .models import Transducer
-from .optim import FlatParams, FusedAdam
+from .optim import FlatParams, FusedAdam, ReduceLROnPlateau, WarmupLR
 
 
 class TrainEngine:
@@ -54,12 +54,49 @@ class TrainEngine:
         self.optim = FusedAdam(self.flat, lr=flags.lr, max_grad_norm=getattr(flags, "gradclip", None))
         self.reducer = BucketedAllReduce(self.flat, process_group)
         self.sub_batch_size = getattr(flags, "sub_batch_size", None)
+        # learning-rate control of the reference's loop (cli/train.py:142-146,189-191)
+        self.warmup = WarmupLR(self.optim, flags.lr, getattr(flags, "warmup_step", 0) or 0)
+        self.sched = None
+        if getattr(flags, "sched", False):
+            self.sched = ReduceLROnPlateau(self.optim, patience=getattr(flags, "sched_patience", 1),
+                                           factor=getattr(flags, "sched_factor", 0.5),
+                                           min_lr=getattr(flags, "sched_min_lr", 1e-6))
+        self.step_count = 0
+
+    # ---- checkpoints in the reference's layout (cli/train.py:321-351): {'optim', 'model', 'sched'}
+    def save(self, path):
+        ckpt = {"optim": self.optim.state_dict(), "model": self.model.state_dict(),
+                "step": self.step_count}
+        if self.sched is not None:
+            ckpt["sched"] = self.sched.state_dict()
+        torch.save(ckpt, path)
+
+    def load(self, path, load_optim=True):
+        """Accepts the reference's checkpoints (``{'model': ...}`` with optional 'optim'/'sched',
+        or a Lightning checkpoint, rnnt/models.py:368-380) and this engine's own."""
+        from .models import convert_lightning2normal
+        ckpt = convert_lightning2normal(torch.load(path, map_location="cpu"))
+        sd = ckpt["model"] if "model" in ckpt else ckpt
+        self.model.load_state_dict(sd)          # copies INTO the flat parameter buffer views
+        config.bump_param_epoch()
+        if load_optim and "optim" in ckpt:
+            self.optim.load_state_dict(ckpt["optim"])
+        if self.sched is not None and "sched" in ckpt:
+            self.sched.load_state_dict(ckpt["sched"])
+        self.step_count = int(ckpt.get("step", 0)) if isinstance(ckpt, dict) else 0
+
+    def validation_end(self, val_loss):
+        """Call with the validation loss after each evaluation (cli/train.py:182-184,206-208)."""
+        if self.sched is not None:
+            self.sched.step(val_loss)
 
     def train_step(self, wave, wave_len, ys, ylen):
         """wave f32[B,N] (device), wave_len i32[B] samples (or None), ys i32[B,U], ylen i32[B].
         Returns the mean loss of the local batch as a device tensor (no host sync)."""
         from . import ops
         ops.mark("step:enter")
+        self.step_count += 1
+        self.warmup.step(self.step_count)
         self.model.train()
         self.optim.zero_grad()
         B = wave.shape[0]

@@ -78,3 +78,39 @@ def test_host_side_lengths_give_the_same_step(hip_lib):
     assert res[0][0] == res[1][0]
     assert torch.equal(res[0][1], res[1][1]) or \
         (res[0][1] - res[1][1]).abs().max().item() <= 2e-5 * res[0][1].abs().max().item()
+
+
+def test_checkpoint_round_trip_in_the_reference_layout(hip_lib, tmp_path):
+    """save() writes {'optim', 'model', 'sched'} as cli/train.py:321-336 does; a fresh engine that
+    loads it continues bit-identically, and the 'optim' entry loads into torch.optim.Adam."""
+    from edgedict_amd.trainer import TrainEngine
+    fl = _flags()
+    fl.sched, fl.warmup_step = True, 4
+
+    def batch(seed):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        wave = (0.1 * torch.randn(3, 12000, generator=g)).cuda()
+        ys = torch.randint(4, 40, (3, 5), generator=g, dtype=torch.int32).cuda()
+        return wave, torch.tensor([12000, 9000, 11000], dtype=torch.int32), ys, \
+            torch.tensor([5, 3, 4], dtype=torch.int32)
+
+    torch.manual_seed(0)
+    a = TrainEngine(fl, vocab_size=40, device="cuda", compute_dtype="fp32")
+    for s in (1, 2):
+        a.train_step(*batch(s))
+    a.validation_end(3.0)
+    path = str(tmp_path / "2.pt")
+    a.save(path)
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) >= {"optim", "model", "sched"} and "encoder.lstm.lstms.0.weight_ih_l0" in ck["model"]
+    ref = torch.optim.Adam([torch.nn.Parameter(torch.zeros_like(p)) for p in a.flat.params], lr=1.0)
+    ref.load_state_dict(ck["optim"])
+    torch.manual_seed(123)                                   # different initial weights on purpose
+    b = TrainEngine(fl, vocab_size=40, device="cuda", compute_dtype="fp32")
+    b.load(path)
+    assert b.step_count == 2 and b.optim.step_count == 2 and b.sched.best == 3.0
+    la, lb = a.train_step(*batch(3)), b.train_step(*batch(3))
+    torch.cuda.synchronize()
+    assert la.item() == lb.item()
+    assert (a.flat.data - b.flat.data).abs().max().item() <= 1e-7
+    assert abs(a.optim.param_groups[0]["lr"] - fl.lr * 3 / 4) < 1e-12   # warm-up: step 3 of 4
