@@ -48,24 +48,31 @@ __device__ __forceinline__ void glds16(const bf16_t* src, unsigned char* lds_wav
 // (A 3-buffer variant with counted `s_waitcnt vmcnt(8)` + raw s_barrier, 96 KB LDS and ONE workgroup
 // per CU was measured and is slower on every shape of this path: joint logits 4.6 vs 3.6 ms,
 // 4096^3 657 vs 901 TF/s.  Two co-resident workgroups hide latency better than a deeper pipeline.)
-// TILE = 128: 128x128 output tile, wave tile 64x64 (grids that fill the chip).
-// TILE = 64 : 64x64 output tile, wave tile 32x32, for SMALL problems (e.g. the encoder's chunked dX
-//             products, 1024x1024x4096): the kernel is bound by the per-CU L2->LDS fetch rate
-//             (~55 GB/s per CU, measured the same at one or two workgroups and 4 or 8 waves per CU),
-//             so a problem with 64 big tiles uses a quarter of the chip's fetch bandwidth; 4x the
-//             workgroups fetch 2x the bytes at 4x the rate.
-template <int TILE>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs g) {
-    constexpr int THREADS = 256, WAVES = 4;
-    constexpr int BM = TILE, BN = TILE;
-    constexpr int MI = TILE / 32, NJ = TILE / 32;   // 16x16 MFMA tiles per wave along M / N
-    constexpr int PIECES = TILE / 8 / WAVES;        // 1 KiB DMA pieces per wave, operand and K tile
-    constexpr int TILE_BYTES = TILE * BK * 2;
-    constexpr int BUF_BYTES = 2 * TILE_BYTES;
-    constexpr int CCH = TILE / 8;                   // 16-byte chunks per staged C row
+// Instantiations <TM, TN, WT> (output tile TM x TN, wave tile WT x WT, (TM/WT) x (TN/WT) waves):
+//   <128,128,64>  4 waves, 64 KB LDS, 2 workgroups per CU: the default for grids that fill the chip.
+//   (<256,128,64>, 8 waves, 96 KB LDS, ONE workgroup per CU, was measured: 25 % fewer operand bytes
+//    per flop and half the per-tile overheads do not make up for the lost second workgroup -
+//    joint logits 4.19 vs 3.54 ms, dhid 2.63 vs 2.35 ms.  Instantiate it with
+//    EDGEDICT_GEMM_NT_TILE=256 to re-measure.)
+//   <64,64,32>    4 waves, 32 KB: SMALL problems (the encoder's chunked dX products,
+//                 1024x1024x4096: 64 big tiles would use a quarter of the chip's fetch bandwidth;
+//                 4x the workgroups fetch 2x the bytes at 4x the rate).
+template <int TM, int TN, int WT>
+__global__ __launch_bounds__((TM / WT) * (TN / WT) * 64, (TM / WT) * (TN / WT) == 4 ? 2 : 1)
+void gemm_nt_kernel(NtArgs g) {
+    constexpr int WAVES_N = TN / WT;
+    constexpr int WAVES = (TM / WT) * WAVES_N, THREADS = WAVES * 64;
+    constexpr int BM = TM, BN = TN;
+    constexpr int MI = WT / 16, NJ = WT / 16;       // 16x16 MFMA tiles per wave along M / N
+    constexpr int PIECES_A = TM / 8 / WAVES;        // 1 KiB DMA pieces per wave and K tile
+    constexpr int PIECES_B = TN / 8 / WAVES;
+    constexpr int A_BYTES = TM * BK * 2, B_BYTES = TN * BK * 2;
+    constexpr int BUF_BYTES = A_BYTES + B_BYTES;
+    constexpr int CCH = TN / 8;                     // 16-byte chunks per staged C row
+    static_assert(TM * TN * 2 <= 2 * BUF_BYTES, "C staging must fit in the operand buffers");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF_BYTES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1;     // wave rows wm * (MI*16), wave cols wn * (NJ*16)
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;   // wave rows wm * WT, wave cols wn * WT
     const int r16 = lane & 15, kq = lane >> 4;
     const int KT = g.K / BK;
 
@@ -85,21 +92,20 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs g) {
     // 16-byte chunk (l%8) ^ (l/8) of its row (source-side swizzle, LDS image stays lane-linear)
     const int prow = lane >> 3;
     const int chunk = (lane & 7) ^ prow;
-    const bf16_t* asrc[PIECES];
-    const bf16_t* bsrc[PIECES];
+    const bf16_t* asrc[PIECES_A];
+    const bf16_t* bsrc[PIECES_B];
 #pragma unroll
-    for (int i = 0; i < PIECES; ++i) {
-        const int row = (i * WAVES + wave) * 8 + prow;
-        asrc[i] = g.A + (long long)min(m0 + row, g.M - 1) * g.lda + chunk * 8;
-        bsrc[i] = g.B + (long long)min(n0 + row, g.N - 1) * g.ldb + chunk * 8;
-    }
+    for (int i = 0; i < PIECES_A; ++i)
+        asrc[i] = g.A + (long long)min(m0 + (i * WAVES + wave) * 8 + prow, g.M - 1) * g.lda + chunk * 8;
+#pragma unroll
+    for (int i = 0; i < PIECES_B; ++i)
+        bsrc[i] = g.B + (long long)min(n0 + (i * WAVES + wave) * 8 + prow, g.N - 1) * g.ldb + chunk * 8;
     auto issue = [&](int buf, int k0) {
         unsigned char* base = smem + buf * BUF_BYTES;
 #pragma unroll
-        for (int i = 0; i < PIECES; ++i) {
-            glds16(asrc[i] + k0, base + (i * WAVES + wave) * 1024);
-            glds16(bsrc[i] + k0, base + TILE_BYTES + (i * WAVES + wave) * 1024);
-        }
+        for (int i = 0; i < PIECES_A; ++i) glds16(asrc[i] + k0, base + (i * WAVES + wave) * 1024);
+#pragma unroll
+        for (int i = 0; i < PIECES_B; ++i) glds16(bsrc[i] + k0, base + A_BYTES + (i * WAVES + wave) * 1024);
     };
 
     f32x4_t acc[MI][NJ];
@@ -107,18 +113,18 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs g) {
     // FOUR CONSECUTIVE COLUMNS of one C row -> 8-byte packed stores in the epilogue
     auto compute = [&](int buf) {
         const unsigned char* sA = smem + buf * BUF_BYTES;
-        const unsigned char* sB = sA + TILE_BYTES;
+        const unsigned char* sB = sA + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < BK / 32; ++ks) {
             bf16x8_t a[MI], b[NJ];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                const int ra = wm * (MI * 16) + i * 16 + r16;
+                const int ra = wm * WT + i * 16 + r16;
                 a[i] = *reinterpret_cast<const bf16x8_t*>(sA + ra * 128 + (((ks * 4 + kq) ^ (ra & 7)) << 4));
             }
 #pragma unroll
             for (int i = 0; i < NJ; ++i) {
-                const int rb = wn * (NJ * 16) + i * 16 + r16;
+                const int rb = wn * WT + i * 16 + r16;
                 b[i] = *reinterpret_cast<const bf16x8_t*>(sB + rb * 128 + (((ks * 4 + kq) ^ (rb & 7)) << 4));
             }
 #pragma unroll
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs g) {
         float4 bv[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int nc = n0 + wn * (NJ * 16) + j * 16 + kq * 4;   // 4 consecutive columns of this lane
+            const int nc = n0 + wn * WT + j * 16 + kq * 4;   // 4 consecutive columns of this lane
             bv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (nc < g.N) {   // N % 8 == 0: the 4 columns are all inside or all outside
                 if (g.bias1) bv[j] = *reinterpret_cast<const float4*>(g.bias1 + nc);
@@ -160,17 +166,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs g) {
         }
         // ---- epilogue: the operand tiles are dead after this barrier; C is staged in LDS
         __syncthreads();
-        unsigned char* sC = smem;   // [TILE rows][CCH chunks of 16 B], chunk ^= row & (CCH - 1)
+        unsigned char* sC = smem;   // [TM rows][CCH chunks of 16 B], chunk ^= row & (CCH - 1)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
-            const int nl = wn * (NJ * 16) + j * 16 + kq * 4;        // 4 consecutive columns nl .. nl+3
+            const int nl = wn * WT + j * 16 + kq * 4;        // 4 consecutive columns nl .. nl+3
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                const int ml = wm * (MI * 16) + i * 16 + r16;
+                const int ml = wm * WT + i * 16 + r16;
                 uint2 pk;
                 pk.x = (unsigned)f32_to_bf16(acc[i][j][0]) | ((unsigned)f32_to_bf16(acc[i][j][1]) << 16);
                 pk.y = (unsigned)f32_to_bf16(acc[i][j][2]) | ((unsigned)f32_to_bf16(acc[i][j][3]) << 16);
-                *reinterpret_cast<uint2*>(sC + ml * (TILE * 2) + ((((nl >> 3) ^ (ml & (CCH - 1))) << 4) | ((nl & 4) << 1))) = pk;
+                *reinterpret_cast<uint2*>(sC + ml * (TN * 2) + ((((nl >> 3) ^ (ml & (CCH - 1))) << 4) | ((nl & 4) << 1))) = pk;
             }
         }
         __syncthreads();
@@ -180,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(NtArgs g) {
             const int rl = c / CCH, ch = c % CCH;
             const int row = m0 + rl, col = n0 + ch * 8;
             if (row >= g.M || col >= g.N || ((g.debug & 1) && row > 0)) continue;
-            uint4 v = *reinterpret_cast<const uint4*>(sC + rl * (TILE * 2) + ((ch ^ (rl & (CCH - 1))) << 4));
+            uint4 v = *reinterpret_cast<const uint4*>(sC + rl * (TN * 2) + ((ch ^ (rl & (CCH - 1))) << 4));
             bf16_t* dst = g.C + (long long)row * g.ldc + col;
             if (g.accumulate) {
                 float x[8], y[8];
@@ -220,13 +226,17 @@ int ed_gemm_nt_launch(const void* A, long long lda, const void* B, long long ldb
     g.debug = dbg;
     static const int force_t = [] { const char* e = getenv("EDGEDICT_GEMM_NT_TILE"); return e ? atoi(e) : 0; }();
     const long long tiles128 = (long long)((M + 127) / 128) * ((N + 127) / 128);
-    const int tile = force_t ? force_t : (tiles128 <= 128 ? 64 : 128);   // small problem: spread it out
-    g.n_tiles = (N + tile - 1) / tile;
-    const long long tiles = (long long)((M + tile - 1) / tile) * g.n_tiles;
+    // small problem: spread it out
+    int tm = 128, tn = 128;
+    if (force_t == 64 || (!force_t && tiles128 <= 128)) tm = tn = 64;
+    else if (force_t == 256) tm = 256;   // measured slower everywhere; kept for re-measurement
+    g.n_tiles = (N + tn - 1) / tn;
+    const long long tiles = (long long)((M + tm - 1) / tm) * g.n_tiles;
     ED_CHECK_ARG(tiles < (1ll << 31), "gemm: too many tiles");
     g.tiles = (int)tiles;
-    if (tile == 64) hipLaunchKernelGGL(gemm_nt_kernel<64>, dim3((unsigned)tiles), dim3(256), lds_pad, s, g);
-    else hipLaunchKernelGGL(gemm_nt_kernel<128>, dim3((unsigned)tiles), dim3(256), lds_pad, s, g);
+    if (tm == 64) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 32>), dim3((unsigned)tiles), dim3(256), lds_pad, s, g);
+    else if (tm == 256) hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 64>), dim3((unsigned)tiles), dim3(512), lds_pad, s, g);
+    else hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 64>), dim3((unsigned)tiles), dim3(256), lds_pad, s, g);
     ED_CHECK_LAUNCH("gemm_nt");
     return ED_OK;
 }
