@@ -161,7 +161,8 @@ def main():
         Tp = (xs_frames + 1) // 2
         U1 = args.labels + 1
         J, V = flags.joint_size, flags.bpe_size
-        flop = 2.0 * args.batch * Tp * U1 * J * V
+        rows = int(ops.LAST.get("joint_rows", args.batch * Tp * U1))   # packed lattice: valid cells only
+        flop = 2.0 * rows * J * V
         n, ms = timers.get("joint_logits_gemm", (0, float("nan")))
         peak = MFMA_BF16_PEAK_TF if args.dtype == "bf16" else MFMA_F32_PEAK_TF
         achieved = flop / (ms * 1e-3) / 1e12 if n else float("nan")
@@ -171,7 +172,7 @@ def main():
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as fh:
                 pmc = json.load(fh)["kernels"]
-            tiles = ((args.batch * Tp * U1 + 127) // 128) * ((V + 127) // 128)
+            tiles = ((rows + 127) // 128) * ((V + 127) // 128)
             ent = pmc.get("gemm_nt_kernel<128> [tiles=%d]" % tiles) or pmc.get("gemm_nt_kernel [tiles=%d]" % tiles)
             if ent:
                 traffic = ent["hbm_bytes"]
@@ -203,11 +204,12 @@ def main():
                 "final_loss": loss_val,
             },
             "roofline": {
-                "kernel": "gemm_nt_kernel (bf16 NT, direct-to-LDS) joint logits [%d x %d x %d]"
-                          % (args.batch * Tp * U1, V, J),
+                "kernel": "gemm_nt_kernel (bf16 NT, direct-to-LDS) joint logits [%d x %d x %d] "
+                          "(packed lattice: %d of %d dense cells)"
+                          % (rows, V, J, rows, args.batch * Tp * U1),
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": traffic,
-                "algorithmic_bytes": 2.0 * args.batch * Tp * U1 * (J + V) + 2.0 * V * J,
+                "algorithmic_bytes": 2.0 * rows * (J + V) + 2.0 * V * J,
                 "launch_ms": ms, "launches_timed": n,
             },
             "kernel_ms": {k: round(v[1], 4) for k, v in sorted(timers.items())},

@@ -42,6 +42,10 @@ DEFER_WEIGHT_GRADS = os.environ.get("EDGEDICT_DEFER_DW", "1") != "0"
 # encoder (and, through autograd's stream replay, its backward concurrently with the encoder's)
 DECODER_ON_AUX_STREAM = os.environ.get("EDGEDICT_DECODER_AUX", "1") != "0"
 
+# Transducer.forward(output_loss=True) with HOST-side lengths runs joint + loss on the packed
+# lattice (only the cells inside each utterance's (T_b, U_b+1) box are materialised)
+PACKED_LATTICE = os.environ.get("EDGEDICT_PACKED_LATTICE", "1") != "0"
+
 _state = {"dtype": _parse(os.environ.get("EDGEDICT_DTYPE", "fp32")), "epoch": 0}
 
 

@@ -154,7 +154,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void joint_hidden_fwd(const T* __restrict__ E1,
                                                         const T* __restrict__ D1,
                                                         T* __restrict__ hid, int B, int Tn, int U1,
-                                                        int J) {
+                                                        int J, const int32_t* __restrict__ act_lens,
+                                                        const int32_t* __restrict__ label_lens,
+                                                        const long long* __restrict__ pk_off) {
     constexpr int VEC = ElemIO<T>::VEC;
     const int chunks = J / VEC;  // J % VEC == 0 checked on the host
     const long long n = (long long)B * Tn * U1 * chunks;
@@ -166,11 +168,17 @@ __global__ __launch_bounds__(256) void joint_hidden_fwd(const T* __restrict__ E1
         const long long bt = btu / U1;
         const int b = (int)(bt / Tn);
         float e[VEC], d[VEC], o[VEC];
+        long long orow = btu;
+        if (pk_off) {   // packed lattice: only cells inside the utterance's (T_b, U_b + 1) box exist
+            const int t = (int)(bt % Tn), Ub = label_lens[b];
+            if (t >= act_lens[b] || u > Ub) continue;
+            orow = pk_off[b] + (long long)t * (Ub + 1) + u;
+        }
         ElemIO<T>::load_vec(E1 + bt * J + c * VEC, e);
         ElemIO<T>::load_vec(D1 + ((long long)b * U1 + u) * J + c * VEC, d);
 #pragma unroll
         for (int k = 0; k < VEC; ++k) o[k] = tanhf(e[k] + d[k]);
-        ElemIO<T>::store_vec(hid + btu * J + c * VEC, o);
+        ElemIO<T>::store_vec(hid + orow * J + c * VEC, o);
     }
 }
 
@@ -203,7 +211,10 @@ __global__ __launch_bounds__(256) void joint_hidden_bwd(const T* __restrict__ dh
                                                         const T* __restrict__ hid,
                                                         float* __restrict__ dE1,
                                                         float* __restrict__ dD1, int B, int Tn,
-                                                        int U1, int J, int t_per_block) {
+                                                        int U1, int J, int t_per_block,
+                                                        const int32_t* __restrict__ act_lens,
+                                                        const int32_t* __restrict__ label_lens,
+                                                        const long long* __restrict__ pk_off) {
     __shared__ float4 red[2][JB_NU][2][64];   // lane-wise hand-off of partial label sums (36 KB)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int jv = lane & 7, ug = lane >> 3;
@@ -211,6 +222,10 @@ __global__ __launch_bounds__(256) void joint_hidden_bwd(const T* __restrict__ dh
     const int b = blockIdx.y;
     const int t0 = blockIdx.z * t_per_block, t1 = min(Tn, t0 + t_per_block);
     const bool jlive = j0 < J;   // J % 8 == 0 checked on the host
+    // packed lattice: utterance b owns rows pk_off[b] + t*(U_b+1) + u, t < T_b, u <= U_b
+    const int Tb = pk_off ? act_lens[b] : Tn;
+    const int Ulim = pk_off ? label_lens[b] + 1 : U1;
+    const long long rbase = pk_off ? pk_off[b] : (long long)b * Tn * U1;
     for (int uc = 0; uc < U1; uc += JB_UCHUNK) {
         float usum[JB_NU][8];
 #pragma unroll
@@ -218,12 +233,12 @@ __global__ __launch_bounds__(256) void joint_hidden_bwd(const T* __restrict__ dh
 #pragma unroll
             for (int e = 0; e < 8; ++e) usum[i][e] = 0.f;
         for (int t = t0 + wave; t < t1; t += 4) {
-            const long long base = (((long long)b * Tn + t) * U1) * J + j0;
+            const long long base = (rbase + (long long)t * Ulim) * J + j0;
             float tsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < JB_NU; ++i) {
                 const int u = uc + ug + 8 * i;
-                if (u < U1 && jlive) {
+                if (u < Ulim && t < Tb && jlive) {
                     float h[8], g[8];
                     Load8<T>::ld(hid + base + (long long)u * J, h);
                     Load8<T>::ld(dhid + base + (long long)u * J, g);
@@ -485,8 +500,9 @@ extern "C" int edgedict_spec_mask(float* x, int B, int T, int F, const int32_t* 
     return ED_OK;
 }
 
-extern "C" int edgedict_joint_hidden_fwd(int dtype, const void* E1, const void* D1, void* hid,
-                                         int B, int T, int U1, int J, void* stream_) {
+static int joint_hidden_fwd_impl(int dtype, const void* E1, const void* D1, void* hid, int B, int T,
+                                 int U1, int J, const int32_t* act_lens, const int32_t* label_lens,
+                                 const long long* pk_off, void* stream_) {
     ED_CHECK_ARG(dtype == ED_F32 || dtype == ED_BF16, "joint_hidden_fwd: bad dtype");
     ED_CHECK_ARG(B > 0 && T > 0 && U1 > 0 && J > 0, "joint_hidden_fwd: bad shape");
     const int vec = dtype == ED_F32 ? 4 : 8;
@@ -496,15 +512,29 @@ extern "C" int edgedict_joint_hidden_fwd(int dtype, const void* E1, const void* 
     const long long n = (long long)B * T * U1 * (J / vec);
     const int grid = ed_grid_for(n, 256, 256 * 16);
     if (dtype == ED_F32)
-        hipLaunchKernelGGL(joint_hidden_fwd<float>, dim3(grid), dim3(256), 0, s, (const float*)E1, (const float*)D1, (float*)hid, B, T, U1, J);
+        hipLaunchKernelGGL(joint_hidden_fwd<float>, dim3(grid), dim3(256), 0, s, (const float*)E1, (const float*)D1, (float*)hid, B, T, U1, J, act_lens, label_lens, pk_off);
     else
-        hipLaunchKernelGGL(joint_hidden_fwd<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)E1, (const bf16_t*)D1, (bf16_t*)hid, B, T, U1, J);
+        hipLaunchKernelGGL(joint_hidden_fwd<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)E1, (const bf16_t*)D1, (bf16_t*)hid, B, T, U1, J, act_lens, label_lens, pk_off);
     ED_CHECK_LAUNCH("joint_hidden_fwd");
     return ED_OK;
 }
 
-extern "C" int edgedict_joint_hidden_bwd(int dtype, const void* dhid, const void* hid, float* dE1,
-                                         float* dD1, int B, int T, int U1, int J, void* stream_) {
+extern "C" int edgedict_joint_hidden_fwd(int dtype, const void* E1, const void* D1, void* hid,
+                                         int B, int T, int U1, int J, void* stream_) {
+    return joint_hidden_fwd_impl(dtype, E1, D1, hid, B, T, U1, J, nullptr, nullptr, nullptr, stream_);
+}
+
+extern "C" int edgedict_joint_hidden_fwd_packed(int dtype, const void* E1, const void* D1, void* hid,
+                                                const int32_t* act_lens, const int32_t* label_lens,
+                                                const long long* row_offsets, int B, int T, int U1,
+                                                int J, void* stream_) {
+    ED_CHECK_ARG(act_lens && label_lens && row_offsets, "joint_hidden_fwd_packed: null lengths/offsets");
+    return joint_hidden_fwd_impl(dtype, E1, D1, hid, B, T, U1, J, act_lens, label_lens, row_offsets, stream_);
+}
+
+static int joint_hidden_bwd_impl(int dtype, const void* dhid, const void* hid, float* dE1, float* dD1,
+                                 int B, int T, int U1, int J, const int32_t* act_lens,
+                                 const int32_t* label_lens, const long long* pk_off, void* stream_) {
     ED_CHECK_ARG(dtype == ED_F32 || dtype == ED_BF16, "joint_hidden_bwd: bad dtype");
     ED_CHECK_ARG(B > 0 && T > 0 && U1 > 0 && J > 0, "joint_hidden_bwd: bad shape");
     ED_CHECK_ARG(dhid && hid && dE1 && dD1, "joint_hidden_bwd: null pointer");
@@ -524,11 +554,25 @@ extern "C" int edgedict_joint_hidden_bwd(int dtype, const void* dhid, const void
     tslabs = (T + tpb - 1) / tpb;
     dim3 grid(jblocks, B, tslabs);
     if (dtype == ED_F32)
-        hipLaunchKernelGGL(joint_hidden_bwd<float>, grid, dim3(256), 0, s, (const float*)dhid, (const float*)hid, dE1, dD1, B, T, U1, J, tpb);
+        hipLaunchKernelGGL(joint_hidden_bwd<float>, grid, dim3(256), 0, s, (const float*)dhid, (const float*)hid, dE1, dD1, B, T, U1, J, tpb, act_lens, label_lens, pk_off);
     else
-        hipLaunchKernelGGL(joint_hidden_bwd<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dhid, (const bf16_t*)hid, dE1, dD1, B, T, U1, J, tpb);
+        hipLaunchKernelGGL(joint_hidden_bwd<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dhid, (const bf16_t*)hid, dE1, dD1, B, T, U1, J, tpb, act_lens, label_lens, pk_off);
     ED_CHECK_LAUNCH("joint_hidden_bwd");
     return ED_OK;
+}
+
+extern "C" int edgedict_joint_hidden_bwd(int dtype, const void* dhid, const void* hid, float* dE1,
+                                         float* dD1, int B, int T, int U1, int J, void* stream_) {
+    return joint_hidden_bwd_impl(dtype, dhid, hid, dE1, dD1, B, T, U1, J, nullptr, nullptr, nullptr, stream_);
+}
+
+extern "C" int edgedict_joint_hidden_bwd_packed(int dtype, const void* dhid, const void* hid,
+                                                float* dE1, float* dD1, const int32_t* act_lens,
+                                                const int32_t* label_lens,
+                                                const long long* row_offsets, int B, int T, int U1,
+                                                int J, void* stream_) {
+    ED_CHECK_ARG(act_lens && label_lens && row_offsets, "joint_hidden_bwd_packed: null lengths/offsets");
+    return joint_hidden_bwd_impl(dtype, dhid, hid, dE1, dD1, B, T, U1, J, act_lens, label_lens, row_offsets, stream_);
 }
 
 extern "C" int edgedict_adam_step(float* p, const float* g, float* m, float* v, long long n,

@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void rnnt_lse_gather(
     const T* __restrict__ acts, const int32_t* __restrict__ labels,
     const int32_t* __restrict__ act_lens, const int32_t* __restrict__ label_lens, int B, int Tm,
     int U1, int V, int blank, float* __restrict__ denom, float* __restrict__ lpb,
-    float* __restrict__ lpl, int vec_ok) {
+    float* __restrict__ lpl, int vec_ok, const long long* __restrict__ pk_off) {
     constexpr int VEC = ElemIO<T>::VEC;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -59,7 +59,10 @@ __global__ __launch_bounds__(256) void rnnt_lse_gather(
         const int b = (int)(bt / Tm);
         const int Tb = act_lens[b], Ub = label_lens[b];
         if (t >= Tb || u > Ub) continue;  // outside the utterance's lattice: never read
-        const T* z = acts + row * (long long)V;
+        // packed lattice: only the valid cells exist, utterance b starts at row pk_off[b] and its
+        // rows are (U_b + 1) apart in t
+        const long long arow = pk_off ? pk_off[b] + (long long)t * (Ub + 1) + u : row;
+        const T* z = acts + arow * (long long)V;
         float m = -INFINITY, s = 0.f;
         if (vec_ok) {
             for (int v = lane * VEC; v < V; v += 64 * VEC) {
@@ -238,7 +241,8 @@ __global__ __launch_bounds__(256) void rnnt_grad(
     const int32_t* __restrict__ act_lens, const int32_t* __restrict__ label_lens, int B, int Tm,
     int U1, int V, int blank, const float* __restrict__ denom, const double* __restrict__ alphas,
     const double* __restrict__ betas, const double* __restrict__ ll, float scale_host,
-    const float* __restrict__ scale_dev, int scale_stride, int vec_ok) {
+    const float* __restrict__ scale_dev, int scale_stride, int vec_ok,
+    const long long* __restrict__ pk_off) {
     constexpr int VEC = ElemIO<T>::VEC;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -251,9 +255,11 @@ __global__ __launch_bounds__(256) void rnnt_grad(
         const int b = (int)(bt / Tm);
         const int Tb = act_lens[b], Ub = label_lens[b];
         const float scale = scale_host * (scale_dev ? scale_dev[(long long)b * scale_stride] : 1.f);
-        const T* z = acts + row * (long long)V;
-        T* g = grads + row * (long long)V;
         const bool inside = (t < Tb && u <= Ub);
+        if (pk_off && !inside) continue;   // packed lattice: cells outside the box do not exist
+        const long long arow = pk_off ? pk_off[b] + (long long)t * (Ub + 1) + u : row;
+        const T* z = acts + arow * (long long)V;
+        T* g = grads + arow * (long long)V;
         float c_all = 0.f, c_blank = -INFINITY, c_label = -INFINITY;
         int y = -1;
         if (inside) {
@@ -335,11 +341,10 @@ extern "C" const void* edgedict_rnnt_workspace_view(const void* workspace, int B
     return nullptr;
 }
 
-extern "C" int edgedict_rnnt_loss_forward(const void* acts, int acts_dtype, const int32_t* labels,
-                                          const int32_t* act_lens, const int32_t* label_lens,
-                                          int B, int T, int U1, int V, int blank, float* costs,
-                                          float* reduced, float reduce_scale, void* workspace,
-                                          void* stream_) {
+static int loss_forward(const void* acts, int acts_dtype, const int32_t* labels,
+                        const int32_t* act_lens, const int32_t* label_lens, int B, int T, int U1,
+                        int V, int blank, float* costs, float* reduced, float reduce_scale,
+                        void* workspace, const long long* pk_off, void* stream_) {
     if (int rc = check_common(B, T, U1, V, blank, acts_dtype)) return rc;
     ED_CHECK_ARG(acts && (labels || U1 == 1) && act_lens && label_lens && costs && workspace,
                  "rnnt_loss_forward: null pointer argument");
@@ -360,11 +365,11 @@ extern "C" int edgedict_rnnt_loss_forward(const void* acts, int acts_dtype, cons
     if (acts_dtype == ED_F32)
         hipLaunchKernelGGL(rnnt_lse_gather<float>, dim3(grid1), dim3(256), 0, stream,
                            (const float*)acts, labels, act_lens, label_lens, B, T, U1, V, blank,
-                           denom, lpb, lpl, vec_ok);
+                           denom, lpb, lpl, vec_ok, pk_off);
     else
         hipLaunchKernelGGL(rnnt_lse_gather<bf16_t>, dim3(grid1), dim3(256), 0, stream,
                            (const bf16_t*)acts, labels, act_lens, label_lens, B, T, U1, V, blank,
-                           denom, lpb, lpl, vec_ok);
+                           denom, lpb, lpl, vec_ok, pk_off);
     ED_CHECK_LAUNCH("rnnt_lse_gather");
 
     const int threads = ((U1 + 63) / 64) * 64;
@@ -378,12 +383,31 @@ extern "C" int edgedict_rnnt_loss_forward(const void* acts, int acts_dtype, cons
     return ED_OK;
 }
 
-extern "C" int edgedict_rnnt_loss_backward(const void* acts, int acts_dtype, void* grads,
-                                           const int32_t* labels, const int32_t* act_lens,
-                                           const int32_t* label_lens, int B, int T, int U1, int V,
-                                           int blank, const void* workspace, float grad_scale_host,
-                                           const float* grad_scale_dev, int grad_scale_stride,
-                                           void* stream_) {
+extern "C" int edgedict_rnnt_loss_forward(const void* acts, int acts_dtype, const int32_t* labels,
+                                          const int32_t* act_lens, const int32_t* label_lens,
+                                          int B, int T, int U1, int V, int blank, float* costs,
+                                          float* reduced, float reduce_scale, void* workspace,
+                                          void* stream_) {
+    return loss_forward(acts, acts_dtype, labels, act_lens, label_lens, B, T, U1, V, blank, costs,
+                        reduced, reduce_scale, workspace, nullptr, stream_);
+}
+
+extern "C" int edgedict_rnnt_loss_forward_packed(const void* acts, int acts_dtype,
+                                                 const int32_t* labels, const int32_t* act_lens,
+                                                 const int32_t* label_lens,
+                                                 const long long* row_offsets, int B, int T, int U1,
+                                                 int V, int blank, float* costs, float* reduced,
+                                                 float reduce_scale, void* workspace, void* stream_) {
+    ED_CHECK_ARG(row_offsets, "rnnt_loss_forward_packed: null row_offsets");
+    return loss_forward(acts, acts_dtype, labels, act_lens, label_lens, B, T, U1, V, blank, costs,
+                        reduced, reduce_scale, workspace, row_offsets, stream_);
+}
+
+static int loss_backward(const void* acts, int acts_dtype, void* grads, const int32_t* labels,
+                         const int32_t* act_lens, const int32_t* label_lens, int B, int T, int U1,
+                         int V, int blank, const void* workspace, float grad_scale_host,
+                         const float* grad_scale_dev, int grad_scale_stride,
+                         const long long* pk_off, void* stream_) {
     if (int rc = check_common(B, T, U1, V, blank, acts_dtype)) return rc;
     ED_CHECK_ARG(acts && grads && (labels || U1 == 1) && act_lens && label_lens && workspace,
                  "rnnt_loss_backward: null pointer argument");
@@ -402,12 +426,35 @@ extern "C" int edgedict_rnnt_loss_backward(const void* acts, int acts_dtype, voi
         hipLaunchKernelGGL(rnnt_grad<float>, dim3(grid), dim3(256), 0, stream, (const float*)acts,
                            (float*)grads, labels, act_lens, label_lens, B, T, U1, V, blank, denom,
                            alphas, betas, ll, grad_scale_host, grad_scale_dev, grad_scale_stride,
-                           vec_ok);
+                           vec_ok, pk_off);
     else
         hipLaunchKernelGGL(rnnt_grad<bf16_t>, dim3(grid), dim3(256), 0, stream,
                            (const bf16_t*)acts, (bf16_t*)grads, labels, act_lens, label_lens, B, T,
                            U1, V, blank, denom, alphas, betas, ll, grad_scale_host, grad_scale_dev,
-                           grad_scale_stride, vec_ok);
+                           grad_scale_stride, vec_ok, pk_off);
     ED_CHECK_LAUNCH("rnnt_grad");
     return ED_OK;
+}
+
+extern "C" int edgedict_rnnt_loss_backward(const void* acts, int acts_dtype, void* grads,
+                                           const int32_t* labels, const int32_t* act_lens,
+                                           const int32_t* label_lens, int B, int T, int U1, int V,
+                                           int blank, const void* workspace, float grad_scale_host,
+                                           const float* grad_scale_dev, int grad_scale_stride,
+                                           void* stream_) {
+    return loss_backward(acts, acts_dtype, grads, labels, act_lens, label_lens, B, T, U1, V, blank,
+                         workspace, grad_scale_host, grad_scale_dev, grad_scale_stride, nullptr, stream_);
+}
+
+extern "C" int edgedict_rnnt_loss_backward_packed(const void* acts, int acts_dtype, void* grads,
+                                                  const int32_t* labels, const int32_t* act_lens,
+                                                  const int32_t* label_lens,
+                                                  const long long* row_offsets, int B, int T, int U1,
+                                                  int V, int blank, const void* workspace,
+                                                  float grad_scale_host, const float* grad_scale_dev,
+                                                  int grad_scale_stride, void* stream_) {
+    ED_CHECK_ARG(row_offsets, "rnnt_loss_backward_packed: null row_offsets");
+    return loss_backward(acts, acts_dtype, grads, labels, act_lens, label_lens, B, T, U1, V, blank,
+                         workspace, grad_scale_host, grad_scale_dev, grad_scale_stride, row_offsets,
+                         stream_);
 }

@@ -29,6 +29,7 @@ import torch
 from torch import nn
 
 from . import config, encoder_stack, ops, side
+from . import _lib
 from ._lib import require_cuda
 from .loss import _RNNTLossFn
 from .tokenizer import BOS, NUL, PAD
@@ -347,6 +348,104 @@ class _JointFn(torch.autograd.Function):
         return denc, ddec, dw1, db1, dw2, db2, None
 
 
+class _JointLossFn(torch.autograd.Function):
+    """Joint network + RNN-T loss on the PACKED lattice (training path of Transducer.forward).
+
+    Same arithmetic as ``_JointFn`` followed by ``_RNNTLossFn`` (rnnt/models.py:169-179,
+    221,238), but only the cells inside each utterance's (T_b, U_b+1) box exist: hid, logits and
+    their gradients are [M_valid, .] matrices (row of (b,t,u) = off[b] + t (U_b+1) + u).  Cells
+    outside the box have zero gradient and no influence on the loss, so nothing changes
+    numerically; the two big products and the loss kernels just do not touch padding
+    (35 % of the rows on the bench batch).  Needs the lengths on the HOST (they size M_valid)."""
+
+    @staticmethod
+    def forward(ctx, enc, dec, w1, b1, w2, b2, labels, act_lens, label_lens, blank, cd):
+        from ._staging import to_device
+        B, T, P = enc.shape
+        U1, P2 = dec.shape[1], dec.shape[2]
+        J, V = w1.shape[0], w2.shape[0]
+        dev = enc.device
+        al = act_lens.to(torch.int64).cpu()
+        ll = label_lens.to(torch.int64).cpu()
+        if int(al.max()) != T or int(ll.max()) != U1 - 1 or int(al.min()) < 1 or int(ll.min()) < 0:
+            raise ValueError("Input length mismatch")     # wording of warprnnt_pytorch's checks
+        rows = al * (ll + 1)
+        off = torch.zeros(B, dtype=torch.int64)
+        off[1:] = torch.cumsum(rows, 0)[:-1]
+        M = int(rows.sum())
+        off_d = to_device(off, dev)
+        al_d = to_device(al.to(torch.int32), dev)
+        ll_d = to_device(ll.to(torch.int32), dev)
+        w1c = WEIGHTS.get(w1, cd)
+        w2c = WEIGHTS.get(w2, cd)
+        enc2 = enc.reshape(B * T, P)
+        dec2 = dec.reshape(B * U1, P2)
+        E1 = ops.gemm(enc2, w1c[:, :P])
+        D1 = ops.gemm(dec2, w1c[:, P:], bias=b1.detach())
+        hid = torch.empty(M, J, dtype=cd, device=dev)
+        _lib.call("joint_hidden_fwd_packed", _lib.dtype_code(cd), E1, D1, hid, al_d, ll_d, off_d,
+                  B, T, U1, J)
+        ops.LAST["joint_rows"] = M
+        with ops.timed("joint_logits_gemm"):
+            logits = ops.gemm(hid, w2c, bias=b2.detach())
+        lib = _lib.load()
+        ws = torch.empty(lib.edgedict_rnnt_workspace_bytes(B, T, U1), dtype=torch.uint8, device=dev)
+        costs = torch.empty(B, dtype=F32, device=dev)
+        reduced = torch.empty(1, dtype=F32, device=dev)
+        _lib.call("rnnt_loss_forward_packed", logits, _lib.dtype_code(cd), labels, al_d, ll_d, off_d,
+                  B, T, U1, V, int(blank), costs, reduced, 1.0 / B, ws)
+        ctx.save_for_backward(enc2, dec2, w1, w2, hid, logits, labels, al_d, ll_d, off_d, ws)
+        ctx.b1, ctx.b2 = b1, b2
+        ctx.cfg = (cd, B, T, U1, P, P2, J, V, M, int(blank))
+        return reduced
+
+    @staticmethod
+    def backward(ctx, gout):
+        ops.mark("joint_bwd:enter")
+        enc2, dec2, w1, w2, hid, logits, labels, al_d, ll_d, off_d, ws = ctx.saved_tensors
+        cd, B, T, U1, P, P2, J, V, M, blank = ctx.cfg
+        dl = torch.empty_like(logits)
+        _lib.call("rnnt_loss_backward_packed", logits, _lib.dtype_code(cd), dl, labels, al_d, ll_d,
+                  off_d, B, T, U1, V, blank, ws, 1.0 / B, gout.contiguous().float(), 0)
+        del logits
+        w1c = WEIGHTS.get(w1, cd)
+        defer = config.DEFER_WEIGHT_GRADS and all(
+            p.grad is not None and p.grad.dtype == F32 and p.grad.is_contiguous()
+            for p in (w1, ctx.b1, w2, ctx.b2))
+        dw1 = db1 = dw2 = db2 = None
+        with ops.timed("joint_dhid_gemm"):
+            dhid = ops.gemm(dl, WEIGHTS.get(w2, cd, transposed=True))
+        if not defer:
+            dw2 = ops.gemm(dl.t(), hid.t(), out_dtype=F32, split_k=ops.pick_split_k(V, J, M))
+            db2 = ops.colsum(dl)
+        dE1 = torch.empty(B, T, J, dtype=F32, device=dl.device)
+        dD1 = torch.empty(B, U1, J, dtype=F32, device=dl.device)
+        _lib.call("joint_hidden_bwd_packed", _lib.dtype_code(cd), dhid, hid, dE1, dD1, al_d, ll_d,
+                  off_d, B, T, U1, J)
+        del dhid
+        dE1c = ops.cast(dE1, cd).view(B * T, J)
+        dD1c = ops.cast(dD1, cd).view(B * U1, J)
+        denc = ops.gemm(dE1c, w1c[:, :P].t()).view(B, T, P)
+        ddec = ops.gemm(dD1c, w1c[:, P:].t()).view(B, U1, P2)
+        if defer:
+            with side.deferred(dl.device, dl, hid, dE1c, dD1c, dD1, enc2, dec2):
+                ops.gemm(dl.t(), hid.t(), out=w2.grad, accumulate=True, split_k=4, max_wg_per_cu=2)
+                ops.colsum(dl, out=ctx.b2.grad)
+                g1 = w1.grad
+                ops.gemm(dE1c.t(), enc2.t(), out=g1[:, :P], accumulate=True,
+                         split_k=ops.pick_split_k(J, P, B * T))
+                ops.gemm(dD1c.t(), dec2.t(), out=g1[:, P:], accumulate=True,
+                         split_k=ops.pick_split_k(J, P2, B * U1))
+                ops.colsum(dD1.view(B * U1, J), out=ctx.b1.grad)
+        else:
+            dw1 = torch.empty(J, P + P2, dtype=F32, device=dl.device)
+            ops.gemm(dE1c.t(), enc2.t(), out=dw1[:, :P], split_k=ops.pick_split_k(J, P, B * T))
+            ops.gemm(dD1c.t(), dec2.t(), out=dw1[:, P:], split_k=ops.pick_split_k(J, P2, B * U1))
+            db1 = ops.colsum(dD1.view(B * U1, J))
+        ops.mark("joint_bwd:exit")
+        return denc, ddec, dw1, db1, dw2, db2, None, None, None, None, None
+
+
 # ----------------------------------------------------------------------------------------
 # parameter containers with the reference's names, shapes and default initialisation
 class TimeReduction(nn.Module):
@@ -613,6 +712,17 @@ class Transducer(nn.Module):
             h_enc, _ = self.encoder(xs)
             h_dec, _ = self.decoder(ys)
         ops.mark("joint:enter")
+        if (self.output_loss and config.PACKED_LATTICE and not xlen.is_cuda and not ylen.is_cuda
+                and h_enc.dim() == 3 and h_enc.is_cuda):
+            # lengths on the host: joint + loss on the packed lattice (no padding rows anywhere)
+            cd = self.compute_dtype
+            l1, l2 = self.joint.joint[0], self.joint.joint[2]
+            act = self.scale_length(h_enc, xlen)
+            labels = ys.to(torch.int32).contiguous()
+            loss = _JointLossFn.apply(_to_cd(h_enc, cd), _to_cd(h_dec, cd), l1.weight, l1.bias,
+                                      l2.weight, l2.bias, labels, act, ylen, self.blank, cd)
+            ops.mark("joint:exit")
+            return loss
         logits = self.joint(h_enc, h_dec)
         ops.mark("joint:exit")
         if self.output_loss:

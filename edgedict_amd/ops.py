@@ -20,6 +20,7 @@ def _ll(x):
 TIMERS = None   # set to {} to enable: tag -> list of (start_event, end_event)
 
 
+LAST = {}       # last-seen shape facts for bench.py (e.g. rows of the packed joint lattice)
 MARKS = None    # set to [] to collect (tag, host seconds, event on the current stream) marks
 
 

@@ -83,31 +83,6 @@ class SpecAugment(torch.nn.Module):
             f_iv = torch.tensor(rows, dtype=torch.int32).view(B, self.F_num_mask, 2)
         return t_iv, f_iv
 
-    def _stage(self, cpu, dev):
-        """Host -> device through a small ring of pinned buffers (a pageable copy would make the
-        host wait for the device once per step); a slot is reused only after its copy has run."""
-        ring = self.__dict__.setdefault("_ring", [])       # [pinned buffer, event], oldest first
-        n = cpu.numel()
-        idx = None
-        for i, (buf, ev) in enumerate(ring):
-            if buf.numel() >= n and ev.query():
-                idx = i
-                break
-        if idx is None and len(ring) < 8:
-            ring.append([torch.empty(max(n, 1024), dtype=torch.int32).pin_memory(), torch.cuda.Event()])
-            idx = len(ring) - 1
-        elif idx is None:
-            idx = 0
-            ring[0][1].synchronize()
-            if ring[0][0].numel() < n:
-                ring[0][0] = torch.empty(n, dtype=torch.int32).pin_memory()
-        slot = ring.pop(idx)
-        slot[0][:n].copy_(cpu.reshape(-1))
-        out = slot[0][:n].to(dev, non_blocking=True).view(cpu.shape)
-        slot[1].record()
-        ring.append(slot)
-        return out
-
     @torch.no_grad()
     def forward(self, xs):
         from . import ops
@@ -116,8 +91,9 @@ class SpecAugment(torch.nn.Module):
         if t_iv is None and f_iv is None:
             return xs
         dev = xs.device
-        return ops.spec_mask_(xs, None if t_iv is None else self._stage(t_iv, dev),
-                              None if f_iv is None else self._stage(f_iv, dev))
+        from ._staging import to_device
+        return ops.spec_mask_(xs, None if t_iv is None else to_device(t_iv, dev),
+                              None if f_iv is None else to_device(f_iv, dev))
 
 
 def build_transform(feature_type, feature_size, n_fft=512, win_length=400, hop_length=200,

@@ -71,6 +71,22 @@ int edgedict_rnnt_loss_backward(const void* acts, int acts_dtype, void* grads,
                                 const int32_t* label_lens, int B, int T, int U1, int V, int blank,
                                 const void* workspace, float grad_scale_host,
                                 const float* grad_scale_dev, int grad_scale_stride, void* stream);
+/* PACKED lattice variants: `acts` / `grads` hold ONLY the cells inside each utterance's box, row of
+ * cell (b,t,u) = row_offsets[b] + t*(label_lens[b]+1) + u (int64 device array [B], exclusive prefix
+ * sums of act_lens[b]*(label_lens[b]+1)); T, U1 still bound the (dense, small) lattice workspace.
+ * The joint network then only multiplies valid rows: on the E6D2 bench batch 65 % of the dense
+ * B*T*U1 rows.  Arithmetic per cell is identical to the dense entry points. */
+int edgedict_rnnt_loss_forward_packed(const void* acts, int acts_dtype, const int32_t* labels,
+                                      const int32_t* act_lens, const int32_t* label_lens,
+                                      const long long* row_offsets, int B, int T, int U1, int V,
+                                      int blank, float* costs, float* reduced, float reduce_scale,
+                                      void* workspace, void* stream);
+int edgedict_rnnt_loss_backward_packed(const void* acts, int acts_dtype, void* grads,
+                                       const int32_t* labels, const int32_t* act_lens,
+                                       const int32_t* label_lens, const long long* row_offsets,
+                                       int B, int T, int U1, int V, int blank, const void* workspace,
+                                       float grad_scale_host, const float* grad_scale_dev,
+                                       int grad_scale_stride, void* stream);
 /* debug / test accessors into a filled workspace (device pointers):
  * which: 0 = log-softmax denominators f32[B,T,U1], 1 = alphas f64[B,T,U1], 2 = betas f64,
  * 3 = log-likelihoods f64[B,2] (alpha-side, beta-side), 4 = lp_blank f32[B,T,U1], 5 = lp_label */
@@ -294,6 +310,16 @@ int edgedict_joint_hidden_fwd(int dtype, const void* E1, const void* D1, void* h
                               int U1, int J, void* stream);
 int edgedict_joint_hidden_bwd(int dtype, const void* dhid, const void* hid, float* dE1,
                               float* dD1, int B, int T, int U1, int J, void* stream);
+/* packed-lattice forms (see edgedict_rnnt_loss_forward_packed): hid / dhid hold only valid cells;
+ * dE1 rows t >= act_lens[b] and dD1 rows u > label_lens[b] come out as zeros. */
+int edgedict_joint_hidden_fwd_packed(int dtype, const void* E1, const void* D1, void* hid,
+                                     const int32_t* act_lens, const int32_t* label_lens,
+                                     const long long* row_offsets, int B, int T, int U1, int J,
+                                     void* stream);
+int edgedict_joint_hidden_bwd_packed(int dtype, const void* dhid, const void* hid, float* dE1,
+                                     float* dD1, const int32_t* act_lens, const int32_t* label_lens,
+                                     const long long* row_offsets, int B, int T, int U1, int J,
+                                     void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Optimiser step on flat fp32 buffers (torch.optim.Adam semantics, cli/train.py:135-146,268)

@@ -146,3 +146,24 @@ def test_greedy_tokens_bit_exact_vs_reference_golden(hip_lib, name):
         assert t.dtype == np.int64
         assert np.array_equal(t, g["greedy_tokens"][b][:len(t)]), b     # blanks included
     np.testing.assert_allclose(score.cpu().numpy(), g["greedy_score"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["tiny", "E4D1"])
+def test_packed_lattice_path_matches_golden_loss_and_dense_gradients(hip_lib, name):
+    """Lengths on the host route Transducer.forward through the packed lattice (_JointLossFn): only
+    the cells inside each utterance's (T_b, U_b+1) box are materialised.  Same golden loss as the
+    dense path (pinned on the reference), same gradients up to fp32 summation order."""
+    cfg, sd, (xs, ys, xlen, ylen), g = _load(name)
+    dense = _engine(cfg, sd, output_loss=True)
+    ld = dense(xs.cuda(), ys.cuda(), xlen.cuda(), ylen.cuda())
+    ld.backward()
+    packed = _engine(cfg, sd, output_loss=True)
+    lp = packed(xs.cuda(), ys.cuda(), xlen, ylen)           # CPU lengths -> packed path
+    lp.backward()
+    assert lp.shape == (1,)
+    assert abs(lp.item() - float(g["loss_mean"])) / float(g["loss_mean"]) < 1e-5
+    assert lp.item() == ld.item()                            # per-cell arithmetic is identical
+    for (n, a), (_, b) in zip(packed.named_parameters(), dense.named_parameters()):
+        scale = max(b.grad.abs().max().item(), 1e-8)
+        assert (a.grad - b.grad).abs().max().item() <= 2e-5 * scale, n
+    assert packed.decoder.embed.weight.grad[1].abs().max().item() == 0
