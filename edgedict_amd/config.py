@@ -46,6 +46,9 @@ DECODER_ON_AUX_STREAM = os.environ.get("EDGEDICT_DECODER_AUX", "1") != "0"
 # lattice (only the cells inside each utterance's (T_b, U_b+1) box are materialised)
 PACKED_LATTICE = os.environ.get("EDGEDICT_PACKED_LATTICE", "1") != "0"
 
+# inputs shorter than this many frames use the per-layer path even in bf16 (see Encoder.forward)
+STACK_MIN_FRAMES = int(os.environ.get("EDGEDICT_STACK_MIN_FRAMES", "24"))
+
 _state = {"dtype": _parse(os.environ.get("EDGEDICT_DTYPE", "fp32")), "epoch": 0}
 
 

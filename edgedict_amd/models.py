@@ -564,7 +564,10 @@ class Encoder(nn.Module):
         cd = getattr(self, "compute_dtype", None) or config.get_compute_dtype()
         lstm = self.lstm
         drop = getattr(lstm, "dropout", 0) > 0 and self.training    # per-layer path applies it
-        if (isinstance(lstm, ResLayerNormLSTM) and xs.dim() == 3 and xs.shape[1] > 0 and not drop
+        # short inputs (streaming chunks of a few frames) stay on the per-layer kernels: the
+        # wavefront needs ~5 lags of launches to fill, more than 6 x T per-layer steps for small T
+        if (isinstance(lstm, ResLayerNormLSTM) and xs.dim() == 3 and not drop
+                and xs.shape[1] >= config.STACK_MIN_FRAMES
                 and encoder_stack.supported(cd, lstm.hidden_size, xs.shape[2], len(lstm.lstms),
                                             lstm.reductions)):
             # bf16: input LayerNorm + all layers as one layer-pipelined native call per direction

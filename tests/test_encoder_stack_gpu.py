@@ -45,6 +45,7 @@ def _run(enc, xs, dtype, use_stack=True, flags=None, chunk=8, lag=0, hiddens=Non
     from edgedict_amd import config, encoder_stack
     old = (config.USE_ENCODER_STACK, encoder_stack.CHUNK, encoder_stack.LAG, encoder_stack.FLAGS,
            encoder_stack.SPLIT_K)
+    old_min, config.STACK_MIN_FRAMES = config.STACK_MIN_FRAMES, 1     # tiny geometries on purpose
     config.USE_ENCODER_STACK = use_stack
     encoder_stack.CHUNK, encoder_stack.LAG, encoder_stack.SPLIT_K = chunk, lag, 1
     encoder_stack.FLAGS = 0 if flags is None else flags
@@ -61,6 +62,7 @@ def _run(enc, xs, dtype, use_stack=True, flags=None, chunk=8, lag=0, hiddens=Non
     finally:
         (config.USE_ENCODER_STACK, encoder_stack.CHUNK, encoder_stack.LAG, encoder_stack.FLAGS,
          encoder_stack.SPLIT_K) = old
+        config.STACK_MIN_FRAMES = old_min
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -105,11 +107,14 @@ def test_stack_initial_states_and_chunked_streaming(hip_lib):
     case = (3, 12, 16, 32, 3, [1], 2, 0)
     enc, xs = _encoder(case)
     enc.compute_dtype = torch.bfloat16
+    from edgedict_amd import config
+    config.STACK_MIN_FRAMES, old_min = 1, config.STACK_MIN_FRAMES
     with torch.no_grad():
         full, (hf, cf) = enc(xs)
         y1, (h1, c1) = enc(xs[:, :6])
         y2, (h2, c2) = enc(xs[:, 6:], (h1, c1))
     # h is carried as fp32(bf16(h)) and c as fp32, exactly what the kernels keep: bit-exact
+    config.STACK_MIN_FRAMES = old_min
     assert torch.equal(torch.cat([y1, y2], 1), full)
     assert torch.equal(h2, hf) and torch.equal(c2, cf)
 
