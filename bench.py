@@ -173,7 +173,8 @@ def main():
             with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as fh:
                 pmc = json.load(fh)["kernels"]
             tiles = ((rows + 127) // 128) * ((V + 127) // 128)
-            ent = pmc.get("gemm_nt_kernel<128> [tiles=%d]" % tiles) or pmc.get("gemm_nt_kernel [tiles=%d]" % tiles)
+            ent = next((v for k, v in pmc.items()
+                        if k.startswith("gemm_nt_kernel") and k.endswith("[tiles=%d]" % tiles)), None)
             if ent:
                 traffic = ent["hbm_bytes"]
         except (OSError, ValueError, KeyError):
