@@ -179,6 +179,36 @@ def main():
                 traffic = ent["hbm_bytes"]
         except (OSError, ValueError, KeyError):
             pass
+        # ---- dominant kernel: stack_bwd_kernel (the BPTT wavefront launches, ~23 % of all kernel time)
+        # HBM-fetch bound: every launch re-streams W_hh^T of each layer-step it carries (L2 is
+        # invalidated at kernel boundaries).  Algorithmic bytes of ONE layer-step, each operand once:
+        import ctypes
+        from edgedict_amd import _lib
+        H, L, Bq = flags.enc_hidden_size, flags.enc_layers, args.batch
+        rd = 4 * H * H * 2 + Bq * 4 * H * 2 * 2 + 3 * Bq * H * 4 + Bq * H * 2   # W^T, dG image, gates, c_t, c_{t-1}, dC, dY
+        wr = Bq * 4 * H * 2 * 2 + Bq * H * 4                                     # dG (plain + image), dC
+        layer_steps = xs_frames * 2 + Tp * (L - 2)          # layers 0,1 at T0, the rest behind the 2x reduction
+        ms_b, n_b = ctypes.c_float(0), ctypes.c_int(0)
+        stack = None
+        if _lib.load().edgedict_stack_last_timing(1, ctypes.byref(ms_b), ctypes.byref(n_b)) == 0 and n_b.value:
+            per_launch = (rd + wr) * layer_steps / n_b.value
+            period_us = 1e3 * ms_b.value / n_b.value
+            tr = None
+            try:
+                ent = pmc.get("stack_bwd_kernel")
+                tr = ent["hbm_bytes"] if ent else None
+            except NameError:
+                pass
+            stack = {
+                "kernel": "stack_bwd_kernel (BPTT wavefront launch: one time step of every runnable "
+                          "layer; %d launches carry %d layer-steps)" % (n_b.value, layer_steps),
+                "bound": "hbm", "achieved": per_launch / (period_us * 1e-6) / 1e9,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": per_launch / (period_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": tr,
+                "algorithmic_bytes": per_launch, "launch_us": period_us, "launches_timed": n_b.value,
+                "note": "launch_us = HIP-event span of the launch sequence on the recurrence stream "
+                        "/ launches (includes inter-launch gaps and waits for the chunk-GEMM stream)",
+            }
         out = {
             "metric": "utterances/sec (E6D2, 15 s audio)",
             "value": args.batch * world * args.steps / dt,
@@ -204,7 +234,8 @@ def main():
                 "parallelism": "dp%d" % world,
                 "final_loss": loss_val,
             },
-            "roofline": {
+            "roofline": None,        # filled below: the dominant kernel
+            "roofline_mfma": {
                 "kernel": "gemm_nt_kernel (bf16 NT, direct-to-LDS) joint logits [%d x %d x %d] "
                           "(packed lattice: %d of %d dense cells)"
                           % (rows, V, J, rows, args.batch * Tp * U1),
@@ -217,6 +248,7 @@ def main():
             "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 3),
             "host_call_ms": {k: round(v[1], 3) for k, v in sorted(ops.host_summary().items())},
         }
+        out["roofline"] = stack if stack is not None else out["roofline_mfma"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(flags, args.seconds, args.labels)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -104,6 +104,9 @@ __global__ void unpermute_rows_kernel(const float* __restrict__ src, long long s
 struct Runtime {
     hipStream_t R = nullptr, R2 = nullptr, W = nullptr;
     int prio_hi = 0;
+    // timing of the recurrence stream's launch sequence of the last forward / backward call
+    hipEvent_t tev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    int tlaunches[2] = {0, 0};
     // experiment streams, created on first use (and therefore AFTER the three above)
     hipStream_t lazy(hipStream_t& s) {
         if (!s && hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio_hi) != hipSuccess) s = nullptr;
@@ -146,6 +149,9 @@ Runtime* runtime_for_current_device() {
             delete r;
             return nullptr;
         }
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j)
+                if (hipEventCreate(&r->tev[i][j]) != hipSuccess) r->tev[i][j] = nullptr;
         g_rt[dev] = r;
     }
     return g_rt[dev];
@@ -409,6 +415,7 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
 
     int Wtot = 0;
     for (int l = 0; l < L; ++l) Wtot = max(Wtot, g[l].off + (g[l].T - 1) * g[l].m + 2);
+    if (st.rt && st.rt->tev[0][0]) ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][0], st.R));
     const int T_out = (g[L - 1].T + d->layers[L - 1].reduce - 1) / d->layers[L - 1].reduce;
     struct Done { int l, k; };
     for (int w = 0; w < Wtot; ++w) {
@@ -492,9 +499,25 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
             queued[l][k] = 1;
         }
     }
+    if (st.rt && st.rt->tev[0][1]) {
+        ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][1], st.R));
+        st.rt->tlaunches[0] = Wtot;
+    }
     ED_TRY(st.chain(st.R, st.C));
     if (st.R2 != st.R) ED_TRY(st.chain(st.R2, st.C));
     for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.S[l], st.C));
+    return ED_OK;
+}
+
+extern "C" int edgedict_stack_last_timing(int backward, float* ms, int* launches) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    ED_CHECK_ARG(ms && launches, "stack_last_timing: null pointer");
+    Runtime* r = runtime_for_current_device();
+    const int i = backward ? 1 : 0;
+    ED_CHECK_ARG(r && r->tev[i][0] && r->tev[i][1] && r->tlaunches[i] > 0, "stack_last_timing: nothing recorded");
+    ED_CHECK_HIP(hipEventSynchronize(r->tev[i][1]));
+    ED_CHECK_HIP(hipEventElapsedTime(ms, r->tev[i][0], r->tev[i][1]));
+    *launches = r->tlaunches[i];
     return ED_OK;
 }
 
@@ -569,6 +592,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
 
     int Wtot = 0;
     for (int l = 0; l < L; ++l) Wtot = max(Wtot, g[l].off + (g[l].T - 1) * g[l].m + 1);
+    if (st.rt && st.rt->tev[1][0]) ED_CHECK_HIP(hipEventRecord(st.rt->tev[1][0], st.R));
     struct Done { int l, k, t; };
     for (int w = 0; w < Wtot; ++w) {
         EdBwdLaunch Lcs[2];
@@ -638,6 +662,10 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                 }
             }
         }
+    }
+    if (st.rt && st.rt->tev[1][1]) {
+        ED_CHECK_HIP(hipEventRecord(st.rt->tev[1][1], st.R));
+        st.rt->tlaunches[1] = Wtot;
     }
     // ---- input LayerNorm parameters: dX_0 = dG_0 W_ih (all frames), then the two column sums
     {

@@ -270,6 +270,10 @@ int edgedict_stack_pack_weights(const float* w_ih, const float* w_hh, const floa
                                 const float* b_hh, int H, int I, void* wih_p, void* wih_t,
                                 float* bias_p, void* whh_f, void* whh_b, void* stream);
 int edgedict_stack_forward(const edgedict_stack_desc_t* desc, void* stream);
+/* measurement aid: HIP-event time (on the recurrence stream) from the first to the last wavefront
+ * launch of the most recent forward (backward = 0) or backward (1) call on this device, and the
+ * number of launches in it; blocks until that call's launches have executed. */
+int edgedict_stack_last_timing(int backward, float* ms, int* launches);
 int edgedict_stack_backward(const edgedict_stack_desc_t* desc, void* stream);
 
 /* ------------------------------------------------------------------------------------
