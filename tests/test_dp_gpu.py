@@ -1,0 +1,87 @@
+"""GPU, world_size 2 (two processes sharing cuda:0, gloo transport): the REAL training engine —
+auxiliary streams, deferred and in-place accumulated weight gradients, the packed lattice, the
+bucket hooks — under data parallelism.  Two ranks that each take half of a batch must end up with
+the parameters of one process that takes the whole batch (equal shard sizes: the mean of the shard
+means is the global mean), and with identical parameters on both ranks."""
+import os
+import sys
+import types
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _flags():
+    return types.SimpleNamespace(
+        downsample=3, win_length=320, hop_length=160, n_fft=512, feature_size=80, dither=0.0,
+        sample_rate=16000, lr=1e-3, gradclip=None, sub_batch_size=None, bpe_size=40,
+        vocab_embed_size=8, enc_hidden_size=64, enc_layers=3, enc_dropout=0.0, enc_proj_size=24,
+        dec_hidden_size=32, dec_layers=2, dec_dropout=0.0, dec_proj_size=16, joint_size=32,
+        enc_time_reductions=[1], delta=False)
+
+
+def _batch():
+    g = torch.Generator(device="cpu").manual_seed(7)
+    wave = 0.1 * torch.randn(4, 16000, generator=g)
+    wlen = torch.tensor([16000, 15000, 12000, 14000], dtype=torch.int32)
+    ys = torch.randint(4, 40, (4, 6), generator=g, dtype=torch.int32)
+    ylen = torch.tensor([6, 5, 6, 3], dtype=torch.int32)
+    return wave, wlen, ys, ylen
+
+
+def _steps(eng, wave, wlen, ys, ylen, n=2):
+    losses = []
+    for _ in range(n):
+        losses.append(eng.train_step(wave.cuda(), wlen, ys.cuda(), ylen))
+    torch.cuda.synchronize()
+    return [float(x) for x in losses], eng.flat.data.detach().cpu().clone()
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from edgedict_amd.dp import shard_batch
+    from edgedict_amd.trainer import TrainEngine
+    torch.manual_seed(100 + rank)          # different initial weights: the engine must broadcast rank 0's
+    eng = TrainEngine(_flags(), vocab_size=40, device="cuda", compute_dtype="bf16")
+    shard = shard_batch(list(_batch()), rank, world)
+    losses, params = _steps(eng, *shard)
+    q.put((rank, losses, params.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_ranks_equal_one_process_on_the_whole_batch(hip_lib):
+    world, port = 2, 29700 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(world):
+        r, losses, params = q.get(timeout=240)
+        got[r] = (losses, torch.from_numpy(params))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert torch.equal(got[0][1], got[1][1])                 # replicas stay identical
+    from edgedict_amd.trainer import TrainEngine
+    torch.manual_seed(100)                                    # rank 0's initial weights
+    eng = TrainEngine(_flags(), vocab_size=40, device="cuda", compute_dtype="bf16")
+    losses, ref = _steps(eng, *_batch())
+    # mean of the shard losses = loss of the whole batch (equal shards), step by step
+    for k in range(2):
+        both = 0.5 * (got[0][0][k] + got[1][0][k])
+        assert abs(both - losses[k]) <= 2e-2 * abs(losses[k]), (k, both, losses[k])
+    diff = (got[0][1] - ref).abs().max().item()
+    assert diff <= 5e-4, diff                                # two Adam steps of lr 1e-3, bf16 activations
