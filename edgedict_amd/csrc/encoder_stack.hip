@@ -571,15 +571,18 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
         const int M = y.T * B;
         float* tmpW = (float*)(ws + wl.tmpW);
         float* tmpB = (float*)(ws + wl.tmpB);
-        const int sk = d->split_k > 0 ? d->split_k : 2;
+        // layers 1 and 0 finish last: little (layer 1) or nothing (layer 0) is left to disturb, so
+        // their products may take the whole chip - the tail after the last BPTT launch was 0.8 ms
+        const int sk = d->split_k > 0 ? d->split_k : (l == 0 ? 8 : l == 1 ? 4 : 2);
+        const int cap = l <= 1 ? 4 : 2;
         int S = 1;
         // dW_ih = dG^T X,  dW_hh = dG^T H_prev as QUIET products (K slices written once, no atomics:
         // a concurrent kernel with dirty lines makes every BPTT launch boundary 3-10x dearer);
         // rows come out in interleaved gate order and are summed + un-permuted in one pass
-        ED_TRY(ed_gemm_quiet_partials(ED_BF16, y.G, 4ll * H, 0, y.X, y.I, 0, 4 * H, y.I, M, sk, 2, tmpW, &S, st.W));
+        ED_TRY(ed_gemm_quiet_partials(ED_BF16, y.G, 4ll * H, 0, y.X, y.I, 0, 4 * H, y.I, M, sk, cap, tmpW, &S, st.W));
         hipLaunchKernelGGL(unpermute_rows_kernel, dim3(ed_grid_for(4ll * H * y.I, 256, 4096)),
                            dim3(256), 0, st.W, tmpW, 4ll * H * y.I, S, y.dW_ih, nullptr, H, y.I, acc_grads);
-        ED_TRY(ed_gemm_quiet_partials(ED_BF16, y.G, 4ll * H, 0, y.Yx, H, 0, 4 * H, H, M, sk, 2, tmpW, &S, st.W));
+        ED_TRY(ed_gemm_quiet_partials(ED_BF16, y.G, 4ll * H, 0, y.Yx, H, 0, 4 * H, H, M, sk, cap, tmpW, &S, st.W));
         hipLaunchKernelGGL(unpermute_rows_kernel, dim3(ed_grid_for(4ll * H * H, 256, 4096)),
                            dim3(256), 0, st.W, tmpW, 4ll * H * H, S, y.dW_hh, nullptr, H, H, acc_grads);
         ED_TRY(ed_stack_zero(tmpB, (size_t)4 * H * sizeof(float), st.W));

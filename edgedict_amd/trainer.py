@@ -117,5 +117,11 @@ class TrainEngine:
             total = loss.detach() if total is None else total + loss.detach()
         scale = self.reducer.finish()
         self.optim.step(grad_scale=scale)
+        if self.compute_dtype == torch.bfloat16 and config.USE_ENCODER_STACK:
+            # next step's weight images, beside its front-end (after Adam in stream order)
+            from . import encoder_stack, side
+            aux = side.stream(self.device)
+            aux.wait_stream(torch.cuda.current_stream(self.device))
+            encoder_stack.prepack(self.model.encoder, aux)
         ops.mark("step:exit")
         return total
