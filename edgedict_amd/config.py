@@ -42,6 +42,9 @@ DEFER_WEIGHT_GRADS = os.environ.get("EDGEDICT_DEFER_DW", "1") != "0"
 # encoder (and, through autograd's stream replay, its backward concurrently with the encoder's)
 DECODER_ON_AUX_STREAM = os.environ.get("EDGEDICT_DECODER_AUX", "1") != "0"
 
+# ... enqueued before the encoder (1) or after it (0, default: measured 1.1 ms faster per step)
+DECODER_ENQUEUE_FIRST = os.environ.get("EDGEDICT_DECODER_FIRST", "0") != "0"
+
 # Transducer.forward(output_loss=True) with HOST-side lengths runs joint + loss on the packed
 # lattice (only the cells inside each utterance's (T_b, U_b+1) box are materialised)
 PACKED_LATTICE = os.environ.get("EDGEDICT_PACKED_LATTICE", "1") != "0"

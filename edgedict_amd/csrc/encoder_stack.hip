@@ -566,32 +566,42 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     std::vector<int> deferred;   // layers whose weight gradients run after the BPTT (DW_AT_END)
 
     const int acc_grads = (d->flags & EDGEDICT_STACK_ACCUM_GRADS) ? 1 : 0;
-    auto weight_grads = [&](int l) -> int {
+    // weight gradients of layer l over frames [t0, t1): dW_ih (+)= dG^T X, dW_hh (+)= dG^T H_prev,
+    // db (+)= colsum dG.  Issued per SEGMENT of `dw_seg` chunks as the layer's BPTT passes them, so
+    // the products are spread under the whole recurrence instead of piling up behind the last
+    // layers (the BPTT launches next to a busy W stream take 27 us instead of 16).
+    auto weight_grads = [&](int l, int t0, int t1, bool first, bool last_of_all) -> int {
         const edgedict_stack_layer_t& y = d->layers[l];
-        const int M = y.T * B;
+        const int M = (t1 - t0) * B;
+        const long long r0 = (long long)t0 * B;
         float* tmpW = (float*)(ws + wl.tmpW);
         float* tmpB = (float*)(ws + wl.tmpB);
-        // layers 1 and 0 finish last: little (layer 1) or nothing (layer 0) is left to disturb, so
-        // their products may take the whole chip - the tail after the last BPTT launch was 0.8 ms
-        const int sk = d->split_k > 0 ? d->split_k : (l == 0 ? 8 : l == 1 ? 4 : 2);
-        const int cap = l <= 1 ? 4 : 2;
+        // the very last product has nothing left to disturb: it may take the whole chip
+        const int sk = d->split_k > 0 ? d->split_k : (last_of_all ? 8 : 2);
+        const int cap = last_of_all ? 4 : 2;
+        const int acc = (acc_grads || !first) ? 1 : 0;
         int S = 1;
-        // dW_ih = dG^T X,  dW_hh = dG^T H_prev as QUIET products (K slices written once, no atomics:
-        // a concurrent kernel with dirty lines makes every BPTT launch boundary 3-10x dearer);
-        // rows come out in interleaved gate order and are summed + un-permuted in one pass
-        ED_TRY(ed_gemm_quiet_partials(ED_BF16, y.G, 4ll * H, 0, y.X, y.I, 0, 4 * H, y.I, M, sk, cap, tmpW, &S, st.W));
+        // QUIET products (K slices written once, no atomics: a concurrent kernel with dirty lines
+        // makes every BPTT launch boundary 3-10x dearer); rows come out in interleaved gate order
+        // and are summed + un-permuted in one pass
+        ED_TRY(ed_gemm_quiet_partials(ED_BF16, bptr(y.G) + r0 * 4 * H, 4ll * H, 0, bptr(y.X) + r0 * y.I, y.I, 0,
+                                      4 * H, y.I, M, sk, cap, tmpW, &S, st.W));
         hipLaunchKernelGGL(unpermute_rows_kernel, dim3(ed_grid_for(4ll * H * y.I, 256, 4096)),
-                           dim3(256), 0, st.W, tmpW, 4ll * H * y.I, S, y.dW_ih, nullptr, H, y.I, acc_grads);
-        ED_TRY(ed_gemm_quiet_partials(ED_BF16, y.G, 4ll * H, 0, y.Yx, H, 0, 4 * H, H, M, sk, cap, tmpW, &S, st.W));
+                           dim3(256), 0, st.W, tmpW, 4ll * H * y.I, S, y.dW_ih, nullptr, H, y.I, acc);
+        ED_TRY(ed_gemm_quiet_partials(ED_BF16, bptr(y.G) + r0 * 4 * H, 4ll * H, 0, bptr(y.Yx) + r0 * H, H, 0,
+                                      4 * H, H, M, sk, cap, tmpW, &S, st.W));
         hipLaunchKernelGGL(unpermute_rows_kernel, dim3(ed_grid_for(4ll * H * H, 256, 4096)),
-                           dim3(256), 0, st.W, tmpW, 4ll * H * H, S, y.dW_hh, nullptr, H, H, acc_grads);
+                           dim3(256), 0, st.W, tmpW, 4ll * H * H, S, y.dW_hh, nullptr, H, H, acc);
         ED_TRY(ed_stack_zero(tmpB, (size_t)4 * H * sizeof(float), st.W));
-        ED_TRY(edgedict_colsum(ED_BF16, y.G, 4ll * H, tmpB, M, 4 * H, st.W));
+        ED_TRY(edgedict_colsum(ED_BF16, bptr(y.G) + r0 * 4 * H, 4ll * H, tmpB, M, 4 * H, st.W));
         hipLaunchKernelGGL(unpermute_rows_kernel, dim3(ed_grid_for(4ll * H, 256, 4096)), dim3(256),
-                           0, st.W, tmpB, 0, 1, y.db, y.db_hh, H, 1, acc_grads);
+                           0, st.W, tmpB, 0, 1, y.db, y.db_hh, H, 1, acc);
         ED_CHECK_LAUNCH("unpermute_rows_kernel");
         return ED_OK;
     };
+    int dw_seg = 1 << 20;   // measured: 8 / 4 / 2 / 1 chunks per segment cost +0.3 / +0.6 / +1.6 / +5.3 ms per step
+    if (const char* e = getenv("EDGEDICT_STACK_DW_SEG")) dw_seg = max(1, atoi(e));
+    if (d->flags & EDGEDICT_STACK_DW_AT_END) dw_seg = 1 << 20;
 
     int Wtot = 0;
     for (int l = 0; l < L; ++l) Wtot = max(Wtot, g[l].off + (g[l].T - 1) * g[l].m + 1);
@@ -656,12 +666,17 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                 ED_TRY(st.record(Eb[l - 1][k], S));
                 queued[l - 1][k] = 1;
             }
-            if (done[i].t == 0) {   // the layer's BPTT is complete: weight gradients
+            // chunks complete from the last to the first: a segment [k, k + dw_seg) is complete when
+            // its lowest chunk is (k a multiple of dw_seg, counted so that the LAST segment issued,
+            // the one ending at chunk 0, is a full one)
+            if (k % dw_seg == 0) {
                 if (d->flags & EDGEDICT_STACK_DW_AT_END) {
-                    deferred.push_back(l);
+                    if (k == 0) deferred.push_back(l);
                 } else {
+                    const int k1 = min(g[l].nchunks, k + dw_seg);
+                    const int t0 = k * g[l].cf, t1 = min(y.T, k1 * g[l].cf);
                     ED_TRY(st.chain(st.RS(l), st.W));
-                    ED_TRY(weight_grads(l));
+                    ED_TRY(weight_grads(l, t0, t1, k1 == g[l].nchunks, l == 0 && k == 0));
                 }
             }
         }
@@ -694,7 +709,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     if (!deferred.empty()) {
         ED_TRY(st.chain(st.R, st.W));
         if (st.R2 != st.R) ED_TRY(st.chain(st.R2, st.W));
-        for (int l : deferred) ED_TRY(weight_grads(l));
+        for (int l : deferred) ED_TRY(weight_grads(l, 0, d->layers[l].T, true, false));
     }
     ED_TRY(st.chain(st.R, st.C));
     if (st.R2 != st.R) ED_TRY(st.chain(st.R2, st.C));

@@ -50,7 +50,13 @@ __device__ __forceinline__ float ftanh(float x) {
 // =====================================================================================
 // forward
 // =====================================================================================
-constexpr int FCH = 2;   // k-steps per register buffer: 2 x (4 A + 4 W) x 16 B = 256 B / lane, two buffers
+#ifndef ED_FCH
+#define ED_FCH 2
+#endif
+#ifndef ED_FWD_OCC
+#define ED_FWD_OCC 2
+#endif
+constexpr int FCH = ED_FCH;   // k-steps per register buffer: 2 x (4 A + 4 W) x 16 B = 256 B / lane, two buffers
 
 struct __attribute__((aligned(16))) FwdShared {
     float4 hand[4][3][4][64];   // [source wave][destination slot][gate][lane]   48 KB
@@ -315,7 +321,7 @@ __device__ __forceinline__ void fwd_norm_role(const EdFwdNorm& p, int rb, int B,
     }
 }
 
-__global__ __launch_bounds__(256, 2) void stack_fwd_kernel(EdFwdLaunch L) {
+__global__ __launch_bounds__(256, ED_FWD_OCC) void stack_fwd_kernel(EdFwdLaunch L) {
     __shared__ FwdShared sh;
     const int UB = L.H >> 4, RG = (L.B + 63) >> 6;
     const int nsb = L.nstep * UB * RG;
@@ -333,7 +339,13 @@ __global__ __launch_bounds__(256, 2) void stack_fwd_kernel(EdFwdLaunch L) {
 // =====================================================================================
 // backward (BPTT step)
 // =====================================================================================
-constexpr int BCH = 4;   // k-steps per register buffer: 4 x (2 A + 2 W) x 16 B = 256 B / lane, two buffers
+#ifndef ED_BCH
+#define ED_BCH 4
+#endif
+#ifndef ED_BWD_OCC
+#define ED_BWD_OCC 2
+#endif
+constexpr int BCH = ED_BCH;   // k-steps per register buffer: 4 x (2 A + 2 W) x 16 B = 256 B / lane, two buffers
 
 struct __attribute__((aligned(16))) BwdShared {
     float4 hand[4][3][64];   // [source wave][destination slot][lane]   12 KB
@@ -498,7 +510,7 @@ __device__ __forceinline__ void bwd_step_role(const EdBwdStep& p, int nb, int rg
     }
 }
 
-__global__ __launch_bounds__(256, 2) void stack_bwd_kernel(EdBwdLaunch L) {
+__global__ __launch_bounds__(256, ED_BWD_OCC) void stack_bwd_kernel(EdBwdLaunch L) {
     __shared__ BwdShared sh;
     const int NB = L.H >> 5, RG = (L.B + 31) >> 5;
     const int bid = blockIdx.x;

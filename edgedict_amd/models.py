@@ -704,11 +704,18 @@ class Transducer(nn.Module):
             main = torch.cuda.current_stream(xs.device)
             aux = side.stream(xs.device)
             ready = main.record_event()          # ys (and the parameters) are ready here
-            h_enc, _ = self.encoder(xs)          # enqueued first: it is the long pole
-            aux.wait_event(ready)
-            ys.record_stream(aux)
-            with torch.cuda.stream(aux):
-                h_dec, _ = self.decoder(ys)
+            if config.DECODER_ENQUEUE_FIRST:
+                aux.wait_event(ready)
+                ys.record_stream(aux)
+                with torch.cuda.stream(aux):
+                    h_dec, _ = self.decoder(ys)
+                h_enc, _ = self.encoder(xs)
+            else:
+                h_enc, _ = self.encoder(xs)          # enqueued first: it is the long pole
+                aux.wait_event(ready)
+                ys.record_stream(aux)
+                with torch.cuda.stream(aux):
+                    h_dec, _ = self.decoder(ys)
             main.wait_stream(aux)
             h_dec.record_stream(main)
         else:

@@ -34,3 +34,17 @@ t0, e0 = marks[i0][1], marks[i0][2]
 print("%-18s %10s %10s" % ("mark", "host ms", "gpu ms"))
 for tag, t, ev in marks[i0:i1 + 1]:
     print("%-18s %10.2f %10.2f" % (tag, 1e3 * (t - t0), e0.elapsed_time(ev)))
+
+# ---- the same step enqueued against an IDLE GPU (synchronised first): the host columns are then
+# the un-throttled enqueue cost, the gpu column shows where the GPU has to wait for the host
+torch.cuda.synchronize()
+ops.MARKS = []
+eng.train_step(*batch)
+torch.cuda.synchronize()
+marks = ops.MARKS
+ops.MARKS = None
+t0, e0 = marks[0][1], marks[0][2]
+print("\nafter a device synchronise (GPU idle at step:enter)")
+print("%-18s %10s %10s" % ("mark", "host ms", "gpu ms"))
+for tag, t, ev in marks:
+    print("%-18s %10.2f %10.2f" % (tag, 1e3 * (t - t0), e0.elapsed_time(ev)))

@@ -8,7 +8,7 @@
 #include <vector>
 
 int main() {
-    const int B = 64, H = 1024, T = 200, NSMAX = 6;
+    const int B = 64, H = 1024, T = 200, NSMAX = 8;
     struct Slot { bf16_t *G, *f0, *f1, *Y, *W; float* C; };
     std::vector<Slot> sl(NSMAX);
     for (auto& s : sl) {
@@ -22,7 +22,7 @@ int main() {
     hipStream_t st; hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
     for (int shared = 0; shared < 2; ++shared)
-        for (int ns : {1, 2, 4, 6}) {
+        for (int ns : {1, 2, 3, 4, 5, 6, 8}) {
             float ms = 0;
             for (int rep = 0; rep < 2; ++rep) {
                 hipEventRecord(a, st);
