@@ -13,6 +13,8 @@
 // host between frames; token ids and scores stay on the device until the caller reads them.
 #include "common.hpp"
 
+#include <vector>
+
 namespace {
 
 // hid[b, :] = tanh(E1[b*e_stride + :] + D1[b, :])
@@ -219,5 +221,457 @@ extern "C" int edgedict_greedy_decode(
                                h_new, c_state, c_new, L, B, H);
     }
     ED_CHECK_LAUNCH("greedy_decode");
+    return ED_OK;
+}
+
+
+// =====================================================================================
+// Beam search (Graves 2012) as the reference's legacy Transducer.beam_search runs it
+// (/root/reference/models.py:121-202, prefix=False), for a batch of utterances in lockstep.
+//
+// Per utterance and frame the reference keeps two Python lists: A (hypotheses still to expand) and
+// B (hypotheses that emitted blank in this frame).  Here A is a score POOL in list order:
+//   pool[0 .. W)                 the (at most W) survivors of the previous frame
+//   pool[W + e*V + k]            child k of the e-th expansion of this frame (-inf for k == blank
+//                                and for popped entries)
+// so "max(A), first one on ties" is an arg-max with lowest-index tie break over the pool.  A child
+// is materialised (token-tree node, state) only when it is popped.  Hypothesis = (node of the token
+// tree, prediction-network state reference, last token, fp64 log-probability); the state a
+// hypothesis carries is the one BEFORE its last token was consumed (models.py:170-171,185), the
+// expansion recomputes the step on that last token.  B keeps its first W entries in insertion order
+// (the reference's `sorted(...)` calls discard their result, models.py:141,195-196).
+// One lockstep iteration = pop -> prediction-network step -> joint -> expand for every utterance
+// whose loop is still open; the host reads the open flags once per iteration after the first W
+// (an utterance needs at least W expansions per frame to fill B).
+// =====================================================================================
+namespace {
+
+struct BeamPtrs {
+    double* pool;        // [B][W + EM*V]
+    double* bp_logp;     // [B][W]   survivors of the previous frame
+    int32_t* bp_node;    // [B][W]
+    int32_t* n_bp;       // [B]
+    float* bp_h[2];      // [B][W][L][H] double-buffered per frame
+    float* bp_c[2];
+    double* bn_logp;     // [B][W]   B of the current frame (first W entries)
+    int32_t* bn_node;
+    int32_t* bn_ref;
+    int32_t* n_b;        // [B]      len(B)
+    double* max_b;       // [B]
+    int32_t* exp_node;   // [B][EM]  node / state reference / score of the e-th popped hypothesis
+    int32_t* exp_ref;
+    double* exp_logp;
+    int32_t* e_count;    // [B]
+    float* f_h;          // [B][EM][L][H] states created in this frame
+    float* f_c;
+    int2* nodes;         // [B][NODES] (parent, token)
+    int32_t* n_nodes;    // [B]
+    int32_t* open;       // [B] the while-loop of this utterance is still running
+    int32_t* lens;       // [B]
+    int32_t* flags;      // [0] expansion cap hit, [1] node cap hit
+    long long* total_exp;// [1]
+};
+
+__global__ void beam_frame_begin(BeamPtrs p, int t, int W, int EMV) {
+    const int b = blockIdx.x;
+    const bool act = t < p.lens[b];
+    if (threadIdx.x == 0) {
+        p.open[b] = act ? 1 : 0;
+        if (act) {
+            p.e_count[b] = 0;
+            p.n_b[b] = 0;
+            p.max_b[b] = -INFINITY;
+        }
+    }
+    if (act)
+        for (int i = threadIdx.x; i < W; i += blockDim.x)
+            p.pool[(size_t)b * (W + EMV) + i] = i < p.n_bp[b] ? p.bp_logp[b * W + i] : -INFINITY;
+}
+
+// y* = max(A) (first on ties), removed from A; its last token -> pred, its state -> h/c_state
+__global__ __launch_bounds__(256) void beam_pop(BeamPtrs p, int cur, int W, int V, int EM, int L,
+                                                int H, int B, int NODES, int bos,
+                                                int32_t* __restrict__ pred, float* __restrict__ h_state,
+                                                float* __restrict__ c_state) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (!p.open[b]) return;
+    double* pool = p.pool + (size_t)b * (W + (size_t)EM * V);
+    const int n = W + p.e_count[b] * V;
+    double best = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int i = tid; i < n; i += 256) {
+        const double v = pool[i];
+        if (v > best) { best = v; arg = i; }
+    }
+    __shared__ double sb[256];
+    __shared__ int sa[256];
+    __shared__ int s_ref;
+    sb[tid] = best; sa[tid] = arg;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) {
+            const double ob = sb[tid + off];
+            const int oa = sa[tid + off];
+            if (ob > sb[tid] || (ob == sb[tid] && oa < sa[tid])) { sb[tid] = ob; sa[tid] = oa; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int idx = sa[0];
+        const int e = p.e_count[b];
+        int node, ref, tok;
+        if (idx < W) {
+            node = p.bp_node[b * W + idx];
+            ref = idx;
+        } else {
+            const int ep = (idx - W) / V, k = (idx - W) % V;
+            int nn = p.n_nodes[b];
+            if (nn >= NODES) { p.flags[1] = 1; nn = NODES - 1; }
+            p.nodes[(size_t)b * NODES + nn] = make_int2(p.exp_node[b * EM + ep], k);
+            p.n_nodes[b] = nn + 1;
+            node = nn;
+            ref = W + ep;
+        }
+        tok = node < 0 ? bos : p.nodes[(size_t)b * NODES + node].y;
+        pool[idx] = -INFINITY;
+        p.exp_node[b * EM + e] = node;
+        p.exp_ref[b * EM + e] = ref;
+        p.exp_logp[b * EM + e] = sb[0];
+        pred[b] = tok;
+        s_ref = ref;
+    }
+    __syncthreads();
+    const int ref = s_ref;
+    const size_t LH = (size_t)L * H;
+    const float* sh = ref < W ? p.bp_h[cur] + ((size_t)b * W + ref) * LH : p.f_h + ((size_t)b * EM + (ref - W)) * LH;
+    const float* sc = ref < W ? p.bp_c[cur] + ((size_t)b * W + ref) * LH : p.f_c + ((size_t)b * EM + (ref - W)) * LH;
+    for (int i = tid; i < (int)LH; i += 256) {
+        const int l = i / H, j = i % H;
+        h_state[((size_t)l * B + b) * H + j] = sh[i];
+        c_state[((size_t)l * B + b) * H + j] = sc[i];
+    }
+}
+
+// log-softmax of the joint's logits; children into the pool, the blank child into B, the new
+// prediction-network state into the frame's state pool; then the reference's stop test
+__global__ __launch_bounds__(256) void beam_expand(BeamPtrs p, const float* __restrict__ logits,
+                                                   const float* __restrict__ h_new,
+                                                   const float* __restrict__ c_new, int W, int V,
+                                                   int EM, int L, int H, int B, int blank) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (!p.open[b]) return;
+    const float* z = logits + (size_t)b * V;
+    __shared__ float sf[256];
+    __shared__ double sd[256];
+    float m = -INFINITY;
+    for (int v = tid; v < V; v += 256) m = fmaxf(m, z[v]);
+    sf[tid] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) sf[tid] = fmaxf(sf[tid], sf[tid + off]);
+        __syncthreads();
+    }
+    m = sf[0];
+    __syncthreads();
+    float s = 0.f;
+    for (int v = tid; v < V; v += 256) s += expf(z[v] - m);
+    sf[tid] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) sf[tid] += sf[tid + off];
+        __syncthreads();
+    }
+    const float logs = logf(sf[0]);
+    const int e = p.e_count[b];
+    const double base = p.exp_logp[b * EM + e];
+    double* pool = p.pool + (size_t)b * (W + (size_t)EM * V);
+    double* seg = pool + W + (size_t)e * V;
+    for (int v = tid; v < V; v += 256)
+        seg[v] = v == blank ? -INFINITY : base + (double)((z[v] - m) - logs);
+    const size_t LH = (size_t)L * H;
+    float* dh = p.f_h + ((size_t)b * EM + e) * LH;
+    float* dc = p.f_c + ((size_t)b * EM + e) * LH;
+    for (int i = tid; i < (int)LH; i += 256) {
+        const int l = i / H, j = i % H;
+        dh[i] = h_new[((size_t)l * B + b) * H + j];
+        dc[i] = c_new[((size_t)l * B + b) * H + j];
+    }
+    __syncthreads();
+    // max(A) after this expansion
+    const int n = W + (e + 1) * V;
+    double best = -INFINITY;
+    for (int i = tid; i < n; i += 256) best = fmax(best, pool[i]);
+    sd[tid] = best;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) sd[tid] = fmax(sd[tid], sd[tid + off]);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const double lpb = base + (double)((z[blank] - m) - logs);
+        const int j = p.n_b[b];
+        if (j < W) {
+            p.bn_logp[b * W + j] = lpb;
+            p.bn_node[b * W + j] = p.exp_node[b * EM + e];
+            p.bn_ref[b * W + j] = p.exp_ref[b * EM + e];
+        }
+        p.n_b[b] = j + 1;
+        const double mb = fmax(p.max_b[b], lpb);
+        p.max_b[b] = mb;
+        p.e_count[b] = e + 1;
+        atomicAdd((unsigned long long*)p.total_exp, 1ull);
+        if (j + 1 >= W && mb >= sd[0]) {
+            p.open[b] = 0;
+        } else if (e + 1 >= EM) {
+            p.flags[0] = 1;
+            p.open[b] = 0;
+        }
+    }
+}
+
+// B = B[:W] becomes the next frame's survivors (states gathered into the other buffer)
+__global__ __launch_bounds__(256) void beam_frame_end(BeamPtrs p, int t, int cur, int W, int EM,
+                                                      int L, int H) {
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (t >= p.lens[b]) return;
+    const int n = min(p.n_b[b], W);
+    const size_t LH = (size_t)L * H;
+    for (int j = 0; j < n; ++j) {
+        const int ref = p.bn_ref[b * W + j];
+        const float* sh = ref < W ? p.bp_h[cur] + ((size_t)b * W + ref) * LH : p.f_h + ((size_t)b * EM + (ref - W)) * LH;
+        const float* sc = ref < W ? p.bp_c[cur] + ((size_t)b * W + ref) * LH : p.f_c + ((size_t)b * EM + (ref - W)) * LH;
+        float* dh = p.bp_h[cur ^ 1] + ((size_t)b * W + j) * LH;
+        float* dc = p.bp_c[cur ^ 1] + ((size_t)b * W + j) * LH;
+        for (int i = tid; i < (int)LH; i += 256) { dh[i] = sh[i]; dc[i] = sc[i]; }
+    }
+    if (tid < n) {
+        p.bp_logp[b * W + tid] = p.bn_logp[b * W + tid];
+        p.bp_node[b * W + tid] = p.bn_node[b * W + tid];
+    }
+    if (tid == 0) p.n_bp[b] = n;
+}
+
+__global__ void beam_init(BeamPtrs p, int B, int W) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    p.n_bp[b] = 1;               // B = [empty hypothesis], models.py:148
+    p.bp_logp[b * W] = 0.0;
+    p.bp_node[b * W] = -1;
+    p.n_nodes[b] = 0;
+    p.open[b] = 0;
+    if (b == 0) { p.flags[0] = p.flags[1] = 0; *p.total_exp = 0; }
+}
+
+struct BeamWs {
+    Ws step;   // the greedy loop's per-iteration buffers (prediction-network step + joint)
+    size_t h_state, c_state;
+    size_t pool, bp_logp, bp_node, n_bp, bp_h0, bp_h1, bp_c0, bp_c1, bn_logp, bn_node, bn_ref, n_b, max_b,
+        exp_node, exp_ref, exp_logp, e_count, f_h, f_c, nodes, n_nodes, open, lens, flags, total_exp, total;
+};
+inline BeamWs beam_layout(int esz, int B, int T, int J, int V, int E, int L, int H, int P2, int W, int EM) {
+    BeamWs w;
+    w.step = ws_layout(esz, B, J, V, E, L, H, P2);
+    size_t o = w.step.total;
+    auto take = [&](size_t bytes) { size_t r = o; o += align256(bytes); return r; };
+    const size_t LH = (size_t)L * H, NODES = (size_t)T * EM + 1;
+    w.h_state = take((size_t)B * LH * 4);
+    w.c_state = take((size_t)B * LH * 4);
+    w.pool = take((size_t)B * (W + (size_t)EM * V) * 8);
+    w.bp_logp = take((size_t)B * W * 8);
+    w.bp_node = take((size_t)B * W * 4);
+    w.n_bp = take((size_t)B * 4);
+    w.bp_h0 = take((size_t)B * W * LH * 4);
+    w.bp_h1 = take((size_t)B * W * LH * 4);
+    w.bp_c0 = take((size_t)B * W * LH * 4);
+    w.bp_c1 = take((size_t)B * W * LH * 4);
+    w.bn_logp = take((size_t)B * W * 8);
+    w.bn_node = take((size_t)B * W * 4);
+    w.bn_ref = take((size_t)B * W * 4);
+    w.n_b = take((size_t)B * 4);
+    w.max_b = take((size_t)B * 8);
+    w.exp_node = take((size_t)B * EM * 4);
+    w.exp_ref = take((size_t)B * EM * 4);
+    w.exp_logp = take((size_t)B * EM * 8);
+    w.e_count = take((size_t)B * 4);
+    w.f_h = take((size_t)B * EM * LH * 4);
+    w.f_c = take((size_t)B * EM * LH * 4);
+    w.nodes = take((size_t)B * NODES * 8);
+    w.n_nodes = take((size_t)B * 4);
+    w.open = take((size_t)B * 4);
+    w.lens = take((size_t)B * 4);
+    w.flags = take(8);
+    w.total_exp = take(8);
+    w.total = o;
+    return w;
+}
+
+}  // namespace
+
+extern "C" size_t edgedict_beam_workspace_bytes(int dtype, int B, int T, int J, int V, int E, int L,
+                                                int H, int P2, int W, int max_expansions) {
+    if (B <= 0 || W <= 0 || max_expansions <= 0) return 0;
+    return beam_layout(dtype == ED_F32 ? 4 : 2, B, T < 0 ? 0 : T, J, V, E, L, H, P2, W, max_expansions).total;
+}
+
+extern "C" int edgedict_beam_search(
+    int dtype, const void* E1, long long e_row_stride, long long e_frame_stride, int B, int T,
+    const int32_t* lens_host, int J, const void* W1d, long long ldw1, const float* b1, int P2,
+    const void* W2, const float* b2, int V, const void* emb, int emb_dtype, int E, int L,
+    const void* const* w_ih, const void* const* w_hh, const float* const* b_ih,
+    const float* const* b_hh, int H, const void* Wp, const float* bp, int blank, int bos, int W,
+    int max_expansions, int32_t* tokens_host, int max_tokens, int32_t* ntokens_host,
+    double* score_host, long long* expansions_host, void* workspace, void* stream_) {
+    ED_CHECK_ARG(dtype == ED_F32 || dtype == ED_BF16, "beam_search: bad dtype");
+    ED_CHECK_ARG(B > 0 && T >= 0 && J > 0 && V > 0 && L > 0 && H > 0 && P2 > 0 && E > 0 && W > 0 &&
+                     max_expansions >= W && max_tokens >= 0,
+                 "beam_search: bad shape (max_expansions must be >= W)");
+    ED_CHECK_ARG((T == 0 || E1) && W1d && b1 && W2 && b2 && emb && w_ih && w_hh && b_ih && b_hh &&
+                     Wp && bp && lens_host && tokens_host && ntokens_host && score_host && workspace,
+                 "beam_search: null pointer");
+    ED_CHECK_ARG(blank >= 0 && blank < V && bos >= 0 && bos < V, "beam_search: blank/bos outside the vocabulary");
+    for (int b = 0; b < B; ++b)
+        ED_CHECK_ARG(lens_host[b] >= 0 && lens_host[b] <= T, "beam_search: lens[%d] = %d outside [0, %d]", b, lens_host[b], T);
+    hipStream_t s = (hipStream_t)stream_;
+    const int esz = dtype == ED_F32 ? 4 : 2, EM = max_expansions;
+    const int NODES = T * EM + 1;
+    const BeamWs w = beam_layout(esz, B, T, J, V, E, L, H, P2, W, EM);
+    char* p = (char*)workspace;
+    void* D1 = p + w.step.D1;
+    void* hid = p + w.step.hid;
+    float* logits = (float*)(p + w.step.logits);
+    int32_t* pred = (int32_t*)(p + w.step.pred);
+    void* x = p + w.step.x;
+    void* G = p + w.step.G;
+    void* Hprev = p + w.step.Hprev;
+    void* Y[2] = {p + w.step.Y0, p + w.step.Y1};
+    float* Cst = (float*)(p + w.step.Cst);
+    float* h_new = (float*)(p + w.step.h_new);
+    float* c_new = (float*)(p + w.step.c_new);
+    void* dec_new = p + w.step.dec_new;
+    float* h_state = (float*)(p + w.h_state);
+    float* c_state = (float*)(p + w.c_state);
+    BeamPtrs q;
+    q.pool = (double*)(p + w.pool);
+    q.bp_logp = (double*)(p + w.bp_logp);
+    q.bp_node = (int32_t*)(p + w.bp_node);
+    q.n_bp = (int32_t*)(p + w.n_bp);
+    q.bp_h[0] = (float*)(p + w.bp_h0); q.bp_h[1] = (float*)(p + w.bp_h1);
+    q.bp_c[0] = (float*)(p + w.bp_c0); q.bp_c[1] = (float*)(p + w.bp_c1);
+    q.bn_logp = (double*)(p + w.bn_logp);
+    q.bn_node = (int32_t*)(p + w.bn_node);
+    q.bn_ref = (int32_t*)(p + w.bn_ref);
+    q.n_b = (int32_t*)(p + w.n_b);
+    q.max_b = (double*)(p + w.max_b);
+    q.exp_node = (int32_t*)(p + w.exp_node);
+    q.exp_ref = (int32_t*)(p + w.exp_ref);
+    q.exp_logp = (double*)(p + w.exp_logp);
+    q.e_count = (int32_t*)(p + w.e_count);
+    q.f_h = (float*)(p + w.f_h);
+    q.f_c = (float*)(p + w.f_c);
+    q.nodes = (int2*)(p + w.nodes);
+    q.n_nodes = (int32_t*)(p + w.n_nodes);
+    q.open = (int32_t*)(p + w.open);
+    q.lens = (int32_t*)(p + w.lens);
+    q.flags = (int32_t*)(p + w.flags);
+    q.total_exp = (long long*)(p + w.total_exp);
+
+    const size_t LH = (size_t)L * H;
+    ED_CHECK_HIP(hipMemcpyAsync(q.lens, lens_host, (size_t)B * 4, hipMemcpyHostToDevice, s));
+    // the empty hypothesis' state is zero (Decoder.forward(empty, None), rnnt/models.py:150-153)
+    ED_CHECK_HIP(hipMemsetAsync(q.bp_h[0], 0, (size_t)B * W * LH * 4, s));
+    ED_CHECK_HIP(hipMemsetAsync(q.bp_c[0], 0, (size_t)B * W * LH * 4, s));
+    // rows of finished / not yet popped utterances flow through the step kernels: keep them finite
+    ED_CHECK_HIP(hipMemsetAsync(h_state, 0, (size_t)B * LH * 4, s));
+    ED_CHECK_HIP(hipMemsetAsync(c_state, 0, (size_t)B * LH * 4, s));
+    ED_CHECK_HIP(hipMemsetAsync(pred, 0, (size_t)B * 4, s));
+    hipLaunchKernelGGL(beam_init, dim3((B + 63) / 64), dim3(64), 0, s, q, B, W);
+    std::vector<int32_t> open_h(B);
+    int maxlen = 0;
+    for (int b = 0; b < B; ++b) maxlen = lens_host[b] > maxlen ? lens_host[b] : maxlen;
+
+    int cur = 0;
+    for (int t = 0; t < maxlen; ++t) {
+        hipLaunchKernelGGL(beam_frame_begin, dim3(B), dim3(64), 0, s, q, t, W, EM * V);
+        const char* e1t = (const char*)E1 + (size_t)t * e_frame_stride * esz;
+        for (int it = 0;; ++it) {
+            int rc;
+            hipLaunchKernelGGL(beam_pop, dim3(B), dim3(256), 0, s, q, cur, W, V, EM, L, H, B, NODES,
+                               bos, pred, h_state, c_state);
+            // prediction-network step on y*'s last token from y*'s state (models.py:164,126-132)
+            if ((rc = edgedict_embedding_fwd(dtype, emb_dtype, pred, 1, emb, x, B, 1, E, V, 0, 0, s)))
+                return rc;
+            const void* xin = x;
+            int xin_dim = E;
+            for (int k = 0; k < L; ++k) {
+                if ((rc = edgedict_gemm(dtype, dtype, xin, xin_dim, 1, w_ih[k], xin_dim, 1, G, 4 * H,
+                                        B, 4 * H, xin_dim, b_ih[k], b_hh[k], 0, 1, s)))
+                    return rc;
+                if ((rc = edgedict_lstm_forward(dtype, G, Hprev, Y[k & 1], Cst, w_hh[k], nullptr,
+                                                h_state + (size_t)k * B * H, c_state + (size_t)k * B * H,
+                                                h_new + (size_t)k * B * H, c_new + (size_t)k * B * H,
+                                                B, 1, H, nullptr, s)))
+                    return rc;
+                xin = Y[k & 1];
+                xin_dim = H;
+            }
+            if ((rc = edgedict_gemm(dtype, dtype, xin, H, 1, Wp, H, 1, dec_new, P2, B, P2, H, bp,
+                                    nullptr, 0, 1, s)))
+                return rc;
+            // joint(x_t, pred) (models.py:165): D1 = pred W1d^T + b1; hid = tanh(E1[:,t] + D1); logits
+            if ((rc = edgedict_gemm(dtype, dtype, dec_new, P2, 1, W1d, ldw1, 1, D1, J, B, J, P2, b1,
+                                    nullptr, 0, 1, s)))
+                return rc;
+            if (dtype == ED_F32)
+                hipLaunchKernelGGL(add_tanh_rows<float>, dim3(ed_grid_for((long long)B * J, 256)),
+                                   dim3(256), 0, s, (const float*)e1t, e_row_stride,
+                                   (const float*)D1, (float*)hid, B, J);
+            else
+                hipLaunchKernelGGL(add_tanh_rows<bf16_t>, dim3(ed_grid_for((long long)B * J, 256)),
+                                   dim3(256), 0, s, (const bf16_t*)e1t, e_row_stride,
+                                   (const bf16_t*)D1, (bf16_t*)hid, B, J);
+            if ((rc = edgedict_gemm(dtype, ED_F32, hid, J, 1, W2, J, 1, logits, V, B, V, J, b2,
+                                    nullptr, 0, 1, s)))
+                return rc;
+            hipLaunchKernelGGL(beam_expand, dim3(B), dim3(256), 0, s, q, logits, h_new, c_new, W, V,
+                               EM, L, H, B, blank);
+            if (it + 1 >= W) {   // B cannot hold W hypotheses before W expansions
+                ED_CHECK_HIP(hipMemcpyAsync(open_h.data(), q.open, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+                ED_CHECK_HIP(hipStreamSynchronize(s));
+                int any = 0;
+                for (int b = 0; b < B; ++b) any |= open_h[b];
+                if (!any) break;
+            }
+        }
+        hipLaunchKernelGGL(beam_frame_end, dim3(B), dim3(256), 0, s, q, t, cur, W, EM, L, H);
+        cur ^= 1;
+    }
+    ED_CHECK_LAUNCH("beam_search");
+    // results: B[0] of the last frame (models.py:201-202), token tree walked on the host
+    std::vector<double> logp((size_t)B * W);
+    std::vector<int32_t> node((size_t)B * W), nn(B);
+    std::vector<int2> nodes((size_t)B * NODES);
+    int32_t flags[2];
+    long long total = 0;
+    ED_CHECK_HIP(hipMemcpyAsync(logp.data(), q.bp_logp, logp.size() * 8, hipMemcpyDeviceToHost, s));
+    ED_CHECK_HIP(hipMemcpyAsync(node.data(), q.bp_node, node.size() * 4, hipMemcpyDeviceToHost, s));
+    ED_CHECK_HIP(hipMemcpyAsync(nn.data(), q.n_nodes, nn.size() * 4, hipMemcpyDeviceToHost, s));
+    ED_CHECK_HIP(hipMemcpyAsync(nodes.data(), q.nodes, nodes.size() * 8, hipMemcpyDeviceToHost, s));
+    ED_CHECK_HIP(hipMemcpyAsync(flags, q.flags, 8, hipMemcpyDeviceToHost, s));
+    ED_CHECK_HIP(hipMemcpyAsync(&total, q.total_exp, 8, hipMemcpyDeviceToHost, s));
+    ED_CHECK_HIP(hipStreamSynchronize(s));
+    ED_CHECK_ARG(!flags[0], "beam_search: an utterance needed more than max_expansions = %d expansions in one frame", EM);
+    ED_CHECK_ARG(!flags[1], "beam_search: token tree overflow");
+    if (expansions_host) *expansions_host = total;
+    std::vector<int32_t> rev;
+    for (int b = 0; b < B; ++b) {
+        rev.clear();
+        for (int n = node[(size_t)b * W]; n >= 0; n = nodes[(size_t)b * NODES + n].x)
+            rev.push_back(nodes[(size_t)b * NODES + n].y);
+        const int len = (int)rev.size();
+        ntokens_host[b] = len;
+        ED_CHECK_ARG(len <= max_tokens, "beam_search: hypothesis of %d tokens exceeds max_tokens = %d", len, max_tokens);
+        for (int i = 0; i < len; ++i) tokens_host[(size_t)b * max_tokens + i] = rev[len - 1 - i];
+        score_host[b] = -logp[(size_t)b * W];
+    }
     return ED_OK;
 }

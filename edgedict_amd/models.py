@@ -755,6 +755,15 @@ class Transducer(nn.Module):
         from .decode import greedy_decode_batch
         return greedy_decode_batch(self, xs, xlen)
 
+    def beam_search(self, xs, xlen=None, W=10, prefix=False, max_expansions=None):
+        """Beam search of the reference's legacy model (models.py:121-202), batched; see
+        ``decode.beam_search_batch``.  ``prefix=True`` (the prefix-sum variant, :145-161) is not
+        implemented."""
+        if prefix:
+            raise NotImplementedError("beam_search(prefix=True) is not implemented")
+        from .decode import beam_search_batch
+        return beam_search_batch(self, xs, xlen, W, max_expansions)
+
 
 def convert_lightning2normal(checkpoint):
     """Lightning checkpoint -> ``{'model': state_dict}`` (same contract as the reference's

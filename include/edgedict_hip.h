@@ -386,6 +386,33 @@ int edgedict_greedy_decode(int dtype, const void* E1, long long e_row_stride,
                            void* dec_out, int blank, int unk, int32_t* tokens_out, int tok_stride,
                            float* score, void* workspace, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Batched beam search: the reference's legacy Transducer.beam_search (models.py:121-202,
+ * prefix=False; Sequence models.py:212-224) for B utterances in lockstep, over the maintained
+ * model's prediction network and joint.  Operands as edgedict_greedy_decode, plus
+ *   lens_host        HOST int32 [B]: encoder frames of each utterance (<= T)
+ *   bos              the token the empty hypothesis feeds first (BOS = 2, zero state)
+ *   W                beam width;  max_expansions >= W: cap on pops per utterance and frame
+ *                    (exceeding it is an error, never a silent truncation)
+ *   tokens_host      HOST int32 [B, max_tokens]: tokens of B[0] (no blanks, no BOS)
+ *   ntokens_host     HOST int32 [B];  score_host HOST fp64 [B] = -log p of that hypothesis
+ *   expansions_host  HOST, nullable: total number of expansions (pops) performed
+ * Scores are accumulated in fp64 from fp32 log-softmax values, as the reference's Python floats
+ * are.  The call synchronises the stream (the loop's stop test is data dependent).
+ */
+size_t edgedict_beam_workspace_bytes(int dtype, int B, int T, int J, int V, int E, int L, int H,
+                                     int P2, int W, int max_expansions);
+int edgedict_beam_search(int dtype, const void* E1, long long e_row_stride,
+                         long long e_frame_stride, int B, int T, const int32_t* lens_host, int J,
+                         const void* W1d, long long ldw1, const float* b1, int P2, const void* W2,
+                         const float* b2, int V, const void* emb, int emb_dtype, int E, int L,
+                         const void* const* w_ih, const void* const* w_hh,
+                         const float* const* b_ih, const float* const* b_hh, int H,
+                         const void* Wp, const float* bp, int blank, int bos, int W,
+                         int max_expansions, int32_t* tokens_host, int max_tokens,
+                         int32_t* ntokens_host, double* score_host, long long* expansions_host,
+                         void* workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,90 @@
+"""ORACLE (test infrastructure only - never imported by the product path).
+
+CPU restatement of the reference's transducer beam search, the legacy root-level
+``Transducer.beam_search`` (/root/reference/models.py:121-202, with ``Sequence`` :212-224; the
+``prefix=True`` branch :145-161 is not restated), driven by the MAINTAINED model's arithmetic
+(oracle/models_ref.py: rnnt/models.py encoder, prediction network, joint).  Graves (2012) search,
+one utterance at a time, as written there:
+
+    B = [empty hypothesis, logp 0]
+    for each encoder frame x:
+        A = B; B = []
+        loop:
+            y* = the most probable hypothesis in A (first one on ties: Python ``max``); remove it
+            pred, hidden = prediction network on y*'s LAST token from y*'s stored state
+            logp = log_softmax(joint(x, pred))
+            for every k in the vocabulary: y* + k with logp(y*) + logp[k]  (Python float = fp64 sum
+                of fp32 log-probabilities); k == blank goes to B and keeps y*'s tokens AND y*'s
+                stored state; the others go to A in k order with state = hidden
+            stop when len(B) >= W and max(B) >= max(A)
+        B = B[:W]        # the ``sorted(...)`` calls at :141,:195 discard their result, so this keeps
+                         # the first W hypotheses in INSERTION order, as the reference does
+    return B[0].tokens, -B[0].logp          # likewise the first inserted one, not the best
+
+Adaptations to the maintained model (the legacy class has its own layers and feeds token id 1 from
+a ``None`` state first): the empty hypothesis' "last token" is BOS with zero state - exactly what
+``Decoder.forward(empty, None)`` does (rnnt/models.py:150-153) and what ``greedy_decode`` starts
+from (:247); returned tokens exclude it.  Frames: an utterance of a batch uses the first
+``scale_length(T', xlen)`` encoder frames (rnnt/models.py:223-226); batch-1 with a full-length
+``xlen`` is the reference's loop over every frame.
+
+PARITY STATUS: **unpinned** - the legacy method cannot run on torch 2.x (``volatile=True``
+Variables, the absent ``recurrent`` module) and the reference holds no test or fixture for it.
+"""
+import numpy as np
+import torch
+
+from . import models_ref as M
+
+
+class _Hyp:
+    __slots__ = ("k", "tok", "h", "logp")
+
+    def __init__(self, k, tok, h, logp):
+        self.k, self.tok, self.h, self.logp = k, tok, h, logp
+
+
+def beam_search_one(sd, h_enc, W=10, blank=M.NUL):
+    """h_enc [T, P_enc] fp32 of ONE utterance -> (token list without blanks, -logp)."""
+    L = M.n_dec_layers(sd)
+    H = sd["decoder.lstm.weight_hh_l0"].shape[1]
+    zero = (torch.zeros(L, 1, H), torch.zeros(L, 1, H))
+    V = sd["joint.joint.2.weight"].shape[0]
+    B = [_Hyp([], M.BOS, zero, 0.0)]
+    n_expansions = 0
+    for x in h_enc:
+        A = B
+        B = []
+        while True:
+            y_hat = max(A, key=lambda a: a.logp)
+            A.remove(y_hat)
+            pred, hidden = M.decoder_forward(sd, torch.tensor([[y_hat.tok]]), y_hat.h)
+            logits = M.joint_forward(sd, x[None, :], pred[:, 0])[0]
+            logp = torch.log_softmax(logits, dim=0)
+            n_expansions += 1
+            for k in range(V):
+                lp = y_hat.logp + float(logp[k])
+                if k == blank:
+                    B.append(_Hyp(y_hat.k, y_hat.tok, y_hat.h, lp))
+                else:
+                    A.append(_Hyp(y_hat.k + [k], k, hidden, lp))
+            y_a = max(A, key=lambda a: a.logp)
+            y_b = max(B, key=lambda a: a.logp)
+            if len(B) >= W and y_b.logp >= y_a.logp:
+                break
+        B = B[:W]
+    return list(B[0].k), -B[0].logp, n_expansions
+
+
+def beam_search(sd, xs, xlen=None, W=10, blank=M.NUL, time_reductions=(1,)):
+    """xs [B, T0, I]; returns (list of int64 arrays, fp64 scores [B], total expansions)."""
+    h_enc, _ = M.encoder_forward(sd, xs, None, time_reductions)
+    Bn, T = h_enc.shape[0], h_enc.shape[1]
+    lens = [T] * Bn if xlen is None else [int(v) for v in M.scale_length(T, xlen)]
+    seqs, scores, total = [], [], 0
+    for b in range(Bn):
+        k, s, n = beam_search_one(sd, h_enc[b, :lens[b]], W, blank)
+        seqs.append(np.array(k, dtype=np.int64))
+        scores.append(s)
+        total += n
+    return seqs, np.array(scores, dtype=np.float64), total

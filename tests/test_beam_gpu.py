@@ -1,0 +1,90 @@
+"""GPU: batched beam search (csrc/decode.hip through Transducer.beam_search) against the oracle
+restatement of the reference's legacy beam search (oracle/beam_ref.py) on the committed trained
+tiny model, and on a random-weight model with ragged lengths."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import beam_ref, models_ref as M
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "beam_tiny.npz"))
+CFG = dict(vocab_embed_size=16, vocab_size=40, input_size=24, enc_hidden_size=32, enc_layers=2,
+           enc_proj_size=24, dec_hidden_size=32, dec_layers=2, dec_proj_size=24, joint_size=32)
+
+
+def _engine(sd, dtype="fp32"):
+    from edgedict_amd.models import Transducer
+    m = Transducer(enc_dropout=0.0, dec_dropout=0.0, output_loss=False, **CFG)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    m.compute_dtype = dtype
+    return m
+
+
+def _golden():
+    sd = {k[3:]: torch.from_numpy(G[k]) for k in G.files if k.startswith("sd/")}
+    return sd, torch.from_numpy(G["xs"]), torch.from_numpy(G["xlen"])
+
+
+@pytest.mark.parametrize("W", [1, 2, 4, 10])
+def test_beam_matches_committed_oracle_vectors(hip_lib, W):
+    from edgedict_amd import decode
+    sd, xs, xlen = _golden()
+    m = _engine(sd)
+    with torch.no_grad():
+        seqs, scores = m.beam_search(xs.cuda(), xlen, W=W)
+    for b, s in enumerate(seqs):
+        assert s.dtype == np.int64
+        assert np.array_equal(s, G["W%d_seq%d" % (W, b)]), (W, b, s)
+    assert scores.dtype == torch.float64
+    # fp64 sums of fp32 log-probabilities on both sides; the fp32 encoder / joint differ in
+    # summation order only
+    np.testing.assert_allclose(scores.numpy(), G["W%d_score" % W], rtol=2e-4, atol=2e-4)
+    assert decode.beam_search_batch.last_expansions == int(G["W%d_expansions" % W][0])
+
+
+def test_beam_random_model_ragged_batch_matches_oracle(hip_lib):
+    sd = M.make_state_dict(CFG, 3)
+    xs, ys, xlen, ylen = M.make_batch(CFG, 4, 5, 17, 4)
+    xlen = torch.tensor([17, 9, 17, 3, 12], dtype=torch.int32)
+    m = _engine(sd)
+    with torch.no_grad():
+        seqs, scores = m.beam_search(xs.cuda(), xlen, W=3, max_expansions=400)  # flat distributions: many pops
+    rs, rsc, _ = beam_ref.beam_search(sd, xs, xlen, W=3)
+    for a, b in zip(seqs, rs):
+        assert np.array_equal(a, b)
+    np.testing.assert_allclose(scores.numpy(), rsc, rtol=2e-4, atol=2e-4)
+
+
+def test_beam_all_frames_when_no_lengths_and_batch_invariance(hip_lib):
+    sd, xs, xlen = _golden()
+    m = _engine(sd)
+    with torch.no_grad():
+        full, fs = m.beam_search(xs.cuda(), None, W=4)
+        one, os_ = m.beam_search(xs[1:2].cuda(), None, W=4)
+    assert np.array_equal(full[1], one[0])          # an utterance's search does not depend on its batch
+    np.testing.assert_allclose(fs[1].item(), os_[0].item(), rtol=1e-6)
+    rs, rsc, _ = beam_ref.beam_search(sd, xs, None, W=4)
+    for a, b in zip(full, rs):
+        assert np.array_equal(a, b)
+
+
+def test_beam_expansion_cap_is_an_error_not_a_truncation(hip_lib):
+    sd, xs, xlen = _golden()
+    m = _engine(sd)
+    with pytest.raises(RuntimeError, match="max_expansions"):
+        m.beam_search(xs.cuda(), xlen, W=1, max_expansions=1)
+    with pytest.raises(NotImplementedError):
+        m.beam_search(xs.cuda(), xlen, W=2, prefix=True)
+
+
+def test_beam_bf16_runs_and_returns_valid_tokens(hip_lib):
+    sd, xs, xlen = _golden()
+    m = _engine(sd, "bf16")
+    with torch.no_grad():
+        seqs, scores = m.beam_search(xs.cuda(), xlen, W=4)
+    assert all(((s > 0) & (s < CFG["vocab_size"])).all() for s in seqs)
+    assert torch.isfinite(scores).all() and (scores >= 0).all()
