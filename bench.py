@@ -168,13 +168,19 @@ def main():
         achieved = flop / (ms * 1e-3) / 1e12 if n else float("nan")
         # HBM bytes per launch of that kernel from the committed PMC passes (profiles/collect.sh:
         # separate FETCH_SIZE / WRITE_SIZE runs, gfx950 x2 FETCH correction); null if not collected
+        from edgedict_amd import _lib as _edlib
+        vendor = _edlib.load().edgedict_blaslt_calls() > 0
         traffic = None
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as fh:
                 pmc = json.load(fh)["kernels"]
             tiles = ((rows + 127) // 128) * ((V + 127) // 128)
-            ent = next((v for k, v in pmc.items()
-                        if k.startswith("gemm_nt_kernel") and k.endswith("[tiles=%d]" % tiles)), None)
+            if vendor:   # hipBLASLt kernel names start with Cijk_; the logits product is the big one
+                cands = [v for k, v in pmc.items() if k.startswith("Cijk_")]
+                ent = max(cands, key=lambda v: v["hbm_bytes"]) if cands else None
+            else:
+                ent = next((v for k, v in pmc.items()
+                            if k.startswith("gemm_nt_kernel") and k.endswith("[tiles=%d]" % tiles)), None)
             if ent:
                 traffic = ent["hbm_bytes"]
         except (OSError, ValueError, KeyError):
@@ -236,9 +242,10 @@ def main():
             },
             "roofline": None,        # filled below: the dominant kernel
             "roofline_mfma": {
-                "kernel": "gemm_nt_kernel (bf16 NT, direct-to-LDS) joint logits [%d x %d x %d] "
-                          "(packed lattice: %d of %d dense cells)"
-                          % (rows, V, J, rows, args.batch * Tp * U1),
+                "kernel": "%s joint logits [%d x %d x %d] (packed lattice: %d of %d dense cells)"
+                          % ("hipBLASLt (plain bf16 NT product + bias; csrc/blaslt.cpp)" if vendor
+                             else "gemm_nt_kernel (bf16 NT, direct-to-LDS)", rows, V, J, rows,
+                             args.batch * Tp * U1),
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": traffic,
                 "algorithmic_bytes": 2.0 * rows * (J + V) + 2.0 * V * J,

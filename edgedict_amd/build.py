@@ -69,7 +69,7 @@ def build_all(force=False, verbose=True):
     need_link = (force or rebuilt or not os.path.exists(LIB_PATH)
                  or any(os.path.getmtime(o) > os.path.getmtime(LIB_PATH) for o in objs))
     if need_link:
-        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed:\n%s\n%s" % (" ".join(cmd), r.stderr))

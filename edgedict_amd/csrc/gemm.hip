@@ -20,6 +20,7 @@
 
 #include "common.hpp"
 #include "gemm_nt.hpp"
+#include "blaslt.hpp"
 
 namespace {
 
@@ -449,6 +450,13 @@ static int gemm_impl(int dtype_in, int dtype_out, const void* A, long long lda, 
         const char* e = getenv("EDGEDICT_GEMM_NT");
         return !(e && e[0] == '0');
     }();
+    // the one plain product that is large AND output-heavy (short K: the joint's logits) goes to the
+    // vendor library when it is there (blaslt.cpp says why); everything else runs here
+    if (dtype_in == ED_BF16 && dtype_out == ED_BF16 && a_kmajor && b_kmajor && !accumulate && !bias2 &&
+        split_k == 1 && max_wg_per_cu == 0 && K <= 1024 && N >= 1024 && (long long)M * N >= (1ll << 28) &&
+        lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 &&
+        ed_blaslt_nt_bf16(A, lda, B, ldb, C, ldc, M, N, K, bias1, stream))
+        return ED_OK;
     if (nt_enabled && max_wg_per_cu == 0 &&
         ed_gemm_nt_ok(dtype_in, dtype_out, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, split_k, bias1, bias2))
         return ed_gemm_nt_launch(A, lda, B, ldb, C, ldc, M, N, K, bias1, bias2, accumulate, 0, stream);

@@ -386,6 +386,11 @@ int edgedict_greedy_decode(int dtype, const void* E1, long long e_row_stride,
                            void* dec_out, int blank, int unk, int32_t* tokens_out, int tok_stride,
                            float* score, void* workspace, void* stream);
 
+/* Number of products edgedict_gemm has handed to hipBLASLt in this process (only the large,
+ * short-K bf16 NT product of the joint's logits qualifies; csrc/blaslt.cpp).  0 when the vendor
+ * library is absent or EDGEDICT_BLASLT=0: every product then runs on this library's kernels. */
+long long edgedict_blaslt_calls(void);
+
 /* ------------------------------------------------------------------------------------
  * Batched beam search: the reference's legacy Transducer.beam_search (models.py:121-202,
  * prefix=False; Sequence models.py:212-224) for B utterances in lockstep, over the maintained

@@ -88,3 +88,21 @@ def test_gemm_nt_direct_to_lds_path(hip_lib, M, N, K):
     ref2 = base.double() + (a.double() @ b.double().t())
     err2 = (acc.double() - ref2).abs()
     assert (err2 <= 2.0 ** -7 * ref2.abs() + 2e-3 * (K ** 0.5)).all()
+
+
+def test_large_short_k_product_vendor_route_matches_own_kernel(hip_lib):
+    """M*N >= 2^28 with K <= 1024 (the joint's logits product) may run in hipBLASLt (csrc/blaslt.cpp);
+    a row slice of the same operands is small enough to run in gemm_nt.hip: same values up to the
+    summation order of an fp32-accumulated, bf16-rounded result, ragged M included."""
+    from edgedict_amd import ops
+    M, N, K = 131072 + 37, 2048, 640
+    a = _mk((M, K), torch.bfloat16, 21)
+    b = _mk((N, K), torch.bfloat16, 22)
+    bias = torch.randn(N, generator=torch.Generator().manual_seed(3)).cuda()
+    out = ops.gemm(a, b, bias=bias)
+    assert out.dtype == torch.bfloat16 and out.shape == (M, N)
+    for r0 in (0, 70001, M - 300):
+        own = ops.gemm(a[r0:r0 + 300], b, bias=bias)
+        ref = a[r0:r0 + 300].double() @ b.double().t() + bias.double()
+        assert ((out[r0:r0 + 300].double() - ref).abs() <= 2.0 ** -8 * ref.abs() + 0.03).all()
+        assert ((out[r0:r0 + 300].float() - own.float()).abs() <= 2.0 ** -7 * own.float().abs() + 0.03).all()
