@@ -53,10 +53,18 @@ __device__ __forceinline__ float bf16_to_f32(bf16_t b) {
 }
 // round-to-nearest-even, NaN preserved (same rounding torch uses for .to(bfloat16))
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+    // gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, round-to-nearest-even); the bit
+    // arithmetic it replaces was ~6 VALU instructions per element - a third of rnnt_grad's work
+    const __bf16 b = (__bf16)f;
+    return *reinterpret_cast<const bf16_t*>(&b);
+}
+// two values -> one packed 32-bit word (low half = a), ONE instruction
+__device__ __forceinline__ unsigned f32x2_to_bf16x2(float a, float b) {
+    typedef __attribute__((ext_vector_type(2))) float f32x2_;
+    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_;
+    const f32x2_ v = {a, b};
+    const bf16x2_ r = __builtin_convertvector(v, bf16x2_);
+    return *reinterpret_cast<const unsigned*>(&r);
 }
 
 template <typename T> struct ElemIO;
@@ -89,7 +97,7 @@ template <> struct ElemIO<bf16_t> {
         unsigned w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            w[i] = (unsigned)f32_to_bf16(o[2 * i]) | ((unsigned)f32_to_bf16(o[2 * i + 1]) << 16);
+            w[i] = f32x2_to_bf16x2(o[2 * i], o[2 * i + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };

@@ -150,6 +150,16 @@ __global__ void spec_mask_kernel(float* __restrict__ x, int B, int Tn, int F,
 }
 
 // ---------------------------------------------------------------- joint: hid = tanh(E1[b,t] + D1[b,u])
+template <typename T> __device__ __forceinline__ float joint_tanh(float x) { return tanhf(x); }
+// bf16 mode: v_exp / v_rcp form (abs. error ~1e-7, the result is rounded to bf16 anyway)
+template <> __device__ __forceinline__ float joint_tanh<bf16_t>(float x) {
+    const float xc = fminf(fmaxf(x, -15.f), 15.f);
+    return 1.f - __fdividef(2.f, 1.f + __expf(2.f * xc));
+}
+
+// One workgroup per encoder frame (b, t): a thread keeps its 16-byte column chunk of E1[b,t] in
+// registers and walks u (32-bit index arithmetic only; the flat-index form spent more time in
+// 64-bit divisions than in tanh).
 template <typename T>
 __global__ __launch_bounds__(256) void joint_hidden_fwd(const T* __restrict__ E1,
                                                         const T* __restrict__ D1,
@@ -159,26 +169,29 @@ __global__ __launch_bounds__(256) void joint_hidden_fwd(const T* __restrict__ E1
                                                         const long long* __restrict__ pk_off) {
     constexpr int VEC = ElemIO<T>::VEC;
     const int chunks = J / VEC;  // J % VEC == 0 checked on the host
-    const long long n = (long long)B * Tn * U1 * chunks;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % chunks);
-        const long long btu = i / chunks;
-        const int u = (int)(btu % U1);
-        const long long bt = btu / U1;
-        const int b = (int)(bt / Tn);
-        float e[VEC], d[VEC], o[VEC];
-        long long orow = btu;
+    const int ulanes = max(1, 256 / chunks);          // u values handled side by side
+    const int c = threadIdx.x % chunks, ul = threadIdx.x / chunks;
+    if (ul >= ulanes) return;
+    for (int bt = blockIdx.x; bt < B * Tn; bt += gridDim.x) {
+        const int b = bt / Tn, t = bt - b * Tn;
+        int Ub = U1 - 1;
+        long long row0 = (long long)bt * U1;       // dense: row = (b*T + t)*U1 + u
         if (pk_off) {   // packed lattice: only cells inside the utterance's (T_b, U_b + 1) box exist
-            const int t = (int)(bt % Tn), Ub = label_lens[b];
-            if (t >= act_lens[b] || u > Ub) continue;
-            orow = pk_off[b] + (long long)t * (Ub + 1) + u;
+            Ub = label_lens[b];
+            if (t >= act_lens[b]) continue;
+            row0 = pk_off[b] + (long long)t * (Ub + 1);
         }
-        ElemIO<T>::load_vec(E1 + bt * J + c * VEC, e);
-        ElemIO<T>::load_vec(D1 + ((long long)b * U1 + u) * J + c * VEC, d);
+        float e[VEC];
+        ElemIO<T>::load_vec(E1 + (long long)bt * J + c * VEC, e);
+        const T* drow = D1 + (long long)b * U1 * J + c * VEC;
+        T* orow = hid + row0 * J + c * VEC;
+        for (int u = ul; u <= Ub; u += ulanes) {
+            float d[VEC], o[VEC];
+            ElemIO<T>::load_vec(drow + (long long)u * J, d);
 #pragma unroll
-        for (int k = 0; k < VEC; ++k) o[k] = tanhf(e[k] + d[k]);
-        ElemIO<T>::store_vec(hid + orow * J + c * VEC, o);
+            for (int k = 0; k < VEC; ++k) o[k] = joint_tanh<T>(e[k] + d[k]);
+            ElemIO<T>::store_vec(orow + (long long)u * J, o);
+        }
     }
 }
 
@@ -509,8 +522,8 @@ static int joint_hidden_fwd_impl(int dtype, const void* E1, const void* D1, void
     ED_CHECK_ARG(J % vec == 0, "joint_hidden_fwd: joint size %d must be a multiple of %d", J, vec);
     ED_CHECK_ARG(E1 && D1 && hid, "joint_hidden_fwd: null pointer");
     hipStream_t s = (hipStream_t)stream_;
-    const long long n = (long long)B * T * U1 * (J / vec);
-    const int grid = ed_grid_for(n, 256, 256 * 16);
+    ED_CHECK_ARG(J / vec <= 256, "joint_hidden_fwd: joint size %d too large", J);
+    const int grid = ed_grid_for((long long)B * T, 1, 256 * 64);
     if (dtype == ED_F32)
         hipLaunchKernelGGL(joint_hidden_fwd<float>, dim3(grid), dim3(256), 0, s, (const float*)E1, (const float*)D1, (float*)hid, B, T, U1, J, act_lens, label_lens, pk_off);
     else

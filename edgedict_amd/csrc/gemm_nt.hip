@@ -174,8 +174,8 @@ void gemm_nt_kernel(NtArgs g) {
             for (int i = 0; i < MI; ++i) {
                 const int ml = wm * WT + i * 16 + r16;
                 uint2 pk;
-                pk.x = (unsigned)f32_to_bf16(acc[i][j][0]) | ((unsigned)f32_to_bf16(acc[i][j][1]) << 16);
-                pk.y = (unsigned)f32_to_bf16(acc[i][j][2]) | ((unsigned)f32_to_bf16(acc[i][j][3]) << 16);
+                pk.x = f32x2_to_bf16x2(acc[i][j][0], acc[i][j][1]);
+                pk.y = f32x2_to_bf16x2(acc[i][j][2], acc[i][j][3]);
                 *reinterpret_cast<uint2*>(sC + ml * (TN * 2) + ((((nl >> 3) ^ (ml & (CCH - 1))) << 4) | ((nl & 4) << 1))) = pk;
             }
         }

@@ -50,18 +50,18 @@ __global__ __launch_bounds__(256) void rnnt_lse_gather(
     constexpr int VEC = ElemIO<T>::VEC;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const long long rows = (long long)B * Tm * U1;
-    for (long long row = (long long)blockIdx.x * 4 + wave; row < rows;
-         row += (long long)gridDim.x * 4) {
-        const int u = (int)(row % U1);
-        const long long bt = row / U1;
-        const int t = (int)(bt % Tm);
-        const int b = (int)(bt / Tm);
-        const int Tb = act_lens[b], Ub = label_lens[b];
-        if (t >= Tb || u > Ub) continue;  // outside the utterance's lattice: never read
+    // grid (x, B): the workgroups of column b walk the VALID cells r = t (U_b + 1) + u of utterance b
+    // (cells outside the box are never read) with 32-bit index arithmetic - three 64-bit divisions
+    // per row were as much VALU work as the row itself
+    const int b = blockIdx.y;
+    const int Tb = min(act_lens[b], Tm), Ub = min(label_lens[b], U1 - 1);
+    const int Wb = Ub + 1, nvalid = Tb * Wb;
+    for (int r = blockIdx.x * 4 + wave; r < nvalid; r += gridDim.x * 4) {
+        const int t = r / Wb, u = r - t * Wb;
+        const long long row = ((long long)b * Tm + t) * U1 + u;
         // packed lattice: only the valid cells exist, utterance b starts at row pk_off[b] and its
         // rows are (U_b + 1) apart in t
-        const long long arow = pk_off ? pk_off[b] + (long long)t * (Ub + 1) + u : row;
+        const long long arow = pk_off ? pk_off[b] + r : row;
         const T* z = acts + arow * (long long)V;
         float m = -INFINITY, s = 0.f;
         if (vec_ok) {
@@ -246,18 +246,17 @@ __global__ __launch_bounds__(256) void rnnt_grad(
     constexpr int VEC = ElemIO<T>::VEC;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const long long rows = (long long)B * Tm * U1;
-    for (long long row = (long long)blockIdx.x * 4 + wave; row < rows;
-         row += (long long)gridDim.x * 4) {
-        const int u = (int)(row % U1);
-        const long long bt = row / U1;
-        const int t = (int)(bt % Tm);
-        const int b = (int)(bt / Tm);
-        const int Tb = act_lens[b], Ub = label_lens[b];
-        const float scale = scale_host * (scale_dev ? scale_dev[(long long)b * scale_stride] : 1.f);
+    // grid (x, B), 32-bit index arithmetic (see rnnt_lse_gather).  Dense layout: every cell of the
+    // [Tm, U1] slab of utterance b is written (zeros outside its box); packed: only the box exists.
+    const int b = blockIdx.y;
+    const int Tb = min(act_lens[b], Tm), Ub = min(label_lens[b], U1 - 1);
+    const float scale = scale_host * (scale_dev ? scale_dev[(long long)b * scale_stride] : 1.f);
+    const int Wb = pk_off ? Ub + 1 : U1, ncells = pk_off ? Tb * Wb : Tm * U1;
+    for (int r = blockIdx.x * 4 + wave; r < ncells; r += gridDim.x * 4) {
+        const int t = r / Wb, u = r - t * Wb;
+        const long long row = ((long long)b * Tm + t) * U1 + u;
         const bool inside = (t < Tb && u <= Ub);
-        if (pk_off && !inside) continue;   // packed lattice: cells outside the box do not exist
-        const long long arow = pk_off ? pk_off[b] + (long long)t * (Ub + 1) + u : row;
+        const long long arow = pk_off ? pk_off[b] + r : row;
         const T* z = acts + arow * (long long)V;
         T* g = grads + arow * (long long)V;
         float c_all = 0.f, c_blank = -INFINITY, c_label = -INFINITY;
@@ -361,13 +360,13 @@ static int loss_forward(const void* acts, int acts_dtype, const int32_t* labels,
 
     const size_t esz = acts_dtype == ED_F32 ? 4 : 2;
     const int vec_ok = ((V * esz) % 16 == 0) && (((uintptr_t)acts & 15) == 0);
-    const int grid1 = ed_grid_for((long long)w.cells, 4, 256 * 16);
+    const dim3 grid1(ed_grid_for((long long)T * U1, 4, max(1, 256 * 16 / B)), B);
     if (acts_dtype == ED_F32)
-        hipLaunchKernelGGL(rnnt_lse_gather<float>, dim3(grid1), dim3(256), 0, stream,
+        hipLaunchKernelGGL(rnnt_lse_gather<float>, grid1, dim3(256), 0, stream,
                            (const float*)acts, labels, act_lens, label_lens, B, T, U1, V, blank,
                            denom, lpb, lpl, vec_ok, pk_off);
     else
-        hipLaunchKernelGGL(rnnt_lse_gather<bf16_t>, dim3(grid1), dim3(256), 0, stream,
+        hipLaunchKernelGGL(rnnt_lse_gather<bf16_t>, grid1, dim3(256), 0, stream,
                            (const bf16_t*)acts, labels, act_lens, label_lens, B, T, U1, V, blank,
                            denom, lpb, lpl, vec_ok, pk_off);
     ED_CHECK_LAUNCH("rnnt_lse_gather");
@@ -421,14 +420,14 @@ static int loss_backward(const void* acts, int acts_dtype, void* grads, const in
     const size_t esz = acts_dtype == ED_F32 ? 4 : 2;
     const int vec_ok = ((V * esz) % 16 == 0) && (((uintptr_t)acts & 15) == 0) &&
                        (((uintptr_t)grads & 15) == 0);
-    const int grid = ed_grid_for((long long)w.cells, 4, 256 * 16);
+    const dim3 grid(ed_grid_for((long long)T * U1, 4, max(1, 256 * 16 / B)), B);
     if (acts_dtype == ED_F32)
-        hipLaunchKernelGGL(rnnt_grad<float>, dim3(grid), dim3(256), 0, stream, (const float*)acts,
+        hipLaunchKernelGGL(rnnt_grad<float>, grid, dim3(256), 0, stream, (const float*)acts,
                            (float*)grads, labels, act_lens, label_lens, B, T, U1, V, blank, denom,
                            alphas, betas, ll, grad_scale_host, grad_scale_dev, grad_scale_stride,
                            vec_ok, pk_off);
     else
-        hipLaunchKernelGGL(rnnt_grad<bf16_t>, dim3(grid), dim3(256), 0, stream,
+        hipLaunchKernelGGL(rnnt_grad<bf16_t>, grid, dim3(256), 0, stream,
                            (const bf16_t*)acts, (bf16_t*)grads, labels, act_lens, label_lens, B, T,
                            U1, V, blank, denom, alphas, betas, ll, grad_scale_host, grad_scale_dev,
                            grad_scale_stride, vec_ok, pk_off);
