@@ -236,13 +236,41 @@ int validate(const edgedict_stack_desc_t* d, std::vector<Geom>& g, bool backward
     return ED_OK;
 }
 
-int default_lag(const edgedict_stack_desc_t* d, const std::vector<Geom>& g) {
+int default_lag(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, bool backward) {
     // a layer may start chunk k only after the layer feeding it has finished that chunk and the
     // chunk's GEMM has been ENQUEUED (P launches per chunk, +2 for the norm / enqueue order)
     const int P = d->chunk * g[0].f;
-    int lag = d->lag > 0 ? d->lag : P + 5;
+    // measured (E6D2): forward 8.15 ms at P+3 vs 8.28 at P+5; backward 13.7 at P+5 vs 14.3 at P+3
+    // (its chunk chain is longer: dX product + LayerNorm backward)
+    int lag = d->lag > 0 ? d->lag : P + (backward ? 5 : 3);
     if (lag < P + 2) lag = P + 2;
     return lag | 1;   // odd: half-rate layers alternate between even and odd launches
+}
+
+// ---- dynamic wavefront schedule ----------------------------------------------------------
+// A layer steps in launch w when (a) the chunk its next step opens has been enqueued on the side
+// stream at least `margin` launches ago (the product then has had time to run: the recurrence
+// stream's event wait does not stall), and (b) its pacing allows it.  Pacing: a layer behind a time
+// reduction needs one step per m_l launches only WHILE faster layers run beside it (every launch
+// then carries <= one step per full-rate layer plus every m-th slower one, alternating by layer
+// parity: the chip holds 4 layer-steps at one workgroup per CU); when no faster layer is running -
+// the tail of the forward pass, the head of the backward pass - it steps in every launch, which
+// removes most of the pipeline skew (E6D2: 547 -> ~490 forward launches, 546 -> ~490 backward).
+struct Pace {
+    // period of layer l given the smallest m among the layers j <= l that are "running"
+    static bool allows(int w, int l, int m_l, int m_min_running) {
+        const int period = max(1, m_l / max(1, m_min_running));
+        return period <= 1 || ((w + period * 1024 - (l % period)) % period) == 0;
+    }
+};
+
+int margin_launches(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, bool backward) {
+    // d->lag keeps its meaning "launches between a producer's and a consumer's first step of a chunk"
+    // (P = launches per chunk): forward default P + 3, backward P + 5 -> margins 3 and 6 launches
+    // after the chunk's side-stream work was enqueued
+    const int P = d->chunk * g[0].f;
+    if (d->lag > 0) return max(1, d->lag - P + (backward ? 1 : 0));
+    return backward ? 6 : 3;
 }
 
 #define ED_TRY(expr)            \
@@ -381,8 +409,6 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
             if (d->layers[l].reduce == 2) { st.split = l + 1; break; }
         if (st.split >= L) st.split = L / 2;
     }
-    const int lag = default_lag(d, g);
-    for (int l = 0; l < L; ++l) g[l].off = l * lag;
 
     // ---- prologue on the caller's stream: input LayerNorm (-> X_0, time-major), initial states
     ED_TRY(ed_stack_input_norm(d->x_dtype, d->x, d->in_gamma, d->in_beta, bptr(d->layers[0].X),
@@ -413,12 +439,18 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     };
     ED_TRY(feed_layer0(1));
 
-    int Wtot = 0;
-    for (int l = 0; l < L; ++l) Wtot = max(Wtot, g[l].off + (g[l].T - 1) * g[l].m + 2);
+    const int margin = margin_launches(d, g, false);
+    std::vector<int> next_t(L, 0), stepped_w(L, -2);
+    std::vector<std::vector<int>> ready_w(L);
+    for (int l = 0; l < L; ++l) ready_w[l].assign(g[l].nchunks, l == 0 ? 0 : 0x3fffffff);
+    int launches = 0, idle = 0;
     if (st.rt && st.rt->tev[0][0]) ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][0], st.R));
     const int T_out = (g[L - 1].T + d->layers[L - 1].reduce - 1) / d->layers[L - 1].reduce;
     struct Done { int l, k; };
-    for (int w = 0; w < Wtot; ++w) {
+    for (int w = 0;; ++w) {
+        bool finished = true;
+        for (int l = 0; l < L; ++l) finished = finished && next_t[l] >= g[l].T && stepped_w[l] < w - 1;
+        if (finished) break;
         EdFwdLaunch Lcs[2];
         for (auto& x : Lcs) {
             x.nstep = x.nnorm = 0;
@@ -429,31 +461,10 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
         for (int l = 0; l < L; ++l) {
             const edgedict_stack_layer_t& y = d->layers[l];
             EdFwdLaunch& Lc = Lcs[l >= st.split ? 1 : 0];
-            // ---- time step of layer l
-            int dw = w - g[l].off;
-            if (dw >= 0 && dw % g[l].m == 0 && dw / g[l].m < g[l].T) {
-                const int t = dw / g[l].m;
-                if (t % g[l].cf == 0) {
-                    const int k = t / g[l].cf;
-                    if (l == 0) ED_TRY(feed_layer0(k + 2));
-                    ED_CHECK_ARG(queued[l][k], "encoder_stack: schedule violated (layer %d chunk %d)", l, k);
-                    ED_TRY(st.wait(st.RS(l), Eg[l][k]));
-                }
-                EdFwdStep& s = Lc.step[Lc.nstep++];
-                bf16_t* f0 = bptr(ws + wl.frag0[l]);
-                bf16_t* f1 = bptr(ws + wl.frag1[l]);
-                s.G_t = bptr(y.G) + (long long)t * B * 4 * H;
-                s.hfrag_in = (t & 1) ? f1 : f0;
-                s.hfrag_out = (t & 1) ? f0 : f1;
-                s.Y_t = bptr(y.Yx) + (long long)(t + 1) * BH;
-                s.C_prev = y.Cx + (long long)t * BH;
-                s.C_t = y.Cx + (long long)(t + 1) * BH;
-                s.Wfrag = bptr(y.whh_f);
-            }
-            // ---- LayerNorm of the frame(s) the previous launch finished
-            dw = w - 1 - g[l].off;
-            if (dw >= 0 && dw % g[l].m == 0 && dw / g[l].m < g[l].T) {
-                const int t = dw / g[l].m;
+            // ---- LayerNorm of the frame the previous launch finished (before the step below
+            // advances next_t)
+            if (stepped_w[l] == w - 1) {
+                const int t = next_t[l] - 1;
                 int ta = -1, tb = -1;
                 if (y.reduce == 1) ta = t;
                 else if (t & 1) { ta = t - 1; tb = t; }
@@ -488,7 +499,41 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
                     ++ndone;
                 }
             }
+            // ---- time step of layer l
+            const int t = next_t[l];
+            if (t >= g[l].T) continue;
+            const int k = t / g[l].cf;
+            const bool opens = (t % g[l].cf == 0);
+            if (opens && !(queued[l][k] && w >= ready_w[l][k]) && l > 0) continue;
+            int m_min = g[l].m;   // slowest-changing layers are paced by the faster ones still running
+            for (int j = 0; j < l; ++j)
+                if (next_t[j] < g[j].T) m_min = min(m_min, g[j].m);
+            if (!Pace::allows(w, l, g[l].m, m_min)) continue;
+            if (opens) {
+                if (l == 0) ED_TRY(feed_layer0(k + 2));
+                ED_CHECK_ARG(queued[l][k], "encoder_stack: schedule violated (layer %d chunk %d)", l, k);
+                ED_TRY(st.wait(st.RS(l), Eg[l][k]));
+            }
+            EdFwdStep& sl = Lc.step[Lc.nstep++];
+            bf16_t* f0 = bptr(ws + wl.frag0[l]);
+            bf16_t* f1 = bptr(ws + wl.frag1[l]);
+            sl.G_t = bptr(y.G) + (long long)t * B * 4 * H;
+            sl.hfrag_in = (t & 1) ? f1 : f0;
+            sl.hfrag_out = (t & 1) ? f0 : f1;
+            sl.Y_t = bptr(y.Yx) + (long long)(t + 1) * BH;
+            sl.C_prev = y.Cx + (long long)t * BH;
+            sl.C_t = y.Cx + (long long)(t + 1) * BH;
+            sl.Wfrag = bptr(y.whh_f);
+            stepped_w[l] = w;
+            next_t[l] = t + 1;
         }
+        if (Lcs[0].nstep + Lcs[0].nnorm + Lcs[1].nstep + Lcs[1].nnorm == 0) {
+            // every unfinished layer waits for a side-stream product: nothing to overlap it with
+            ED_CHECK_ARG(++idle < 4096, "encoder_stack: forward schedule made no progress");
+            continue;
+        }
+        idle = 0;
+        ++launches;
         ED_TRY(ed_stack_launch_fwd(Lcs[0], st.R));
         if (st.split < L) ED_TRY(ed_stack_launch_fwd(Lcs[1], st.R2));
         for (int i = 0; i < ndone; ++i) {
@@ -497,8 +542,10 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
             ED_TRY(input_gemm(d, g, l, k, st.S[l]));
             ED_TRY(st.record(Eg[l][k], st.S[l]));
             queued[l][k] = 1;
+            ready_w[l][k] = w + margin;
         }
     }
+    const int Wtot = launches;
     if (st.rt && st.rt->tev[0][1]) {
         ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][1], st.R));
         st.rt->tlaunches[0] = Wtot;
@@ -539,8 +586,6 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
             if (d->layers[l].reduce == 2) { st.split = l + 1; break; }
         if (st.split >= L) st.split = L / 2;
     }
-    const int lag = default_lag(d, g);
-    for (int l = 0; l < L; ++l) g[l].off = (L - 1 - l) * lag;
     const int T_out = (g[L - 1].T + d->layers[L - 1].reduce - 1) / d->layers[L - 1].reduce;
 
     // ---- prologue: running dL/dc = 0, LayerNorm backward of the top layer (all frames)
@@ -603,11 +648,17 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     if (const char* e = getenv("EDGEDICT_STACK_DW_SEG")) dw_seg = max(1, atoi(e));
     if (d->flags & EDGEDICT_STACK_DW_AT_END) dw_seg = 1 << 20;
 
-    int Wtot = 0;
-    for (int l = 0; l < L; ++l) Wtot = max(Wtot, g[l].off + (g[l].T - 1) * g[l].m + 1);
+    const int margin = margin_launches(d, g, true);
+    std::vector<int> next_t(L, 0);          // BPTT steps done; the next one is frame T - 1 - next_t
+    std::vector<std::vector<int>> ready_w(L);
+    for (int l = 0; l < L; ++l) ready_w[l].assign(g[l].nchunks, l == L - 1 ? 0 : 0x3fffffff);
+    int launches = 0, idle = 0;
     if (st.rt && st.rt->tev[1][0]) ED_CHECK_HIP(hipEventRecord(st.rt->tev[1][0], st.R));
     struct Done { int l, k, t; };
-    for (int w = 0; w < Wtot; ++w) {
+    for (int w = 0;; ++w) {
+        bool finished = true;
+        for (int l = 0; l < L; ++l) finished = finished && next_t[l] >= g[l].T;
+        if (finished) break;
         EdBwdLaunch Lcs[2];
         for (auto& x : Lcs) {
             x.nstep = 0;
@@ -617,31 +668,40 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
         int ndone = 0;
         for (int l = L - 1; l >= 0; --l) {
             const edgedict_stack_layer_t& y = d->layers[l];
-            const int dw = w - g[l].off;
-            if (dw < 0 || dw % g[l].m != 0 || dw / g[l].m >= g[l].T) continue;
-            const int t = g[l].T - 1 - dw / g[l].m;
+            if (next_t[l] >= g[l].T) continue;
+            const int t = g[l].T - 1 - next_t[l];
             const int k = t / g[l].cf;
-            if (t == min(g[l].T, (k + 1) * g[l].cf) - 1) {
-                ED_CHECK_ARG(queued[l][k], "encoder_stack: backward schedule violated (layer %d chunk %d)", l, k);
-                ED_TRY(st.wait(st.RS(l), Eb[l][k]));
-            }
+            const bool opens = (t == min(g[l].T, (k + 1) * g[l].cf) - 1);
+            if (opens && !(queued[l][k] && w >= ready_w[l][k])) continue;
+            int m_min = g[l].m;   // paced only while a faster layer below is in flight
+            for (int j = 0; j < l; ++j)
+                if (next_t[j] > 0 && next_t[j] < g[j].T) m_min = min(m_min, g[j].m);
+            if (!Pace::allows(w, l, g[l].m, m_min)) continue;
+            if (opens) ED_TRY(st.wait(st.RS(l), Eb[l][k]));
             EdBwdLaunch& Lc = Lcs[l >= st.split ? 1 : 0];
-            EdBwdStep& s = Lc.step[Lc.nstep++];
+            EdBwdStep& sl = Lc.step[Lc.nstep++];
             bf16_t* f0 = bptr(ws + wl.frag0[l]);
             bf16_t* f1 = bptr(ws + wl.frag1[l]);
-            s.G_t = bptr(y.G) + (long long)t * B * 4 * H;
-            s.gfrag_in = (t == g[l].T - 1) ? nullptr : (((t + 1) & 1) ? f1 : f0);
-            s.gfrag_out = (t == 0) ? nullptr : ((t & 1) ? f1 : f0);
-            s.dY_t = bptr(y.dZ) + (long long)t * BH;
-            s.C_t = y.Cx + (long long)(t + 1) * BH;
-            s.C_prev = y.Cx + (long long)t * BH;
-            s.dC = (float*)(ws + wl.dC[l]);
-            s.WTfrag = bptr(y.whh_b);
+            sl.G_t = bptr(y.G) + (long long)t * B * 4 * H;
+            sl.gfrag_in = (t == g[l].T - 1) ? nullptr : (((t + 1) & 1) ? f1 : f0);
+            sl.gfrag_out = (t == 0) ? nullptr : ((t & 1) ? f1 : f0);
+            sl.dY_t = bptr(y.dZ) + (long long)t * BH;
+            sl.C_t = y.Cx + (long long)(t + 1) * BH;
+            sl.C_prev = y.Cx + (long long)t * BH;
+            sl.dC = (float*)(ws + wl.dC[l]);
+            sl.WTfrag = bptr(y.whh_b);
             if (t == k * g[l].cf) {
                 done[ndone].l = l; done[ndone].k = k; done[ndone].t = t;
                 ++ndone;
             }
+            ++next_t[l];
         }
+        if (Lcs[0].nstep + Lcs[1].nstep == 0) {
+            ED_CHECK_ARG(++idle < 4096, "encoder_stack: backward schedule made no progress");
+            continue;
+        }
+        idle = 0;
+        ++launches;
         ED_TRY(ed_stack_launch_bwd(Lcs[0], st.R));
         if (st.split < L) ED_TRY(ed_stack_launch_bwd(Lcs[1], st.R2));
         for (int i = 0; i < ndone; ++i) {
@@ -665,6 +725,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                                        LNB_GRID, B, H, u0, u1, z.reduce, S));
                 ED_TRY(st.record(Eb[l - 1][k], S));
                 queued[l - 1][k] = 1;
+                ready_w[l - 1][k] = w + margin;
             }
             // chunks complete from the last to the first: a segment [k, k + dw_seg) is complete when
             // its lowest chunk is (k a multiple of dw_seg, counted so that the LAST segment issued,
@@ -681,6 +742,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
             }
         }
     }
+    const int Wtot = launches;
     if (st.rt && st.rt->tev[1][1]) {
         ED_CHECK_HIP(hipEventRecord(st.rt->tev[1][1], st.R));
         st.rt->tlaunches[1] = Wtot;
