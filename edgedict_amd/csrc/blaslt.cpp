@@ -83,8 +83,14 @@ long long g_calls = 0;
 
 }  // namespace
 
-bool ed_blaslt_nt_bf16(const void* A, long long lda, const void* B, long long ldb, void* C,
-                       long long ldc, int M, int N, int K, const float* bias, hipStream_t s) {
+namespace {
+
+// D (column-major m x n, ld ldd, type dtype_d) = alpha op(P) op(Q) + beta D (+ bias over the m rows)
+// with P, Q bf16, fp32 accumulation.  Returns false when the library cannot / may not do it.
+bool run(hipblasOperation_t opP, hipblasOperation_t opQ, const void* P, long long rowsP, long long colsP,
+         long long ldp, const void* Q, long long rowsQ, long long colsQ, long long ldq, void* D,
+         hipDataType dtype_d, int m, int n, long long ldd, float beta, const float* bias, int tag,
+         hipStream_t s) {
     const Api& L = api();
     if (!L.ok) return false;
     int dev = 0;
@@ -99,16 +105,13 @@ bool ed_blaslt_nt_bf16(const void* A, long long lda, const void* B, long long ld
             return false;
         }
     }
-    // row-major C[M,N] = A[M,K] B[N,K]^T  ==  column-major D[N,M] = op(B)[N,K] A'[K,M] with
-    // B seen as column-major [K,N] (ld ldb, transposed) and A as column-major [K,M] (ld lda)
     hipblasLtMatmulDesc_t desc = nullptr;
     hipblasLtMatrixLayout_t la = nullptr, lb = nullptr, lc = nullptr;
     bool done = false;
     do {
         if (L.DescCreate(&desc, HIPBLAS_COMPUTE_32F, HIP_R_32F) != HIPBLAS_STATUS_SUCCESS) break;
-        const hipblasOperation_t opT = HIPBLAS_OP_T, opN = HIPBLAS_OP_N;
-        if (L.DescSet(desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opT, sizeof(opT)) != HIPBLAS_STATUS_SUCCESS) break;
-        if (L.DescSet(desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opN, sizeof(opN)) != HIPBLAS_STATUS_SUCCESS) break;
+        if (L.DescSet(desc, HIPBLASLT_MATMUL_DESC_TRANSA, &opP, sizeof(opP)) != HIPBLAS_STATUS_SUCCESS) break;
+        if (L.DescSet(desc, HIPBLASLT_MATMUL_DESC_TRANSB, &opQ, sizeof(opQ)) != HIPBLAS_STATUS_SUCCESS) break;
         if (bias) {
             const hipblasLtEpilogue_t epi = HIPBLASLT_EPILOGUE_BIAS;
             const hipDataType bt = HIP_R_32F;
@@ -116,10 +119,11 @@ bool ed_blaslt_nt_bf16(const void* A, long long lda, const void* B, long long ld
             if (L.DescSet(desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof(bt)) != HIPBLAS_STATUS_SUCCESS) break;
             if (L.DescSet(desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias, sizeof(bias)) != HIPBLAS_STATUS_SUCCESS) break;
         }
-        if (L.LayoutCreate(&la, HIP_R_16BF, K, N, ldb) != HIPBLAS_STATUS_SUCCESS) break;   // "A" = B^T source
-        if (L.LayoutCreate(&lb, HIP_R_16BF, K, M, lda) != HIPBLAS_STATUS_SUCCESS) break;
-        if (L.LayoutCreate(&lc, HIP_R_16BF, N, M, ldc) != HIPBLAS_STATUS_SUCCESS) break;
-        const auto key = std::make_tuple(M, N, K, lda, ldb, ldc, bias ? 1 : 0);
+        if (L.LayoutCreate(&la, HIP_R_16BF, rowsP, colsP, ldp) != HIPBLAS_STATUS_SUCCESS) break;
+        if (L.LayoutCreate(&lb, HIP_R_16BF, rowsQ, colsQ, ldq) != HIPBLAS_STATUS_SUCCESS) break;
+        if (L.LayoutCreate(&lc, dtype_d, m, n, ldd) != HIPBLAS_STATUS_SUCCESS) break;
+        const long long kdim = opP == HIPBLAS_OP_N ? colsP : rowsP;
+        const auto key = std::make_tuple(m, n, (int)kdim, ldp, ldq, ldd, tag * 4 + (bias ? 1 : 0) + (beta != 0.f ? 2 : 0));
         auto it = d.cache.find(key);
         if (it == d.cache.end()) {
             PerDevice::Entry en{};
@@ -129,9 +133,9 @@ bool ed_blaslt_nt_bf16(const void* A, long long lda, const void* B, long long ld
                 const uint64_t wsmax = WS_BYTES;
                 L.PrefSet(pref, HIPBLASLT_MATMUL_PREF_MAX_WORKSPACE_BYTES, &wsmax, sizeof(wsmax));
                 hipblasLtMatmulHeuristicResult_t res[1];
-                int n = 0;
-                if (L.Heuristic(d.handle, desc, la, lb, lc, lc, pref, 1, res, &n) == HIPBLAS_STATUS_SUCCESS &&
-                    n > 0 && res[0].state == HIPBLAS_STATUS_SUCCESS && res[0].workspaceSize <= WS_BYTES) {
+                int cnt = 0;
+                if (L.Heuristic(d.handle, desc, la, lb, lc, lc, pref, 1, res, &cnt) == HIPBLAS_STATUS_SUCCESS &&
+                    cnt > 0 && res[0].state == HIPBLAS_STATUS_SUCCESS && res[0].workspaceSize <= WS_BYTES) {
                     en.algo = res[0].algo;
                     en.ws = res[0].workspaceSize;
                     en.valid = true;
@@ -142,8 +146,8 @@ bool ed_blaslt_nt_bf16(const void* A, long long lda, const void* B, long long ld
             it = d.cache.emplace(key, en).first;
         }
         if (!it->second.valid) break;
-        const float one = 1.f, zero = 0.f;
-        if (L.Matmul(d.handle, desc, &one, B, la, A, lb, &zero, C, lc, C, lc, &it->second.algo, d.ws,
+        const float one = 1.f;
+        if (L.Matmul(d.handle, desc, &one, P, la, Q, lb, &beta, D, lc, D, lc, &it->second.algo, d.ws,
                      WS_BYTES, s) != HIPBLAS_STATUS_SUCCESS) {
             it->second.valid = false;
             break;
@@ -156,6 +160,32 @@ bool ed_blaslt_nt_bf16(const void* A, long long lda, const void* B, long long ld
     if (lc) L.LayoutDestroy(lc);
     if (desc) L.DescDestroy(desc);
     return done;
+}
+
+}  // namespace
+
+bool ed_blaslt_nt_bf16(const void* A, long long lda, const void* B, long long ldb, void* C,
+                       long long ldc, int M, int N, int K, const float* bias, hipStream_t s) {
+    // row-major C[M,N] = A[M,K] B[N,K]^T  ==  column-major D[N,M] = op(B)[N,K] A'[K,M] with
+    // B seen as column-major [K,N] (ld ldb, transposed) and A as column-major [K,M] (ld lda)
+    return run(HIPBLAS_OP_T, HIPBLAS_OP_N, B, K, N, ldb, A, K, M, lda, C, HIP_R_16BF, N, M, ldc, 0.f, bias, 0, s);
+}
+
+bool ed_blaslt_tn_f32(const void* A, long long lda, const void* B, long long ldb, float* C,
+                      long long ldc, int M, int N, int K, int accumulate, hipStream_t s) {
+    // row-major C[M,N] (+)= A[K,M]^T B[K,N] (both operands K-strided: weight gradients)
+    //   == column-major D[N,M] = B'[N,K] A'[M,K]^T, B' = B seen column-major [N,K] (ld ldb),
+    //      A' = A seen column-major [M,K] (ld lda)
+    // EDGEDICT_BLASLT_BG: 0 none, 1 the encoder stack's weight gradients (the "partials" callers),
+    // 2 also direct accumulating products (the joint's dW2)
+    static const int mode = [] {
+        const char* e = getenv("EDGEDICT_BLASLT_BG");
+        return e ? atoi(e) : 1;   // measured: 27.0 ms (1), 27.7 (2: the loud dW2 delays the
+                                  // small critical kernels between the joint's and the stack's backward), 27.7 (0)
+    }();
+    if (mode <= 0 || (accumulate && mode < 2)) return false;
+    return run(HIPBLAS_OP_N, HIPBLAS_OP_T, B, N, K, ldb, A, M, K, lda, C, HIP_R_32F, N, M, ldc,
+               accumulate ? 1.f : 0.f, nullptr, 1, s);
 }
 
 // number of products the vendor route has taken in this process (bench.py labels its MFMA

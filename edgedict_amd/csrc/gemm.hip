@@ -533,6 +533,14 @@ static int gemm_impl(int dtype_in, int dtype_out, const void* A, long long lda, 
 int ed_gemm_quiet_partials(int dtype_in, const void* A, long long lda, int a_kmajor, const void* B,
                            long long ldb, int b_kmajor, int M, int N, int K, int split_k,
                            int max_wg_per_cu, float* partials, int* slices, hipStream_t stream) {
+    // large bf16 weight-gradient products: the vendor kernel's 256x256 tiles pull half the bytes per
+    // flop through the CU fetch path that the recurrence beside it is bound by (blaslt.cpp)
+    if (dtype_in == ED_BF16 && !a_kmajor && !b_kmajor && (long long)M * N >= (1ll << 18) && K >= 4096 &&
+        lda % 8 == 0 && ldb % 8 == 0 && N % 4 == 0 &&
+        ed_blaslt_tn_f32(A, lda, B, ldb, partials, N, M, N, K, 0, stream)) {
+        *slices = 1;
+        return ED_OK;
+    }
     int p2 = 1;
     while (p2 < split_k && p2 < 8) p2 *= 2;
     const int bk = dtype_in == ED_F32 ? 16 : 64;
@@ -559,6 +567,10 @@ extern "C" int edgedict_gemm_bg(int dtype_in, int dtype_out, const void* A, long
     ED_CHECK_ARG(max_wg_per_cu >= 1 && max_wg_per_cu <= 8, "gemm_bg: max_wg_per_cu must be 1..8");
     ED_CHECK_ARG(!partials || dtype_out == ED_F32, "gemm_bg: the quiet (partials) form needs an fp32 output");
     ED_CHECK_ARG(!partials || (!bias1 && !bias2), "gemm_bg: the quiet (partials) form takes no bias");
+    if (dtype_in == ED_BF16 && dtype_out == ED_F32 && !a_kmajor && !b_kmajor && !bias1 && !bias2 && A && B && C &&
+        (long long)M * N >= (1ll << 18) && K >= 4096 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 &&
+        ed_blaslt_tn_f32(A, lda, B, ldb, (float*)C, ldc, M, N, K, accumulate, (hipStream_t)stream_))
+        return ED_OK;
     return gemm_impl(dtype_in, dtype_out, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, bias1,
                      bias2, accumulate, split_k, stream_, max_wg_per_cu, partials, true);
 }
