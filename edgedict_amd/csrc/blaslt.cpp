@@ -165,10 +165,12 @@ bool run(hipblasOperation_t opP, hipblasOperation_t opQ, const void* P, long lon
 }  // namespace
 
 bool ed_blaslt_nt_bf16(const void* A, long long lda, const void* B, long long ldb, void* C,
-                       long long ldc, int M, int N, int K, const float* bias, hipStream_t s) {
+                       long long ldc, int M, int N, int K, const float* bias, int accumulate,
+                       hipStream_t s) {
     // row-major C[M,N] = A[M,K] B[N,K]^T  ==  column-major D[N,M] = op(B)[N,K] A'[K,M] with
     // B seen as column-major [K,N] (ld ldb, transposed) and A as column-major [K,M] (ld lda)
-    return run(HIPBLAS_OP_T, HIPBLAS_OP_N, B, K, N, ldb, A, K, M, lda, C, HIP_R_16BF, N, M, ldc, 0.f, bias, 0, s);
+    return run(HIPBLAS_OP_T, HIPBLAS_OP_N, B, K, N, ldb, A, K, M, lda, C, HIP_R_16BF, N, M, ldc,
+               accumulate ? 1.f : 0.f, bias, 0, s);
 }
 
 bool ed_blaslt_tn_f32(const void* A, long long lda, const void* B, long long ldb, float* C,

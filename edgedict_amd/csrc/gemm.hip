@@ -455,7 +455,18 @@ static int gemm_impl(int dtype_in, int dtype_out, const void* A, long long lda, 
     if (dtype_in == ED_BF16 && dtype_out == ED_BF16 && a_kmajor && b_kmajor && !accumulate && !bias2 &&
         split_k == 1 && max_wg_per_cu == 0 && K <= 1024 && N >= 1024 && (long long)M * N >= (1ll << 28) &&
         lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 &&
-        ed_blaslt_nt_bf16(A, lda, B, ldb, C, ldc, M, N, K, bias1, stream))
+        ed_blaslt_nt_bf16(A, lda, B, ldb, C, ldc, M, N, K, bias1, 0, stream))
+        return ED_OK;
+    // ... and the long-K, few-tiles products of the encoder stack's backward chain (dX of a chunk:
+    // [768..1536 x 1024 x 4096], 19-23 us there vs 32 us here, tools/blas_probe2.py)
+    static const bool small_vendor = [] {
+        const char* e = getenv("EDGEDICT_BLASLT_SMALL");   // measured: step 27.17 -> 27.01 ms
+        return !(e && e[0] == '0');
+    }();
+    if (small_vendor && dtype_in == ED_BF16 && dtype_out == ED_BF16 && a_kmajor && b_kmajor && !bias1 && !bias2 &&
+        split_k == 1 && max_wg_per_cu == 0 && K >= 2048 && M <= 4096 && N <= 2048 && M >= 256 &&
+        lda % 8 == 0 && ldb % 8 == 0 && ldc % 8 == 0 &&
+        ed_blaslt_nt_bf16(A, lda, B, ldb, C, ldc, M, N, K, nullptr, accumulate, stream))
         return ED_OK;
     if (nt_enabled && max_wg_per_cu == 0 &&
         ed_gemm_nt_ok(dtype_in, dtype_out, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, split_k, bias1, bias2))
