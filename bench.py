@@ -175,8 +175,8 @@ def main():
             with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as fh:
                 pmc = json.load(fh)["kernels"]
             tiles = ((rows + 127) // 128) * ((V + 127) // 128)
-            if vendor:   # hipBLASLt kernel names start with Cijk_; the logits product is the big one
-                cands = [v for k, v in pmc.items() if k.startswith("Cijk_")]
+            if vendor:   # hipBLASLt kernel names contain Cijk_; the logits product moves the most bytes
+                cands = [v for k, v in pmc.items() if "Cijk_" in k]
                 ent = max(cands, key=lambda v: v["hbm_bytes"]) if cands else None
             else:
                 ent = next((v for k, v in pmc.items()
