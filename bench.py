@@ -171,6 +171,7 @@ def main():
         from edgedict_amd import _lib as _edlib
         vendor = _edlib.load().edgedict_blaslt_calls() > 0
         traffic = None
+        mfma_util = None     # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs), same PMC file
         try:
             with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as fh:
                 pmc = json.load(fh)["kernels"]
@@ -183,6 +184,7 @@ def main():
                             if k.startswith("gemm_nt_kernel") and k.endswith("[tiles=%d]" % tiles)), None)
             if ent:
                 traffic = ent["hbm_bytes"]
+                mfma_util = ent.get("mfma_util")
         except (OSError, ValueError, KeyError):
             pass
         # ---- dominant kernel: stack_bwd_kernel (the BPTT wavefront launches, ~23 % of all kernel time)
@@ -249,7 +251,7 @@ def main():
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": traffic,
                 "algorithmic_bytes": 2.0 * rows * (J + V) + 2.0 * V * J,
-                "launch_ms": ms, "launches_timed": n,
+                "launch_ms": ms, "launches_timed": n, "mfma_util_pmc": mfma_util,
             },
             "kernel_ms": {k: round(v[1], 4) for k, v in sorted(timers.items())},
             "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 3),

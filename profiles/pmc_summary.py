@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE).
 
-    python profiles/pmc_summary.py out.json fetch_results.db write_results.db
+    python profiles/pmc_summary.py out.json fetch_results.db write_results.db [mfma_results.db]
 
 Units and gfx950 corrections follow MI355X_MICROARCH.md (HBM section): both counters are in KiB
 (bytes = value * 1024); on gfx950 FETCH_SIZE reports exactly HALF of the bytes of a wide coalesced
@@ -40,9 +40,14 @@ def per_kernel(db, counter):
     return {k: (n, s / n) for k, (n, s) in out.items()}
 
 
-def main(out, fdb, wdb):
+def main(out, fdb, wdb, mdb=None):
     f = per_kernel(fdb, "FETCH_SIZE")
     w = per_kernel(wdb, "WRITE_SIZE")
+    mfma = gui = {}
+    if mdb:   # third pass: matrix-pipe busy cycles over chip-active cycles (gfx94x MfmaUtil formula:
+              # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs))
+        mfma = per_kernel(mdb, "SQ_VALU_MFMA_BUSY_CYCLES")
+        gui = per_kernel(mdb, "GRBM_GUI_ACTIVE")
     res = {}
     for k in sorted(set(f) | set(w)):
         fn, fv = f.get(k, (0, 0.0))
@@ -51,15 +56,20 @@ def main(out, fdb, wdb):
                   "fetch_bytes_raw": fv * 1024.0, "fetch_bytes_corrected": 2.0 * fv * 1024.0,
                   "write_bytes_raw": wv * 1024.0,
                   "hbm_bytes": 2.0 * fv * 1024.0 + wv * 1024.0}
+        if k in mfma and k in gui and gui[k][1] > 0:
+            res[k]["mfma_busy_cycles"] = mfma[k][1]
+            res[k]["gui_active_cycles"] = gui[k][1]
+            res[k]["mfma_util"] = mfma[k][1] / (gui[k][1] * 256 * 4)
     with open(out, "w") as fh:
         json.dump({"note": "per-launch averages; FETCH_SIZE x2 gfx950 correction applied in "
                            "fetch_bytes_corrected / hbm_bytes (MI355X_MICROARCH.md, HBM section)",
                    "kernels": res}, fh, indent=1, sort_keys=True)
     top = sorted(res.items(), key=lambda kv: -kv[1]["hbm_bytes"] * kv[1]["launches"])[:12]
     for k, v in top:
-        print("%-60s n=%5d  fetch(corr) %8.1f MB  write %8.1f MB" %
-              (k[:60], v["launches"], v["fetch_bytes_corrected"] / 1e6, v["write_bytes_raw"] / 1e6))
+        print("%-60s n=%5d  fetch(corr) %8.1f MB  write %8.1f MB  mfma_util %s" %
+              (k[:60], v["launches"], v["fetch_bytes_corrected"] / 1e6, v["write_bytes_raw"] / 1e6,
+               ("%.1f%%" % (100 * v["mfma_util"])) if "mfma_util" in v else "-"))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2], sys.argv[3])
+    main(*sys.argv[1:5])
