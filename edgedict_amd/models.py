@@ -765,6 +765,33 @@ class Transducer(nn.Module):
         return beam_search_batch(self, xs, xlen, W, max_expansions)
 
 
+class _OutsideHotPath(nn.Module):
+    """Names the reference's scripts import next to ``Transducer`` (cli/train.py:18,
+    rnnt/wav2vec.py:12) but whose arithmetic is not on the MI355X hot path (SURVEY.md 8f rank 4,
+    DESIGN.md section 8).  They stay importable so that those scripts load; constructing one fails
+    loudly - there is no eager-PyTorch fallback in this engine."""
+
+    _what = ""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError(
+            "%s is not implemented by the MI355X engine (%s); use the log-mel front-end and the LSTM "
+            "encoder (cli/baseline.py path)" % (type(self).__name__, self._what))
+
+
+class FrontEnd(_OutsideHotPath):
+    _what = "the wav2vec-style convolutional feature extractor of rnnt/models.py:313-365"
+
+
+class ResLayerNormGRU(_OutsideHotPath):
+    _what = "the GRU encoder variant of rnnt/models.py:77-116"
+
+
+class CTCEncoder(_OutsideHotPath):
+    _what = "the CTC encoder of rnnt/models.py:272-311"
+
+
 def convert_lightning2normal(checkpoint):
     """Lightning checkpoint -> ``{'model': state_dict}`` (same contract as the reference's
     rnnt/models.py:366-380): when the file has a ``state_dict`` whose keys carry the Lightning
