@@ -194,6 +194,68 @@ class _LSTMBlockFn(torch.autograd.Function):
         return (dx, dw_ih, dw_hh, db, db.clone(), dgamma, dbeta, None, None, None, None, None)
 
 
+class _GRUBlockFn(torch.autograd.Function):
+    """One 1-layer GRU over the whole sequence + the encoder's residual add / LayerNorm /
+    TimeReduction, as ``_LSTMBlockFn`` (ResLayerNormGRU.forward, rnnt/models.py:99-116).
+
+    forward : G = x W_ih^T + b_ih (one MFMA GEMM) -> T step kernels (csrc/gru.hip) -> fused LN epilogue
+    backward: LN backward -> T BPTT step kernels (G -> input-side, DH -> hidden-side pre-activation
+              gradients) -> dX, dW_ih, dW_hh as GEMMs, both biases as column sums."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, ln_w, ln_b, h0, residual, reduce, cd):
+        B, T, I = x.shape
+        H = w_hh.shape[1]
+        G = ops.gemm(x.view(B * T, I), WEIGHTS.get(w_ih, cd), bias=b_ih.detach()).view(B, T, 3 * H)
+        with ops.timed("gru_fwd_T%d_H%d" % (T, H)):
+            Y, Hprev, HN, hN = ops.gru_forward(G, WEIGHTS.get(w_hh, cd), b_hh.detach(), h0)
+        if ln_w is not None:
+            out, mean, rstd = ops.layernorm_fwd(Y, x if residual else None, ln_w.detach(),
+                                                ln_b.detach(), reduce)
+        else:
+            out, mean, rstd = Y, None, None
+        ctx.save_for_backward(x, w_ih, w_hh, ln_w)
+        ctx.inter = (G, Y, Hprev, HN, mean, rstd)
+        ctx.cfg = (residual, reduce, cd, ln_w is not None)
+        ctx.mark_non_differentiable(hN)
+        return out, hN
+
+    @staticmethod
+    def backward(ctx, dout, _dh):
+        if ctx.inter is None:
+            raise RuntimeError("edgedict_amd: this GRU block's saved gates were consumed by a "
+                               "previous backward (retain_graph is not supported)")
+        x, w_ih, w_hh, ln_w = ctx.saved_tensors
+        G, Y, Hprev, HN, mean, rstd = ctx.inter
+        ctx.inter = None
+        residual, reduce, cd, has_ln = ctx.cfg
+        B, T, I = x.shape
+        H = w_hh.shape[1]
+        dgamma = dbeta = None
+        if has_ln:
+            ds, dgamma, dbeta = ops.layernorm_bwd(dout, Y, x if residual else None,
+                                                  ln_w.detach(), mean, rstd, reduce)
+        else:
+            ds = dout.contiguous()
+        with ops.timed("gru_bwd_T%d_H%d" % (T, H)):
+            DH = ops.gru_backward(G, ds, Hprev, HN, WEIGHTS.get(w_hh, cd, transposed=True))
+        M = B * T
+        dG, dH2, x2 = G.view(M, 3 * H), DH.view(M, 3 * H), x.view(M, I)
+        dw_ih = ops.gemm(dG.t(), x2.t(), out_dtype=F32, split_k=ops.pick_split_k(3 * H, I, M))
+        dw_hh = ops.gemm(dH2.t(), Hprev.view(M, H).t(), out_dtype=F32,
+                         split_k=ops.pick_split_k(3 * H, H, M))
+        db_ih, db_hh = ops.colsum(dG), ops.colsum(dH2)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wih = WEIGHTS.get(w_ih, cd)
+            if residual and has_ln:
+                dx = ds  # d(residual) + dG W_ih, accumulated in place by the GEMM epilogue
+                ops.gemm(dG, wih.t(), out=ds.view(M, I), accumulate=True)
+            else:
+                dx = ops.gemm(dG, wih.t()).view(B, T, I)
+        return (dx, dw_ih, dw_hh, db_ih, db_hh, dgamma, dbeta, None, None, None, None)
+
+
 class _DropoutFn(torch.autograd.Function):
     """Training-mode dropout with a counter-based mask (csrc/elementwise.hip): the backward pass
     re-applies the same (p, seed) to the gradient, no mask tensor is kept."""
@@ -546,6 +608,66 @@ class ResLayerNormLSTM(nn.Module):
         return xs, (torch.stack(new_hs, 0), torch.stack(new_cs, 0))
 
 
+class _GRUParams(nn.Module):
+    """nn.GRU-compatible 1-layer parameter set: weight_ih_l0 [3H,I], weight_hh_l0 [3H,H],
+    bias_ih_l0, bias_hh_l0 [3H]; gate order r,z,n; uniform(-1/sqrt(H), 1/sqrt(H))."""
+
+    def __init__(self, input_size, hidden_size):
+        super().__init__()
+        self.input_size, self.hidden_size, self.num_layers = input_size, hidden_size, 1
+        k = 1.0 / math.sqrt(hidden_size)
+        for name, shape in (("weight_ih", (3 * hidden_size, input_size)),
+                            ("weight_hh", (3 * hidden_size, hidden_size)),
+                            ("bias_ih", (3 * hidden_size,)), ("bias_hh", (3 * hidden_size,))):
+            setattr(self, name + "_l0", nn.Parameter(torch.empty(*shape).uniform_(-k, k)))
+
+    def layer(self, k=0):
+        return tuple(getattr(self, n + "_l0") for n in ("weight_ih", "weight_hh", "bias_ih", "bias_hh"))
+
+    def flatten_parameters(self):
+        pass
+
+
+class ResLayerNormGRU(nn.Module):
+    """Stack of 1-layer GRUs with residual connections, LayerNorm and optional time reduction
+    (reference rnnt/models.py:77-116; the module list is called ``lstms`` there too, so the
+    state-dict keys are those of the LSTM variant with 3H rows).  ``hiddens`` is ONE tensor
+    [L,B,H].  Per-layer kernels only (csrc/gru.hip): this variant is a compatibility module."""
+
+    def __init__(self, input_size, hidden_size, num_layers, dropout=0,
+                 time_reductions=[1], reduction_factor=2):
+        super().__init__()
+        if reduction_factor != 2:
+            raise ValueError("only reduction_factor=2 is implemented (the reference default)")
+        self.dropout = dropout
+        self.hidden_size = hidden_size
+        self.lstms = nn.ModuleList()
+        self.projs = nn.ModuleList()
+        self.reductions = []
+        for i in range(num_layers):
+            self.lstms.append(_GRUParams(input_size, hidden_size))
+            proj = [_LayerNormParams(hidden_size)]
+            if i in time_reductions:
+                proj.append(TimeReduction(reduction_factor))
+            self.reductions.append(2 if i in time_reductions else 1)
+            input_size = hidden_size
+            self.projs.append(nn.Sequential(*proj))
+
+    def forward(self, xs, hiddens=None, cd=None):
+        cd = cd or config.get_compute_dtype()
+        xs = _to_cd(xs, cd) if xs.dtype != cd else xs
+        new_hs = []
+        for i, (gru, proj) in enumerate(zip(self.lstms, self.projs)):
+            h0 = _state(hiddens[i]) if hiddens is not None else None
+            w_ih, w_hh, b_ih, b_hh = gru.layer(0)
+            xs, h = _GRUBlockFn.apply(xs.contiguous(), w_ih, w_hh, b_ih, b_hh, proj[0].weight,
+                                      proj[0].bias, h0, i != 0, self.reductions[i], cd)
+            if self.dropout > 0 and self.training:
+                xs = _dropout(xs, self.dropout)
+            new_hs.append(h)
+        return xs, torch.stack(new_hs, 0)
+
+
 class Encoder(nn.Module):
     """LayerNorm -> ResLayerNormLSTM -> Linear (reference rnnt/models.py:119-136)."""
 
@@ -663,13 +785,10 @@ class Transducer(nn.Module):
         self.blank = blank
         if module_type not in ['GRU', 'LSTM']:
             raise ValueError('Unsupported module type')
-        if module_type == 'GRU':
-            raise NotImplementedError(
-                "the GRU encoder variant is outside the MI355X hot path (SURVEY.md 8f)")
         self.encoder = Encoder(input_size=input_size, hidden_size=enc_hidden_size,
                                num_layers=enc_layers, dropout=enc_dropout,
                                proj_size=enc_proj_size, time_reductions=enc_time_reductions,
-                               module=ResLayerNormLSTM)
+                               module=ResLayerNormGRU if module_type == 'GRU' else ResLayerNormLSTM)
         self.decoder = Decoder(vocab_embed_size=vocab_embed_size, vocab_size=vocab_size,
                                hidden_size=dec_hidden_size, num_layers=dec_layers,
                                dropout=dec_dropout, proj_size=dec_proj_size)
@@ -782,10 +901,6 @@ class _OutsideHotPath(nn.Module):
 
 class FrontEnd(_OutsideHotPath):
     _what = "the wav2vec-style convolutional feature extractor of rnnt/models.py:313-365"
-
-
-class ResLayerNormGRU(_OutsideHotPath):
-    _what = "the GRU encoder variant of rnnt/models.py:77-116"
 
 
 class CTCEncoder(_OutsideHotPath):

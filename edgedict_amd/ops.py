@@ -246,6 +246,39 @@ def lstm_backward(G, dY, Cst, c0, WhhT, WhhT_packed=None):
     return G
 
 
+def gru_forward(G, Whh, b_hh, h0=None):
+    """GRU recurrence over G[B,T,3H] (= x W_ih^T + b_ih, overwritten with r,z,n).
+    Returns (Y, Hprev, HN, hN)."""
+    require_cuda(G)
+    B, T, H3 = G.shape
+    H = H3 // 3
+    assert G.is_contiguous() and Whh.is_contiguous() and Whh.shape == (H3, H) and Whh.dtype == G.dtype
+    assert b_hh.dtype == torch.float32 and b_hh.shape == (H3,)
+    dev = G.device
+    Hprev = torch.empty(B, T, H, dtype=G.dtype, device=dev)
+    Y = torch.empty(B, T, H, dtype=G.dtype, device=dev)
+    HN = torch.empty(B, T, H, dtype=G.dtype, device=dev)
+    hN = torch.empty(B, H, dtype=torch.float32, device=dev)
+    if h0 is not None:
+        assert h0.dtype == torch.float32 and h0.is_contiguous() and h0.shape == (B, H)
+    call("gru_forward", dtype_code(G.dtype), G, Hprev, Y, HN, Whh, b_hh.contiguous(), h0, hN, B, T, H)
+    return Y, Hprev, HN, hN
+
+
+def gru_backward(G, dY, Hprev, HN, WhhT):
+    """BPTT sweep: G (saved r,z,n) becomes the input-side pre-activation gradient; returns DH, the
+    hidden-side one."""
+    B, T, H3 = G.shape
+    H = H3 // 3
+    assert WhhT.shape == (H, H3) and WhhT.is_contiguous() and WhhT.dtype == G.dtype
+    if dY is not None:
+        assert dY.is_contiguous() and dY.dtype == G.dtype and dY.shape == (B, T, H)
+    DH = torch.empty_like(G)
+    dh = torch.empty(B, H, dtype=torch.float32, device=G.device)
+    call("gru_backward", dtype_code(G.dtype), G, DH, dY, Hprev, HN, WhhT, dh, B, T, H)
+    return DH
+
+
 def embedding_fwd(tokens, weight, out_dtype, prepend_bos, bos):
     """tokens int32 [B,U] -> [B, U(+1), E] in out_dtype; weight may be the fp32 master."""
     require_cuda(weight)

@@ -386,6 +386,26 @@ int edgedict_greedy_decode(int dtype, const void* E1, long long e_row_stride,
                            void* dec_out, int blank, int unk, int32_t* tokens_out, int tok_stride,
                            float* score, void* workspace, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * GRU time recurrence (the module_type='GRU' encoder variant, ResLayerNormGRU rnnt/models.py:77-116;
+ * PyTorch nn.GRU semantics, gate order r,z,n).  Batch-first buffers, one kernel per time step:
+ *   G      [B,T,3H] dtype  in : x W_ih^T + b_ih for every t;  out: r, z, n (post-activation)
+ *   Hprev  [B,T,H]  dtype  out: h_{t-1} per step (row t=0 <- h0 or zeros)
+ *   Y      [B,T,H]  dtype  out: h_t;   HN [B,T,H] dtype out: W_hn h_{t-1} + b_hn (saved for BPTT)
+ *   Whh    [3H,H]   dtype; b_hh fp32 [3H]; h0 fp32 [B,H] nullable; hN fp32 [B,H] nullable
+ * backward (after forward, same buffers):
+ *   G      in: r,z,n;  out: dL/d(input-side pre-activations)    -> dX, dW_ih, db_ih
+ *   DH     [B,T,3H] dtype out: dL/d(hidden-side pre-activations) -> dW_hh (with Hprev), db_hh
+ *   dY     [B,T,H] dtype nullable;  WhhT [H,3H] dtype;  dh_ws fp32 [B,H] scratch
+ * Limits: H % 8 == 0.  The gradient wrt h0 is not produced.
+ */
+int edgedict_gru_forward(int dtype, void* G, void* Hprev, void* Y, void* HN, const void* Whh,
+                         const float* b_hh, const float* h0, float* hN, int B, int T, int H,
+                         void* stream);
+int edgedict_gru_backward(int dtype, void* G, void* DH, const void* dY, const void* Hprev,
+                          const void* HN, const void* WhhT, float* dh_ws, int B, int T, int H,
+                          void* stream);
+
 /* Number of products edgedict_gemm has handed to hipBLASLt in this process (only the large,
  * short-K bf16 NT product of the joint's logits qualifies; csrc/blaslt.cpp).  0 when the vendor
  * library is absent or EDGEDICT_BLASLT=0: every product then runs on this library's kernels. */

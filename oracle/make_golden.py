@@ -29,6 +29,10 @@ CASES = {
     "tiny": (dict(vocab_embed_size=8, vocab_size=40, input_size=24, enc_hidden_size=32,
                   enc_layers=3, enc_proj_size=24, dec_hidden_size=16, dec_layers=2,
                   dec_proj_size=16, joint_size=32), 3, 11, 5, 101),
+    # module_type='GRU' encoder variant (ResLayerNormGRU, rnnt/models.py:77-116)
+    "gru_tiny": (dict(vocab_embed_size=8, vocab_size=40, input_size=24, enc_hidden_size=32,
+                      enc_layers=3, enc_proj_size=24, dec_hidden_size=16, dec_layers=2,
+                      dec_proj_size=16, joint_size=32, module_type="GRU"), 3, 11, 5, 202),
     "E4D1": (dict(vocab_embed_size=64, vocab_size=2048, input_size=240, enc_hidden_size=256,
                   enc_layers=4, enc_proj_size=256, dec_hidden_size=256, dec_layers=1,
                   dec_proj_size=256, joint_size=256), 4, 167, 20, 0),
@@ -36,8 +40,25 @@ CASES = {
 
 
 def reference_model(cfg, sd):
-    sys.path.insert(0, REF)
-    import rnnt.models as ref
+    # the repository root holds an `rnnt` shim package of the same name, and the reference's `rnnt`
+    # is a namespace package (no __init__.py), which loses against a regular package wherever it
+    # sits on sys.path: load the reference's modules from their files under the name `rnnt`
+    import importlib.util
+    import types
+    for k in [k for k in sys.modules if k == "rnnt" or k.startswith("rnnt.")]:
+        del sys.modules[k]
+    if REF not in sys.path:
+        sys.path.append(REF)          # `modules.*` (rnnt/models.py:14) lives at the reference's root
+    pkg = types.ModuleType("rnnt")
+    pkg.__path__ = [os.path.join(REF, "rnnt")]
+    sys.modules["rnnt"] = pkg
+    for sub in ("tokenizer", "models"):
+        spec = importlib.util.spec_from_file_location("rnnt." + sub, os.path.join(REF, "rnnt", sub + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules["rnnt." + sub] = mod
+        spec.loader.exec_module(mod)
+    ref = sys.modules["rnnt.models"]
+    assert ref.__file__.startswith(REF), ref.__file__
     m = ref.Transducer(enc_dropout=0.0, dec_dropout=0.0, output_loss=False, **cfg)
     missing = m.load_state_dict(sd, strict=True)
     m.eval()
@@ -57,7 +78,8 @@ def main():
             logits = ref(xs, ys, xlen, ylen)
             act_lens = ref.scale_length(logits, xlen)
             tokens, score = ref.greedy_decode(xs, xlen)
-            enc, (hs, cs) = ref.encoder(xs)
+            enc, hid = ref.encoder(xs)
+            hs, cs = (hid, hid) if cfg.get("module_type") == "GRU" else hid   # GRU: one state tensor
             dec, _ = ref.decoder(ys)
             # oracle restatement must reproduce the reference
             o_logits, o_lens = M.transducer_logits(sd, xs, ys, xlen, ylen)
@@ -79,7 +101,7 @@ def main():
             greedy_score=score.numpy(),
             enc_hN=hs.numpy()[:, :, :8], enc_cN=cs.numpy()[:, :, :8],
         )
-        if name == "tiny":
+        if name in ("tiny", "gru_tiny"):
             out.update(logits=logits.numpy(), enc_out=enc.numpy(), dec_out=dec.numpy())
         else:
             out.update(logits_sample=logits.numpy()[:, ::7, ::3, ::64],

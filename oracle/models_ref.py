@@ -33,13 +33,14 @@ def param_shapes(cfg):
     keys vocab_embed_size, vocab_size, input_size, enc_hidden_size, enc_layers, enc_proj_size,
     dec_hidden_size, dec_layers, dec_proj_size, joint_size."""
     H, L, I = cfg["enc_hidden_size"], cfg["enc_layers"], cfg["input_size"]
+    ng = 3 if cfg.get("module_type", "LSTM") == "GRU" else 4
     out = [("encoder.norm.weight", (I,)), ("encoder.norm.bias", (I,))]
     for i in range(L):
         isz = I if i == 0 else H
-        out += [("encoder.lstm.lstms.%d.weight_ih_l0" % i, (4 * H, isz)),
-                ("encoder.lstm.lstms.%d.weight_hh_l0" % i, (4 * H, H)),
-                ("encoder.lstm.lstms.%d.bias_ih_l0" % i, (4 * H,)),
-                ("encoder.lstm.lstms.%d.bias_hh_l0" % i, (4 * H,)),
+        out += [("encoder.lstm.lstms.%d.weight_ih_l0" % i, (ng * H, isz)),
+                ("encoder.lstm.lstms.%d.weight_hh_l0" % i, (ng * H, H)),
+                ("encoder.lstm.lstms.%d.bias_ih_l0" % i, (ng * H,)),
+                ("encoder.lstm.lstms.%d.bias_hh_l0" % i, (ng * H,)),
                 ("encoder.lstm.projs.%d.0.weight" % i, (H,)),
                 ("encoder.lstm.projs.%d.0.bias" % i, (H,))]
     out += [("encoder.proj.weight", (cfg["enc_proj_size"], H)),
@@ -151,6 +152,50 @@ def lstm_layer(x, w_ih, w_hh, b_ih, b_hh, h0, c0, explicit=False):
     return torch.stack(ys, 1), h, c
 
 
+def gru_layer(x, w_ih, w_hh, b_ih, b_hh, h0):
+    """One batch_first GRU layer, PyTorch cell semantics (gate order r,z,n), spelled out step by
+    step - what nn.GRU computes for ResLayerNormGRU (rnnt/models.py:87-88,107)."""
+    B, T, _ = x.shape
+    H = w_hh.shape[1]
+    h = x.new_zeros(B, H) if h0 is None else h0
+    ys = []
+    for t in range(T):
+        gi = x[:, t] @ w_ih.t() + b_ih
+        gh = h @ w_hh.t() + b_hh
+        ir, iz, inn = gi.split(H, dim=1)
+        hr, hz, hn = gh.split(H, dim=1)
+        r = torch.sigmoid(ir + hr)
+        z = torch.sigmoid(iz + hz)
+        n = torch.tanh(inn + r * hn)
+        h = (1 - z) * n + z * h
+        ys.append(h)
+    return torch.stack(ys, 1), h
+
+
+def is_gru(sd):
+    """module_type='GRU' checkpoints keep the LSTM variant's key names with 3H-row matrices."""
+    w = sd["encoder.lstm.lstms.0.weight_hh_l0"]
+    return w.shape[0] == 3 * w.shape[1]
+
+
+def encoder_forward_gru(sd, xs, hiddens=None, time_reductions=(1,)):
+    """rnnt/models.py:131-136 + :99-116 (ResLayerNormGRU).  Returns (ys [B,T',P], hs [L,B,H])."""
+    x = layer_norm(xs, sd["encoder.norm.weight"], sd["encoder.norm.bias"])
+    hs = []
+    for i in range(n_enc_layers(sd)):
+        p = "encoder.lstm.lstms.%d." % i
+        y, h = gru_layer(x, sd[p + "weight_ih_l0"], sd[p + "weight_hh_l0"], sd[p + "bias_ih_l0"],
+                         sd[p + "bias_hh_l0"], None if hiddens is None else hiddens[i])
+        x = y if i == 0 else x + y
+        x = layer_norm(x, sd["encoder.lstm.projs.%d.0.weight" % i],
+                       sd["encoder.lstm.projs.%d.0.bias" % i])
+        if i in time_reductions:
+            x = time_reduction(x)
+        hs.append(h)
+    y = x @ sd["encoder.proj.weight"].t() + sd["encoder.proj.bias"]
+    return y, torch.stack(hs)
+
+
 def n_enc_layers(sd):
     n = 0
     while "encoder.lstm.lstms.%d.weight_ih_l0" % n in sd:
@@ -166,7 +211,10 @@ def n_dec_layers(sd):
 
 
 def encoder_forward(sd, xs, hiddens=None, time_reductions=(1,), explicit=False):
-    """rnnt/models.py:131-136 + :55-75.  Returns (ys [B,T',P], (hs, cs) [L,B,H])."""
+    """rnnt/models.py:131-136 + :55-75.  Returns (ys [B,T',P], (hs, cs) [L,B,H]); for a GRU
+    state dict (module_type='GRU') the second item is hs alone, as in the reference."""
+    if is_gru(sd):
+        return encoder_forward_gru(sd, xs, hiddens, time_reductions)
     x = layer_norm(xs, sd["encoder.norm.weight"], sd["encoder.norm.bias"])
     hs, cs = [], []
     for i in range(n_enc_layers(sd)):

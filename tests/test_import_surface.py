@@ -23,12 +23,14 @@ def test_reference_import_sites_resolve(module, names):
 
 
 def test_out_of_path_modules_fail_loudly_not_silently():
-    from rnnt.models import FrontEnd, ResLayerNormGRU, Transducer
+    from rnnt.models import CTCEncoder, FrontEnd, ResLayerNormGRU, Transducer
     with pytest.raises(NotImplementedError, match="FrontEnd"):
         FrontEnd()
-    with pytest.raises(NotImplementedError, match="GRU"):
-        ResLayerNormGRU(240, 32, 2)
-    with pytest.raises(NotImplementedError):
-        Transducer(16, 40, 24, 32, 2, 0.0, 24, 32, 1, 0.0, 24, 32, module_type="GRU")
+    with pytest.raises(NotImplementedError, match="CTC"):
+        CTCEncoder(40, 24, 32, 2, 0.0, 24)
+    # the GRU variant IS implemented (csrc/gru.hip): same state-dict key names, 3H-row matrices
+    t = Transducer(16, 40, 24, 32, 2, 0.0, 24, 32, 1, 0.0, 24, 32, module_type="GRU")
+    assert isinstance(t.encoder.lstm, ResLayerNormGRU)
+    assert t.state_dict()["encoder.lstm.lstms.1.weight_hh_l0"].shape == (96, 32)
     with pytest.raises(ValueError):
         Transducer(16, 40, 24, 32, 2, 0.0, 24, 32, 1, 0.0, 24, 32, module_type="RNN")   # rnnt/models.py:191-192
