@@ -884,6 +884,138 @@ class Transducer(nn.Module):
         return beam_search_batch(self, xs, xlen, W, max_expansions)
 
 
+class _CausalConvFn(torch.autograd.Function):
+    """Conv1d(C_in, C_out, k, stride s, padding k-1) followed by dropping the last k-1 frames
+    (CausalConv1d / DilatedConvBlock of rnnt/models.py:314-339), channels-last: im2col gather +
+    one MFMA GEMM; backward = dW GEMM, bias column sum, dcols GEMM + col2im gather."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, cd):
+        B, Tin, C = x.shape
+        Cout, Cin, k = weight.shape
+        assert Cin == C
+        cols = ops.conv_im2col(x.contiguous(), k, stride, cd)
+        Tout = cols.shape[1]
+        w2 = WEIGHTS.get(weight, cd).view(Cout, Cin * k)
+        y = ops.gemm(cols.view(B * Tout, C * k), w2, bias=None if bias is None else bias.detach())
+        ctx.save_for_backward(cols, weight)
+        ctx.cfg = (B, Tin, C, k, stride, cd, bias is not None, x.dtype)
+        return y.view(B, Tout, Cout)
+
+    @staticmethod
+    def backward(ctx, dy):
+        cols, weight = ctx.saved_tensors
+        B, Tin, C, k, stride, cd, has_bias, in_dtype = ctx.cfg
+        Cout = weight.shape[0]
+        Tout = cols.shape[1]
+        M = B * Tout
+        dy2 = dy.contiguous().view(M, Cout)
+        if dy2.dtype != cd:
+            dy2 = ops.cast(dy2, cd)
+        dw = ops.gemm(dy2.t(), cols.view(M, C * k).t(), out_dtype=F32,
+                      split_k=ops.pick_split_k(Cout, C * k, M)).view(Cout, C, k)
+        db = ops.colsum(dy2) if has_bias else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            w2 = WEIGHTS.get(weight, cd).view(Cout, C * k)
+            dcols = ops.gemm(dy2, w2.t()).view(B, Tout, C * k)
+            dx = ops.conv_col2im(dcols, Tin, C, k, stride)
+            if dx.dtype != in_dtype:
+                dx = ops.cast(dx, in_dtype)
+        return dx, dw, db, None, None
+
+
+class _GeluGroupNormFn(torch.autograd.Function):
+    """GroupNorm(1, C)(GELU(y)) on channels-last [B,T,C] (DilatedConvBlock.forward,
+    rnnt/models.py:333-335): statistics over all (t, c) of a sample, affine per channel."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta):
+        out, mean, rstd = ops.gelu_groupnorm_fwd(y.contiguous(), gamma.detach(), beta.detach())
+        ctx.save_for_backward(y, gamma, mean, rstd)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        y, gamma, mean, rstd = ctx.saved_tensors
+        if dout.dtype != y.dtype:
+            dout = ops.cast(dout.contiguous(), y.dtype)
+        dy, dgamma, dbeta = ops.gelu_groupnorm_bwd(y, dout, gamma.detach(), mean, rstd)
+        return dy, dgamma, dbeta
+
+
+class _ConvParams(nn.Module):
+    """nn.Conv1d-compatible parameters: weight [C_out, C_in, k] (kaiming-normal as the reference
+    re-initialises it, rnnt/models.py:317,329), bias [C_out] (nn.Conv1d default init)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride = (kernel_size,), (stride,)
+        self.padding = (kernel_size - 1,)
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size))
+        nn.init.kaiming_normal_(self.weight)
+        if bias:
+            bound = 1.0 / math.sqrt(in_channels * kernel_size)
+            self.bias = nn.Parameter(torch.empty(out_channels).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+
+
+class DilatedConvBlock(nn.Module):
+    """GELU -> GroupNorm(group_norm_size=1, C_in) -> causal strided Conv1d (rnnt/models.py:323-339);
+    channels-last in and out.  Only dilation 1 and one group (what FrontEnd builds)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, dilation=1, group_norm_size=1,
+                 stride=1, bias=True):
+        super().__init__()
+        if dilation != 1 or group_norm_size != 1:
+            raise NotImplementedError("DilatedConvBlock: only dilation=1, group_norm_size=1 (FrontEnd's use)")
+        self.conv = _ConvParams(in_channels, out_channels, kernel_size, stride, bias)
+        self.gn = _LayerNormParams(in_channels)      # weight / bias [C_in], the GroupNorm affine
+
+    def forward(self, x, cd):
+        x = _GeluGroupNormFn.apply(x, self.gn.weight, self.gn.bias)
+        return _CausalConvFn.apply(x, self.conv.weight, self.conv.bias, self.conv.stride[0], cd)
+
+
+class FrontEnd(nn.Module):
+    """Convolutional waveform feature extractor of the reference's cli/train.py
+    (rnnt/models.py:341-365): f32 [B, N] (or [B,1,N]) -> [B, T, C_last], LayerNorm over channels.
+    State-dict keys as the reference: conv1.{weight,bias}, encode.{i}.conv.{weight,bias},
+    encode.{i}.gn.{weight,bias}, layer_norm.{weight,bias}."""
+
+    def __init__(self, frontend_params=[(10, 5, 16)] + [(8, 4, 32)] + [(4, 2, 128)] * 3, bias=True):
+        super().__init__()
+        ks = [p[0] for p in frontend_params]
+        st = [p[1] for p in frontend_params]
+        ch = [p[2] for p in frontend_params]
+        self.conv1 = _ConvParams(1, ch[0], ks[0], st[0], bias)
+        self.encode = nn.Sequential(*[
+            DilatedConvBlock(ch[i - 1], ch[i], ks[i], dilation=1, stride=st[i], group_norm_size=1, bias=bias)
+            for i in range(1, len(st))])
+        self.layer_norm = _LayerNormParams(ch[-1])
+
+    def out_frames(self, n_samples):
+        t = ops.conv_out_frames(n_samples, self.conv1.kernel_size[0], self.conv1.stride[0])
+        for blk in self.encode:
+            t = ops.conv_out_frames(t, blk.conv.kernel_size[0], blk.conv.stride[0])
+        return t
+
+    def forward(self, x):
+        require_cuda(x)
+        cd = getattr(self, "compute_dtype", None) or config.get_compute_dtype()
+        if not isinstance(cd, torch.dtype):
+            cd = config._parse(cd)
+        if x.dim() == 3:                      # B x 1 x T -> B x T (rnnt/models.py:352-353 the other way)
+            x = x[:, 0]
+        x = x.float().contiguous().unsqueeze(-1)          # channels-last [B, N, 1]
+        x = _CausalConvFn.apply(x, self.conv1.weight, self.conv1.bias, self.conv1.stride[0], cd)
+        for blk in self.encode:
+            x = blk(x, cd)
+        return _InputNormFn.apply(x, self.layer_norm.weight, self.layer_norm.bias, cd)
+
+
 class _OutsideHotPath(nn.Module):
     """Names the reference's scripts import next to ``Transducer`` (cli/train.py:18,
     rnnt/wav2vec.py:12) but whose arithmetic is not on the MI355X hot path (SURVEY.md 8f rank 4,
@@ -897,10 +1029,6 @@ class _OutsideHotPath(nn.Module):
         raise NotImplementedError(
             "%s is not implemented by the MI355X engine (%s); use the log-mel front-end and the LSTM "
             "encoder (cli/baseline.py path)" % (type(self).__name__, self._what))
-
-
-class FrontEnd(_OutsideHotPath):
-    _what = "the wav2vec-style convolutional feature extractor of rnnt/models.py:313-365"
 
 
 class CTCEncoder(_OutsideHotPath):

@@ -246,6 +246,55 @@ def lstm_backward(G, dY, Cst, c0, WhhT, WhhT_packed=None):
     return G
 
 
+def conv_out_frames(Tin, k, s):
+    return int(_lib.load().edgedict_conv_out_frames(int(Tin), int(k), int(s)))
+
+
+def conv_im2col(x, k, s, out_dtype):
+    """x [B,Tin,C] channels-last -> cols [B,Tout,C*k] (column c*k + j reads frame t*s - (k-1) + j)."""
+    require_cuda(x)
+    B, Tin, C = x.shape
+    assert x.is_contiguous()
+    Tout = conv_out_frames(Tin, k, s)
+    if Tout <= 0:
+        raise ValueError("conv: %d input frames are too few for kernel %d / stride %d" % (Tin, k, s))
+    cols = torch.empty(B, Tout, C * k, dtype=out_dtype, device=x.device)
+    call("conv_im2col", dtype_code(x.dtype), dtype_code(out_dtype), x, cols, B, Tin, C, int(k), int(s))
+    return cols
+
+
+def conv_col2im(dcols, Tin, C, k, s):
+    B, Tout, CK = dcols.shape
+    assert dcols.is_contiguous() and CK == C * k
+    dx = torch.empty(B, Tin, C, dtype=dcols.dtype, device=dcols.device)
+    call("conv_col2im", dtype_code(dcols.dtype), dcols, dx, B, int(Tin), int(C), int(k), int(s))
+    return dx
+
+
+def gelu_groupnorm_fwd(y, gamma, beta, eps=1e-5):
+    require_cuda(y)
+    B, T, C = y.shape
+    assert y.is_contiguous()
+    out = torch.empty_like(y)
+    mean = torch.empty(B, dtype=torch.float32, device=y.device)
+    rstd = torch.empty(B, dtype=torch.float32, device=y.device)
+    call("gelu_groupnorm_fwd", dtype_code(y.dtype), y, gamma, beta, out, mean, rstd, B, T, C, float(eps))
+    return out, mean, rstd
+
+
+def gelu_groupnorm_bwd(y, dout, gamma, mean, rstd):
+    B, T, C = y.shape
+    dout = dout.contiguous()
+    dy = torch.empty_like(y)
+    dgamma = torch.empty(C, dtype=torch.float32, device=y.device)
+    dbeta = torch.empty(C, dtype=torch.float32, device=y.device)
+    ws = torch.empty(_lib.load().edgedict_gelu_groupnorm_bwd_workspace_bytes(B, T, C), dtype=torch.uint8,
+                     device=y.device)
+    call("gelu_groupnorm_bwd", dtype_code(y.dtype), y, dout, gamma, mean, rstd, dy, dgamma, dbeta, ws,
+         B, T, C)
+    return dy, dgamma, dbeta
+
+
 def gru_forward(G, Whh, b_hh, h0=None):
     """GRU recurrence over G[B,T,3H] (= x W_ih^T + b_ih, overwritten with r,z,n).
     Returns (Y, Hprev, HN, hN)."""

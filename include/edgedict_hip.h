@@ -406,6 +406,32 @@ int edgedict_gru_backward(int dtype, void* G, void* DH, const void* dY, const vo
                           const void* HN, const void* WhhT, float* dh_ws, int B, int T, int H,
                           void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Convolutional waveform front-end (FrontEnd, rnnt/models.py:313-365; DilatedConvBlock :323-339;
+ * CausalConv1d :314-318), channels-last activations [B, T, C].  A convolution = im2col gather +
+ * edgedict_gemm against the weight viewed as [C_out, C_in*k] (column c*k + j); its backward =
+ * two GEMMs + the col2im gather.
+ *   conv_out_frames(Tin, k, s)   frames after Conv1d(padding k-1, stride s) minus the k-1 dropped ones
+ *   conv_im2col   x [B,Tin,C] (in_dtype) -> cols [B,Tout,C*k] (out_dtype); f32->f32, f32->bf16, bf16->bf16
+ *   conv_col2im   dcols [B,Tout,C*k] -> dx [B,Tin,C] (same dtype), gather form (no atomics)
+ *   gelu_groupnorm_fwd  out = GroupNorm_1group(GELU(y)) with per-channel gamma/beta; y,out [B,T,C];
+ *                       mean, rstd fp32 [B] (saved for backward); exact-erf GELU, eps as nn.GroupNorm
+ *   gelu_groupnorm_bwd  dy wrt y, dgamma/dbeta fp32 [C] (written, not accumulated); C <= 256;
+ *                       workspace of gelu_groupnorm_bwd_workspace_bytes(B,T,C) bytes
+ */
+int edgedict_conv_out_frames(int Tin, int k, int s);
+int edgedict_conv_im2col(int in_dtype, int out_dtype, const void* x, void* cols, int B, int Tin, int C,
+                         int k, int s, void* stream);
+int edgedict_conv_col2im(int dtype, const void* dcols, void* dx, int B, int Tin, int C, int k, int s,
+                         void* stream);
+int edgedict_gelu_groupnorm_fwd(int dtype, const void* y, const float* gamma, const float* beta,
+                                void* out, float* mean, float* rstd, int B, int T, int C, float eps,
+                                void* stream);
+size_t edgedict_gelu_groupnorm_bwd_workspace_bytes(int B, int T, int C);
+int edgedict_gelu_groupnorm_bwd(int dtype, const void* y, const void* dout, const float* gamma,
+                                const float* mean, const float* rstd, void* dy, float* dgamma,
+                                float* dbeta, void* workspace, int B, int T, int C, void* stream);
+
 /* Number of products edgedict_gemm has handed to hipBLASLt in this process (only the large,
  * short-K bf16 NT product of the joint's logits qualifies; csrc/blaslt.cpp).  0 when the vendor
  * library is absent or EDGEDICT_BLASLT=0: every product then runs on this library's kernels. */
