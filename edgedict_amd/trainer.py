@@ -124,4 +124,12 @@ class TrainEngine:
             aux.wait_stream(torch.cuda.current_stream(self.device))
             encoder_stack.prepack(self.model.encoder, aux)
         ops.mark("step:exit")
+        if self.step_count == 1:
+            # Everything long-lived (modules, plans, weight images, torch itself) exists now.  A full
+            # cyclic-GC pass over those ~millions of objects takes 20-35 ms of host time and lands in
+            # the middle of a step every few dozen steps (tools/step_trend.py: 27 ms steps with 40-60
+            # ms outliers); frozen, later collections only look at young objects.
+            import gc
+            gc.collect()
+            gc.freeze()
         return total

@@ -44,8 +44,10 @@ def main(out, fdb, wdb, mdb=None):
     f = per_kernel(fdb, "FETCH_SIZE")
     w = per_kernel(wdb, "WRITE_SIZE")
     mfma = gui = {}
-    if mdb:   # third pass: matrix-pipe busy cycles over chip-active cycles (gfx94x MfmaUtil formula:
-              # SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE * 256 CUs * 4 SIMDs))
+    if mdb:   # third pass: matrix-pipe busy cycles of all 1024 SIMDs over chip-active cycles.
+              # rocprofv3 sums GRBM_GUI_ACTIVE over the 8 XCCs (a 1.34 ms kernel reports 22.6 M =
+              # 8 x 2.1 GHz x 1.34 ms), so one XCC's active cycles are GUI_ACTIVE / 8:
+              # util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 256 CUs * 4 SIMDs)
         mfma = per_kernel(mdb, "SQ_VALU_MFMA_BUSY_CYCLES")
         gui = per_kernel(mdb, "GRBM_GUI_ACTIVE")
     res = {}
@@ -59,7 +61,7 @@ def main(out, fdb, wdb, mdb=None):
         if k in mfma and k in gui and gui[k][1] > 0:
             res[k]["mfma_busy_cycles"] = mfma[k][1]
             res[k]["gui_active_cycles"] = gui[k][1]
-            res[k]["mfma_util"] = mfma[k][1] / (gui[k][1] * 256 * 4)
+            res[k]["mfma_util"] = mfma[k][1] / (gui[k][1] / 8.0 * 256 * 4)
     with open(out, "w") as fh:
         json.dump({"note": "per-launch averages; FETCH_SIZE x2 gfx950 correction applied in "
                            "fetch_bytes_corrected / hbm_bytes (MI355X_MICROARCH.md, HBM section)",
