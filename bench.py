@@ -114,6 +114,9 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # the engine's internal streams first, before RCCL / torch create any (see TrainEngine.__init__)
+    from edgedict_amd import side
+    side.stream(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world)

@@ -19,6 +19,7 @@
 //
 // The caller's stream is forked into the internal streams at entry and joined at exit, so the
 // call is an ordinary stream-ordered operation for the caller (and for the caching allocator).
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <mutex>
@@ -140,7 +141,11 @@ Runtime* runtime_for_current_device() {
         // HIP maps streams onto 4 hardware queues round-robin in creation order: create ONLY the
         // three streams the default schedule uses (recurrence, auxiliary, chunk GEMMs; with the
         // caller's stream that is one queue each).  Streams sharing a queue serialise: creating
-        // one more stream before these was measured to cost 13 ms per training step.
+        // one more stream before these was measured to cost 13 ms per training step, and a process
+        // that creates OTHER streams first (torch's stream pool, RCCL at its first collective) pays
+        // 32-65 ms instead of 27 per step (tools/stream_order_probe.py; the priority class of S makes
+        // no difference) - so hosts call edgedict_aux_stream() right after selecting the device,
+        // before anything else creates streams (trainer.TrainEngine, bench.py do).
         r->prio_hi = hi;
         bool ok = hipStreamCreateWithPriority(&r->R, hipStreamNonBlocking, hi) == hipSuccess &&
                   hipStreamCreateWithPriority(&r->W, hipStreamNonBlocking, aux_high ? hi : lo) == hipSuccess &&

@@ -26,6 +26,14 @@ class TrainEngine:
                  process_group=None, state_dict=None):
         self.flags = flags
         self.device = torch.device(device)
+        # The library's three internal HIP streams must exist BEFORE any other stream of this process
+        # (RCCL creates its own at the first collective - the parameter broadcast below; torch's
+        # stream pool at the first torch.cuda.Stream()): HIP hands out its hardware queues in stream
+        # creation order and late-comers share one.  Measured: 27 ms/step vs 32-65 ms with 1-3
+        # foreign streams created first (tools/stream_order_probe.py).
+        from . import side
+        with torch.cuda.device(self.device):
+            side.stream(self.device)
         cd = config._parse(compute_dtype) if compute_dtype is not None else config.get_compute_dtype()
         self.compute_dtype = cd
         self.features = StackedLogFbank(
