@@ -652,6 +652,8 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     int dw_seg = 1 << 20;   // measured: 8 / 4 / 2 / 1 chunks per segment cost +0.3 / +0.6 / +1.6 / +5.3 ms per step
     if (const char* e = getenv("EDGEDICT_STACK_DW_SEG")) dw_seg = max(1, atoi(e));
     if (d->flags & EDGEDICT_STACK_DW_AT_END) dw_seg = 1 << 20;
+    int tail_split = 0;   // measured: 4 -> +0.2..0.7 ms per step (BPTT period 23.6 -> 24.8 us outweighs the shorter tail)
+    if (const char* e = getenv("EDGEDICT_STACK_TAIL_SPLIT")) tail_split = atoi(e);
 
     const int margin = margin_launches(d, g, true);
     std::vector<int> next_t(L, 0);          // BPTT steps done; the next one is frame T - 1 - next_t
@@ -735,7 +737,20 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
             // chunks complete from the last to the first: a segment [k, k + dw_seg) is complete when
             // its lowest chunk is (k a multiple of dw_seg, counted so that the LAST segment issued,
             // the one ending at chunk 0, is a full one)
-            if (k % dw_seg == 0) {
+            // Experiment (EDGEDICT_STACK_TAIL_SPLIT=n, off by default): split the two layers that
+            // finish LAST once more - frames [nchunks/n * cf, T) issued when the BPTT passes that
+            // chunk - so that less work is left for the 0.7 ms tail after the last launch.  Measured
+            // slower: the extra products disturb more BPTT launches than the tail shrinks.
+            const int k_split = (l <= 1 && tail_split > 1 && g[l].nchunks >= 2 * tail_split && dw_seg >= g[l].nchunks &&
+                                 !(d->flags & EDGEDICT_STACK_DW_AT_END))
+                                    ? g[l].nchunks / tail_split : 0;
+            if (k_split > 0 && k == k_split) {
+                ED_TRY(st.chain(st.RS(l), st.W));
+                ED_TRY(weight_grads(l, k * g[l].cf, y.T, true, false));
+            } else if (k_split > 0 && k == 0) {
+                ED_TRY(st.chain(st.RS(l), st.W));
+                ED_TRY(weight_grads(l, 0, k_split * g[l].cf, false, l == 0));
+            } else if (k_split == 0 && k % dw_seg == 0) {
                 if (d->flags & EDGEDICT_STACK_DW_AT_END) {
                     if (k == 0) deferred.push_back(l);
                 } else {
