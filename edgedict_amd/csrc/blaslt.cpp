@@ -9,7 +9,8 @@
 // The library is bound lazily with dlopen/dlsym (the process usually has PyTorch's copy loaded
 // already under the same SONAME), so libedgedict_hip.so has no link-time dependency on it; if it
 // is absent, or has no solution for a shape, the caller's own kernel runs.  State kept: one
-// handle + a 64 MiB workspace per device and a small shape -> algorithm cache.
+// handle per device, a 64 MiB workspace per (device, stream) that has used the route, and a small
+// shape -> algorithm cache.
 // EDGEDICT_BLASLT=0 turns the route off.
 #include "blaslt.hpp"
 
@@ -70,7 +71,10 @@ constexpr size_t WS_BYTES = 64ull << 20;
 
 struct PerDevice {
     hipblasLtHandle_t handle = nullptr;
-    void* ws = nullptr;
+    // one workspace PER STREAM: products on different streams run concurrently (chunk dX on the side
+    // stream beside weight gradients on the low-priority stream), and stream-K kernels keep partial
+    // sums and flags in the workspace - sharing one between two running kernels deadlocks them
+    std::map<hipStream_t, void*> ws;
     bool failed = false;
     // (M, N, K, lda, ldb, ldc, bias) -> algorithm (valid == false: the library has none)
     struct Entry { hipblasLtMatmulAlgo_t algo; size_t ws; bool valid; };
@@ -99,10 +103,20 @@ bool run(hipblasOperation_t opP, hipblasOperation_t opQ, const void* P, long lon
     PerDevice& d = g_dev[dev];
     if (d.failed) return false;
     if (!d.handle) {
-        if (L.Create(&d.handle) != HIPBLAS_STATUS_SUCCESS || hipMalloc(&d.ws, WS_BYTES) != hipSuccess) {
+        if (L.Create(&d.handle) != HIPBLAS_STATUS_SUCCESS) {
             d.failed = true;
             d.handle = nullptr;
             return false;
+        }
+    }
+    void* ws = nullptr;
+    {
+        auto wit = d.ws.find(s);
+        if (wit == d.ws.end()) {
+            if (d.ws.size() >= 8 || hipMalloc(&ws, WS_BYTES) != hipSuccess) return false;   // own kernel instead
+            d.ws.emplace(s, ws);
+        } else {
+            ws = wit->second;
         }
     }
     hipblasLtMatmulDesc_t desc = nullptr;
@@ -147,7 +161,7 @@ bool run(hipblasOperation_t opP, hipblasOperation_t opQ, const void* P, long lon
         }
         if (!it->second.valid) break;
         const float one = 1.f;
-        if (L.Matmul(d.handle, desc, &one, P, la, Q, lb, &beta, D, lc, D, lc, &it->second.algo, d.ws,
+        if (L.Matmul(d.handle, desc, &one, P, la, Q, lb, &beta, D, lc, D, lc, &it->second.algo, ws,
                      WS_BYTES, s) != HIPBLAS_STATUS_SUCCESS) {
             it->second.valid = false;
             break;
