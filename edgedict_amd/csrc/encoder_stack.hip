@@ -135,7 +135,7 @@ Runtime* runtime_for_current_device() {
     if (!g_rt[dev]) {
         Runtime* r = new Runtime();
         int lo = 0, hi = 0;
-        hipDeviceGetStreamPriorityRange(&lo, &hi);   // lo = least, hi = greatest priority
+        if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) lo = hi = 0;   // lo = least, hi = greatest priority
         const char* e = getenv("EDGEDICT_AUX_PRIORITY");
         const bool aux_high = e && e[0] == '1';
         // HIP maps streams onto 4 hardware queues round-robin in creation order: create ONLY the
@@ -241,17 +241,6 @@ int validate(const edgedict_stack_desc_t* d, std::vector<Geom>& g, bool backward
     return ED_OK;
 }
 
-int default_lag(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, bool backward) {
-    // a layer may start chunk k only after the layer feeding it has finished that chunk and the
-    // chunk's GEMM has been ENQUEUED (P launches per chunk, +2 for the norm / enqueue order)
-    const int P = d->chunk * g[0].f;
-    // measured (E6D2): forward 8.15 ms at P+3 vs 8.28 at P+5; backward 13.7 at P+5 vs 14.3 at P+3
-    // (its chunk chain is longer: dX product + LayerNorm backward)
-    int lag = d->lag > 0 ? d->lag : P + (backward ? 5 : 3);
-    if (lag < P + 2) lag = P + 2;
-    return lag | 1;   // odd: half-rate layers alternate between even and odd launches
-}
-
 // ---- dynamic wavefront schedule ----------------------------------------------------------
 // A layer steps in launch w when (a) the chunk its next step opens has been enqueued on the side
 // stream at least `margin` launches ago (the product then has had time to run: the recurrence
@@ -272,7 +261,9 @@ struct Pace {
 int margin_launches(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, bool backward) {
     // d->lag keeps its meaning "launches between a producer's and a consumer's first step of a chunk"
     // (P = launches per chunk): forward default P + 3, backward P + 5 -> margins 3 and 6 launches
-    // after the chunk's side-stream work was enqueued
+    // after the chunk's side-stream work was enqueued.  Measured (E6D2): forward 8.15 ms at P+3 vs
+    // 8.28 at P+5; backward 13.7 at P+5 vs 14.3 at P+3 (its chunk chain is longer: dX product +
+    // LayerNorm backward); margins of 2 / 3 lose 1 ms.
     const int P = d->chunk * g[0].f;
     if (d->lag > 0) return max(1, d->lag - P + (backward ? 1 : 0));
     return backward ? 6 : 3;

@@ -512,7 +512,9 @@ static int gemm_impl(int dtype_in, int dtype_out, const void* A, long long lda, 
         // background: only as many workgroups as are resident at once (see the kernel)
         static const int n_cu = [] {
             int dev = 0, n = 256;
-            if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            if (hipGetDevice(&dev) != hipSuccess ||
+                hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+                n = 256;
             return n > 0 ? n : 256;
         }();
         long long cap = (long long)max_wg_per_cu * n_cu;

@@ -10,7 +10,6 @@ finished every parameter in it, so RCCL traffic overlaps the remaining BPTT
 gradients) so each ring step moves MBs per link rather than paying latency many times.
 The sum is turned into the mean inside the Adam kernel (``grad_scale = 1/world``).
 """
-import torch
 import torch.distributed as dist
 
 

@@ -13,7 +13,6 @@ import numpy as np
 import torch
 from torch import nn
 
-from . import _lib
 from ._lib import call, dtype_code, require_cuda
 from .ops import _ll
 

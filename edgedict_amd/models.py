@@ -24,7 +24,6 @@ There is no CPU or eager-PyTorch fallback: tensors must live on an MI355X.
 import math
 import weakref
 
-import numpy as np
 import torch
 from torch import nn
 

@@ -9,7 +9,7 @@ gradients into another, so the update is a single streaming kernel over ~51 M el
 import torch
 
 from . import config
-from ._lib import call, require_cuda
+from ._lib import call
 from .ops import _ll
 
 

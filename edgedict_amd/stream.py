@@ -13,12 +13,12 @@ import time
 
 import torch
 
-from . import _lib, ops
-from .decode import SearchState, init_search_state, run_search
+
+from .decode import init_search_state, run_search
 from .features import StackedLogFbank
 from .flags import model_kwargs
 from .models import Transducer, convert_lightning2normal
-from .tokenizer import BOS, NUL, UNK
+from .tokenizer import NUL, UNK
 
 
 class StreamTransducerDecoder:

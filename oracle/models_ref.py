@@ -20,9 +20,7 @@ inputs, checks this restatement against it and stores the reference's outputs un
 """
 import math
 
-import numpy as np
 import torch
-import torch.nn.functional as F
 
 NUL, PAD, BOS, UNK = 0, 1, 2, 3
 

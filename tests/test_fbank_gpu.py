@@ -1,5 +1,4 @@
 """GPU parity of the fused log-mel kernel against the CPU oracle (dither off)."""
-import numpy as np
 import pytest
 import torch
 

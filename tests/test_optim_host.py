@@ -3,7 +3,7 @@ the reference configures (cli/train.py:142-146), its warm-up rule (cli/train.py:
 torch.optim.Adam state-dict layout its checkpoints carry (cli/train.py:321-336)."""
 import torch
 
-from edgedict_amd.optim import FlatParams, FusedAdam, ReduceLROnPlateau, WarmupLR
+from edgedict_amd.optim import FusedAdam, ReduceLROnPlateau, WarmupLR
 
 
 def _net():

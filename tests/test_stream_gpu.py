@@ -1,5 +1,4 @@
 """GPU: streaming decode (single-stream API and batched) vs the CPU stream oracle, bit-exact ids."""
-import numpy as np
 import pytest
 import torch
 
