@@ -275,6 +275,22 @@ int margin_launches(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, 
         if (st__ != ED_OK) return st__; \
     } while (0)
 
+// ---- dry run: the schedulers below also run WITHOUT a device (edgedict_stack_schedule): every
+// device call is skipped and the launch index of each layer-step / chunk product is recorded, so the
+// host logic (dependencies, pacing, slot counts) is testable on a CPU-only machine.
+struct ScheduleTrace {
+    int32_t* step_launch = nullptr;      // [sum_l T_l], layer-major: launch that carries step (l, t)
+    int32_t* chunk_enqueued = nullptr;   // [sum_l nchunks_l]: launches issued when the chunk's side-stream
+                                         // product was enqueued (-1: available from the start)
+    std::vector<int> toff, coff;
+    int launches = 0, max_slots = 0;
+};
+thread_local ScheduleTrace* g_trace = nullptr;
+#define ED_DEV(expr)                      \
+    do {                                  \
+        if (!g_trace) ED_TRY(expr);       \
+    } while (0)
+
 struct Streams {
     hipStream_t C, R, R2, W;
     int split;   // layers >= split run their recurrence on R2 (experiment; L = never)
@@ -307,7 +323,7 @@ struct Streams {
 
 int open_streams(const edgedict_stack_desc_t* d, void* stream_, Streams& st) {
     st.C = (hipStream_t)stream_;
-    st.serial = (d->flags & EDGEDICT_STACK_SERIAL) != 0;
+    st.serial = (d->flags & EDGEDICT_STACK_SERIAL) != 0 || g_trace != nullptr;
     st.rt = nullptr;
     if (st.serial) {
         st.R = st.R2 = st.W = st.C;
@@ -407,11 +423,11 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     }
 
     // ---- prologue on the caller's stream: input LayerNorm (-> X_0, time-major), initial states
-    ED_TRY(ed_stack_input_norm(d->x_dtype, d->x, d->in_gamma, d->in_beta, bptr(d->layers[0].X),
+    ED_DEV(ed_stack_input_norm(d->x_dtype, d->x, d->in_gamma, d->in_beta, bptr(d->layers[0].X),
                                d->in_mean, d->in_rstd, B, d->T0, d->I0, d->eps, st.C));
     for (int l = 0; l < L; ++l) {
         const edgedict_stack_layer_t& y = d->layers[l];
-        ED_TRY(ed_stack_init_state(d->h0 ? d->h0 + l * BH : nullptr, d->c0 ? d->c0 + l * BH : nullptr,
+        ED_DEV(ed_stack_init_state(d->h0 ? d->h0 + l * BH : nullptr, d->c0 ? d->c0 + l * BH : nullptr,
                                    bptr(y.Yx), y.Cx, bptr(ws + wl.frag0[l]), B, H, st.C));
     }
     ED_TRY(st.chain(st.C, st.R));
@@ -427,7 +443,8 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     int next_g0 = 0;   // next chunk of layer 0 whose input product has not been enqueued
     auto feed_layer0 = [&](int upto) -> int {
         for (; next_g0 < g[0].nchunks && next_g0 <= upto; ++next_g0) {
-            ED_TRY(input_gemm(d, g, 0, next_g0, st.S[0]));
+            ED_DEV(input_gemm(d, g, 0, next_g0, st.S[0]));
+            if (g_trace) g_trace->chunk_enqueued[g_trace->coff[0] + next_g0] = g_trace->launches;
             ED_TRY(st.record(Eg[0][next_g0], st.S[0]));
             queued[0][next_g0] = 1;
         }
@@ -522,6 +539,7 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
             sl.Wfrag = bptr(y.whh_f);
             stepped_w[l] = w;
             next_t[l] = t + 1;
+            if (g_trace) g_trace->step_launch[g_trace->toff[l] + t] = g_trace->launches;
         }
         if (Lcs[0].nstep + Lcs[0].nnorm + Lcs[1].nstep + Lcs[1].nnorm == 0) {
             // every unfinished layer waits for a side-stream product: nothing to overlap it with
@@ -530,12 +548,17 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
         }
         idle = 0;
         ++launches;
-        ED_TRY(ed_stack_launch_fwd(Lcs[0], st.R));
-        if (st.split < L) ED_TRY(ed_stack_launch_fwd(Lcs[1], st.R2));
+        ED_DEV(ed_stack_launch_fwd(Lcs[0], st.R));
+        if (st.split < L) ED_DEV(ed_stack_launch_fwd(Lcs[1], st.R2));
+        if (g_trace) {
+            g_trace->max_slots = max(g_trace->max_slots, max(Lcs[0].nstep + Lcs[1].nstep, Lcs[0].nnorm + Lcs[1].nnorm));
+            ++g_trace->launches;
+        }
         for (int i = 0; i < ndone; ++i) {
             const int l = done[i].l + 1, k = done[i].k;
             ED_TRY(st.chain(st.RS(done[i].l), st.S[l]));
-            ED_TRY(input_gemm(d, g, l, k, st.S[l]));
+            ED_DEV(input_gemm(d, g, l, k, st.S[l]));
+            if (g_trace) g_trace->chunk_enqueued[g_trace->coff[l] + k] = g_trace->launches;
             ED_TRY(st.record(Eg[l][k], st.S[l]));
             queued[l][k] = 1;
             ready_w[l][k] = w + margin;
@@ -550,6 +573,33 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     if (st.R2 != st.R) ED_TRY(st.chain(st.R2, st.C));
     for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.S[l], st.C));
     return ED_OK;
+}
+
+extern "C" int edgedict_stack_schedule(const edgedict_stack_desc_t* d, int backward, int32_t* step_launch,
+                                       int32_t* chunk_enqueued, int32_t* n_launches, int32_t* max_slots) {
+    ED_CHECK_ARG(d && step_launch && chunk_enqueued && n_launches && max_slots, "stack_schedule: null pointer");
+    ScheduleTrace tr;
+    {
+        std::vector<Geom> g;
+        ED_TRY(validate(d, g, backward != 0));
+        int to = 0, co = 0;
+        for (int l = 0; l < d->L; ++l) {
+            tr.toff.push_back(to);
+            tr.coff.push_back(co);
+            to += g[l].T;
+            co += g[l].nchunks;
+        }
+        for (int i = 0; i < to; ++i) step_launch[i] = -1;
+        for (int i = 0; i < co; ++i) chunk_enqueued[i] = -1;
+    }
+    tr.step_launch = step_launch;
+    tr.chunk_enqueued = chunk_enqueued;
+    g_trace = &tr;
+    const int rc = backward ? edgedict_stack_backward(d, nullptr) : edgedict_stack_forward(d, nullptr);
+    g_trace = nullptr;
+    *n_launches = tr.launches;
+    *max_slots = tr.max_slots;
+    return rc;
 }
 
 extern "C" int edgedict_stack_last_timing(int backward, float* ms, int* launches) {
@@ -585,10 +635,10 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     const int T_out = (g[L - 1].T + d->layers[L - 1].reduce - 1) / d->layers[L - 1].reduce;
 
     // ---- prologue: running dL/dc = 0, LayerNorm backward of the top layer (all frames)
-    for (int l = 0; l < L; ++l) ED_TRY(ed_stack_zero(ws + wl.dC[l], (size_t)BH * sizeof(float), st.C));
+    for (int l = 0; l < L; ++l) ED_DEV(ed_stack_zero(ws + wl.dC[l], (size_t)BH * sizeof(float), st.C));
     {
         const edgedict_stack_layer_t& y = d->layers[L - 1];
-        ED_TRY(ed_stack_ln_bwd(bptr(d->dout), H, (long long)T_out * H, bptr(y.Yx) + BH,
+        ED_DEV(ed_stack_ln_bwd(bptr(d->dout), H, (long long)T_out * H, bptr(y.Yx) + BH,
                                y.residual ? bptr(y.X) : nullptr, y.ln_gamma, y.mean, y.rstd,
                                bptr(y.dZ), (float*)(ws + wl.lnpart[L - 1]) + (size_t)g[L - 1].nchunks * LNB_GRID * 2 * H,
                                LNB_GRID_TOP, B, H, 0, y.T, y.reduce, st.C));
@@ -612,6 +662,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     // the products are spread under the whole recurrence instead of piling up behind the last
     // layers (the BPTT launches next to a busy W stream take 27 us instead of 16).
     auto weight_grads = [&](int l, int t0, int t1, bool first, bool last_of_all) -> int {
+        if (g_trace) return ED_OK;
         const edgedict_stack_layer_t& y = d->layers[l];
         const int M = (t1 - t0) * B;
         const long long r0 = (long long)t0 * B;
@@ -693,6 +744,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                 ++ndone;
             }
             ++next_t[l];
+            if (g_trace) g_trace->step_launch[g_trace->toff[l] + t] = g_trace->launches;
         }
         if (Lcs[0].nstep + Lcs[1].nstep == 0) {
             ED_CHECK_ARG(++idle < 4096, "encoder_stack: backward schedule made no progress");
@@ -700,8 +752,12 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
         }
         idle = 0;
         ++launches;
-        ED_TRY(ed_stack_launch_bwd(Lcs[0], st.R));
-        if (st.split < L) ED_TRY(ed_stack_launch_bwd(Lcs[1], st.R2));
+        ED_DEV(ed_stack_launch_bwd(Lcs[0], st.R));
+        if (st.split < L) ED_DEV(ed_stack_launch_bwd(Lcs[1], st.R2));
+        if (g_trace) {
+            g_trace->max_slots = max(g_trace->max_slots, Lcs[0].nstep + Lcs[1].nstep);
+            ++g_trace->launches;
+        }
         for (int i = 0; i < ndone; ++i) {
             const int l = done[i].l, k = done[i].k;
             const edgedict_stack_layer_t& y = d->layers[l];
@@ -712,18 +768,19 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                 const long long r0 = (long long)t0 * B;
                 hipStream_t S = st.S[l];
                 ED_TRY(st.chain(st.RS(l), S));
-                ED_TRY(edgedict_gemm(ED_BF16, ED_BF16, bptr(y.G) + r0 * 4 * H, 4ll * H, 1,
+                ED_DEV(edgedict_gemm(ED_BF16, ED_BF16, bptr(y.G) + r0 * 4 * H, 4ll * H, 1,
                                      y.wih_t ? y.wih_t : y.wih_p, y.wih_t ? 4ll * H : y.I,
                                      y.wih_t ? 1 : 0, bptr(y.dX) + r0 * y.I, y.I, (t1 - t0) * B, y.I,
                                      4 * H, nullptr, nullptr, y.dX == y.dZ ? 1 : 0, 1, S));
                 const int u0 = k * g[l - 1].cf, u1 = min(z.T, u0 + g[l - 1].cf);
-                ED_TRY(ed_stack_ln_bwd(bptr(y.dX), (long long)B * y.I, y.I, bptr(z.Yx) + BH,
+                ED_DEV(ed_stack_ln_bwd(bptr(y.dX), (long long)B * y.I, y.I, bptr(z.Yx) + BH,
                                        z.residual ? bptr(z.X) : nullptr, z.ln_gamma, z.mean, z.rstd,
                                        bptr(z.dZ), (float*)(ws + wl.lnpart[l - 1]) + (size_t)k * LNB_GRID * 2 * H,
                                        LNB_GRID, B, H, u0, u1, z.reduce, S));
                 ED_TRY(st.record(Eb[l - 1][k], S));
                 queued[l - 1][k] = 1;
                 ready_w[l - 1][k] = w + margin;
+                if (g_trace) g_trace->chunk_enqueued[g_trace->coff[l - 1] + k] = g_trace->launches;
             }
             // chunks complete from the last to the first: a segment [k, k + dw_seg) is complete when
             // its lowest chunk is (k a multiple of dw_seg, counted so that the LAST segment issued,
@@ -763,10 +820,10 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
         const edgedict_stack_layer_t& y = d->layers[0];
         bf16_t* dX0 = bptr(ws + wl.dX0);
         ED_TRY(st.chain(st.RS(0), st.S[0]));
-        ED_TRY(edgedict_gemm(ED_BF16, ED_BF16, y.G, 4ll * H, 1, y.wih_t ? y.wih_t : y.wih_p,
+        ED_DEV(edgedict_gemm(ED_BF16, ED_BF16, y.G, 4ll * H, 1, y.wih_t ? y.wih_t : y.wih_p,
                              y.wih_t ? 4ll * H : y.I, y.wih_t ? 1 : 0, dX0, y.I, y.T * B, y.I, 4 * H,
                              nullptr, nullptr, 0, 1, st.S[0]));
-        ED_TRY(ed_stack_input_norm_bwd(d->x_dtype, d->x, dX0, d->in_mean, d->in_rstd, d->d_in_gamma,
+        ED_DEV(ed_stack_input_norm_bwd(d->x_dtype, d->x, dX0, d->in_mean, d->in_rstd, d->d_in_gamma,
                                        d->d_in_beta, B, d->T0, d->I0, st.S[0]));
         // LayerNorm parameter gradients: sum the per-workgroup partial rows of every launch
         for (int l = 1; l < L; ++l) ED_TRY(st.chain(st.S[l], st.S[0]));
@@ -774,9 +831,9 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
             const edgedict_stack_layer_t& z = d->layers[l];
             const float* part = (const float*)(ws + wl.lnpart[l]);
             if (l == L - 1)   // only the top layer's all-frames call (it ran on the caller's stream)
-                ED_TRY(ed_stack_sum_parts(part + (size_t)g[l].nchunks * LNB_GRID * 2 * H, LNB_GRID_TOP, H, z.dgamma, z.dbeta, st.S[0]));
+                ED_DEV(ed_stack_sum_parts(part + (size_t)g[l].nchunks * LNB_GRID * 2 * H, LNB_GRID_TOP, H, z.dgamma, z.dbeta, st.S[0]));
             else
-                ED_TRY(ed_stack_sum_parts(part, g[l].nchunks * LNB_GRID, H, z.dgamma, z.dbeta, st.S[0]));
+                ED_DEV(ed_stack_sum_parts(part, g[l].nchunks * LNB_GRID, H, z.dgamma, z.dbeta, st.S[0]));
         }
     }
     if (!deferred.empty()) {

@@ -282,3 +282,55 @@ class EncoderStackFn(torch.autograd.Function):
         for gb in grads:
             out += [gb["dW_ih"], gb["dW_hh"], gb["db"], gb["db"].clone(), gb["dgamma"], gb["dbeta"]]
         return tuple(out)
+
+
+def schedule(T0, I0, H, reductions, B=64, chunk=None, backward=False, lag=0):
+    """Dry run of the native scheduler (no device): returns ``(step_launch, chunk_enqueued,
+    n_launches, max_slots)`` where ``step_launch[l][t]`` is the launch index that carries step t of
+    layer l and ``chunk_enqueued[l][k]`` the number of launches issued when chunk k's side-stream
+    product was enqueued (-1 = available from the start).  Used by tests/test_stack_schedule.py."""
+    import numpy as np
+    lib = _lib.load()
+    L = len(reductions)
+    chunk = chunk or CHUNK
+    layers = (StackLayer * L)()
+    dummy = ctypes.c_void_p(0x1000)          # never dereferenced in a dry run
+    fdummy = ctypes.cast(dummy, _fp)
+    T, I = T0, I0
+    Ts = []
+    for l in range(L):
+        y = layers[l]
+        y.T, y.I, y.reduce, y.residual = T, I, reductions[l], 1 if l > 0 else 0
+        for name, typ in StackLayer._fields_[4:]:
+            setattr(y, name, fdummy if typ is _fp else dummy)
+        Ts.append(T)
+        T = (T + reductions[l] - 1) // reductions[l]
+        I = H
+    d = StackDesc()
+    d.B, d.H, d.L, d.chunk, d.lag, d.split_k, d.flags, d.eps = B, H, L, chunk, lag, 0, 0, 1e-5
+    d.layers = layers
+    d.x, d.x_dtype, d.T0, d.I0 = dummy, 1, T0, I0
+    for name in ("in_gamma", "in_beta", "in_mean", "in_rstd", "d_in_gamma", "d_in_beta"):
+        setattr(d, name, fdummy)
+    d.h0 = d.c0 = None
+    d.out = d.dout = d.ws = dummy
+    d.ws_bytes = 1 << 62
+    f0 = 1
+    for r in reductions:
+        f0 *= r
+    fl, f = [], f0
+    for l in range(L):
+        fl.append(f)
+        f //= reductions[l]
+    nch = [(Ts[l] + chunk * fl[l] - 1) // (chunk * fl[l]) for l in range(L)]
+    steps = np.full(sum(Ts), -2, dtype=np.int32)
+    enq = np.full(sum(nch), -2, dtype=np.int32)
+    nl, ms = ctypes.c_int32(0), ctypes.c_int32(0)
+    rc = lib.edgedict_stack_schedule(ctypes.byref(d), 1 if backward else 0,
+                                     steps.ctypes.data_as(ctypes.c_void_p), enq.ctypes.data_as(ctypes.c_void_p),
+                                     ctypes.byref(nl), ctypes.byref(ms))
+    _lib.check(rc, "stack_schedule")
+    so = np.cumsum([0] + Ts)
+    co = np.cumsum([0] + nch)
+    return ([steps[so[l]:so[l + 1]] for l in range(L)], [enq[co[l]:co[l + 1]] for l in range(L)],
+            int(nl.value), int(ms.value))

@@ -274,6 +274,14 @@ int edgedict_stack_forward(const edgedict_stack_desc_t* desc, void* stream);
  * launch of the most recent forward (backward = 0) or backward (1) call on this device, and the
  * number of launches in it; blocks until that call's launches have executed. */
 int edgedict_stack_last_timing(int backward, float* ms, int* launches);
+/* Dry run of the scheduler (no device needed, nothing is launched; buffer pointers in the descriptor
+ * only have to be non-NULL): the launch index that carries every layer-step and the number of
+ * launches issued when each chunk's side-stream product was enqueued.
+ *   step_launch     HOST int32 [sum_l T_l], layer-major, frame t of layer l at offset(l) + t
+ *   chunk_enqueued  HOST int32 [sum_l nchunks_l], nchunks_l = ceil(T_l / (chunk * f_l)); -1 = from the start
+ *   n_launches, max_slots  HOST int32: launches of the step kernel, most layer-steps in one launch */
+int edgedict_stack_schedule(const edgedict_stack_desc_t* d, int backward, int32_t* step_launch,
+                            int32_t* chunk_enqueued, int32_t* n_launches, int32_t* max_slots);
 int edgedict_stack_backward(const edgedict_stack_desc_t* desc, void* stream);
 
 /* ------------------------------------------------------------------------------------

@@ -1,0 +1,77 @@
+"""CPU: the encoder stack's dynamic wavefront schedule (csrc/encoder_stack.hip) run DRY through
+``edgedict_stack_schedule`` - no device, nothing launched - and checked for the invariants the
+kernels rely on: every layer-step is carried by exactly one launch, in recurrence order; a layer
+never opens a chunk before the side-stream product that feeds it was enqueued, and that product is
+enqueued only after the producing layer finished (and, forward, normalised) the chunk's frames; a
+launch never carries more layer-steps than the launch structure holds; the E6D2 launch counts."""
+import numpy as np
+import pytest
+from hypothesis import given, settings, strategies as st
+
+from edgedict_amd import encoder_stack as es
+
+MAX_SLOTS = 8
+
+
+def _geometry(T0, reductions, chunk):
+    L = len(reductions)
+    Ts, T = [], T0
+    for r in reductions:
+        Ts.append(T)
+        T = (T + r - 1) // r
+    f = int(np.prod(reductions))
+    fl = []
+    for r in reductions:
+        fl.append(f)
+        f //= r
+    cf = [chunk * x for x in fl]
+    return L, Ts, cf
+
+
+def _check(T0, reductions, chunk, backward):
+    L, Ts, cf = _geometry(T0, reductions, chunk)
+    steps, enq, n, max_slots = es.schedule(T0, 64, 64, reductions, B=3, chunk=chunk, backward=backward)
+    assert 1 <= max_slots <= MAX_SLOTS
+    per_launch = np.zeros(n, dtype=int)
+    for l in range(L):
+        s = steps[l].astype(int)
+        assert len(s) == Ts[l] and (s >= 0).all() and (s < n).all()
+        order = s if not backward else s[::-1]
+        assert (np.diff(order) > 0).all(), "a layer steps at most once per launch, in recurrence order"
+        np.add.at(per_launch, s, 1)
+    assert per_launch.max() == max_slots and (per_launch >= 0).all()
+    for l in range(L):
+        nch = len(enq[l])
+        for k in range(nch):
+            lo, hi = k * cf[l], min(Ts[l], (k + 1) * cf[l]) - 1
+            opening = steps[l][hi] if backward else steps[l][lo]      # first step of the chunk in run order
+            e = int(enq[l][k])
+            src = (l + 1) if backward else (l - 1)
+            if src < 0 or src >= L:
+                assert e <= opening                                  # fed from the input / the loss side
+                continue
+            assert e >= 0 and opening >= e, "consumer launch comes after the product was enqueued"
+            # the producing layer's frames of this chunk (same chunk index, its own frame rate)
+            plo, phi = k * cf[src], min(Ts[src], (k + 1) * cf[src]) - 1
+            last = int(steps[src][plo] if backward else steps[src][phi])
+            # backward: enqueued right after the producer's launch; forward: after the launch that
+            # carries the LayerNorm of the producer's last frame, i.e. one launch later
+            assert e >= last + (1 if backward else 2), (l, k, e, last)
+    return n
+
+
+@pytest.mark.parametrize("backward", [False, True])
+def test_e6d2_schedule(backward):
+    n = _check(401, [1, 2, 1, 1, 1, 1], 12, backward)
+    # static-lag schedule: 547 / 546 launches; dynamic: layers behind the reduction run every launch
+    # when no faster layer runs beside them
+    assert n == (501 if backward else 487)
+
+
+@settings(max_examples=60, deadline=None, derandomize=True)
+@given(st.integers(1, 90), st.lists(st.sampled_from([1, 1, 2]), min_size=1, max_size=6),
+       st.integers(1, 6), st.booleans())
+def test_schedule_invariants_on_random_geometries(T0, reductions, chunk, backward):
+    if int(np.prod(reductions)) > 4:          # at most two time reductions (period 4), as tested on the GPU
+        reductions = [1 if i > 1 else r for i, r in enumerate(reductions)]
+    _check(T0, reductions, chunk, backward)
