@@ -99,7 +99,7 @@ def read_flagfile(path, **overrides):
 
 def model_kwargs(flags, vocab_size=None, input_size=None):
     """Constructor kwargs of ``Transducer`` as the reference's scripts build them
-    (rnnt/stream.py:53-67, cli/train.py:113-126)."""
+    (rnnt/stream.py:53-67, cli/train.py:113-126, cli/lightning.py:50-65)."""
     if input_size is None:
         input_size = flags.feature_size * (3 if flags.delta else 1) * max(1, flags.downsample)
     return dict(
@@ -111,4 +111,5 @@ def model_kwargs(flags, vocab_size=None, input_size=None):
         dec_hidden_size=flags.dec_hidden_size, dec_layers=flags.dec_layers,
         dec_dropout=flags.dec_dropout, dec_proj_size=flags.dec_proj_size,
         joint_size=flags.joint_size,
+        module_type=getattr(flags, "enc_type", "LSTM"),      # cli/lightning.py:63
     )
