@@ -3,3 +3,8 @@ from edgedict_amd.models import (Transducer, Encoder, Decoder, Joint, ResLayerNo
                                  TimeReduction, convert_lightning2normal,
                                  FrontEnd, ResLayerNormGRU, CTCEncoder)
 from edgedict_amd.loss import RNNTLoss  # noqa: F401
+from rnnt import _reference_fallback  # noqa: E402
+
+# names the engine does not provide (corpus readers, audio-file transforms, wav2vec pieces ...) fall
+# through to the reference checkout when one is on sys.path
+__getattr__ = _reference_fallback("models", __file__)

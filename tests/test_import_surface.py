@@ -34,3 +34,30 @@ def test_out_of_path_modules_fail_loudly_not_silently():
     assert t.state_dict()["encoder.lstm.lstms.1.weight_hh_l0"].shape == (96, 32)
     with pytest.raises(ValueError):
         Transducer(16, 40, 24, 32, 2, 0.0, 24, 32, 1, 0.0, 24, 32, module_type="RNN")   # rnnt/models.py:191-192
+
+
+def test_unshimmed_names_fall_through_to_a_reference_checkout(tmp_path):
+    """The reference's `rnnt` is a namespace package; this repository's regular `rnnt` package would
+    shadow it completely.  Modules and names the shim does not provide must still resolve to a
+    reference checkout that FOLLOWS this repository on sys.path (a fake one here)."""
+    import subprocess
+    import sys
+    ref = tmp_path / "ref" / "rnnt"
+    ref.mkdir(parents=True)
+    (ref / "args.py").write_text("FLAGS = 'reference flags'\n")
+    (ref / "tokenizer.py").write_text("NUL = 99\nclass HuggingFaceTokenizer:\n    origin = 'reference'\n")
+    (ref / "dataset.py").write_text("from rnnt.tokenizer import PAD\nclass Librispeech:\n    pad = PAD\n")
+    (ref / "models.py").write_text("class Transducer:\n    origin = 'reference'\n")
+    repo = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "import rnnt.args, rnnt.models\n"
+        "from rnnt.tokenizer import HuggingFaceTokenizer, NUL\n"
+        "from rnnt.dataset import seq_collate, Librispeech\n"
+        "assert rnnt.args.FLAGS == 'reference flags'\n"
+        "assert HuggingFaceTokenizer.origin == 'reference' and NUL == 0\n"          # constants: the engine's
+        "assert seq_collate.__module__ == 'edgedict_amd.collate' and Librispeech.pad == 1\n"
+        "assert rnnt.models.Transducer.__module__ == 'edgedict_amd.models'\n"        # shimmed modules win
+        "print('ok')\n" % (repo, str(tmp_path / "ref")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-800:]
