@@ -2,9 +2,11 @@
 
 Only the log-mel path of the north-star is implemented on the GPU: ``FilterbankFeatures`` and the
 frame stacking ``Downsample`` (pure data movement).  ``build_transform`` returns the same triple
-``(transform_train, transform_test, input_size)`` as the reference (rnnt/transforms.py:165-203);
-SpecAugment masking runs on the resident batch (``SpecAugment``, one kernel); deltas and CMVN
-are outside the hot path and raise if requested.
+``(transform_train, transform_test, input_size)`` as the reference (rnnt/transforms.py:165-203):
+the train transform carries the SpecAugment masks (``SpecAugment``, one kernel on the resident
+stacked batch), the test transform does not; both accept the reference's per-utterance call
+``t(x)`` and the batched ``t(wave, wave_len)``.  Deltas and CMVN are outside the hot path
+ and raise if requested.
 """
 import torch
 
@@ -39,13 +41,22 @@ class _FusedFbankDownsample(torch.nn.Module):
     the reference layout [B, D*n_frame, T0] so callers can still ``.transpose(1, 2)`` it
     (rnnt/stream.py:96, rnnt/dataset.py:103)."""
 
-    def __init__(self, n_frame, pad_to_divisible, **fb):
+    def __init__(self, n_frame, pad_to_divisible, augment=None, **fb):
         super().__init__()
         self.inner = StackedLogFbank(n_frame=n_frame, pad_to_divisible=pad_to_divisible, **fb)
+        self.augment = augment          # SpecAugment of the TRAIN transform (rnnt/transforms.py:196-200)
 
-    def forward(self, x):
-        xs, _ = self.inner(x)
-        return xs.transpose(1, 2)
+    def forward(self, x, lengths=None):
+        """``forward(x)``: the reference's per-utterance call, returns [B, D*n_frame, T0].
+        ``forward(wave [B,N], wave_len [B])``: the batched form for a trainer that collates raw
+        audio (``wave_collate``), returns ``(xs [B, T0, D*n_frame], xlen [B])`` time-major, the
+        lengths on the host when they came from the host."""
+        xs, xlen = self.inner(x, lengths)
+        if self.augment is not None:
+            xs = self.augment(xs)
+        if lengths is None:
+            return xs.transpose(1, 2)
+        return xs, xlen
 
 
 class SpecAugment(torch.nn.Module):
@@ -107,11 +118,17 @@ def build_transform(feature_type, feature_size, n_fft=512, win_length=400, hop_l
     fb = dict(n_filt=feature_size, n_fft=n_fft, win_length=win_length, hop_length=hop_length,
               dither=dither)
     input_size = feature_size
+    aug = None
+    if (T_mask > 0 and T_num_mask > 0) or (F_mask > 0 and F_num_mask > 0):
+        aug = SpecAugment(T_mask, T_num_mask, F_mask, F_num_mask)
     if downsample > 1:
         test = _FusedFbankDownsample(downsample, pad_to_divisible, **fb)
+        train = _FusedFbankDownsample(downsample, pad_to_divisible, augment=aug, **fb) if aug else test
         input_size = input_size * downsample
     else:
-        test = FilterbankFeatures(**fb)
-    # SpecAugment masks (T_mask/F_mask) belong to the train transform only; they are applied by
-    # the input pipeline, not by the engine -> train == test here.
-    return test, test, input_size
+        if aug is not None:
+            raise NotImplementedError("SpecAugment masks are implemented on the stacked features "
+                                      "(downsample > 1), as the shipped flagfiles use them")
+        test = train = FilterbankFeatures(**fb)
+    # the masks belong to the train transform only (rnnt/transforms.py:193-201)
+    return train, test, input_size

@@ -70,3 +70,33 @@ def test_prediction_network_dropout_trains_and_is_identity_in_eval(hip_lib):
     c.square().sum().backward()
     for n, q in dec.named_parameters():
         assert q.grad is not None and torch.isfinite(q.grad).all(), n
+
+
+def test_build_transform_triple_train_masks_test_does_not(hip_lib):
+    """rnnt/transforms.py:165-203: (transform_train, transform_test, input_size); the masks belong
+    to the train transform only.  Both call forms: per-utterance ``t(x)`` -> [B, D*n, T0] (reference
+    layout) and batched ``t(wave, wave_len)`` -> (xs [B, T0, D*n], xlen)."""
+    from edgedict_amd.transforms import build_transform
+    kw = dict(feature_type="logfbank", feature_size=80, n_fft=512, win_length=320, hop_length=200,
+              downsample=3)
+    train, test, input_size = build_transform(T_mask=50, T_num_mask=2, F_mask=5, F_num_mask=1, **kw)
+    assert input_size == 240 and train is not test
+    plain_train, plain_test, _ = build_transform(**kw)
+    assert plain_train is plain_test                         # no masks requested
+    g = torch.Generator().manual_seed(0)
+    wave = (0.1 * torch.randn(3, 16000, generator=g)).cuda()
+    wl = torch.tensor([16000, 12000, 9000], dtype=torch.int32)
+    train, test = train.cuda(), test.cuda()                  # nn.Modules: buffers follow .to(device)
+    for t in (train, test):
+        t.inner.fbank.dither = 0.0
+    ref = test(wave.clone())
+    assert ref.shape[0] == 3 and ref.shape[1] == 240
+    xs_t, xlen = test(wave.clone(), wl)
+    assert xs_t.shape == (3, ref.shape[2], 240) and not xlen.is_cuda
+    assert torch.equal(xs_t[0].t(), ref[0])                  # same features, time-major
+    random.seed(5)
+    xs_a, xlen_a = train(wave.clone(), wl)
+    assert torch.equal(xlen_a, xlen)
+    zeroed = (xs_a == 0) & (xs_t != 0)
+    assert zeroed.any()                                      # something was masked ...
+    assert torch.equal(xs_a[~zeroed], xs_t[~zeroed])         # ... and nothing else changed
