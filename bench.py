@@ -53,14 +53,17 @@ def synth_batch(flags, B, seconds, U, seed, device):
 def cpu_baseline(flags, seconds, U, budget_s=25.0):
     """Oracle ('port') timed on the host cores: restated log-mel + reference-equivalent torch
     CPU encoder/prediction/joint + vectorised RNN-T DP loss, forward + backward (no optimiser),
-    on a bounded sample of the same workload."""
+    on a bounded sample of the same workload.  torch's default (one thread per hardware thread)
+    oversubscribes these LSTM-bound graphs, so the thread count is swept first (one iteration
+    each) and the sample is timed at the best one."""
     from oracle import features_ref as Fr
     from oracle import models_ref as M
     from oracle import rnnt_loss_ref as R
     from edgedict_amd.flags import model_kwargs
     cfg = {k: v for k, v in model_kwargs(flags).items() if not k.endswith("dropout")}
     B = 4
-    threads = torch.get_num_threads()
+    ncpu = os.cpu_count() or 1
+    default_threads = torch.get_num_threads()
     sd = {k: v.requires_grad_(True) for k, v in M.make_state_dict(cfg, 0).items()}
     g = torch.Generator(device="cpu").manual_seed(1)
     wave = (0.1 * torch.randn(B, int(seconds * 16000), generator=g)).clamp_(-1, 1)
@@ -81,16 +84,96 @@ def cpu_baseline(flags, seconds, U, budget_s=25.0):
         return float(costs.mean())
 
     one()  # warm-up
+    sweep = {}
+    for th in sorted({t for t in (8, 16, 32, 64, 128, default_threads) if t <= max(ncpu, 1)} or {1}):
+        torch.set_num_threads(th)
+        t0 = time.time()
+        one()
+        sweep[th] = B / (time.time() - t0)
+    best = max(sweep, key=sweep.get)
+    torch.set_num_threads(best)
     t0 = time.time()
     iters = 0
-    while iters < 2 or (time.time() - t0 < budget_s and iters < 8):
+    while iters < 2 or (time.time() - t0 < budget_s and iters < 6):
         one()
         iters += 1
     dt = time.time() - t0
-    return {"value": B * iters / dt, "unit": "utterances/s", "cores": threads, "kind": "port",
-            "sample": "%d iterations of %d x %.0f s utterances (U=%d), E6D2, fp32 fwd+bwd incl. "
-                      "log-mel and RNN-T loss, no optimiser step; torch CPU with %d threads"
-                      % (iters, B, seconds, U, threads)}
+    torch.set_num_threads(default_threads)
+    return {"value": B * iters / dt, "unit": "utterances/s", "cores": best, "kind": "port",
+            "host_cpus": ncpu,
+            "thread_sweep_utt_per_s": {str(k): round(v, 3) for k, v in sorted(sweep.items())},
+            "sample": "%d iterations of %d x %.0f s utterances (U=%d), %s model, fp32 fwd+bwd incl. "
+                      "log-mel and RNN-T loss, no optimiser step; torch CPU at the best of the "
+                      "swept thread counts (%d threads; host has %d logical CPUs)"
+                      % (iters, B, seconds, U, getattr(flags, "preset_name", "E6D2"), best, ncpu)}
+
+
+def loss_delta(engine, flags, batch, n_utt=4):
+    """'RNN-T loss delta vs ref' (BASELINE.json metric) on the benched configuration, OUTSIDE the
+    timed region: the first ``n_utt`` utterances of the bench batch, the engine's current weights,
+    dither off / no SpecAugment / eval mode, through (a) the bf16 path that was timed, (b) the
+    engine's fp32 parity mode and (c) the CPU oracle (oracle/models_ref.py pinned on the
+    reference module + float64 RNN-T DP).  Returns relative errors of the mean loss."""
+    from edgedict_amd.features import StackedLogFbank
+    from oracle import models_ref as M
+    from oracle import rnnt_loss_ref as R
+    wave, wave_len, ys, ylen = batch
+    dev = wave.device
+    fb = StackedLogFbank(n_frame=flags.downsample, pad_to_divisible=True, out_dtype=torch.float32,
+                         sample_rate=getattr(flags, "sample_rate", 16000), win_length=flags.win_length,
+                         hop_length=flags.hop_length, n_fft=flags.n_fft, n_filt=flags.feature_size,
+                         dither=0.0).to(dev)
+    model = engine.model
+    was_training, cd0 = model.training, model.compute_dtype
+    model.eval()
+    out = {}
+    try:
+        with torch.no_grad():
+            xs, xlen = fb(wave[:n_utt], wave_len[:n_utt])
+            yl = ylen[:n_utt].clone()
+            for name in ("bf16", "fp32"):
+                model.compute_dtype = name
+                out[name] = float(model(xs, ys[:n_utt], xlen, yl).item())
+            sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+            xs_c, xlen_c, ys_c = xs.float().cpu(), xlen.cpu().to(torch.int32), ys[:n_utt].cpu()
+            t0 = time.time()
+            logits, act = M.transducer_logits(sd, xs_c, ys_c, xlen_c, yl)
+            costs, _ = R.rnnt_loss(logits.double().numpy(), ys_c[:, :int(yl.max())].numpy(),
+                                   act.numpy(), yl.numpy(), want_grads=False)
+            ref = float(costs.mean())
+            out["oracle_s"] = round(time.time() - t0, 2)
+    finally:
+        model.compute_dtype = cd0
+        model.train(was_training)
+    return {"utterances": n_utt, "oracle_loss": ref, "engine_loss_bf16": out["bf16"],
+            "engine_loss_fp32": out["fp32"],
+            "loss_rel_err_bf16": abs(out["bf16"] - ref) / abs(ref),
+            "loss_rel_err_fp32": abs(out["fp32"] - ref) / abs(ref),
+            "oracle_seconds": out["oracle_s"],
+            "note": "mean RNN-T loss of the first %d utterances of the bench batch, engine weights "
+                    "after the timed steps, vs the CPU oracle (reference-pinned model restatement + "
+                    "float64 loss); north-star bound 1e-3 relative in fp32" % n_utt}
+
+
+def self_spawn(args):
+    """``python bench.py --gpus N`` with N > 1 and no launcher environment: start the N ranks
+    ourselves through torch.distributed.run (one process per GPU, RCCL) - never report n_gpus = 1
+    for a run that asked for more."""
+    import socket
+    import subprocess
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev < args.gpus:
+        raise SystemExit("bench.py: --gpus %d requested but %d HIP device(s) are visible; refusing to "
+                         "report a smaller job as n_gpus=%d" % (args.gpus, n_dev, args.gpus))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
@@ -104,14 +187,21 @@ def main():
     ap.add_argument("--preset", default="E6D2")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-loss-delta", action="store_true")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_spawn(args)                       # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if world != args.gpus:
+        raise SystemExit("bench.py: WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("bench.py: LOCAL_RANK %d but only %d HIP device(s) visible"
+                         % (local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # the engine's internal streams first, before RCCL / torch create any (see TrainEngine.__init__)
@@ -126,6 +216,7 @@ def main():
     from edgedict_amd.trainer import TrainEngine
 
     flags = make_flags(args.preset, gradclip=None, dither=1e-5)
+    flags.preset_name = args.preset
     flags.sub_batch_size = args.batch          # one slice: the lattice fits in 288 GB of HBM
     torch.manual_seed(0)
     engine = TrainEngine(flags, device=device, compute_dtype=args.dtype)
@@ -160,6 +251,17 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     loss_val = float(loss.item())
+    # evidence of what actually ran: the ranks RCCL connected and the device each one drove
+    joined = world
+    devices = [torch.cuda.current_device()]
+    if world > 1:
+        joined = dist.get_world_size()
+        ids = torch.zeros(world, dtype=torch.int64, device=device)
+        ids[rank] = torch.cuda.current_device() + 1
+        dist.all_reduce(ids)
+        devices = [int(i) - 1 for i in ids.tolist()]
+        if joined != args.gpus or any(i < 0 for i in devices):
+            raise SystemExit("bench.py: %d ranks joined, --gpus %d" % (joined, args.gpus))
 
     if rank == 0:
         # dominant kernel: the joint's second Linear, logits = hid[B*T'*U1, J] x W2[V, J]^T
@@ -227,7 +329,9 @@ def main():
             "metric": "utterances/sec (E6D2, 15 s audio)",
             "value": args.batch * world * args.steps / dt,
             "unit": "utterances/s",
-            "n_gpus": world,
+            "n_gpus": joined,
+            "rccl_ranks": joined if world > 1 else None,
+            "rank_devices": devices,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps,
@@ -264,6 +368,11 @@ def main():
             "host_call_ms": {k: round(v[1], 3) for k, v in sorted(ops.host_summary().items())},
         }
         out["roofline"] = stack if stack is not None else out["roofline_mfma"]
+        if not args.no_loss_delta:
+            ld = loss_delta(engine, flags, batch)
+            out["loss_delta_vs_ref"] = ld
+            out["config"]["loss_rel_err"] = ld["loss_rel_err_" + ("bf16" if args.dtype == "bf16" else "fp32")]
+            out["config"]["loss_rel_err_fp32"] = ld["loss_rel_err_fp32"]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(flags, args.seconds, args.labels)
             out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -126,7 +126,14 @@ __global__ void rnnt_alpha_beta(const float* __restrict__ lpb, const float* __re
     const int b = blockIdx.x >> 1;
     const int dir = blockIdx.x & 1;
     const int u = threadIdx.x;
-    const int Tb = act_lens[b], Ub = label_lens[b];
+    // clamped exactly as rnnt_lse_gather / rnnt_grad clamp them: malformed lengths (the Python shim
+    // rejects them, a raw C-ABI caller may not) can neither index past the [Tm, U1] slab nor past
+    // the exchange buffer; an empty utterance (Tb <= 0) has likelihood 0 => cost +inf, never garbage
+    const int Tb = max(0, min(act_lens[b], Tm)), Ub = max(0, min(label_lens[b], U1 - 1));
+    if (Tb == 0) {
+        if (threadIdx.x == 0) ll[2 * b + dir] = -(double)INFINITY;
+        return;
+    }
     const int stride = blockDim.x + 2;
     const long long base = (long long)b * Tm * U1;
     const bool col_ok = (u <= Ub);

@@ -846,7 +846,9 @@ class Transducer(nn.Module):
             cd = self.compute_dtype
             l1, l2 = self.joint.joint[0], self.joint.joint[2]
             act = self.scale_length(h_enc, xlen)
-            labels = ys.to(torch.int32).contiguous()
+            # the loss kernels take a raw device pointer: a host-side label batch (seq_collate
+            # output with only xs uploaded) is moved, as Decoder.forward does for its own copy
+            labels = ys.to(device=h_enc.device, dtype=torch.int32).contiguous()
             loss = _JointLossFn.apply(_to_cd(h_enc, cd), _to_cd(h_dec, cd), l1.weight, l1.bias,
                                       l2.weight, l2.bias, labels, act, ylen, self.blank, cd)
             ops.mark("joint:exit")
@@ -855,8 +857,8 @@ class Transducer(nn.Module):
         ops.mark("joint:exit")
         if self.output_loss:
             xlen = self.scale_length(logits, xlen)
-            labels = ys.to(torch.int32).contiguous()
             dev = logits.device   # lengths may live on the host (no sync for the slicing above)
+            labels = ys.to(device=dev, dtype=torch.int32).contiguous()
             loss = _RNNTLossFn.apply(
                 logits, labels,
                 xlen.to(device=dev, dtype=torch.int32, non_blocking=True).contiguous(),

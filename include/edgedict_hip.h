@@ -4,10 +4,15 @@
  * This is the drop-in boundary one level below the Python class surface
  * (rnnt.models.Transducer / rnnt.stream.PytorchStreamDecoder).  Every entry point
  *   - takes raw DEVICE pointers, sizes and a hipStream_t (passed as void*),
- *   - allocates nothing: the caller (the PyTorch caching allocator in our host code)
- *     owns every buffer including workspaces,
- *   - keeps no global mutable state, so it is re-entrant per device/stream
- *     (nn.DataParallel drives one Python thread per GPU in one process),
+ *   - allocates no caller-visible buffer: the caller (the PyTorch caching allocator in our host
+ *     code) owns every tensor and workspace it passes in,
+ *   - keeps exactly this per-DEVICE state, created lazily under a mutex and never exposed: three
+ *     internal HIP streams + an event pool for the encoder-stack scheduler (edgedict_aux_stream,
+ *     edgedict_stack_*), the timing record read by edgedict_stack_last_timing, and - only when a
+ *     product is routed to the vendor library - one hipBLASLt handle per device with a 64 MiB
+ *     workspace per (device, stream).  Entry points are re-entrant per device; calls that touch
+ *     the same device from several host threads must be serialised by the caller
+ *     (nn.DataParallel's one-thread-per-GPU pattern is fine: different devices),
  *   - never aborts: it returns ED_OK or a negative status and leaves a message in
  *     edgedict_last_error() (thread-local) which the binding raises as RuntimeError.
  *

@@ -36,6 +36,16 @@ CASES = {
     "E4D1": (dict(vocab_embed_size=64, vocab_size=2048, input_size=240, enc_hidden_size=256,
                   enc_layers=4, enc_proj_size=256, dec_hidden_size=256, dec_layers=1,
                   dec_proj_size=256, joint_size=256), 4, 167, 20, 0),
+    # the BENCHED configuration (BASELINE config 2; flagfiles/E6D2.txt) at full model size and full
+    # 15 s length (T0 = 401 stacked frames -> T' = 201, U = 64), two utterances
+    "E6D2": (dict(vocab_embed_size=64, vocab_size=2048, input_size=240, enc_hidden_size=1024,
+                  enc_layers=6, enc_proj_size=640, dec_hidden_size=256, dec_layers=2,
+                  dec_proj_size=256, joint_size=640), 2, 401, 64, 7),
+    # BASELINE config 3's model (flagfiles/E6D2_LARGE_Batch.txt: prediction net 2x512 -> 640,
+    # hop 320 -> T0 = 251 at 15 s), eval mode (dec_dropout inactive)
+    "E6D2_LARGE": (dict(vocab_embed_size=64, vocab_size=2048, input_size=240, enc_hidden_size=1024,
+                        enc_layers=6, enc_proj_size=640, dec_hidden_size=512, dec_layers=2,
+                        dec_proj_size=640, joint_size=640), 2, 251, 64, 9),
 }
 
 
@@ -65,12 +75,14 @@ def reference_model(cfg, sd):
     return m
 
 
-def main():
+def main(only=None):
     torch.manual_seed(0)
     torch.set_num_threads(8)
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
     for name, (cfg, B, T0, U, seed) in CASES.items():
+        if only and name not in only:
+            continue
         sd = M.make_state_dict(cfg, seed)
         xs, ys, xlen, ylen = M.make_batch(cfg, seed + 1, B, T0, U)
         ref = reference_model(cfg, sd)
@@ -114,4 +126,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main(sys.argv[1:])

@@ -1,0 +1,147 @@
+"""GPU parity AT THE BENCHED SIZE (BASELINE config 2: E6D2, 15 s -> T0 = 401, T' = 201, U = 64,
+H = 1024, 6 layers, V = 2048; and config 3's model E6D2_LARGE: prediction net 2x512 -> 640,
+T0 = 251): the kernels `bench.py` times - the bf16 wavefront encoder stack, the packed-lattice
+joint + RNN-T loss - and the fp32 parity mode are compared with
+
+  * the goldens recorded from the REFERENCE module (oracle/make_golden.py ran
+    /root/reference/rnnt/models.py:228-241 on these weights and inputs), and
+  * float64 CPU autograd through the pinned oracle (oracle/models_ref.py) with the analytic
+    float64 RNN-T gradient (oracle/rnnt_loss_ref.py) for EVERY parameter gradient.
+
+Tolerances: fp32 mode - loss 1e-5 relative (north-star bound 1e-3), gradients 2e-3 of each tensor's
+max; bf16 mode - loss 5e-3 relative, encoder outputs 2e-2 norm-relative, gradients 6e-2
+norm-relative per tensor (bf16 has 8 mantissa bits; six recurrent layers of 201-401 steps).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import models_ref as M
+from oracle import rnnt_loss_ref as R
+from oracle.make_golden import CASES
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+_cache = {}
+
+
+def _load(name):
+    cfg, B, T0, U, seed = CASES[name]
+    g = np.load(os.path.join(GOLD, "transducer_%s.npz" % name))
+    sd = M.make_state_dict(cfg, seed)
+    batch = M.make_batch(cfg, seed + 1, B, T0, U)
+    return cfg, sd, batch, g
+
+
+def _fp64_reference(name):
+    """float64 loss and parameter gradients of the mean RNN-T loss, CPU (about 15 s for E6D2)."""
+    if name not in _cache:
+        cfg, sd, (xs, ys, xlen, ylen), g = _load(name)
+        sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+        logits, act_lens = M.transducer_logits(sd64, xs.double(), ys, xlen, ylen)
+        costs, dlogits = R.rnnt_loss_torch_fast(logits.detach(), ys[:, :int(ylen.max())], act_lens, ylen)
+        logits.backward(dlogits / xs.shape[0])
+        # the oracle's float64 costs agree with the golden (reference logits -> float64 DP)
+        np.testing.assert_allclose(costs.numpy(), g["costs"], rtol=1e-6)
+        _cache[name] = (float(costs.mean()), {k: v.grad for k, v in sd64.items()})
+    return _cache[name]
+
+
+def _engine(cfg, sd, dtype):
+    from edgedict_amd.models import Transducer
+    m = Transducer(enc_dropout=0.0, dec_dropout=0.0, output_loss=True, **cfg)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    m.compute_dtype = dtype
+    return m
+
+
+def _nrel(a, b):
+    return (a.double() - b.double()).norm().item() / max(b.double().norm().item(), 1e-30)
+
+
+@pytest.mark.parametrize("name", ["E6D2", "E6D2_LARGE"])
+def test_fp32_mode_loss_and_every_gradient_vs_fp64_oracle(hip_lib, name):
+    cfg, sd, (xs, ys, xlen, ylen), g = _load(name)
+    ref_loss, ref_grads = _fp64_reference(name)
+    m = _engine(cfg, sd, "fp32")
+    loss = m(xs.cuda(), ys.cuda(), xlen, ylen)          # host lengths: the packed lattice, as benched
+    loss.backward()
+    assert abs(loss.item() - float(g["loss_mean"])) / float(g["loss_mean"]) < 1e-5
+    assert abs(loss.item() - ref_loss) / ref_loss < 1e-5
+    for n, p in m.named_parameters():
+        ref = ref_grads[n]
+        scale = max(ref.abs().max().item(), 1e-12)
+        err = (p.grad.double().cpu() - ref).abs().max().item() / scale
+        assert err < 2e-3, (n, err)
+
+
+@pytest.mark.parametrize("name", ["E6D2", "E6D2_LARGE"])
+def test_bf16_benched_path_vs_reference_golden_and_fp64_gradients(hip_lib, name):
+    """The path bench.py times: wavefront encoder stack + packed-lattice joint/loss, bf16."""
+    from edgedict_amd import config, ops
+    cfg, sd, (xs, ys, xlen, ylen), g = _load(name)
+    ref_loss, ref_grads = _fp64_reference(name)
+    assert config.USE_ENCODER_STACK and config.PACKED_LATTICE
+    m = _engine(cfg, sd, "bf16")
+    ops.TIMERS = {}
+    try:
+        loss = m(xs.cuda(), ys.cuda(), xlen, ylen)
+        loss.backward()
+        torch.cuda.synchronize()
+        timers = ops.timer_summary()
+    finally:
+        ops.TIMERS = None
+    # it really was the wavefront stack and the packed lattice
+    assert any(k.startswith("enc_stack_fwd_T%d" % xs.shape[1]) for k in timers), sorted(timers)
+    assert int(ops.LAST["joint_rows"]) == int((g["act_lens"].astype(np.int64) * (ylen.numpy() + 1)).sum())
+    rel = abs(loss.item() - float(g["loss_mean"])) / float(g["loss_mean"])
+    assert rel < 5e-3, rel
+    with torch.no_grad():
+        enc, _ = m.encoder(xs.cuda())
+    e = enc.float().cpu().numpy()[:, ::5, ::16]
+    r = np.linalg.norm(e - g["enc_out_sample"]) / np.linalg.norm(g["enc_out_sample"])
+    assert r < 2e-2, r
+    worst = {}
+    for n, p in m.named_parameters():
+        worst[n] = _nrel(p.grad.cpu(), ref_grads[n])
+    bad = {n: v for n, v in worst.items() if not v < 6e-2}
+    assert not bad, bad
+
+
+def test_bf16_stack_gradients_h1024_l6_short_sequence_vs_fp64(hip_lib):
+    """Encoder only, H = 1024, 6 layers, B = 5 (partial row tile), T0 = 26: wavefront stack (bf16) and
+    per-layer path (fp32) against float64 autograd through the oracle encoder."""
+    from edgedict_amd.models import Encoder
+    cfg = CASES["E6D2"][0]
+    sd = M.make_state_dict(cfg, 21)
+    g = torch.Generator(device="cpu").manual_seed(22)
+    xs = torch.randn(5, 26, 240, generator=g)
+    w = torch.randn(5, 13, cfg["enc_proj_size"], generator=g)
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items() if k.startswith("encoder.")}
+    y, _ = M.encoder_forward(sd64, xs.double())
+    (y * w.double()).sum().backward()
+    for dtype, tol_y, tol_g in (("fp32", 1e-5, 1e-4), ("bf16", 2e-2, 6e-2)):
+        enc = Encoder(240, 1024, 6, 0.0, cfg["enc_proj_size"])
+        enc.load_state_dict({k[len("encoder."):]: v for k, v in sd.items() if k.startswith("encoder.")})
+        enc = enc.cuda()
+        enc.compute_dtype = torch.float32 if dtype == "fp32" else torch.bfloat16
+        out, _ = enc(xs.cuda())
+        (out.float() * w.cuda()).sum().backward()
+        assert _nrel(out.float().cpu(), y.detach()) < tol_y, dtype
+        for n, p in enc.named_parameters():
+            r = _nrel(p.grad.cpu(), sd64["encoder." + n].grad)
+            assert r < tol_g, (dtype, n, r)
+
+
+def test_host_side_labels_are_moved_not_dereferenced(hip_lib):
+    """seq_collate leaves ys on the host; the packed-lattice branch must upload it (the loss kernels
+    take a raw device pointer) - same loss as with device-side labels."""
+    cfg, sd, (xs, ys, xlen, ylen), g = _load("tiny")
+    m = _engine(cfg, sd, "fp32")
+    a = m(xs.cuda(), ys.cuda(), xlen, ylen).item()
+    b = m(xs.cuda(), ys, xlen, ylen).item()
+    assert a == b
+    assert abs(a - float(g["loss_mean"])) / float(g["loss_mean"]) < 1e-5

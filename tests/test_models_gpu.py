@@ -40,7 +40,7 @@ def test_state_dict_keys_and_shapes_match_reference_layout(hip_lib):
     assert got == want
 
 
-@pytest.mark.parametrize("name", ["tiny", "gru_tiny", "E4D1"])
+@pytest.mark.parametrize("name", ["tiny", "gru_tiny", "E4D1", "E6D2", "E6D2_LARGE"])
 def test_logits_match_reference_golden(hip_lib, name):
     cfg, sd, (xs, ys, xlen, ylen), g = _load(name)
     m = _engine(cfg, sd, output_loss=False)
@@ -57,7 +57,7 @@ def test_logits_match_reference_golden(hip_lib, name):
         np.testing.assert_allclose(out[:, ::7, ::3, ::64], g["logits_sample"], rtol=1e-4, atol=1e-4)
 
 
-@pytest.mark.parametrize("name", ["tiny", "gru_tiny", "E4D1"])
+@pytest.mark.parametrize("name", ["tiny", "gru_tiny", "E4D1", "E6D2", "E6D2_LARGE"])
 def test_loss_matches_golden_within_1e3_relative(hip_lib, name):
     cfg, sd, (xs, ys, xlen, ylen), g = _load(name)
     m = _engine(cfg, sd, output_loss=True)
@@ -137,7 +137,7 @@ def test_bf16_mode_tracks_fp32_loss(hip_lib):
         assert p.grad is not None and torch.isfinite(p.grad).all(), name
 
 
-@pytest.mark.parametrize("name", ["tiny", "gru_tiny", "E4D1"])
+@pytest.mark.parametrize("name", ["tiny", "gru_tiny", "E4D1", "E6D2", "E6D2_LARGE"])
 def test_greedy_tokens_bit_exact_vs_reference_golden(hip_lib, name):
     cfg, sd, (xs, ys, xlen, ylen), g = _load(name)
     m = _engine(cfg, sd, output_loss=False).eval()

@@ -21,7 +21,7 @@ def _load(name):
     return cfg, sd, batch, g
 
 
-@pytest.mark.parametrize("name", ["tiny", "gru_tiny", "E4D1"])
+@pytest.mark.parametrize("name", ["tiny", "gru_tiny", "E4D1", "E6D2", "E6D2_LARGE"])
 def test_oracle_reproduces_reference_outputs(name):
     cfg, sd, (xs, ys, xlen, ylen), g = _load(name)
     assert np.array_equal(xlen.numpy(), g["xlen"]) and np.array_equal(ylen.numpy(), g["ylen"])
@@ -37,7 +37,7 @@ def test_oracle_reproduces_reference_outputs(name):
     np.testing.assert_allclose(costs, g["costs"], rtol=1e-6)
 
 
-@pytest.mark.parametrize("name", ["tiny", "gru_tiny", "E4D1"])
+@pytest.mark.parametrize("name", ["tiny", "gru_tiny", "E4D1", "E6D2"])
 def test_oracle_greedy_tokens_bit_exact(name):
     cfg, sd, (xs, ys, xlen, ylen), g = _load(name)
     with torch.no_grad():
