@@ -51,6 +51,11 @@ struct FbankArgs {
     int win_lo, win_hi;     // non-zero window support [lo, hi)
     float preemph;
     int do_log;
+    int mask_only;          // 1: `lengths` only masks frames >= ceil(len/hop); the signal is the whole
+                            //    padded row (parts/features.py:298-336 semantics); 0: the row ENDS at
+                            //    lengths[b] (per-utterance transform, rnnt/dataset.py:102-103)
+    int copies;             // the feature vector is written `copies` times, o_copy apart
+    long long o_copy;       // (parts/features.py:111-123 frame "splicing")
 };
 
 template <typename TO>
@@ -65,9 +70,10 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a) {
     const bool active = frame_id < total;
     const int b = active ? (int)(frame_id / a.frames_out) : 0;
     const int f = active ? (int)(frame_id % a.frames_out) : 0;
-    const int Nb = a.lengths ? min(a.lengths[b], a.N) : a.N;
+    const int Lb = a.lengths ? min(a.lengths[b], a.N) : a.N;
+    const int Nb = a.mask_only ? a.N : Lb;
     const int n_frames = Nb > 0 ? 1 + Nb / a.hop : 0;  // torch.stft(center=True)
-    const int seq_len = (Nb + a.hop - 1) / a.hop;      // get_seq_len: ceil(N / hop)
+    const int seq_len = (Lb + a.hop - 1) / a.hop;      // get_seq_len: ceil(N / hop)
     const bool compute = active && f < n_frames && f < seq_len;
 
     if (compute) {
@@ -126,7 +132,49 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a) {
             for (int k = lo; k < hi; ++k) acc += w[k] * re[k];
             v = a.do_log ? logf(acc + 1e-20f) : acc;
         }
-        ElemIO<TO>::store(out + obase + (long long)m * a.o_m, v);
+        for (int c = 0; c < a.copies; ++c)
+            ElemIO<TO>::store(out + obase + c * a.o_copy + (long long)m * a.o_m, v);
+    }
+}
+
+// normalize_batch of parts/features.py:80-109 (rnnt/features.py:7-30) on x[b, row, f] (f32,
+// frame stride 1): mean and UNBIASED std over the first n_b = min(ceil(len_b / hop), F) frames -
+// per feature row (mode 1: one workgroup per (b, row)) or over all rows of the utterance (mode 2:
+// one workgroup per b) - then (x - mean) / (std + 1e-5) on those frames (later frames are masked
+// to zero by the caller's contract and stay untouched).  Two-pass, fp32, HBM/launch-bound.
+__device__ __forceinline__ float block_sum256(float v, float* part) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return part[0] + part[1] + part[2] + part[3];
+}
+
+__global__ __launch_bounds__(256) void feat_normalize_kernel(
+    float* __restrict__ x, const int32_t* __restrict__ lengths, int N, int hop, int rows, int F,
+    long long o_b, long long o_row, int mode) {
+    __shared__ float part[4];
+    const int b = mode == 1 ? blockIdx.x / rows : blockIdx.x;
+    const int r0 = mode == 1 ? blockIdx.x % rows : 0;
+    const int nr = mode == 1 ? 1 : rows;
+    const int Lb = lengths ? min(lengths[b], N) : N;
+    const int n = min((Lb + hop - 1) / hop, F);
+    if (n <= 0) return;
+    float* base = x + (long long)b * o_b + (long long)r0 * o_row;
+    const long long cnt = (long long)nr * n;
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < cnt; i += 256) s += base[(i / n) * o_row + (i % n)];
+    const float mean = block_sum256(s, part) / (float)cnt;
+    float q = 0.f;
+    for (long long i = threadIdx.x; i < cnt; i += 256) {
+        const float d = base[(i / n) * o_row + (i % n)] - mean;
+        q += d * d;
+    }
+    const float var = block_sum256(q, part) / (float)(cnt - 1);   // cnt == 1 -> NaN, as torch.std
+    const float inv = 1.f / (sqrtf(var) + 1e-5f);
+    for (long long i = threadIdx.x; i < cnt; i += 256) {
+        float* e = base + (i / n) * o_row + (i % n);
+        *e = (*e - mean) * inv;
     }
 }
 
@@ -144,16 +192,16 @@ extern "C" int edgedict_dither(float* wave, long long wave_stride, int B, int N,
     return ED_OK;
 }
 
-extern "C" int edgedict_fbank_forward(const float* wave, long long wave_stride, int B, int N,
+static int fbank_launch(const float* wave, long long wave_stride, int B, int N,
                                       const int32_t* lengths, const float* window,
                                       const float* twiddle, const float* fb,
                                       const int32_t* fb_range, int n_fft, int win_lo, int win_hi,
                                       int hop, int n_mels, float preemph, int do_log, void* out,
                                       int out_dtype, long long o_b, long long o_group,
                                       long long o_k, long long o_m, int stack, int frames_out,
-                                      void* stream_) {
+                                      int mask_only, int copies, long long o_copy, void* stream_) {
     ED_CHECK_ARG(out_dtype == ED_F32 || out_dtype == ED_BF16, "fbank: bad output dtype");
-    ED_CHECK_ARG(B >= 0 && N >= 0 && hop > 0 && n_mels > 0 && stack > 0, "fbank: bad shape");
+    ED_CHECK_ARG(B >= 0 && N >= 0 && hop > 0 && n_mels > 0 && stack > 0 && copies >= 1, "fbank: bad shape");
     int log2n = 0;
     while ((1 << log2n) < n_fft) ++log2n;
     ED_CHECK_ARG((1 << log2n) == n_fft && n_fft >= 64 && n_fft <= 2048,
@@ -169,6 +217,7 @@ extern "C" int edgedict_fbank_forward(const float* wave, long long wave_stride, 
     a.B = B; a.N = N; a.n_fft = n_fft; a.log2n = log2n; a.hop = hop; a.n_mels = n_mels;
     a.stack = stack; a.frames_out = frames_out; a.win_lo = win_lo; a.win_hi = win_hi;
     a.preemph = preemph; a.do_log = do_log;
+    a.mask_only = mask_only; a.copies = copies; a.o_copy = o_copy;
     const long long total = (long long)B * frames_out;
     const long long blocks = (total + 3) / 4;
     ED_CHECK_ARG(blocks < (1ll << 31), "fbank: too many frames");
@@ -179,5 +228,40 @@ extern "C" int edgedict_fbank_forward(const float* wave, long long wave_stride, 
     else
         hipLaunchKernelGGL(fbank_kernel<bf16_t>, dim3((unsigned)blocks), dim3(256), lds, s, a);
     ED_CHECK_LAUNCH("fbank");
+    return ED_OK;
+}
+
+extern "C" int edgedict_fbank_forward(const float* wave, long long wave_stride, int B, int N,
+                                      const int32_t* lengths, const float* window,
+                                      const float* twiddle, const float* fb,
+                                      const int32_t* fb_range, int n_fft, int win_lo, int win_hi,
+                                      int hop, int n_mels, float preemph, int do_log, void* out,
+                                      int out_dtype, long long o_b, long long o_group,
+                                      long long o_k, long long o_m, int stack, int frames_out,
+                                      void* stream_) {
+    return fbank_launch(wave, wave_stride, B, N, lengths, window, twiddle, fb, fb_range, n_fft, win_lo,
+                        win_hi, hop, n_mels, preemph, do_log, out, out_dtype, o_b, o_group, o_k, o_m,
+                        stack, frames_out, 0, 1, 0, stream_);
+}
+
+extern "C" int edgedict_fbank_forward_masked(const float* wave, long long wave_stride, int B, int N,
+                                             const int32_t* seq_len, const float* window,
+                                             const float* twiddle, const float* fb,
+                                             const int32_t* fb_range, int n_fft, int win_lo,
+                                             int win_hi, int hop, int n_mels, float preemph,
+                                             int do_log, float* out, long long o_b, long long o_m,
+                                             int frames_out, int copies, long long o_copy,
+                                             int normalize, void* stream_) {
+    ED_CHECK_ARG(normalize >= 0 && normalize <= 2, "fbank_masked: normalize must be 0 (none), 1 (per_feature) or 2 (all_features)");
+    const int rc = fbank_launch(wave, wave_stride, B, N, seq_len, window, twiddle, fb, fb_range, n_fft,
+                                win_lo, win_hi, hop, n_mels, preemph, do_log, out, ED_F32, o_b, 1, 0,
+                                o_m, 1, frames_out, 1, copies, o_copy, stream_);
+    if (rc != ED_OK || normalize == 0 || B == 0 || frames_out == 0) return rc;
+    const int rows = n_mels * copies;
+    ED_CHECK_ARG(o_copy == (long long)n_mels * o_m || copies == 1, "fbank_masked: copies must be adjacent row blocks");
+    const int F = min(frames_out, 1 + N / hop);
+    hipLaunchKernelGGL(feat_normalize_kernel, dim3(normalize == 1 ? (unsigned)(B * rows) : (unsigned)B),
+                       dim3(256), 0, (hipStream_t)stream_, out, seq_len, N, hop, rows, F, o_b, o_m, normalize);
+    ED_CHECK_LAUNCH("fbank_masked normalize");
     return ED_OK;
 }

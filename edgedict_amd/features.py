@@ -180,3 +180,84 @@ class StackedLogFbank(nn.Module):
             F_b = 1 + src.to(torch.int32) // self.fbank.hop_length
             xlen = ((F_b + k - 1) // k if self.pad_to_divisible else F_b // k).to(torch.int32)
         return out, xlen
+
+
+class PartsFilterbankFeatures(FilterbankFeatures):
+    """The Jasper-derived twin of the reference, ``parts/features.py:228-357`` (exported as
+    ``parts.features.FilterbankFeatures`` by the import shim): seconds-based constructor,
+    ``forward(x, seq_len)`` with per-utterance sample counts, window choice, ``normalize_batch``
+    ('per_feature' / 'all_features'), the frame "splicing" of :111-123, inputs shorter than
+    ``n_fft`` zero-padded to ``win_length`` (:289-294) and padding of the frame axis (:339-345).
+    Same kernel as ``FilterbankFeatures`` (csrc/fbank.hip) through ``edgedict_fbank_forward_masked``:
+    here ``seq_len`` only masks frames - the STFT sees the whole padded row, as the reference's does.
+    Output: float32 ``[B, nfilt * frame_splicing, frames (+ padding)]``."""
+
+    _NORMALIZE = {"none": 0, None: 0, "per_feature": 1, "all_features": 2}
+
+    def __init__(self, sample_rate=8000, window_size=0.02, window_stride=0.01, window="hamming",
+                 normalize="per_feature", n_fft=None, preemph=0.97, nfilt=64, lowfreq=0,
+                 highfreq=None, log=True, dither=1e-5, pad_to=8, max_duration=16.7,
+                 frame_splicing=1):
+        win_length = int(sample_rate * window_size)
+        hop_length = int(sample_rate * window_stride)
+        super().__init__(sample_rate=sample_rate, win_length=win_length, hop_length=hop_length,
+                         n_fft=n_fft, window=window, normalize="none", log=log, dither=dither,
+                         pad_to=0, max_duration=max_duration, preemph=preemph, n_filt=nfilt,
+                         f_min=lowfreq, f_max=highfreq)
+        if normalize not in self._NORMALIZE:
+            # the reference's normalize_batch silently returns x for unknown types (:108-109)
+            normalize = "none"
+        self.normalize = normalize
+        self.pad_to = pad_to
+        self.nfilt = nfilt
+        self.frame_splicing = frame_splicing
+
+    @torch.no_grad()
+    def forward(self, x, seq_len):
+        require_cuda(x, self.fb)
+        if x.dim() != 2 or x.dtype != torch.float32 or x.stride(1) != 1:
+            raise ValueError("waveform must be a float32 [B, N] tensor with unit sample stride")
+        B, N = x.shape
+        if self.dither > 0:      # in place on the caller's tensor (parts/features.py:304-305)
+            import ctypes
+            self._seed = (self._seed * 1664525 + 1013904223) & 0xFFFFFFFF
+            call("dither", x, _ll(x.stride(0)), B, N, None, float(self.dither), ctypes.c_uint(self._seed))
+        if N < self.n_fft:       # parts/features.py:289-294
+            if N > self.win_length:
+                raise RuntimeError("The expanded size of the tensor (%d) must match the existing size "
+                                   "(%d): an input longer than win_length but shorter than n_fft cannot "
+                                   "be zero-padded (parts/features.py:289-294 fails the same way)"
+                                   % (self.win_length, N))
+            padded = torch.zeros(B, self.win_length, dtype=torch.float32, device=x.device)
+            padded[:, :N] = x
+            x, N = padded, self.win_length
+        F_ = self.n_frames(N)
+        rows = self.n_filt * self.frame_splicing
+        if self.pad_to < 0:
+            Fp = max(self.max_length, F_)
+        elif self.pad_to > 0:
+            Fp = F_ + self.pad_to - F_ % self.pad_to     # a whole pad_to when already a multiple
+        else:
+            Fp = F_
+        out = (torch.zeros if Fp != F_ else torch.empty)(B, rows, Fp, dtype=torch.float32, device=x.device)
+        lengths = None
+        if seq_len is not None:
+            lengths = seq_len.to(device=x.device, dtype=torch.int32).reshape(-1).contiguous()
+            if lengths.numel() != B:
+                raise ValueError("seq_len must hold one sample count per utterance")
+        lo, hi = self._win_support
+        call("fbank_forward_masked", x, _ll(x.stride(0)), B, N, lengths, self._window_full,
+             self._twiddle, self.fb, self._fb_range, self.n_fft, lo, hi, self.hop_length,
+             self.n_filt, float(self.preemph if self.preemph is not None else 0.0),
+             int(bool(self.log)), out, _ll(rows * Fp), _ll(Fp), F_, self.frame_splicing,
+             _ll(self.n_filt * Fp), self._NORMALIZE[self.normalize])
+        return out
+
+    @classmethod
+    def from_config(cls, cfg, log=False):
+        """parts/features.py:349-357."""
+        return cls(sample_rate=cfg['sample_rate'], window_size=cfg['window_size'],
+                   window_stride=cfg['window_stride'], n_fft=cfg['n_fft'], nfilt=cfg['features'],
+                   window=cfg['window'], normalize=cfg['normalize'],
+                   max_duration=cfg.get('max_duration', 16.7), dither=cfg['dither'],
+                   pad_to=cfg.get("pad_to", 0), frame_splicing=cfg.get("frame_splicing", 1), log=log)

@@ -815,6 +815,10 @@ class Transducer(nn.Module):
     def forward(self, xs, ys, xlen, ylen):
         xs = xs[:, :xlen.max()].contiguous()
         ys = ys[:, :ylen.max()].contiguous()
+        if xs.is_cuda and not ys.is_cuda:
+            # a host-side label batch (seq_collate output with only xs uploaded): one upload here,
+            # the prediction network and the loss kernels both read the device copy
+            ys = ys.to(xs.device, non_blocking=True)
         if config.DECODER_ON_AUX_STREAM and xs.is_cuda:
             # the prediction network does not depend on the encoder: it runs on the auxiliary
             # stream under the encoder's recurrences.  Autograd replays each node on its forward

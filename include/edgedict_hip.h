@@ -373,6 +373,21 @@ int edgedict_fbank_forward(const float* wave, long long wave_stride, int B, int 
                            int win_hi, int hop, int n_mels, float preemph, int do_log, void* out,
                            int out_dtype, long long o_b, long long o_group, long long o_k,
                            long long o_m, int stack, int frames_out, void* stream);
+/* The Jasper-derived twin, FilterbankFeatures.forward(x, seq_len) of parts/features.py:298-347:
+ * the STFT runs over the whole padded row (reflect padding at N, not at the utterance end),
+ * seq_len (samples, int32 [B], nullable) only MASKS frames f >= ceil(seq_len/hop) to zero;
+ *   out fp32 [b*o_b + (c*n_mels + m)*o_m + f], c < copies ("frame splicing" as the reference writes
+ *   it, :111-123, stacks `copies` identical blocks along the feature axis; o_copy = n_mels*o_m),
+ *   frames_out <= o_m (a larger o_m leaves the caller's pad_to padding untouched: pre-zeroed);
+ *   normalize 0 none / 1 per_feature / 2 all_features = normalize_batch (:80-109): mean and
+ *   unbiased std over the first ceil(seq_len/hop) frames, std + 1e-5. */
+int edgedict_fbank_forward_masked(const float* wave, long long wave_stride, int B, int N,
+                                  const int32_t* seq_len, const float* window,
+                                  const float* twiddle, const float* fb, const int32_t* fb_range,
+                                  int n_fft, int win_lo, int win_hi, int hop, int n_mels,
+                                  float preemph, int do_log, float* out, long long o_b,
+                                  long long o_m, int frames_out, int copies, long long o_copy,
+                                  int normalize, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Batched greedy / streaming search: the whole per-frame loop of Transducer.greedy_decode

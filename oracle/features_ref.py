@@ -8,10 +8,12 @@ The reference module itself cannot be imported here (needs librosa, and its lega
 cited lines with ``torch.stft(..., return_complex=True)`` and an independent restatement of
 ``librosa.filters.mel`` (0.7.2 defaults: Slaney scale, area normalisation).
 
-PARITY STATUS: **unpinned by reference outputs** (the reference holds no fixture for this path
-and cannot run here); pinned only on closed-form properties checked in
-tests/test_oracle_features.py (frame counts of SURVEY.md A1, filter normalisation, known mel
-edge frequencies).
+PARITY STATUS: **pinned**.  ``oracle/make_golden_features.py`` EXECUTES the reference's own
+``FilterbankFeatures`` (rnnt/features.py and the parts/features.py twin) and ``Downsample`` classes,
+lifted from their files with ``ast`` (torch.stft respelled for torch 2.x, ``librosa.filters.mel``
+supplied by HuggingFace transformers' independent Slaney implementation), stores their outputs in
+``tests/golden/features.npz`` and asserts this restatement reproduces them;
+``tests/test_oracle_features.py`` re-checks it on every run without the reference.
 """
 import math
 
@@ -83,3 +85,75 @@ def downsample(feat, n_frame=3, pad_to_divisible=True):
 def stacked_features(x, n_frame=3, pad_to_divisible=True, **kw):
     """waveform [B,N] -> model input [B, T0, n_filt*n_frame] (dataset transposes, rnnt/dataset.py:103)."""
     return downsample(log_fbank(x, **kw), n_frame, pad_to_divisible).transpose(1, 2)
+
+
+# ---------------------------------------------------------------- parts/features.py twin
+_WINDOWS = {"hann": torch.hann_window, "hamming": torch.hamming_window,
+            "blackman": torch.blackman_window, "bartlett": torch.bartlett_window}
+
+
+def normalize_batch(x, seq_len, normalize_type):
+    """parts/features.py:80-109 (rnnt/features.py:7-30): per-utterance mean / UNBIASED std over the
+    first seq_len frames, per feature row or over all features; std += 1e-5."""
+    if normalize_type == "per_feature":
+        out = torch.empty_like(x)
+        for i in range(x.shape[0]):
+            n = int(seq_len[i])
+            mean = x[i, :, :n].mean(dim=1)
+            std = x[i, :, :n].std(dim=1) + 1e-5
+            out[i] = (x[i] - mean[:, None]) / std[:, None]
+        return out
+    if normalize_type == "all_features":
+        out = torch.empty_like(x)
+        for i in range(x.shape[0]):
+            n = int(seq_len[i])
+            out[i] = (x[i] - x[i, :, :n].mean()) / (x[i, :, :n].std() + 1e-5)
+        return out
+    return x
+
+
+def parts_log_fbank(x, seq_len, sample_rate=8000, window_size=0.02, window_stride=0.01,
+                    window="hamming", normalize="per_feature", n_fft=None, preemph=0.97, nfilt=64,
+                    lowfreq=0, highfreq=None, log=True, dither=0.0, pad_to=8, max_duration=16.7,
+                    frame_splicing=1):
+    """Restatement of the Jasper-derived twin, parts/features.py:232-347 (dither off):
+    seconds-based geometry (:250-252), inputs shorter than n_fft zero-padded to win_length
+    (:289-294), ``forward(x, seq_len)`` with per-utterance sample counts (:298-301), frame
+    "splicing" (:111-123 - as written it concatenates ``frame_splicing`` COPIES of the features
+    along the feature axis: cat(x[:, :, :n+1], x[:, :, n+1:]) is x), normalisation (:329), masking
+    beyond ceil(seq_len / hop) (:332-336) and padding of the frame axis (:339-345: with pad_to > 0
+    ALWAYS pad_to - F % pad_to extra frames, i.e. a full pad_to when F is already a multiple)."""
+    assert dither == 0.0
+    win_length = int(sample_rate * window_size)
+    hop_length = int(sample_rate * window_stride)
+    n_fft = n_fft or 2 ** math.ceil(math.log2(win_length))
+    highfreq = highfreq or sample_rate / 2
+    frames = torch.ceil(seq_len.float() / hop_length).int()
+    if preemph is not None:
+        x = torch.cat([x[:, :1], x[:, 1:] - preemph * x[:, :-1]], dim=1)
+    if x.shape[-1] < n_fft:
+        if x.shape[-1] > win_length:
+            raise RuntimeError("parts FilterbankFeatures: input longer than win_length but shorter "
+                               "than n_fft cannot be padded (the reference's copy fails the same way)")
+        x = torch.cat([x, x.new_zeros(x.shape[0], win_length - x.shape[-1])], dim=1)
+    win = _WINDOWS[window](win_length, periodic=False, dtype=torch.float32) if window in _WINDOWS else None
+    spec = torch.stft(x, n_fft=n_fft, hop_length=hop_length, win_length=win_length, window=win,
+                      center=True, pad_mode="reflect", return_complex=True)
+    power = spec.real ** 2 + spec.imag ** 2
+    fb = torch.from_numpy(mel_filters(sample_rate, n_fft, nfilt, lowfreq, highfreq))
+    feat = torch.matmul(fb.unsqueeze(0), power)
+    if log:
+        feat = torch.log(feat + 1e-20)
+    if frame_splicing > 1:
+        feat = torch.cat([feat] * frame_splicing, dim=1)
+    feat = normalize_batch(feat, frames, normalize)
+    F_ = feat.shape[-1]
+    mask = torch.arange(F_)[None, :] >= frames[:, None]
+    feat = feat.masked_fill(mask[:, None, :], 0.0)
+    if pad_to < 0:
+        max_length = 1 + math.ceil((max_duration * sample_rate - win_length) / hop_length)
+        max_length += 16 - (max_length % 16)
+        feat = torch.nn.functional.pad(feat, (0, max_length - F_))
+    elif pad_to > 0:
+        feat = torch.nn.functional.pad(feat, (0, pad_to - F_ % pad_to))
+    return feat

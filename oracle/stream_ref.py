@@ -5,9 +5,13 @@ CPU restatement of the reference's single-stream online decoder,
 oracle.models_ref / oracle.features_ref.  Token *ids* are returned instead of text so parity can
 be checked bit-exactly without a BPE vocabulary.
 
-PARITY STATUS: the loop is pinned indirectly — every sub-module call it makes is the
-reference-pinned oracle of models_ref; the reference's own ``rnnt.stream`` cannot be imported
-here (needs torchaudio + absl + a checkpoint).
+PARITY STATUS: **pinned**.  ``oracle/make_golden_stream.py`` EXECUTES the reference's own
+``PytorchStreamDecoder.reset`` / ``.decode`` (lifted from rnnt/stream.py with ``ast``; its
+``__init__`` - flags, checkpoint, vocabulary - bypassed) on the reference ``Transducer``'s
+sub-modules and the reference's own feature classes, stores the returned texts in
+``tests/golden/stream.npz`` and asserts this restatement emits the same ids, chunk by chunk, for
+single streams, resets and independent multi-stream runs; ``tests/test_oracle_stream.py``
+re-checks it without the reference.
 """
 import torch
 

@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu)")
+    # the CPU oracle (LSTM-bound torch graphs) is 4-5x SLOWER with one thread per hardware thread on
+    # the GPU box's 256 logical CPUs than with 16 (bench.py's cpu_baseline sweep): cap it
+    import torch
+    if (os.cpu_count() or 1) > 32:
+        torch.set_num_threads(16)
 
 
 def pytest_collection_modifyitems(config, items):

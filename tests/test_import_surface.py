@@ -11,6 +11,7 @@ import pytest
     ("rnnt.stream", ["PytorchStreamDecoder"]),                    # stream.py:17
     ("rnnt.transforms", ["build_transform"]),                     # cli/baseline.py, rnnt/stream.py:11
     ("rnnt.features", ["FilterbankFeatures"]),                    # rnnt/transforms.py:7
+    ("parts.features", ["FilterbankFeatures"]),                   # the Jasper-derived twin, parts/features.py:228
     ("rnnt.dataset", ["seq_collate", "zero_pad_concat", "end_pad_concat"]),   # cli/train.py:17
     ("rnnt.tokenizer", ["NUL", "PAD", "BOS"]),                    # rnnt/models.py:13
     ("warprnnt_pytorch", ["RNNTLoss"]),                           # rnnt/models.py:9
@@ -58,6 +59,35 @@ def test_unshimmed_names_fall_through_to_a_reference_checkout(tmp_path):
         "assert HuggingFaceTokenizer.origin == 'reference' and NUL == 0\n"          # constants: the engine's
         "assert seq_collate.__module__ == 'edgedict_amd.collate' and Librispeech.pad == 1\n"
         "assert rnnt.models.Transducer.__module__ == 'edgedict_amd.models'\n"        # shimmed modules win
+        "print('ok')\n" % (repo, str(tmp_path / "ref")))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
+    assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-800:]
+
+
+def test_parts_shim_keeps_the_rest_of_the_reference_package_importable(tmp_path):
+    """stream.py:12 and modules/tokenizer.py:5 import parts.text.cleaners; the `parts` shim must not
+    hide it (nor parts.segment etc.), while parts.features.FilterbankFeatures is the engine's twin
+    and other names of that module fall through to the reference file."""
+    import os
+    import subprocess
+    import sys
+    ref = tmp_path / "ref" / "parts"
+    (ref / "text").mkdir(parents=True)
+    (ref / "__init__.py").write_text("")
+    (ref / "text" / "__init__.py").write_text("")
+    (ref / "text" / "cleaners.py").write_text("def english_cleaners(t):\n    return t.lower()\n")
+    (ref / "segment.py").write_text("class AudioSegment:\n    origin = 'reference'\n")
+    (ref / "features.py").write_text("class SpectrogramFeatures:\n    origin = 'reference'\n"
+                                     "class FilterbankFeatures:\n    origin = 'reference'\n")
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys; sys.path[:0] = [%r, %r]\n"
+        "from parts.text.cleaners import english_cleaners\n"
+        "from parts.segment import AudioSegment\n"
+        "from parts.features import FilterbankFeatures, SpectrogramFeatures\n"
+        "assert english_cleaners('AB') == 'ab' and AudioSegment.origin == 'reference'\n"
+        "assert FilterbankFeatures.__module__ == 'edgedict_amd.features'\n"
+        "assert SpectrogramFeatures.origin == 'reference'\n"
         "print('ok')\n" % (repo, str(tmp_path / "ref")))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(tmp_path))
     assert out.returncode == 0 and out.stdout.strip() == "ok", out.stderr[-800:]

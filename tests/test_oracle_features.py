@@ -1,4 +1,7 @@
-"""CPU: closed-form pins for the log-mel oracle (the reference's rnnt.features cannot run here)."""
+"""CPU: pins for the log-mel oracle - tests/golden/features.npz holds outputs of the REFERENCE's own
+FilterbankFeatures (rnnt/features.py and the parts/features.py twin) and Downsample classes,
+executed by oracle/make_golden_features.py; plus closed-form properties."""
+import os
 import math
 
 import numpy as np
@@ -53,3 +56,44 @@ def test_downsample_layout_and_streaming_truncation():
     assert z[1, 1 * 4 + 2, 1] == feat[1, 2, 4]
     assert torch.all(z[:, 4:, 2] == 0)
     assert Fr.downsample(feat, 3, False).shape == (2, 12, 2)
+
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "features.npz"))
+
+
+def _wave(seed, B, N):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return 0.1 * torch.randn(B, N, generator=g)
+
+
+def test_mel_table_matches_third_party_librosa_equivalent():
+    """golden mel tables come from HuggingFace transformers' mel_filter_bank(norm='slaney',
+    mel_scale='slaney'), an independent implementation of librosa.filters.mel."""
+    from edgedict_amd.features import mel_filterbank
+    for key, (sr, nfft, n) in {"mel_80": (16000, 512, 80), "mel_64": (16000, 512, 64),
+                               "mel_8k_64": (8000, 256, 64)}.items():
+        np.testing.assert_allclose(Fr.mel_filters(sr, nfft, n), GOLD[key], atol=2e-9)
+        np.testing.assert_allclose(mel_filterbank(sr, nfft, n), GOLD[key], atol=1e-7)
+
+
+def test_oracle_reproduces_reference_filterbank_and_downsample_outputs():
+    from oracle.make_golden_features import RNNT_CASES
+    for i, (seed, B, N, win, hop, nf, stride) in enumerate(RNNT_CASES):
+        assert list(GOLD["rnnt%d_cfg" % i]) == [seed, B, N, win, hop, nf, stride]
+        x = _wave(seed, B, N)
+        mine = Fr.log_fbank(x, win_length=win, hop_length=hop, n_fft=512, n_filt=nf)
+        np.testing.assert_allclose(mine.numpy()[:, :, ::stride], GOLD["rnnt%d_feat" % i], atol=2e-5)
+        if stride == 1:
+            for pad, tag in ((True, "pad"), (False, "trunc")):
+                z = Fr.downsample(mine, 3, pad)
+                np.testing.assert_allclose(z.numpy(), GOLD["rnnt%d_stack_%s" % (i, tag)], atol=2e-5)
+
+
+def test_oracle_reproduces_reference_parts_twin_outputs():
+    from oracle.make_golden_features import PARTS_CASES
+    for i, (kw, seed, B, N, seq) in enumerate(PARTS_CASES):
+        x = _wave(seed, B, N)
+        mine = Fr.parts_log_fbank(x, torch.tensor(seq, dtype=torch.int32), **kw)
+        ref = GOLD["parts%d_feat" % i]
+        assert mine.shape == ref.shape
+        np.testing.assert_allclose(mine.numpy(), ref, atol=5e-5)

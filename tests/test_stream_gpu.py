@@ -74,3 +74,58 @@ def test_batched_streams_equal_independent_streams_and_masked_reset(hip_lib):
         for s in range(S):
             want = oracles[s].decode(chunk[s:s + 1].clone())
             assert got[s].tolist() == want, (c, s)
+
+
+# ---------------------------------------------------------------------------------------------
+# reference-executed goldens (tests/golden/stream.npz, oracle/make_golden_stream.py)
+import os            # noqa: E402
+
+import numpy as np   # noqa: E402
+
+GOLD = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stream.npz"))
+
+
+def _golden_case(name):
+    from edgedict_amd.flags import make_flags
+    from edgedict_amd.models import Transducer
+    from oracle.make_golden_stream import CASES, HOP, WIN, state_dict
+    cfg, wseed, xseed, S, n_chunks, resets, bias = CASES[name]
+    sd = state_dict(cfg, wseed, bias)
+    m = Transducer(enc_dropout=0.0, dec_dropout=0.0, output_loss=False, **cfg)
+    m.load_state_dict(sd)
+    g = torch.Generator(device="cpu").manual_seed(xseed)
+    wave = 0.1 * torch.randn(S, WIN + n_chunks * HOP, generator=g)
+    return make_flags("E6D2"), m.cuda(), wave, S, n_chunks, resets, GOLD[name + "_texts"], WIN, HOP
+
+
+@pytest.mark.parametrize("name", ["small", "E6D2"])
+def test_single_stream_text_equals_reference_decoder(hip_lib, name):
+    """PytorchStreamDecoder.decode(frame) -> str against the text the REFERENCE's own reset/decode
+    (rnnt/stream.py:78-120) returned for the same chunks (blanks, symbols, the '<unk>' rule, reset)."""
+    from edgedict_amd.stream import PytorchStreamDecoder
+    from oracle.make_golden_stream import StubVocab
+    flags, m, wave, S, n_chunks, resets, texts, WIN, HOP = _golden_case(name)
+    dec = PytorchStreamDecoder(flags, transducer=m, tokenizer=StubVocab(), dither=0)
+    for c in range(n_chunks):
+        if 0 in resets.get(c, []):
+            dec.reset()
+        got = dec.decode(wave[:, c * HOP:c * HOP + WIN].clone())
+        assert got == str(texts[0, c]), (c, got, str(texts[0, c]))
+
+
+@pytest.mark.parametrize("name", ["small_multi", "E6D2_multi"])
+def test_batched_streams_equal_independent_reference_decoders(hip_lib, name):
+    """BatchedStreamDecoder (S streams in lock-step, masked reset) against S independent runs of the
+    reference's decoder loop - BASELINE config 4's path, pinned on reference-executed vectors."""
+    from edgedict_amd.stream import BatchedStreamDecoder
+    from oracle.make_golden_stream import ids_of
+    flags, m, wave, S, n_chunks, resets, texts, WIN, HOP = _golden_case(name)
+    dec = BatchedStreamDecoder(m, flags, S, dither=0)
+    for c in range(n_chunks):
+        if resets.get(c):
+            mask = torch.zeros(S, dtype=torch.bool)
+            mask[resets[c]] = True
+            dec.reset(mask)
+        got = dec.decode(wave[:, c * HOP:c * HOP + WIN].cuda().contiguous()).cpu().numpy()
+        for s in range(S):
+            assert [t for t in got[s].tolist() if t != 0] == ids_of(str(texts[s, c])), (c, s)
