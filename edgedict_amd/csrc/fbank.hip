@@ -54,6 +54,8 @@ struct FbankArgs {
     int mask_only;          // 1: `lengths` only masks frames >= ceil(len/hop); the signal is the whole
                             //    padded row (parts/features.py:298-336 semantics); 0: the row ENDS at
                             //    lengths[b] (per-utterance transform, rnnt/dataset.py:102-103)
+    int n_signal;           // samples [n_signal, N) are zero padding appended AFTER the pre-emphasis
+                            // (parts/features.py:289-294 pads the pre-emphasised short signal)
     int copies;             // the feature vector is written `copies` times, o_copy apart
     long long o_copy;       // (parts/features.py:111-123 frame "splicing")
 };
@@ -88,7 +90,7 @@ __global__ __launch_bounds__(256) void fbank_kernel(FbankArgs a) {
                 n = min(max(n, 0), Nb - 1);
                 const float cur = x[n];
                 const float y = (n > 0) ? cur - a.preemph * x[n - 1] : cur;
-                v = y * a.window[i];
+                v = (n < a.n_signal) ? y * a.window[i] : 0.f;
             }
             const int r = (int)(__brev((unsigned)i) >> (32 - a.log2n));
             re[r] = v;
@@ -199,7 +201,8 @@ static int fbank_launch(const float* wave, long long wave_stride, int B, int N,
                                       int hop, int n_mels, float preemph, int do_log, void* out,
                                       int out_dtype, long long o_b, long long o_group,
                                       long long o_k, long long o_m, int stack, int frames_out,
-                                      int mask_only, int copies, long long o_copy, void* stream_) {
+                                      int mask_only, int copies, long long o_copy, int n_signal,
+                                      void* stream_) {
     ED_CHECK_ARG(out_dtype == ED_F32 || out_dtype == ED_BF16, "fbank: bad output dtype");
     ED_CHECK_ARG(B >= 0 && N >= 0 && hop > 0 && n_mels > 0 && stack > 0 && copies >= 1, "fbank: bad shape");
     int log2n = 0;
@@ -217,7 +220,7 @@ static int fbank_launch(const float* wave, long long wave_stride, int B, int N,
     a.B = B; a.N = N; a.n_fft = n_fft; a.log2n = log2n; a.hop = hop; a.n_mels = n_mels;
     a.stack = stack; a.frames_out = frames_out; a.win_lo = win_lo; a.win_hi = win_hi;
     a.preemph = preemph; a.do_log = do_log;
-    a.mask_only = mask_only; a.copies = copies; a.o_copy = o_copy;
+    a.mask_only = mask_only; a.copies = copies; a.o_copy = o_copy; a.n_signal = n_signal;
     const long long total = (long long)B * frames_out;
     const long long blocks = (total + 3) / 4;
     ED_CHECK_ARG(blocks < (1ll << 31), "fbank: too many frames");
@@ -241,7 +244,7 @@ extern "C" int edgedict_fbank_forward(const float* wave, long long wave_stride, 
                                       void* stream_) {
     return fbank_launch(wave, wave_stride, B, N, lengths, window, twiddle, fb, fb_range, n_fft, win_lo,
                         win_hi, hop, n_mels, preemph, do_log, out, out_dtype, o_b, o_group, o_k, o_m,
-                        stack, frames_out, 0, 1, 0, stream_);
+                        stack, frames_out, 0, 1, 0, N, stream_);
 }
 
 extern "C" int edgedict_fbank_forward_masked(const float* wave, long long wave_stride, int B, int N,
@@ -251,11 +254,12 @@ extern "C" int edgedict_fbank_forward_masked(const float* wave, long long wave_s
                                              int win_hi, int hop, int n_mels, float preemph,
                                              int do_log, float* out, long long o_b, long long o_m,
                                              int frames_out, int copies, long long o_copy,
-                                             int normalize, void* stream_) {
+                                             int normalize, int n_signal, void* stream_) {
     ED_CHECK_ARG(normalize >= 0 && normalize <= 2, "fbank_masked: normalize must be 0 (none), 1 (per_feature) or 2 (all_features)");
     const int rc = fbank_launch(wave, wave_stride, B, N, seq_len, window, twiddle, fb, fb_range, n_fft,
                                 win_lo, win_hi, hop, n_mels, preemph, do_log, out, ED_F32, o_b, 1, 0,
-                                o_m, 1, frames_out, 1, copies, o_copy, stream_);
+                                o_m, 1, frames_out, 1, copies, o_copy,
+                                n_signal > 0 && n_signal < N ? n_signal : N, stream_);
     if (rc != ED_OK || normalize == 0 || B == 0 || frames_out == 0) return rc;
     const int rows = n_mels * copies;
     ED_CHECK_ARG(o_copy == (long long)n_mels * o_m || copies == 1, "fbank_masked: copies must be adjacent row blocks");

@@ -218,6 +218,7 @@ class PartsFilterbankFeatures(FilterbankFeatures):
         if x.dim() != 2 or x.dtype != torch.float32 or x.stride(1) != 1:
             raise ValueError("waveform must be a float32 [B, N] tensor with unit sample stride")
         B, N = x.shape
+        n_signal = 0
         if self.dither > 0:      # in place on the caller's tensor (parts/features.py:304-305)
             import ctypes
             self._seed = (self._seed * 1664525 + 1013904223) & 0xFFFFFFFF
@@ -230,6 +231,7 @@ class PartsFilterbankFeatures(FilterbankFeatures):
                                    % (self.win_length, N))
             padded = torch.zeros(B, self.win_length, dtype=torch.float32, device=x.device)
             padded[:, :N] = x
+            n_signal = N         # the reference pads AFTER its pre-emphasis: the pad stays exactly zero
             x, N = padded, self.win_length
         F_ = self.n_frames(N)
         rows = self.n_filt * self.frame_splicing
@@ -250,7 +252,7 @@ class PartsFilterbankFeatures(FilterbankFeatures):
              self._twiddle, self.fb, self._fb_range, self.n_fft, lo, hi, self.hop_length,
              self.n_filt, float(self.preemph if self.preemph is not None else 0.0),
              int(bool(self.log)), out, _ll(rows * Fp), _ll(Fp), F_, self.frame_splicing,
-             _ll(self.n_filt * Fp), self._NORMALIZE[self.normalize])
+             _ll(self.n_filt * Fp), self._NORMALIZE[self.normalize], int(n_signal))
         return out
 
     @classmethod

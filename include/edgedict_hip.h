@@ -380,14 +380,16 @@ int edgedict_fbank_forward(const float* wave, long long wave_stride, int B, int 
  *   it, :111-123, stacks `copies` identical blocks along the feature axis; o_copy = n_mels*o_m),
  *   frames_out <= o_m (a larger o_m leaves the caller's pad_to padding untouched: pre-zeroed);
  *   normalize 0 none / 1 per_feature / 2 all_features = normalize_batch (:80-109): mean and
- *   unbiased std over the first ceil(seq_len/hop) frames, std + 1e-5. */
+ *   unbiased std over the first ceil(seq_len/hop) frames, std + 1e-5;
+ *   n_signal (0 or N: none): samples [n_signal, N) are zeros appended AFTER the pre-emphasis - the
+ *   reference zero-pads the already pre-emphasised short input to win_length (:289-294). */
 int edgedict_fbank_forward_masked(const float* wave, long long wave_stride, int B, int N,
                                   const int32_t* seq_len, const float* window,
                                   const float* twiddle, const float* fb, const int32_t* fb_range,
                                   int n_fft, int win_lo, int win_hi, int hop, int n_mels,
                                   float preemph, int do_log, float* out, long long o_b,
                                   long long o_m, int frames_out, int copies, long long o_copy,
-                                  int normalize, void* stream);
+                                  int normalize, int n_signal, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Batched greedy / streaming search: the whole per-frame loop of Transducer.greedy_decode
