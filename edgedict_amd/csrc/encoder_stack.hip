@@ -108,6 +108,9 @@ struct Runtime {
     // timing of the recurrence stream's launch sequence of the last forward / backward call
     hipEvent_t tev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     int tlaunches[2] = {0, 0};
+    // give-up code of the weights-stationary kernels: pinned host word the device writes on failure
+    unsigned* wsr_err_host = nullptr;
+    unsigned* wsr_err_dev = nullptr;
     // experiment streams, created on first use (and therefore AFTER the three above)
     hipStream_t lazy(hipStream_t& s) {
         if (!s && hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio_hi) != hipSuccess) s = nullptr;
@@ -157,6 +160,11 @@ Runtime* runtime_for_current_device() {
         for (int i = 0; i < 2; ++i)
             for (int j = 0; j < 2; ++j)
                 if (hipEventCreate(&r->tev[i][j]) != hipSuccess) r->tev[i][j] = nullptr;
+        if (hipHostMalloc((void**)&r->wsr_err_host, 64, hipHostMallocMapped) == hipSuccess) {
+            r->wsr_err_host[0] = 0;
+            if (hipHostGetDevicePointer((void**)&r->wsr_err_dev, r->wsr_err_host, 0) != hipSuccess)
+                r->wsr_err_dev = nullptr;
+        }
         g_rt[dev] = r;
     }
     return g_rt[dev];
@@ -172,8 +180,9 @@ constexpr int LNB_GRID_TOP = 512;   // ... of the top layer's all-frames call
 
 struct WsLayout {
     std::vector<size_t> frag0, frag1, dC, lnpart;   // per layer
-    size_t tmpW = 0, tmpB = 0, dX0 = 0, total = 0;
+    size_t tmpW = 0, tmpB = 0, dX0 = 0, wsr_sync = 0, total = 0;
 };
+constexpr size_t WSR_SYNC_BYTES = 64 * 1024;   // [0] give-up code, [16..24) layer counters, [64..) 8 tickets per launch
 
 WsLayout ws_layout(const edgedict_stack_desc_t* d) {
     WsLayout w;
@@ -203,6 +212,7 @@ WsLayout ws_layout(const edgedict_stack_desc_t* d) {
     w.tmpW = off; off += align256((size_t)8 * 4 * d->H * maxK * sizeof(float));   // up to 8 K slices
     w.tmpB = off; off += align256((size_t)4 * d->H * sizeof(float));
     w.dX0 = off; off += align256((size_t)d->T0 * d->B * d->I0 * sizeof(bf16_t));
+    w.wsr_sync = off; off += WSR_SYNC_BYTES;
     w.total = off;
     return w;
 }
@@ -404,6 +414,135 @@ extern "C" int edgedict_stack_pack_weights(const float* w_ih, const float* w_hh,
     return ED_OK;
 }
 
+namespace {
+
+bool wsr_applicable(const edgedict_stack_desc_t* d) {
+    if (!(d->flags & EDGEDICT_STACK_WSR) || d->H != 1024 || d->B > 64 || d->L > ED_STACK_MAX_SLOTS) return false;
+    for (int l = 0; l < d->L; ++l)
+        if (!d->layers[l].whh_r) return false;
+    return true;
+}
+
+// Forward pass with the weights-stationary recurrence kernel (wsr_kernels.hip): launch w carries chunk
+// k_l of every layer whose input product for that chunk has been enqueued; after the launch the side
+// stream normalises the frames each layer finished and multiplies them into the next layer's gates.
+// Layer l runs chunk k one launch after layer l-1 did (the recurrence stream waits for the product's
+// event).  Called with the prologue done and the internal streams forked from the caller's.
+int forward_wsr(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Streams& st, const WsLayout& wl) {
+    const int B = d->B, H = d->H, L = d->L;
+    const long long BH = (long long)B * H;
+    char* ws = (char*)d->ws;
+    unsigned* sync = (unsigned*)(ws + wl.wsr_sync);
+    ED_DEV(ed_stack_zero(sync, WSR_SYNC_BYTES, st.R));
+    const int T_out = (g[L - 1].T + d->layers[L - 1].reduce - 1) / d->layers[L - 1].reduce;
+    std::vector<std::vector<hipEvent_t>> Eg(L);
+    std::vector<std::vector<char>> queued(L);
+    for (int l = 0; l < L; ++l) {
+        Eg[l].assign(g[l].nchunks, nullptr);
+        queued[l].assign(g[l].nchunks, 0);
+    }
+    int next_g0 = 0;
+    auto feed_layer0 = [&](int upto) -> int {
+        for (; next_g0 < g[0].nchunks && next_g0 <= upto; ++next_g0) {
+            ED_DEV(input_gemm(d, g, 0, next_g0, st.S[0]));
+            if (g_trace) g_trace->chunk_enqueued[g_trace->coff[0] + next_g0] = g_trace->launches;
+            ED_TRY(st.record(Eg[0][next_g0], st.S[0]));
+            queued[0][next_g0] = 1;
+        }
+        return ED_OK;
+    };
+    ED_TRY(feed_layer0(2));
+    std::vector<int> next_k(L, 0);
+    // launches between the one that finishes chunk k of layer l and the one that runs chunk k of
+    // layer l+1: with 1 every launch waits for the side-stream work (LayerNorm + product) of the
+    // launch before it - nothing overlaps; with 2 that work runs under the next launch.
+    int delay = 2;
+    if (const char* e = getenv("EDGEDICT_WSR_DELAY")) delay = max(1, atoi(e));
+    std::vector<std::vector<int>> ready_at(L);
+    for (int l = 0; l < L; ++l) ready_at[l].assign(g[l].nchunks, 0);
+    int launches = 0;
+    if (st.rt && st.rt->tev[0][0]) ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][0], st.R));
+    const size_t max_launches = (WSR_SYNC_BYTES / 4 - 64) / 8;
+    for (;;) {
+        EdWsrLaunch Lc;
+        Lc.nslot = 0;
+        Lc.B = B;
+        Lc.err = sync;
+        Lc.ticket = sync + 64 + (size_t)launches * 8;
+        int ran_l[ED_STACK_MAX_SLOTS], ran_k[ED_STACK_MAX_SLOTS];
+        bool pending = false;
+        for (int l = 0; l < L; ++l) {
+            const int k = next_k[l];
+            if (k >= g[l].nchunks) continue;
+            pending = true;
+            if (l == 0) ED_TRY(feed_layer0(k + 2));
+            if (!queued[l][k] || launches < ready_at[l][k]) continue;   // product not enqueued yet / too fresh
+            const edgedict_stack_layer_t& y = d->layers[l];
+            const int t0 = k * g[l].cf, t1 = min(y.T, t0 + g[l].cf);
+            ED_TRY(st.wait(st.R, Eg[l][k]));
+            EdWsrSlot& S = Lc.slot[Lc.nslot];
+            S.G = bptr(y.G) + (long long)t0 * B * 4 * H;
+            S.img0 = bptr(ws + wl.frag0[l]);
+            S.img1 = bptr(ws + wl.frag1[l]);
+            S.Y = bptr(y.Yx) + (long long)(t0 + 1) * BH;
+            S.C_prev = y.Cx + (long long)t0 * BH;
+            S.C = y.Cx + (long long)(t0 + 1) * BH;
+            S.Wreg = bptr(y.whh_r);
+            S.counter = sync + 16 + l;
+            S.base = 32u * (unsigned)t0;
+            S.t0 = t0;
+            S.nsteps = t1 - t0;
+            ran_l[Lc.nslot] = l;
+            ran_k[Lc.nslot] = k;
+            ++Lc.nslot;
+            if (g_trace)
+                for (int t = t0; t < t1; ++t) g_trace->step_launch[g_trace->toff[l] + t] = g_trace->launches;
+        }
+        if (!pending) break;
+        ED_CHECK_ARG(Lc.nslot > 0, "encoder_stack: weights-stationary schedule made no progress");
+        ED_CHECK_ARG((size_t)launches < max_launches, "encoder_stack: too many weights-stationary launches");
+        ED_DEV(ed_wsr_launch_fwd(Lc, st.R));
+        ++launches;
+        if (g_trace) {
+            g_trace->max_slots = max(g_trace->max_slots, Lc.nslot);
+            ++g_trace->launches;
+        }
+        // side stream: LayerNorm of the finished frames, then the next layer's input product
+        for (int i = 0; i < Lc.nslot; ++i) {
+            const int l = ran_l[i], k = ran_k[i];
+            const edgedict_stack_layer_t& y = d->layers[l];
+            const int t0 = k * g[l].cf, t1 = min(y.T, t0 + g[l].cf);
+            hipStream_t S = st.S[l + 1 < L ? l + 1 : l];
+            ED_TRY(st.chain(st.R, S));
+            if (l + 1 < L) {
+                ED_DEV(ed_stack_chunk_norm(bptr(y.Yx) + BH, y.residual ? bptr(y.X) : nullptr, y.ln_gamma, y.ln_beta,
+                                           bptr(d->layers[l + 1].X), BH, H, y.mean, y.rstd, B, H, y.T, t0, t1,
+                                           y.reduce, d->eps, S));
+                ED_DEV(input_gemm(d, g, l + 1, k, S));
+                if (g_trace) g_trace->chunk_enqueued[g_trace->coff[l + 1] + k] = g_trace->launches;
+                ED_TRY(st.record(Eg[l + 1][k], S));
+                queued[l + 1][k] = 1;
+                ready_at[l + 1][k] = launches + delay - 1;   // `launches` already counts this launch
+            } else {
+                ED_DEV(ed_stack_chunk_norm(bptr(y.Yx) + BH, y.residual ? bptr(y.X) : nullptr, y.ln_gamma, y.ln_beta,
+                                           bptr(d->out), H, (long long)T_out * H, y.mean, y.rstd, B, H, y.T, t0, t1,
+                                           y.reduce, d->eps, S));
+            }
+            ++next_k[l];
+        }
+    }
+    if (st.rt && st.rt->tev[0][1]) {
+        ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][1], st.R));
+        st.rt->tlaunches[0] = launches;
+    }
+    // a launch that ran into a bounded spin left its code in sync[0]: copy it to the pinned host word
+    if (st.rt && st.rt->wsr_err_dev && !g_trace)
+        ED_CHECK_HIP(hipMemcpyAsync(st.rt->wsr_err_host + 1, sync, 4, hipMemcpyDeviceToHost, st.R));
+    return ED_OK;
+}
+
+}  // namespace
+
 extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stream_) {
     std::lock_guard<std::mutex> lock(g_mu);
     std::vector<Geom> g;
@@ -433,6 +572,13 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     ED_TRY(st.chain(st.C, st.R));
     if (st.R2 != st.R) ED_TRY(st.chain(st.C, st.R2));
     for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.C, st.S[l]));
+
+    if (wsr_applicable(d)) {
+        ED_TRY(forward_wsr(d, g, st, wl));
+        ED_TRY(st.chain(st.R, st.C));
+        for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.S[l], st.C));
+        return ED_OK;
+    }
 
     std::vector<std::vector<hipEvent_t>> Eg(L);
     std::vector<std::vector<char>> queued(L);   // schedule self-check: producer enqueued before consumer
@@ -573,6 +719,23 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     if (st.R2 != st.R) ED_TRY(st.chain(st.R2, st.C));
     for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.S[l], st.C));
     return ED_OK;
+}
+
+extern "C" int edgedict_stack_pack_wsr(const float* w_hh, int H, void* whh_r, void* stream_) {
+    ED_CHECK_ARG(H == 1024, "stack_pack_wsr: the weights-stationary kernels are built for H = 1024 (got %d)", H);
+    ED_CHECK_ARG(w_hh && whh_r, "stack_pack_wsr: null pointer");
+    return ed_wsr_pack_fwd(w_hh, (bf16_t*)whh_r, (hipStream_t)stream_);
+}
+
+extern "C" int edgedict_stack_wsr_error(void) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    Runtime* r = runtime_for_current_device();
+    if (!r || !r->wsr_err_host) return 0;
+    volatile unsigned* p = r->wsr_err_host;
+    const unsigned code = p[1] ? p[1] : p[0];
+    p[0] = 0;
+    p[1] = 0;
+    return (int)code;
 }
 
 extern "C" int edgedict_stack_schedule(const edgedict_stack_desc_t* d, int backward, int32_t* step_launch,

@@ -336,6 +336,49 @@ __global__ __launch_bounds__(256, ED_FWD_OCC) void stack_fwd_kernel(EdFwdLaunch 
     }
 }
 
+// LayerNorm of the frames [t0, t1) one layer has finished (weights-stationary path: the recurrence
+// kernel carries whole chunks, so the norm of a chunk is its own small launch on the side stream):
+// one workgroup per (output frame, 4 batch rows), same arithmetic as the norm role above.
+struct ChunkNormArgs {
+    const bf16_t* Yx1;      // h_t at Yx1 + t * B * H
+    const bf16_t* X;        // residual rows (time-major) or null
+    const float* gamma;
+    const float* beta;
+    bf16_t* out;            // frame tau, row b at out + tau * out_st + b * out_sb
+    long long out_st, out_sb;
+    float* mean;
+    float* rstd;
+    int B, H, T, t0, reduce;
+    float eps;
+};
+__global__ __launch_bounds__(256) void stack_chunk_norm_kernel(ChunkNormArgs a) {
+    const int RB = (a.B + 3) >> 2;
+    const int fo = blockIdx.x / RB, rb = blockIdx.x % RB;
+    const long long BH = (long long)a.B * a.H;
+    EdFwdNorm p;
+    int ta, tb = -1;
+    if (a.reduce == 1) ta = a.t0 + fo;
+    else {
+        ta = a.t0 + 2 * fo;                 // t0 is even under time reduction
+        tb = ta + 1 < a.T ? ta + 1 : -1;    // an odd last frame has no partner: it counts as zero
+    }
+    const int tau = ta / a.reduce;
+    p.y0 = a.Yx1 + (long long)ta * BH;
+    p.r0 = a.X ? a.X + (long long)ta * BH : nullptr;
+    p.y1 = tb >= 0 ? a.Yx1 + (long long)tb * BH : nullptr;
+    p.r1 = (tb >= 0 && a.X) ? a.X + (long long)tb * BH : nullptr;
+    p.gamma = a.gamma;
+    p.beta = a.beta;
+    p.out = a.out + (long long)tau * a.out_st;
+    p.out_stride = a.out_sb;
+    p.mean0 = a.mean + (long long)ta * a.B;
+    p.rstd0 = a.rstd + (long long)ta * a.B;
+    p.mean1 = tb >= 0 ? a.mean + (long long)tb * a.B : nullptr;
+    p.rstd1 = tb >= 0 ? a.rstd + (long long)tb * a.B : nullptr;
+    p.scale = a.reduce == 1 ? 1.f : 0.5f;
+    fwd_norm_role(p, rb, a.B, a.H, a.eps);
+}
+
 // =====================================================================================
 // backward (BPTT step)
 // =====================================================================================
@@ -733,6 +776,20 @@ int ed_stack_launch_fwd(const EdFwdLaunch& L, hipStream_t s) {
     if (grid == 0) return ED_OK;
     hipLaunchKernelGGL(stack_fwd_kernel, dim3(grid), dim3(256), 0, s, L);
     ED_CHECK_LAUNCH("stack_fwd_kernel");
+    return ED_OK;
+}
+
+int ed_stack_chunk_norm(const bf16_t* Yx1, const bf16_t* X, const float* gamma, const float* beta,
+                        bf16_t* out, long long out_st, long long out_sb, float* mean, float* rstd,
+                        int B, int H, int T, int t0, int t1, int reduce, float eps, hipStream_t s) {
+    if (t1 <= t0) return ED_OK;
+    ChunkNormArgs a;
+    a.Yx1 = Yx1; a.X = X; a.gamma = gamma; a.beta = beta; a.out = out; a.out_st = out_st;
+    a.out_sb = out_sb; a.mean = mean; a.rstd = rstd; a.B = B; a.H = H; a.T = T; a.t0 = t0;
+    a.reduce = reduce; a.eps = eps;
+    const int frames_out = reduce == 1 ? t1 - t0 : (t1 - t0 + 1) / 2;
+    hipLaunchKernelGGL(stack_chunk_norm_kernel, dim3(frames_out * ((B + 3) >> 2)), dim3(256), 0, s, a);
+    ED_CHECK_LAUNCH("stack_chunk_norm_kernel");
     return ED_OK;
 }
 

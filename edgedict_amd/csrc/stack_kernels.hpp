@@ -60,6 +60,34 @@ struct EdBwdLaunch {
     int B, H;
 };
 
+// ---- weights-stationary recurrence (wsr_kernels.hip): ONE launch carries a chunk of frames of every
+// runnable layer; a layer lives on the 32 CUs of one XCD with W_hh in registers (H = 1024, B <= 64)
+struct EdWsrSlot {
+    bf16_t* G;                 // frames [t0, t0+nsteps): [n][B, 4H] interleaved; in pre-activations, out gates
+    bf16_t* img0;              // h fragment images [H/32][B16/16][64][8] (ping-pong): step t reads
+    bf16_t* img1;              //   (t & 1 ? img1 : img0) and writes the other one
+    bf16_t* Y;                 // h_t rows of frame t0 (plain [B, H]), then t0+1, ...
+    const float* C_prev;       // c_{t0-1} [B, H]
+    float* C;                  // c_t rows of frame t0, ...
+    const bf16_t* Wreg;        // register image of W_hh (ed_wsr_pack_fwd)
+    unsigned* counter;         // arrivals of this layer: == base when the launch starts
+    unsigned base;
+    int t0, nsteps;
+};
+struct EdWsrLaunch {
+    EdWsrSlot slot[ED_STACK_MAX_SLOTS];
+    int nslot;                 // slot i runs on the XCD whose XCC_ID is i
+    int B;
+    unsigned* ticket;          // [8] zeroed role tickets of THIS launch
+    unsigned* err;             // [1] give-up code (0 = fine), shared by the whole call
+};
+int ed_wsr_pack_fwd(const float* w_hh, bf16_t* out, hipStream_t s);
+int ed_wsr_launch_fwd(const EdWsrLaunch& L, hipStream_t s);
+// LayerNorm(+ residual, + pair mean under time reduction) of the frames [t0, t1) a layer finished
+int ed_stack_chunk_norm(const bf16_t* Yx1, const bf16_t* X, const float* gamma, const float* beta,
+                        bf16_t* out, long long out_st, long long out_sb, float* mean, float* rstd,
+                        int B, int H, int T, int t0, int t1, int reduce, float eps, hipStream_t s);
+
 // kernels / launchers implemented in stack_kernels.hip
 int ed_stack_launch_fwd(const EdFwdLaunch& L, hipStream_t s);
 int ed_stack_launch_bwd(const EdBwdLaunch& L, hipStream_t s);

@@ -25,7 +25,7 @@ class StackLayer(ctypes.Structure):
     _fields_ = [("T", ctypes.c_int), ("I", ctypes.c_int), ("reduce", ctypes.c_int),
                 ("residual", ctypes.c_int),
                 ("wih_p", _vp), ("wih_t", _vp), ("bias_p", _fp), ("whh_f", _vp), ("whh_b", _vp),
-                ("ln_gamma", _fp), ("ln_beta", _fp),
+                ("whh_r", _vp), ("ln_gamma", _fp), ("ln_beta", _fp),
                 ("X", _vp), ("G", _vp), ("Yx", _vp), ("Cx", _fp), ("mean", _fp), ("rstd", _fp),
                 ("dZ", _vp), ("dX", _vp), ("dW_ih", _fp), ("dW_hh", _fp), ("db", _fp), ("db_hh", _fp),
                 ("dgamma", _fp), ("dbeta", _fp)]
@@ -45,12 +45,19 @@ class StackDesc(ctypes.Structure):
 SERIAL = 1
 DW_AT_END = 2
 ACCUM_GRADS = 8
+WSR = 32          # weights-stationary recurrence kernels (csrc/wsr_kernels.hip) when H = 1024, B <= 64
 
 # schedule knobs (env overrides are for tuning runs; the defaults are what bench.py measures)
 CHUNK = int(os.environ.get("EDGEDICT_STACK_CHUNK", "12"))
 LAG = int(os.environ.get("EDGEDICT_STACK_LAG", "0"))
 SPLIT_K = int(os.environ.get("EDGEDICT_STACK_SPLITK", "0"))
 FLAGS = int(os.environ.get("EDGEDICT_STACK_FLAGS", "0"))
+# opt-in: measured on MI355X the weights-stationary forward takes 7.85 ms against 7.75 ms
+# for the launch-per-step kernels at E6D2 - its 8.6 us steps are faster than a 19 us frame of step
+# launches, but no other kernel can run beside a grid that fills whole XCDs (workgroups are bound to
+# XCDs round-robin at dispatch), so the chunk products serialise with it instead of overlapping
+if os.environ.get("EDGEDICT_STACK_WSR", "0") == "1":
+    FLAGS |= WSR
 
 
 def _p(t):
@@ -64,7 +71,7 @@ def supported(cd, H, I0, L, reductions):
 
 class _PackedLayer:
     """bf16 weight images of one LSTM layer, rebuilt when the fp32 masters change."""
-    __slots__ = ("key", "ref", "wih_p", "wih_t", "bias_p", "whh_f", "whh_b")
+    __slots__ = ("key", "ref", "wih_p", "wih_t", "bias_p", "whh_f", "whh_b", "whh_r")
 
     def __init__(self, owner):
         self.key = None
@@ -89,6 +96,7 @@ def packed_weights(w_ih, w_hh, b_ih, b_hh):
         ent.bias_p = torch.empty(H4, dtype=F32, device=dev)
         ent.whh_f = torch.empty(H4 * H, dtype=BF16, device=dev)
         ent.whh_b = torch.empty(H4 * H, dtype=BF16, device=dev)
+        ent.whh_r = torch.empty(H4 * H, dtype=BF16, device=dev) if H == 1024 else None
         srcs = [t.detach().contiguous() for t in (w_ih, w_hh, b_ih, b_hh)]
         for t in srcs:
             if t.dtype != F32:
@@ -97,12 +105,25 @@ def packed_weights(w_ih, w_hh, b_ih, b_hh):
         check(lib.edgedict_stack_pack_weights(ptr(srcs[0]), ptr(srcs[1]), ptr(srcs[2]), ptr(srcs[3]),
                                               H, I, ptr(ent.wih_p), ptr(ent.wih_t), ptr(ent.bias_p), ptr(ent.whh_f),
                                               ptr(ent.whh_b), stream_ptr()), "stack_pack_weights")
+        if ent.whh_r is not None:      # register image of the weights-stationary forward kernel
+            check(lib.edgedict_stack_pack_wsr(ptr(srcs[1]), H, ptr(ent.whh_r), stream_ptr()), "stack_pack_wsr")
         ent.key = key
     return ent
 
 
 def clear_cache():
     _PACKED.clear()
+
+
+def check_wsr_error():
+    """Raise if a weights-stationary launch on this device ran into one of its bounded spins (its
+    workgroups could not all become resident, or a peer never arrived): the results of that call are
+    garbage.  The code is a pinned host word the library copies at the end of each call; reading it
+    costs nothing and clears it.  Call after a synchronize for an up-to-date answer."""
+    code = _lib.load().edgedict_stack_wsr_error()
+    if code:
+        raise RuntimeError("edgedict_amd: a weights-stationary encoder launch gave up (code %d); set "
+                           "EDGEDICT_STACK_WSR=0 to use the launch-per-step kernels" % code)
 
 
 _PREPACK_EVENT = [None]
@@ -153,11 +174,11 @@ class _Plan:
             self.layer_bufs.append(bufs)
             y = self.larr[l]
             y.T, y.I, y.reduce, y.residual = T, I, reductions[l], int(l != 0)
-            y.wih_p, y.wih_t, y.bias_p, y.whh_f, y.whh_b = map(
-                _p, (pk.wih_p, pk.wih_t, pk.bias_p, pk.whh_f, pk.whh_b))
+            y.wih_p, y.wih_t, y.bias_p, y.whh_f, y.whh_b, y.whh_r = map(
+                _p, (pk.wih_p, pk.wih_t, pk.bias_p, pk.whh_f, pk.whh_b, pk.whh_r))
             g, b = ln_w.detach(), ln_b.detach()
             y.ln_gamma, y.ln_beta = _p(g), _p(b)
-            self.keep += [pk.wih_p, pk.wih_t, pk.bias_p, pk.whh_f, pk.whh_b, g, b]
+            self.keep += [pk.wih_p, pk.wih_t, pk.bias_p, pk.whh_f, pk.whh_b, pk.whh_r, g, b]
             for k, v in bufs.items():
                 setattr(y, k, _p(v))
             T = (T + reductions[l] - 1) // reductions[l]
@@ -183,6 +204,7 @@ class _Plan:
 
     def forward(self):
         lib = _lib.load()
+        check_wsr_error()      # a PREVIOUS weights-stationary launch that gave up (host word, no sync)
         ops.mark("stack_fwd:enter")
         with ops.host_timed("stack_forward_call"):
             check(lib.edgedict_stack_forward(ctypes.byref(self.desc), stream_ptr()), "stack_forward")
@@ -284,7 +306,7 @@ class EncoderStackFn(torch.autograd.Function):
         return tuple(out)
 
 
-def schedule(T0, I0, H, reductions, B=64, chunk=None, backward=False, lag=0):
+def schedule(T0, I0, H, reductions, B=64, chunk=None, backward=False, lag=0, flags=0):
     """Dry run of the native scheduler (no device): returns ``(step_launch, chunk_enqueued,
     n_launches, max_slots)`` where ``step_launch[l][t]`` is the launch index that carries step t of
     layer l and ``chunk_enqueued[l][k]`` the number of launches issued when chunk k's side-stream
@@ -307,7 +329,7 @@ def schedule(T0, I0, H, reductions, B=64, chunk=None, backward=False, lag=0):
         T = (T + reductions[l] - 1) // reductions[l]
         I = H
     d = StackDesc()
-    d.B, d.H, d.L, d.chunk, d.lag, d.split_k, d.flags, d.eps = B, H, L, chunk, lag, 0, 0, 1e-5
+    d.B, d.H, d.L, d.chunk, d.lag, d.split_k, d.flags, d.eps = B, H, L, chunk, lag, 0, flags, 1e-5
     d.layers = layers
     d.x, d.x_dtype, d.T0, d.I0 = dummy, 1, T0, I0
     for name in ("in_gamma", "in_beta", "in_mean", "in_rstd", "d_in_gamma", "d_in_beta"):

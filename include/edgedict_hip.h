@@ -208,6 +208,9 @@ typedef struct edgedict_stack_layer {
     const float* bias_p;   /* f32  [4H]     b_ih + b_hh, interleaved */
     const void* whh_f;     /* bf16 forward fragment image of W_hh (4H*H) */
     const void* whh_b;     /* bf16 backward fragment image of W_hh (4H*H); backward only */
+    const void* whh_r;     /* bf16 REGISTER image of W_hh for the weights-stationary forward kernel
+                              (edgedict_stack_pack_wsr; H = 1024 only), nullable: without it, or without
+                              EDGEDICT_STACK_WSR, the launch-per-step kernels run */
     const float* ln_gamma; /* f32 [H] */
     const float* ln_beta;  /* f32 [H] */
     void* X;               /* bf16 [T, B, I]    layer input (layer 0: written by the input LayerNorm) */
@@ -234,6 +237,10 @@ typedef struct edgedict_stack_layer {
    time reduction launch on separate streams so their kernel boundaries overlap.  A 5th HIP stream
    shares a hardware queue with a busy one: measured 66.8 vs 34.5 ms per step.  Do not use. */
 #define EDGEDICT_STACK_ACCUM_GRADS 8 /* dW_ih / dW_hh / db / db_hh are existing gradient buffers: += instead of = */
+#define EDGEDICT_STACK_WSR 32 /* weights-stationary recurrence (csrc/wsr_kernels.hip): one launch carries a CHUNK
+   of frames of every runnable layer, a layer on the 32 CUs of one XCD with W_hh in registers and h_t
+   exchanged through that XCD's L2.  Needs H = 1024, B <= 64, L <= 8 and whh_r of every layer;
+   otherwise (silently) the launch-per-step kernels run.  Forward only so far. */
 #define EDGEDICT_STACK_SIDE_STREAM_PER_LAYER 4 /* experiment: chunk GEMMs on one side stream PER LAYER.
    Measured 2x SLOWER end to end: more streams than hardware queues serialises everything. */
 
@@ -274,6 +281,12 @@ size_t edgedict_stack_workspace_bytes(const edgedict_stack_desc_t* desc);
 int edgedict_stack_pack_weights(const float* w_ih, const float* w_hh, const float* b_ih,
                                 const float* b_hh, int H, int I, void* wih_p, void* wih_t,
                                 float* bias_p, void* whh_f, void* whh_b, void* stream);
+/* W_hh [4H, H] f32 (H = 1024) -> bf16 register image for EDGEDICT_STACK_WSR (8 MB): workgroup j of a
+ * layer's XCD loads rows [j*256 KB, (j+1)*256 KB) of it once per launch and keeps them in registers. */
+int edgedict_stack_pack_wsr(const float* w_hh, int H, void* whh_r, void* stream);
+/* give-up code of the last weights-stationary launch on the current device that ran into a bounded
+ * spin (0 = none since the last call of this function; reading clears it) - see csrc/wsr_kernels.hip */
+int edgedict_stack_wsr_error(void);
 int edgedict_stack_forward(const edgedict_stack_desc_t* desc, void* stream);
 /* measurement aid: HIP-event time (on the recurrence stream) from the first to the last wavefront
  * launch of the most recent forward (backward = 0) or backward (1) call on this device, and the

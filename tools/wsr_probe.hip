@@ -19,7 +19,8 @@
 //   hipcc -O3 --offload-arch=gfx950 tools/wsr_probe.hip -o tools/wsr_probe.bin
 //   tools/wsr_probe.bin [T=400] [mode]      mode bits: 1 skip MFMA, 2 skip exchange, 4 one instance, 8 gather through registers,
 //                                        16 plain loads + agent acquire fence, 32 plain (write-back) image stores,
-//                                        64 whole-image gather before the first MFMA (no chunk overlap)
+//                                        64 whole-image gather before the first MFMA (no chunk overlap),
+//                                        128 spread every layer over all 8 XCDs (4 CUs each): cross-XCD exchange
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -97,9 +98,13 @@ __global__ __launch_bounds__(256, 1) void wsr_probe(Args a) {
         atomicAdd(&a.err[1 + xcc], 1u);
     }
     __syncthreads();
-    const int cu = (int)role_s;
-    const int inst = (int)xcc;
+    int cu = (int)role_s;
+    int inst = (int)xcc;
     if (cu >= CUS) return;                       // surplus block on this XCD (census reports it)
+    if (a.mode & 128) {                          // SPREAD: every instance takes 4 CUs of every XCD
+        inst = cu >> 2;
+        cu = (int)xcc * 4 + (cu & 3);
+    }
     if ((a.mode & 4) && inst != 0) return;
 
     // ---- stationary weights: 2 tiles x 32 k-steps x 8 bf16 = 256 VGPRs
