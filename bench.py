@@ -331,6 +331,11 @@ def main():
             "unit": "utterances/s",
             "n_gpus": joined,
             "rccl_ranks": joined if world > 1 else None,
+            # gradient exchange: buckets of the flat fp32 gradient buffer and how many of them were handed
+            # to RCCL from INSIDE the backward pass (per encoder layer, as its weight gradients became final)
+            "exchange": {"buckets": len(engine.reducer.bounds),
+                         "left_during_backward": engine.reducer.last_issued_early,
+                         "bytes": 4 * engine.flat.numel} if world > 1 else None,
             "rank_devices": devices,
             "steps": args.steps,
             "warmup": args.warmup,

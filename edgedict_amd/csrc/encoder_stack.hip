@@ -852,6 +852,9 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
         hipLaunchKernelGGL(unpermute_rows_kernel, dim3(ed_grid_for(4ll * H, 256, 4096)), dim3(256),
                            0, st.W, tmpB, 0, 1, y.db, y.db_hh, H, 1, acc);
         ED_CHECK_LAUNCH("unpermute_rows_kernel");
+        // frames [0, t1) were the last ones of this layer: its weight gradients are final once the
+        // auxiliary stream reaches this point
+        if (t0 == 0 && d->grads_final) d->grads_final(l, d->grads_final_user);
         return ED_OK;
     };
     int dw_seg = 1 << 20;   // measured: 8 / 4 / 2 / 1 chunks per segment cost +0.3 / +0.6 / +1.6 / +5.3 ms per step

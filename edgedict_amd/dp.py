@@ -1,25 +1,48 @@
 """Data-parallel gradient exchange: one process per GPU, RCCL (``backend='nccl'``) over xGMI.
 
 The reference scales with ``nn.DataParallel`` (cli/train.py:152-153: broadcast + reduce to GPU0)
-or Lightning DDP (cli/lightning.py:325-331).  Here utterances are sharded over ranks with no
-data-path collective; the only exchange is the gradient all-reduce, issued per *bucket* — a
-contiguous slice of the flat gradient buffer (optim.FlatParams) — as soon as autograd has
-finished every parameter in it, so RCCL traffic overlaps the remaining BPTT
-(joint -> prediction net -> encoder layer 5 ... 0).  MI355X xGMI is point-to-point
-(7 links/GPU): buckets are large (default 64 MiB => 4 collectives for the 203 MB of E6D2
-gradients) so each ring step moves MBs per link rather than paying latency many times.
-The sum is turned into the mean inside the Adam kernel (``grad_scale = 1/world``).
+or Lightning DDP (cli/lightning.py:325-331: bucketed all-reduce overlapped with backward).  Here
+utterances are sharded over ranks with no data-path collective; the only exchange is the gradient
+all-reduce, issued per *bucket* - a contiguous slice of the flat gradient buffer
+(optim.FlatParams) - as soon as every parameter in it is final, so RCCL traffic overlaps the rest
+of the backward pass.  A parameter becomes final in one of two ways:
+
+  * autograd accumulated it (``register_post_accumulate_grad_hook``): the fp32 parity mode, the
+    prediction network, the projections;
+  * the engine accumulated it straight into the flat buffer on the auxiliary stream, behind
+    autograd's back (bf16 mode: the encoder stack's and the joint network's weight gradients, 99 % of
+    the bytes) and reports it through ``ready(params, stream)`` - from the joint's backward node, and
+    from INSIDE the encoder stack's native backward call, per layer, the moment that layer's last
+    weight-gradient kernel is enqueued (``edgedict_stack_desc_t.grads_final``).  The collective is
+    then ordered behind that stream's position: the buckets of encoder layers 5 ... 1 leave while
+    the layers below are still in their BPTT.
+
+Buckets are cut at the boundaries the engine passes (one per encoder layer: 34 MB of fp32, the
+joint, the rest), never smaller than ``min_bytes``: xGMI is point-to-point (7 links per GPU), so a
+ring step should move MBs per link rather than pay latency many times.  The sum is turned into the
+mean inside the Adam kernel (``grad_scale = 1/world``).
 """
+import torch
 import torch.distributed as dist
+
+import os
+
+# set by the training engine when world_size > 1: callable(params, stream) -> None
+READY_HOOK = None
+# smallest bucket cut at a boundary (bytes); tests shrink it to exercise per-layer buckets on tiny models
+MIN_BUCKET_BYTES = int(os.environ.get("EDGEDICT_DP_MIN_BUCKET", str(1 << 20)))
 
 
 class BucketedAllReduce:
-    def __init__(self, flat, process_group=None, bucket_bytes=64 << 20):
+    def __init__(self, flat, process_group=None, bucket_bytes=64 << 20, boundaries=(), min_bytes=None):
+        """``boundaries``: parameters at which a new bucket must start (in parameter order)."""
         self.flat = flat
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        # buckets are built from the END of the flat buffer: backward reaches those params first
         per = max(1, bucket_bytes // 4)
+        lo_min = max(1, (MIN_BUCKET_BYTES if min_bytes is None else min_bytes) // 4)
+        starts = {id(p) for p in boundaries}
+        # buckets are built from the END of the flat buffer: backward reaches those params first
         bounds = []
         hi = flat.numel
         cur_lo = hi
@@ -30,7 +53,7 @@ class BucketedAllReduce:
             acc += p.numel()
             cur_lo = off
             self.param_bucket[id(p)] = len(bounds)
-            if acc >= per:
+            if acc >= per or (id(p) in starts and acc >= lo_min):
                 bounds.append((cur_lo, hi))
                 hi, acc = cur_lo, 0
         if acc > 0:
@@ -40,36 +63,62 @@ class BucketedAllReduce:
         for p in flat.params:
             self.expected[self.param_bucket[id(p)]] += 1
         self.pending = list(self.expected)
+        self.issued = [False] * len(bounds)
         self.handles = []
+        self.issued_early = 0     # buckets that left before finish() in this step ...
+        self.last_issued_early = 0   # ... and in the last finished one (reporting / tests)
         self._hooks = []
         self.armed = True   # disarm while accumulating sub-batches; arm for the last backward
         if self.world > 1:
             for p in flat.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
-    def _on_grad(self, p):
-        if not self.armed:
+    def _issue(self, b):
+        lo, hi = self.bounds[b]
+        self.issued[b] = True
+        self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM,
+                                            group=self.group, async_op=True))
+
+    def _done(self, p, stream=None):
+        b = self.param_bucket.get(id(p))
+        if b is None or self.issued[b]:
             return
-        b = self.param_bucket[id(p)]
         self.pending[b] -= 1
         if self.pending[b] == 0:
-            lo, hi = self.bounds[b]
-            self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM,
-                                                group=self.group, async_op=True))
+            self.issued_early += 1
+            if stream is None:
+                self._issue(b)
+            else:
+                # the collective waits for the current stream's position: make that the stream the
+                # gradients were accumulated on
+                with torch.cuda.stream(stream):
+                    self._issue(b)
+
+    def _on_grad(self, p):
+        if self.armed and self.world > 1:
+            self._done(p)
+
+    def ready(self, params, stream=None):
+        """``params`` were accumulated in place (no autograd hook fires for them) by work enqueued
+        on ``stream`` (None = the current stream) up to this moment."""
+        if not self.armed or self.world <= 1:
+            return
+        for p in params:
+            self._done(p, stream)
 
     def finish(self):
-        """Wait for every bucket; flush buckets whose hooks did not all fire (unused params)."""
+        """Flush the buckets that are not out yet (parameters finalised at the very end of the
+        backward pass, unused parameters), then wait for every bucket."""
         if self.world > 1:
-            for b, left in enumerate(self.pending):
-                if left > 0:
-                    lo, hi = self.bounds[b]
-                    self.handles.append(dist.all_reduce(self.flat.grad[lo:hi],
-                                                        op=dist.ReduceOp.SUM, group=self.group,
-                                                        async_op=True))
+            for b in range(len(self.bounds)):
+                if not self.issued[b]:
+                    self._issue(b)
             for h in self.handles:
                 h.wait()
         self.handles = []
         self.pending = list(self.expected)
+        self.issued = [False] * len(self.bounds)
+        self.last_issued_early, self.issued_early = self.issued_early, 0
         return 1.0 / self.world
 
 

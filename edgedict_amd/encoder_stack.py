@@ -39,7 +39,11 @@ class StackDesc(ctypes.Structure):
                 ("x", _vp), ("x_dtype", ctypes.c_int), ("T0", ctypes.c_int), ("I0", ctypes.c_int),
                 ("in_gamma", _fp), ("in_beta", _fp), ("in_mean", _fp), ("in_rstd", _fp),
                 ("h0", _fp), ("c0", _fp), ("out", _vp), ("dout", _vp),
-                ("d_in_gamma", _fp), ("d_in_beta", _fp), ("ws", _vp), ("ws_bytes", ctypes.c_size_t)]
+                ("d_in_gamma", _fp), ("d_in_beta", _fp), ("ws", _vp), ("ws_bytes", ctypes.c_size_t),
+                ("grads_final", _vp), ("grads_final_user", _vp)]
+
+
+GRADS_FINAL_CB = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_void_p)
 
 
 SERIAL = 1
@@ -62,6 +66,11 @@ if os.environ.get("EDGEDICT_STACK_WSR", "0") == "1":
 
 def _p(t):
     return None if t is None else t.data_ptr()
+
+
+def side_stream(device):
+    from . import side
+    return side.stream(device)
 
 
 def supported(cd, H, I0, L, reductions):
@@ -255,10 +264,32 @@ class _Plan:
             d.flags &= ~ACCUM_GRADS
         dout = dout.contiguous()
         d.dout, d.d_in_gamma, d.d_in_beta = _p(dout), _p(dig), _p(dib)
+        # data parallelism: tell the gradient exchange when a layer's weight gradients are final on the
+        # auxiliary stream, so its bucket leaves while the layers below are still in their BPTT
+        from . import dp
+        cb = None
+        if direct and dp.READY_HOOK is not None:
+            hook, aux = dp.READY_HOOK, side_stream(dev)
+
+            errors = []
+
+            def _on_final(layer, _user, params=params, hook=hook, aux=aux):
+                try:        # an exception must not unwind through the C frames of the scheduler
+                    hook(params[6 * layer:6 * layer + 4], aux)
+                except BaseException as exc:   # noqa: BLE001 - re-raised below
+                    errors.append(exc)
+            cb = GRADS_FINAL_CB(_on_final)
+            d.grads_final = ctypes.cast(cb, ctypes.c_void_p).value
+        else:
+            d.grads_final = None
+        d.grads_final_user = None
         lib = _lib.load()
         ops.mark("stack_bwd:enter")
         with ops.host_timed("stack_backward_call"):
             check(lib.edgedict_stack_backward(ctypes.byref(d), stream_ptr()), "stack_backward")
+        d.grads_final = None
+        if cb is not None and errors:
+            raise errors[0]
         ops.mark("stack_bwd:exit")
         return None if direct else (dig, dib, grads)
 

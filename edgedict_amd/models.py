@@ -98,6 +98,14 @@ def _state(t):
     return t.contiguous()
 
 
+def _grads_ready(params, device):
+    """Tell the data-parallel gradient exchange (dp.BucketedAllReduce.ready) that ``params`` were
+    accumulated in place by work enqueued on the auxiliary stream up to now."""
+    from . import dp
+    if dp.READY_HOOK is not None:
+        dp.READY_HOOK(params, side.stream(device))
+
+
 # ----------------------------------------------------------------------------------------
 # autograd plumbing around the kernels
 class _InputNormFn(torch.autograd.Function):
@@ -400,6 +408,7 @@ class _JointFn(torch.autograd.Function):
                 ops.gemm(dD1c.t(), dec2.t(), out=g1[:, P:], accumulate=True,
                          split_k=ops.pick_split_k(J, P2, B * U1))
                 ops.colsum(dD1.view(B * U1, J), out=ctx.b1.grad)
+            _grads_ready((w1, ctx.b1, w2, ctx.b2), dl.device)
         if not defer:
             dw1 = torch.empty(J, P + P2, dtype=F32, device=dl.device)
             ops.gemm(dE1c.t(), enc2.t(), out=dw1[:, :P], split_k=ops.pick_split_k(J, P, B * T))
@@ -498,6 +507,7 @@ class _JointLossFn(torch.autograd.Function):
                 ops.gemm(dD1c.t(), dec2.t(), out=g1[:, P:], accumulate=True,
                          split_k=ops.pick_split_k(J, P2, B * U1))
                 ops.colsum(dD1.view(B * U1, J), out=ctx.b1.grad)
+            _grads_ready((w1, ctx.b1, w2, ctx.b2), dl.device)
         else:
             dw1 = torch.empty(J, P + P2, dtype=F32, device=dl.device)
             ops.gemm(dE1c.t(), enc2.t(), out=dw1[:, :P], split_k=ops.pick_split_k(J, P, B * T))

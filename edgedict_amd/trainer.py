@@ -60,7 +60,17 @@ class TrainEngine:
                 dist.broadcast(p.data, src=0, group=process_group)
         self.flat = FlatParams(self.model)
         self.optim = FusedAdam(self.flat, lr=flags.lr, max_grad_norm=getattr(flags, "gradclip", None))
-        self.reducer = BucketedAllReduce(self.flat, process_group)
+        # bucket boundaries follow the order backward finishes things in: the joint, the prediction
+        # network, then one bucket per encoder layer (its four LSTM tensors are contiguous in the flat
+        # buffer), the small LayerNorm tensors last
+        enc = self.model.encoder
+        cuts = [self.model.joint.joint[0].weight, self.model.decoder.embed.weight]
+        if hasattr(enc.lstm, "lstms"):
+            cuts += [m.layer(0)[0] for m in enc.lstm.lstms] + [enc.lstm.projs[0][0].weight]
+        self.reducer = BucketedAllReduce(self.flat, process_group, boundaries=cuts)
+        if self.world > 1:
+            from . import dp
+            dp.READY_HOOK = self.reducer.ready     # in-place accumulated gradients report here
         self.sub_batch_size = getattr(flags, "sub_batch_size", None)
         # learning-rate control of the reference's loop (cli/train.py:142-146,189-191)
         self.warmup = WarmupLR(self.optim, flags.lr, getattr(flags, "warmup_step", 0) or 0)

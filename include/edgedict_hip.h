@@ -266,6 +266,15 @@ typedef struct edgedict_stack_desc {
     float* d_in_beta;
     void* ws;              /* edgedict_stack_workspace_bytes(desc) bytes, 256-byte aligned */
     size_t ws_bytes;
+    /* backward, optional: called on the HOST, synchronously from edgedict_stack_backward, as soon as the
+       LAST kernel that accumulates dW_ih / dW_hh / db of `layer` has been enqueued on the auxiliary
+       stream (edgedict_aux_stream(2)) - the layers finish top-down, layer L-1 roughly L-1 chunks of
+       launches before layer 0.  A data-parallel host orders that layer's gradient all-reduce behind
+       the auxiliary stream's position at that moment, so the exchange of layers L-1 .. 1 runs under
+       the BPTT of the layers below (reference: DDP's bucketed all-reduce, cli/lightning.py:325-331).
+       The callback must not call back into this library. */
+    void (*grads_final)(int layer, void* user);
+    void* grads_final_user;
 } edgedict_stack_desc_t;
 
 /* sizeof(edgedict_stack_layer_t) (which = 0) / sizeof(edgedict_stack_desc_t) (which = 1): lets a

@@ -106,3 +106,55 @@ def test_flagfile_reader_and_presets(tmp_path):
     assert g.apex is True and abs(g.lr - 5e-4) < 1e-12 and g.feature == "logfbank"
     large = make_flags("E6D2_LARGE_Batch")
     assert (large.dec_hidden_size, large.dec_proj_size, large.hop_length) == (512, 640, 320)
+
+
+def _worker_ready(rank, world, port, q):
+    """Parameters accumulated behind autograd's back report through ready(): their buckets leave
+    before finish(), cut at the boundaries passed in, and the reduced gradient is still exact."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from edgedict_amd.dp import BucketedAllReduce
+    from edgedict_amd.optim import FlatParams
+    model = _model()
+    flat = FlatParams(model)
+    params = list(model.parameters())
+    red = BucketedAllReduce(flat, bucket_bytes=1 << 30, boundaries=[params[0], params[2], params[4]], min_bytes=4)
+    assert len(red.bounds) == 3                       # one bucket per Linear, cut at its first tensor
+    g = torch.Generator().manual_seed(5 + rank)
+    flat.zero_grad()
+    for p in params:                                   # "kernels" wrote the gradients in place
+        p.grad.copy_(torch.randn(p.shape, generator=g))
+    mine = flat.grad.clone()
+    red.ready(params[4:6])                             # last layer first, as backward finishes things
+    red.ready(params[2:3])                             # half a bucket: must not leave yet
+    early = red.issued_early
+    red.ready(params[3:4])
+    early2 = red.issued_early
+    scale = red.finish()                               # flushes the first Linear's bucket
+    q.put((rank, mine.numpy(), flat.grad.clone().numpy(), early, early2, red.last_issued_early, scale))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_in_place_gradients_report_ready_and_leave_early():
+    world, port = 2, 31500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_ready, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in range(world):
+        r = q.get(timeout=60)
+        out[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    import numpy as np
+    total = out[0][0] + out[1][0]
+    for r in range(world):
+        np.testing.assert_allclose(out[r][1], total, rtol=1e-6, atol=1e-6)
+        assert out[r][2:] == (1, 2, 2, 0.5)

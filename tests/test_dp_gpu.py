@@ -48,13 +48,16 @@ def _worker(rank, world, port, q):
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
+    os.environ["EDGEDICT_DP_MIN_BUCKET"] = "1024"        # tiny model: still one bucket per encoder layer
     from edgedict_amd.dp import shard_batch
     from edgedict_amd.trainer import TrainEngine
     torch.manual_seed(100 + rank)          # different initial weights: the engine must broadcast rank 0's
     eng = TrainEngine(_flags(), vocab_size=40, device="cuda", compute_dtype="bf16")
     shard = shard_batch(list(_batch()), rank, world)
     losses, params = _steps(eng, *shard)
-    q.put((rank, losses, params.numpy()))
+    early = (eng.reducer.last_issued_early, len(eng.reducer.bounds),
+             [eng.reducer.param_bucket[id(m.layer(0)[1])] for m in eng.model.encoder.lstm.lstms])
+    q.put((rank, losses, params.numpy(), early))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -69,12 +72,18 @@ def test_two_ranks_equal_one_process_on_the_whole_batch(hip_lib):
         p.start()
     got = {}
     for _ in range(world):
-        r, losses, params = q.get(timeout=240)
-        got[r] = (losses, torch.from_numpy(params))
+        r, losses, params, early = q.get(timeout=240)
+        got[r] = (losses, torch.from_numpy(params), early)
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
     assert torch.equal(got[0][1], got[1][1])                 # replicas stay identical
+    # the exchange is overlapped: one bucket per encoder layer (distinct bucket ids) plus the joint's left
+    # from INSIDE the backward pass (edgedict_stack_desc_t.grads_final / the joint's deferred block),
+    # only the small remainder was flushed by finish()
+    n_early, n_buckets, layer_buckets = got[0][2]
+    assert len(set(layer_buckets)) == 3, layer_buckets
+    assert n_early >= 4 and n_early < n_buckets, (n_early, n_buckets)
     from edgedict_amd.trainer import TrainEngine
     torch.manual_seed(100)                                    # rank 0's initial weights
     eng = TrainEngine(_flags(), vocab_size=40, device="cuda", compute_dtype="bf16")
