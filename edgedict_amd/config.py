@@ -49,6 +49,10 @@ DECODER_ENQUEUE_FIRST = os.environ.get("EDGEDICT_DECODER_FIRST", "0") != "0"
 # lattice (only the cells inside each utterance's (T_b, U_b+1) box are materialised)
 PACKED_LATTICE = os.environ.get("EDGEDICT_PACKED_LATTICE", "1") != "0"
 
+# bf16 packed-lattice training path: log-softmax partials fused into the logits product's epilogue
+# (csrc/gemm_nt256.hip) instead of a separate pass over the logits (rnnt_lse_gather)
+FUSED_LSE = os.environ.get("EDGEDICT_FUSED_LSE", "1") != "0"
+
 # inputs shorter than this many frames use the per-layer path even in bf16 (see Encoder.forward)
 STACK_MIN_FRAMES = int(os.environ.get("EDGEDICT_STACK_MIN_FRAMES", "24"))
 

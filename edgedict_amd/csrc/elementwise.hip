@@ -329,7 +329,7 @@ __global__ __launch_bounds__(256) void joint_hidden_bwd(const T* __restrict__ dh
 // grad_scale is read from device memory (gradient clipping coefficient) when given.
 __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                             float* __restrict__ m, float* __restrict__ v, long long n, float lr,
-                            float b1, float b2, float eps, float bc1, float bc2,
+                            float b1, float b2, float omb1, float omb2, float eps, float bc1, float bc2,
                             float weight_decay, float grad_scale_host,
                             const float* __restrict__ grad_scale,
                             bf16_t* __restrict__ p_bf16) {
@@ -341,8 +341,8 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
         float gi = g[i] * gs;
         float pi = p[i];
         if (weight_decay != 0.f) gi += weight_decay * pi;
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float mi = b1 * m[i] + omb1 * gi;
+        const float vi = b2 * v[i] + omb2 * gi * gi;
         m[i] = mi;
         v[i] = vi;
         pi -= step * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
@@ -595,10 +595,16 @@ extern "C" int edgedict_adam_step(float* p, const float* g, float* m, float* v, 
     ED_CHECK_ARG(n >= 0 && step >= 1, "adam_step: bad size/step");
     if (n == 0) return ED_OK;
     ED_CHECK_ARG(p && g && m && v, "adam_step: null pointer");
-    const float bc1 = 1.f - powf(beta1, (float)step);
-    const float bc2 = 1.f - powf(beta2, (float)step);
+    // torch.optim.Adam works out 1 - beta and 1 - beta^step in DOUBLE from the Python floats and only
+    // then rounds to fp32; the betas arrive here as fp32 images of decimal literals, and 1.f - 0.999f
+    // differs from (float)(1 - 0.999) by 1.3e-5 relative (it shows in exp_avg_sq).  Recover the decimal
+    // (7 significant digits) and do the same arithmetic in double.
+    const double b1d = nearbyint((double)beta1 * 1e7) / 1e7, b2d = nearbyint((double)beta2 * 1e7) / 1e7;
+    const float omb1 = (float)(1.0 - b1d), omb2 = (float)(1.0 - b2d);
+    const float bc1 = (float)(1.0 - pow(b1d, (double)step));
+    const float bc2 = (float)(1.0 - pow(b2d, (double)step));
     hipLaunchKernelGGL(adam_kernel, dim3(ed_grid_for(n, 256 * 4, 256 * 8)), dim3(256), 0,
-                       (hipStream_t)stream_, p, g, m, v, n, lr, beta1, beta2, eps, bc1, bc2,
+                       (hipStream_t)stream_, p, g, m, v, n, lr, beta1, beta2, omb1, omb2, eps, bc1, bc2,
                        weight_decay, grad_scale_host, grad_scale, (bf16_t*)p_bf16);
     ED_CHECK_LAUNCH("adam_step");
     return ED_OK;

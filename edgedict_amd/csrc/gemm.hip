@@ -450,6 +450,10 @@ static int gemm_impl(int dtype_in, int dtype_out, const void* A, long long lda, 
         const char* e = getenv("EDGEDICT_GEMM_NT");
         return !(e && e[0] == '0');
     }();
+    // large bf16 NT products: the 256 x 256-tile kernel (gemm_nt256.hip), ahead of the vendor route
+    if (nt_enabled && max_wg_per_cu == 0 && ed_gemm_nt256_ok(M, N, K, accumulate) &&
+        ed_gemm_nt_ok(dtype_in, dtype_out, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, split_k, bias1, bias2))
+        return ed_gemm_nt256_launch(A, lda, B, ldb, C, ldc, M, N, K, bias1, bias2, stream);
     // the one plain product that is large AND output-heavy (short K: the joint's logits) goes to the
     // vendor library when it is there (blaslt.cpp says why); everything else runs here
     if (dtype_in == ED_BF16 && dtype_out == ED_BF16 && a_kmajor && b_kmajor && !accumulate && !bias2 &&
@@ -570,6 +574,17 @@ extern "C" int edgedict_gemm(int dtype_in, int dtype_out, const void* A, long lo
                              int accumulate, int split_k, void* stream_) {
     return gemm_impl(dtype_in, dtype_out, A, lda, a_kmajor, B, ldb, b_kmajor, C, ldc, M, N, K, bias1,
                      bias2, accumulate, split_k, stream_, 0);
+}
+
+extern "C" int edgedict_gemm_nt_lse(const void* A, long long lda, const void* B, long long ldb, void* C,
+                                    long long ldc, int M, int N, int K, const float* bias,
+                                    float* lse_part, void* stream_) {
+    ED_CHECK_ARG(A && B && C && lse_part, "gemm_nt_lse: null pointer");
+    ED_CHECK_ARG(ed_gemm_nt256_shape_ok(M, N, K) &&
+                 ed_gemm_nt_ok(ED_BF16, ED_BF16, A, lda, 1, B, ldb, 1, C, ldc, M, N, K, 1, bias, nullptr),
+                 "gemm_nt_lse: needs bf16 K-contiguous operands, K %% 64 == 0, K >= 128, N %% 8 == 0, "
+                 "16-byte aligned pointers and leading dimensions (M=%d N=%d K=%d)", M, N, K);
+    return ed_gemm_nt256_launch(A, lda, B, ldb, C, ldc, M, N, K, bias, nullptr, (hipStream_t)stream_, lse_part);
 }
 
 extern "C" int edgedict_gemm_bg(int dtype_in, int dtype_out, const void* A, long long lda,

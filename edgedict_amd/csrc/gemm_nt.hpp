@@ -7,3 +7,11 @@ bool ed_gemm_nt_ok(int dtype_in, int dtype_out, const void* A, long long lda, in
 int ed_gemm_nt_launch(const void* A, long long lda, const void* B, long long ldb, void* C,
                       long long ldc, int M, int N, int K, const float* bias1, const float* bias2,
                       int accumulate, int lds_pad, hipStream_t s);
+// 256 x 256 macro-tile variant (gemm_nt256.hip) for large products
+bool ed_gemm_nt256_ok(int M, int N, int K, int accumulate);
+bool ed_gemm_nt256_shape_ok(int M, int N, int K);
+// lse_part (nullable): [M][ceil(N/64)][2] fp32 = (max, sum exp(x - max)) of the bf16-rounded C values of
+// each row over 64-column slots
+int ed_gemm_nt256_launch(const void* A, long long lda, const void* B, long long ldb, void* C,
+                         long long ldc, int M, int N, int K, const float* bias1, const float* bias2,
+                         hipStream_t s, float* lse_part = nullptr);

@@ -104,6 +104,51 @@ __global__ __launch_bounds__(256) void rnnt_lse_gather(
     }
 }
 
+// kernel 1 with the row maxima / exp-sums already reduced per 64-column slot by the logits product's
+// epilogue (gemm_nt256.hip): half a wave per lattice row combines the `slots` pairs, one lane picks the
+// blank / label logits out of the stored row.  Reads 8 * slots + 4 bytes per row instead of 2 V.
+__global__ __launch_bounds__(256) void rnnt_lse_from_parts(
+    const bf16_t* __restrict__ acts, const float2* __restrict__ parts, int slots,
+    const int32_t* __restrict__ labels, const int32_t* __restrict__ act_lens,
+    const int32_t* __restrict__ label_lens, int Tm, int U1, int V, int blank,
+    float* __restrict__ denom, float* __restrict__ lpb, float* __restrict__ lpl,
+    const long long* __restrict__ pk_off) {
+    const int half = (threadIdx.x & 63) >> 5, l32 = threadIdx.x & 31, wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int Tb = min(act_lens[b], Tm), Ub = min(label_lens[b], U1 - 1);
+    const int Wb = Ub + 1, nvalid = Tb * Wb;
+    for (int r0 = (blockIdx.x * 4 + wave) * 2; r0 < nvalid; r0 += gridDim.x * 8) {
+        const int r = r0 + half;
+        const bool live = r < nvalid;
+        const int t = live ? r / Wb : 0, u = live ? r - t * Wb : 0;
+        const long long row = ((long long)b * Tm + t) * U1 + u;
+        const long long arow = pk_off[b] + (live ? r : 0);
+        float m = -INFINITY, sm = 0.f;
+        for (int k = l32; k < slots; k += 32) {
+            const float2 p = parts[arow * slots + k];
+            const float nm = fmaxf(m, p.x);
+            sm = (nm == -INFINITY) ? 0.f : sm * __expf(m - nm) + p.y * __expf(p.x - nm);
+            m = nm;
+        }
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) {      // within the 32-lane half
+            const float om = __shfl_xor(m, off, 64), os = __shfl_xor(sm, off, 64);
+            const float nm = fmaxf(m, om);
+            sm = (nm == -INFINITY) ? 0.f : sm * __expf(m - nm) + os * __expf(om - nm);
+            m = nm;
+        }
+        if (live && l32 == 0) {
+            const float lse = m + logf(sm);
+            const bf16_t* z = acts + arow * (long long)V;
+            denom[row] = lse;
+            lpb[row] = bf16_to_f32(z[blank]) - lse;
+            float l = 0.f;
+            if (u < Ub) l = bf16_to_f32(z[labels[(long long)b * (U1 - 1) + u]]) - lse;
+            lpl[row] = l;
+        }
+    }
+}
+
 // log(exp(a)+exp(b)) with float64 carry: only the add/sub/max are fp64, the correction term
 // log1p(exp(-|a-b|)) in [0, ln 2] is evaluated in fp32 (abs error ~1e-7).
 __device__ __forceinline__ double log_add64(double a, double b) {
@@ -350,7 +395,8 @@ extern "C" const void* edgedict_rnnt_workspace_view(const void* workspace, int B
 static int loss_forward(const void* acts, int acts_dtype, const int32_t* labels,
                         const int32_t* act_lens, const int32_t* label_lens, int B, int T, int U1,
                         int V, int blank, float* costs, float* reduced, float reduce_scale,
-                        void* workspace, const long long* pk_off, void* stream_) {
+                        void* workspace, const long long* pk_off, void* stream_,
+                        const float* lse_parts = nullptr, int lse_slots = 0) {
     if (int rc = check_common(B, T, U1, V, blank, acts_dtype)) return rc;
     ED_CHECK_ARG(acts && (labels || U1 == 1) && act_lens && label_lens && costs && workspace,
                  "rnnt_loss_forward: null pointer argument");
@@ -368,7 +414,14 @@ static int loss_forward(const void* acts, int acts_dtype, const int32_t* labels,
     const size_t esz = acts_dtype == ED_F32 ? 4 : 2;
     const int vec_ok = ((V * esz) % 16 == 0) && (((uintptr_t)acts & 15) == 0);
     const dim3 grid1(ed_grid_for((long long)T * U1, 4, max(1, 256 * 16 / B)), B);
-    if (acts_dtype == ED_F32)
+    if (lse_parts) {
+        ED_CHECK_ARG(acts_dtype == ED_BF16 && pk_off && lse_slots > 0,
+                     "rnnt_loss_forward: log-sum-exp partials need bf16 logits on the packed lattice");
+        const dim3 gridp(ed_grid_for((long long)T * U1, 8, max(1, 256 * 16 / B)), B);
+        hipLaunchKernelGGL(rnnt_lse_from_parts, gridp, dim3(256), 0, stream, (const bf16_t*)acts,
+                           (const float2*)lse_parts, lse_slots, labels, act_lens, label_lens, T, U1, V,
+                           blank, denom, lpb, lpl, pk_off);
+    } else if (acts_dtype == ED_F32)
         hipLaunchKernelGGL(rnnt_lse_gather<float>, grid1, dim3(256), 0, stream,
                            (const float*)acts, labels, act_lens, label_lens, B, T, U1, V, blank,
                            denom, lpb, lpl, vec_ok, pk_off);
@@ -407,6 +460,20 @@ extern "C" int edgedict_rnnt_loss_forward_packed(const void* acts, int acts_dtyp
     ED_CHECK_ARG(row_offsets, "rnnt_loss_forward_packed: null row_offsets");
     return loss_forward(acts, acts_dtype, labels, act_lens, label_lens, B, T, U1, V, blank, costs,
                         reduced, reduce_scale, workspace, row_offsets, stream_);
+}
+
+extern "C" int edgedict_rnnt_loss_forward_packed_parts(const void* acts, const int32_t* labels,
+                                                       const int32_t* act_lens,
+                                                       const int32_t* label_lens,
+                                                       const long long* row_offsets, int B, int T,
+                                                       int U1, int V, int blank, float* costs,
+                                                       float* reduced, float reduce_scale,
+                                                       void* workspace, const float* lse_parts,
+                                                       int lse_slots, void* stream_) {
+    ED_CHECK_ARG(row_offsets && lse_parts, "rnnt_loss_forward_packed_parts: null pointer");
+    ED_CHECK_ARG(lse_slots == (V + 63) / 64, "rnnt_loss_forward_packed_parts: lse_slots must be ceil(V / 64)");
+    return loss_forward(acts, ED_BF16, labels, act_lens, label_lens, B, T, U1, V, blank, costs,
+                        reduced, reduce_scale, workspace, row_offsets, stream_, lse_parts, lse_slots);
 }
 
 static int loss_backward(const void* acts, int acts_dtype, void* grads, const int32_t* labels,

@@ -67,6 +67,10 @@ class BucketedAllReduce:
         self.handles = []
         self.issued_early = 0     # buckets that left before finish() in this step ...
         self.last_issued_early = 0   # ... and in the last finished one (reporting / tests)
+        self.early_buckets, self.last_early_buckets = [], []    # their indices, in issue order
+        self.early_by, self.last_early_by = [], []              # 'ready' / 'hook': what completed them
+        self.ready_calls = 0         # ready() invocations in the last finished step
+        self._ready_calls = 0
         self._hooks = []
         self.armed = True   # disarm while accumulating sub-batches; arm for the last backward
         if self.world > 1:
@@ -86,6 +90,8 @@ class BucketedAllReduce:
         self.pending[b] -= 1
         if self.pending[b] == 0:
             self.issued_early += 1
+            self.early_buckets.append(b)
+            self.early_by.append("ready" if stream is not None else "hook")
             if stream is None:
                 self._issue(b)
             else:
@@ -103,6 +109,7 @@ class BucketedAllReduce:
         on ``stream`` (None = the current stream) up to this moment."""
         if not self.armed or self.world <= 1:
             return
+        self._ready_calls += 1
         for p in params:
             self._done(p, stream)
 
@@ -119,6 +126,9 @@ class BucketedAllReduce:
         self.pending = list(self.expected)
         self.issued = [False] * len(self.bounds)
         self.last_issued_early, self.issued_early = self.issued_early, 0
+        self.last_early_buckets, self.early_buckets = self.early_buckets, []
+        self.last_early_by, self.early_by = self.early_by, []
+        self.ready_calls, self._ready_calls = self._ready_calls, 0
         return 1.0 / self.world
 
 

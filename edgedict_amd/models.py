@@ -456,14 +456,26 @@ class _JointLossFn(torch.autograd.Function):
         _lib.call("joint_hidden_fwd_packed", _lib.dtype_code(cd), E1, D1, hid, al_d, ll_d, off_d,
                   B, T, U1, J)
         ops.LAST["joint_rows"] = M
-        with ops.timed("joint_logits_gemm"):
-            logits = ops.gemm(hid, w2c, bias=b2.detach())
         lib = _lib.load()
         ws = torch.empty(lib.edgedict_rnnt_workspace_bytes(B, T, U1), dtype=torch.uint8, device=dev)
         costs = torch.empty(B, dtype=F32, device=dev)
         reduced = torch.empty(1, dtype=F32, device=dev)
-        _lib.call("rnnt_loss_forward_packed", logits, _lib.dtype_code(cd), labels, al_d, ll_d, off_d,
-                  B, T, U1, V, int(blank), costs, reduced, 1.0 / B, ws)
+        if config.FUSED_LSE and cd == torch.bfloat16 and J >= 128 and J % 64 == 0 and V % 8 == 0 and M >= 256:
+            # logits product with the log-softmax partials in its epilogue (gemm_nt256.hip): the loss
+            # finishes the denominators from M x V/64 pairs instead of re-reading the logits
+            slots = (V + 63) // 64
+            parts = torch.empty(M, slots, 2, dtype=F32, device=dev)
+            logits = torch.empty(M, V, dtype=cd, device=dev)
+            with ops.timed("joint_logits_gemm"):
+                _lib.call("gemm_nt_lse", hid, ops._ll(J), w2c, ops._ll(J), logits, ops._ll(V), M, V, J,
+                          b2.detach(), parts)
+            _lib.call("rnnt_loss_forward_packed_parts", logits, labels, al_d, ll_d, off_d, B, T, U1, V,
+                      int(blank), costs, reduced, 1.0 / B, ws, parts, slots)
+        else:
+            with ops.timed("joint_logits_gemm"):
+                logits = ops.gemm(hid, w2c, bias=b2.detach())
+            _lib.call("rnnt_loss_forward_packed", logits, _lib.dtype_code(cd), labels, al_d, ll_d, off_d,
+                      B, T, U1, V, int(blank), costs, reduced, 1.0 / B, ws)
         ctx.save_for_backward(enc2, dec2, w1, w2, hid, logits, labels, al_d, ll_d, off_d, ws)
         ctx.b1, ctx.b2 = b1, b2
         ctx.cfg = (cd, B, T, U1, P, P2, J, V, M, int(blank))

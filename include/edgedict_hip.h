@@ -71,6 +71,15 @@ int edgedict_rnnt_loss_forward(const void* acts, int acts_dtype, const int32_t* 
                                const int32_t* act_lens, const int32_t* label_lens, int B, int T,
                                int U1, int V, int blank, float* costs, float* reduced,
                                float reduce_scale, void* workspace, void* stream);
+/* packed-lattice forward (bf16 logits) with the per-row log-sum-exp partials produced by
+ * edgedict_gemm_nt_lse: lse_parts [M_valid][lse_slots][2], lse_slots = ceil(V/64).  Same results as
+ * edgedict_rnnt_loss_forward_packed up to the summation order of the denominators. */
+int edgedict_rnnt_loss_forward_packed_parts(const void* acts, const int32_t* labels,
+                                            const int32_t* act_lens, const int32_t* label_lens,
+                                            const long long* row_offsets, int B, int T, int U1,
+                                            int V, int blank, float* costs, float* reduced,
+                                            float reduce_scale, void* workspace,
+                                            const float* lse_parts, int lse_slots, void* stream);
 int edgedict_rnnt_loss_backward(const void* acts, int acts_dtype, void* grads,
                                 const int32_t* labels, const int32_t* act_lens,
                                 const int32_t* label_lens, int B, int T, int U1, int V, int blank,
@@ -128,6 +137,16 @@ int edgedict_gemm_bg(int dtype_in, int dtype_out, const void* A, long long lda, 
                      const void* B, long long ldb, int b_kmajor, void* C, long long ldc, int M,
                      int N, int K, const float* bias1, const float* bias2, int accumulate,
                      int split_k, int max_wg_per_cu, float* partials, void* stream);
+
+/* C[M,N] = A[M,K] B[N,K]^T + bias (bf16, both operands K-contiguous: the joint's logits product,
+ * rnnt/models.py:177) with the log-softmax partials of every row fused into the epilogue:
+ * lse_part [M][ceil(N/64)][2] fp32 = (max, sum exp(x - max)) of the bf16-rounded outputs over 64-column
+ * slots - edgedict_rnnt_loss_forward_packed_parts finishes the denominators from them instead of
+ * re-reading the M x N logits.  K %% 64 == 0, K >= 128, N %% 8 == 0. */
+int edgedict_gemm_nt_lse(const void* A, long long lda, const void* B, long long ldb, void* C,
+                         long long ldc, int M, int N, int K, const float* bias, float* lse_part,
+                         void* stream);
+
 
 /* ------------------------------------------------------------------------------------
  * LayerNorm fused with the residual add and the encoder's TimeReduction.

@@ -55,8 +55,13 @@ def _worker(rank, world, port, q):
     eng = TrainEngine(_flags(), vocab_size=40, device="cuda", compute_dtype="bf16")
     shard = shard_batch(list(_batch()), rank, world)
     losses, params = _steps(eng, *shard)
-    early = (eng.reducer.last_issued_early, len(eng.reducer.bounds),
-             [eng.reducer.param_bucket[id(m.layer(0)[1])] for m in eng.model.encoder.lstm.lstms])
+    red = eng.reducer
+    early = (list(red.last_early_buckets), len(red.bounds),
+             [red.param_bucket[id(m.layer(0)[1])] for m in eng.model.encoder.lstm.lstms],
+             red.param_bucket[id(eng.model.encoder.norm.weight)],
+             red.param_bucket[id(eng.model.joint.joint[2].weight)], red.ready_calls,
+             list(red.last_early_by), {n: red.param_bucket[id(p)] for n, p in eng.model.named_parameters()},
+             list(red.expected))
     q.put((rank, losses, params.numpy(), early))
     dist.barrier()
     dist.destroy_process_group()
@@ -81,9 +86,21 @@ def test_two_ranks_equal_one_process_on_the_whole_batch(hip_lib):
     # the exchange is overlapped: one bucket per encoder layer (distinct bucket ids) plus the joint's left
     # from INSIDE the backward pass (edgedict_stack_desc_t.grads_final / the joint's deferred block),
     # only the small remainder was flushed by finish()
-    n_early, n_buckets, layer_buckets = got[0][2]
+    early, n_buckets, layer_buckets, norm_bucket, joint_bucket, ready_calls, by, names, expected = got[0][2]
     assert len(set(layer_buckets)) == 3, layer_buckets
-    assert n_early >= 4 and n_early < n_buckets, (n_early, n_buckets)
+    assert ready_calls == 4, ready_calls                     # the joint's block + one call per encoder layer
+    assert joint_bucket in early and all(b in early for b in layer_buckets), (early, layer_buckets)
+    # top layer first: the order the BPTT finishes the layers in
+    pos = [early.index(b) for b in layer_buckets]
+    assert pos[2] < pos[1] < pos[0], (early, layer_buckets)
+    # the encoder layers' and the joint's buckets were completed by ready() (in-place accumulation reported
+    # from inside the backward pass), not by autograd hooks or finish()
+    for b in layer_buckets + [joint_bucket]:
+        assert by[early.index(b)] == "ready", (b, early, by)
+    # the input LayerNorm's gradients are final only at the very end of the stack's backward: its bucket
+    # leaves after every layer's (from finish(), or from its hook once the native call has returned)
+    if norm_bucket in early:
+        assert early.index(norm_bucket) > max(pos), (early, norm_bucket)
     from edgedict_amd.trainer import TrainEngine
     torch.manual_seed(100)                                    # rank 0's initial weights
     eng = TrainEngine(_flags(), vocab_size=40, device="cuda", compute_dtype="bf16")

@@ -106,3 +106,26 @@ def test_large_short_k_product_vendor_route_matches_own_kernel(hip_lib):
         ref = a[r0:r0 + 300].double() @ b.double().t() + bias.double()
         assert ((out[r0:r0 + 300].double() - ref).abs() <= 2.0 ** -8 * ref.abs() + 0.03).all()
         assert ((out[r0:r0 + 300].float() - own.float()).abs() <= 2.0 ** -7 * own.float().abs() + 0.03).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(256 * 33 + 37, 4096, 128), (256 * 66 + 1, 2048, 640), (256 * 130, 1000, 192)])
+def test_gemm_nt256_macro_tile_path(hip_lib, M, N, K):
+    """Large bf16 NT products (>= 512 macro-tiles) run gemm_nt256.hip (256 x 256 tiles, half-tile DMA
+    pipeline with counted waits): ragged M and N edges, both biases, strided A - against fp64 on row
+    slices, and against the 128 x 128 kernel on the same operands (EDGEDICT_GEMM_NT256 is read once per
+    process, so the comparison kernel is reached through a row slice that is too small for this path)."""
+    from edgedict_amd import ops
+    a_full = _mk((M, K + 64), torch.bfloat16, 31)
+    a = a_full[:, 64:]
+    b = _mk((N, K), torch.bfloat16, 32)
+    b1 = torch.randn(N, generator=torch.Generator().manual_seed(4)).cuda()
+    b2 = torch.randn(N, generator=torch.Generator().manual_seed(5)).cuda()
+    out = ops.gemm(a, b, bias=b1, bias2=b2)
+    assert out.dtype == torch.bfloat16 and out.shape == (M, N)
+    for r0 in (0, 255, M // 2 + 3, M - 300):
+        ref = a[r0:r0 + 300].double() @ b.double().t() + b1.double() + b2.double()
+        err = (out[r0:r0 + 300].double() - ref).abs()
+        assert (err <= 2.0 ** -8 * ref.abs() + 1e-3 * (K ** 0.5)).all(), r0
+        small = ops.gemm(a[r0:r0 + 300], b, bias=b1, bias2=b2)        # 128 x 128 kernel
+        assert ((out[r0:r0 + 300].float() - small.float()).abs() <= 2.0 ** -7 * small.float().abs() + 0.03).all()
+    assert torch.isfinite(out.float()).all()

@@ -132,3 +132,67 @@ def test_full_size_lattice_properties(hip_lib):
                                     ll[:1].cpu())
     assert abs(cf[0].item() - costs[0].item()) / cf[0].item() < 1e-5
     assert (gf[0].float() - gr[0].cpu()).abs().max().item() < 2e-5
+
+
+def test_fused_lse_epilogue_matches_separate_pass(hip_lib):
+    """The logits product with log-softmax partials in its epilogue (edgedict_gemm_nt_lse +
+    edgedict_rnnt_loss_forward_packed_parts) against the plain product followed by the pass over the
+    logits (edgedict_rnnt_loss_forward_packed): identical logits, denominators equal up to the summation
+    order, costs within 1e-6 relative - and the model-level loss / gradients do not move."""
+    import ctypes
+    from edgedict_amd import _lib, config
+    from edgedict_amd.ops import _ll
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    B, T, U1, V, J = 5, 37, 9, 2048, 640
+    act = torch.tensor([37, 30, 12, 37, 5], dtype=torch.int32)
+    lab = torch.tensor([8, 3, 8, 0, 6], dtype=torch.int32)
+    rows = act.long() * (lab.long() + 1)
+    off = torch.zeros(B, dtype=torch.int64)
+    off[1:] = torch.cumsum(rows, 0)[:-1]
+    M = int(rows.sum())
+    hid = torch.tanh(torch.randn(M, J, generator=g)).to(torch.bfloat16).cuda()
+    w2 = (torch.randn(V, J, generator=g) / 8).to(torch.bfloat16).cuda()
+    b2 = torch.randn(V, generator=g).cuda()
+    labels = torch.randint(1, V, (B, U1 - 1), generator=g, dtype=torch.int32).cuda()
+    act_d, lab_d, off_d = act.cuda(), lab.cuda(), off.cuda()
+    ws_bytes = lib.edgedict_rnnt_workspace_bytes(B, T, U1)
+
+    def run(fused):
+        ws = torch.zeros(ws_bytes, dtype=torch.uint8, device="cuda")
+        costs = torch.empty(B, device="cuda")
+        red = torch.empty(1, device="cuda")
+        logits = torch.empty(M, V, dtype=torch.bfloat16, device="cuda")
+        if fused:
+            parts = torch.empty(M, V // 64, 2, device="cuda")
+            _lib.call("gemm_nt_lse", hid, _ll(J), w2, _ll(J), logits, _ll(V), M, V, J, b2, parts)
+            _lib.call("rnnt_loss_forward_packed_parts", logits, labels, act_d, lab_d, off_d, B, T, U1, V, 0,
+                      costs, red, 1.0 / B, ws, parts, V // 64)
+        else:
+            _lib.call("gemm", 1, 1, hid, _ll(J), 1, w2, _ll(J), 1, logits, _ll(V), M, V, J, b2, None, 0, 1)
+            _lib.call("rnnt_loss_forward_packed", logits, 1, labels, act_d, lab_d, off_d, B, T, U1, V, 0,
+                      costs, red, 1.0 / B, ws)
+        torch.cuda.synchronize()
+        n = B * T * U1
+        denom = torch.frombuffer(ws.cpu().numpy().tobytes()[:4 * n], dtype=torch.float32).clone()
+        return logits.float().cpu(), denom.view(B, T, U1), costs.cpu(), red.item()
+
+    lf, df, cf, rf = run(True)
+    lp, dp, cp, rp = run(False)
+    # the 128x128 / vendor kernels and the 256x256 kernel sum in different orders: one bf16 ulp at most
+    assert ((lf - lp).abs() <= 2.0 ** -7 * lp.abs() + 1e-2).all()
+    ref = lf.double().logsumexp(dim=1)          # denominators of the FUSED run's own stored logits
+    k = 0
+    for b in range(B):
+        for t in range(int(act[b])):
+            for u in range(int(lab[b]) + 1):
+                assert abs(df[b, t, u].item() - ref[k].item()) < 2e-5, (b, t, u)
+                k += 1
+    assert ((cf - cp).abs() <= 2e-3 * cp.abs()).all()       # different logits rounding (summation order)
+    # same logits -> same costs to 1e-6: run the separate pass on the fused run's logits
+    ws = torch.zeros(ws_bytes, dtype=torch.uint8, device="cuda")
+    costs = torch.empty(B, device="cuda")
+    red = torch.empty(1, device="cuda")
+    _lib.call("rnnt_loss_forward_packed", lf.to(torch.bfloat16).cuda(), 1, labels, act_d, lab_d, off_d, B, T, U1,
+              V, 0, costs, red, 1.0 / B, ws)
+    assert ((costs.cpu() - cf).abs() <= 1e-6 * cf.abs()).all(), (costs.cpu(), cf)

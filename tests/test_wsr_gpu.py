@@ -85,9 +85,11 @@ def test_wsr_multi_stream_schedule_is_bit_exact_vs_one_stream(hip_lib, case):
 def test_wsr_dry_run_schedule_covers_every_frame_once(hip_lib):
     """edgedict_stack_schedule with the WSR flag: every (layer, frame) is carried by exactly one launch,
     in order, a layer's chunk never before the launch that finished its input chunk, <= L slots."""
+    import os
     import numpy as np
     from edgedict_amd import encoder_stack
     old = encoder_stack.FLAGS
+    os.environ["EDGEDICT_WSR_DELAY"] = "1"
     try:
         for T0, chunk in ((401, 12), (401, 6), (251, 5), (37, 1)):
             steps, enq, n, slots = encoder_stack.schedule(T0, 240, 1024, [1, 2, 1, 1, 1, 1], B=64, chunk=chunk,
@@ -106,3 +108,4 @@ def test_wsr_dry_run_schedule_covers_every_frame_once(hip_lib):
             assert n == nch0 + 5, (T0, chunk, n)     # wavefront: one extra launch per layer
     finally:
         encoder_stack.FLAGS = old
+        os.environ.pop("EDGEDICT_WSR_DELAY", None)

@@ -21,6 +21,9 @@ def bench(name, M, N, K, ta=False, tb=False, out_dtype=torch.bfloat16, split_k=1
     print("%-28s M=%7d N=%5d K=%7d  %8.3f ms  %7.1f TF/s" % (name, M, N, K, ms, 2.0 * M * N * K / ms / 1e9))
 
 M = 64 * 201 * 65
+MP = 543526      # packed lattice of the bench batch
+bench("joint logits packed (NT)", MP, 2048, 640)
+bench("joint dhid packed W2^T (NT)", MP, 640, 2048)
 bench("joint logits (NT)", M, 2048, 640)
 bench("joint dhid (NN)", M, 640, 2048, tb=True)
 bench("joint dW2 (TN, splitk)", 2048, 640, M, ta=True, tb=True, out_dtype=torch.float32, split_k=9)
