@@ -188,8 +188,14 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-loss-delta", action="store_true")
+    ap.add_argument("--own-kernels-only", action="store_true",
+                    help="route NO product to hipBLASLt (EDGEDICT_BLASLT=0, _BG=0, _SMALL=0)")
+    ap.add_argument("--no-own-kernels-run", action="store_true",
+                    help="skip the second, shorter run that fills value_own_kernels")
     args = ap.parse_args()
 
+    if args.own_kernels_only:                  # read once, when the library first routes a product
+        os.environ.update(EDGEDICT_BLASLT="0", EDGEDICT_BLASLT_BG="0", EDGEDICT_BLASLT_SMALL="0")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_spawn(args)                       # does not return
     rank = int(os.environ.get("RANK", "0"))
@@ -284,12 +290,12 @@ def main():
             with open(os.path.join(ROOT, "profiles", "pmc_latest.json")) as fh:
                 pmc = json.load(fh)["kernels"]
             tiles = ((rows + 127) // 128) * ((V + 127) // 128)
-            if vendor:   # hipBLASLt kernel names contain Cijk_; the logits product moves the most bytes
-                cands = [v for k, v in pmc.items() if "Cijk_" in k]
-                ent = max(cands, key=lambda v: v["hbm_bytes"]) if cands else None
-            else:
-                ent = next((v for k, v in pmc.items()
-                            if k.startswith("gemm_nt_kernel") and k.endswith("[tiles=%d]" % tiles)), None)
+            # the summaries label GEMM launches by grid threads / 256; this kernel has 512-thread workgroups
+            tiles256 = 2 * ((rows + 255) // 256) * ((V + 255) // 256)
+            ent = next((v for k, v in pmc.items()
+                        if k.startswith("gemm_nt256_kernel") and k.endswith("[tiles=%d]" % tiles256)), None)
+            if ent is None:
+                ent = next((v for k, v in pmc.items() if k.startswith("gemm_nt256_kernel")), None)
             if ent:
                 traffic = ent["hbm_bytes"]
                 mfma_util = ent.get("mfma_util")
@@ -359,10 +365,9 @@ def main():
             },
             "roofline": None,        # filled below: the dominant kernel
             "roofline_mfma": {
-                "kernel": "%s joint logits [%d x %d x %d] (packed lattice: %d of %d dense cells)"
-                          % ("hipBLASLt (plain bf16 NT product + bias; csrc/blaslt.cpp)" if vendor
-                             else "gemm_nt_kernel (bf16 NT, direct-to-LDS)", rows, V, J, rows,
-                             args.batch * Tp * U1),
+                "kernel": "gemm_nt256_kernel (own: bf16 NT, 256x256 tiles, half-tile DMA pipeline, log-sum-exp "
+                          "partials fused in the epilogue) joint logits [%d x %d x %d] (packed lattice: %d of "
+                          "%d dense cells)" % (rows, V, J, rows, args.batch * Tp * U1),
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": traffic,
                 "algorithmic_bytes": 2.0 * rows * (J + V) + 2.0 * V * J,
@@ -373,6 +378,25 @@ def main():
             "host_call_ms": {k: round(v[1], 3) for k, v in sorted(ops.host_summary().items())},
         }
         out["roofline"] = stack if stack is not None else out["roofline_mfma"]
+        out["vendor_gemm_calls"] = int(_edlib.load().edgedict_blaslt_calls())
+        if world == 1 and not args.own_kernels_only and not args.no_own_kernels_run:
+            # the same step with EVERY product on the hand-written kernels (the default run leaves the
+            # encoder's background weight-gradient products and the small chunk dX products to hipBLASLt,
+            # DESIGN.md 4.2): a second, shorter run in a fresh process
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--own-kernels-only", "--no-cpu-baseline",
+                   "--no-loss-delta", "--steps", str(min(args.steps, 12)), "--warmup", "3",
+                   "--preset", args.preset, "--batch", str(args.batch), "--seconds", str(args.seconds),
+                   "--labels", str(args.labels), "--dtype", args.dtype]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                sub = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                out["value_own_kernels"] = sub["value"]
+                out["ms_per_step_own_kernels"] = sub["ms_per_step"]
+                out["own_kernels_vendor_gemm_calls"] = sub.get("vendor_gemm_calls")
+            except Exception as exc:      # noqa: BLE001 - the headline number must not depend on this
+                out["value_own_kernels"] = None
+                out["own_kernels_error"] = repr(exc)[:200]
         if not args.no_loss_delta:
             ld = loss_delta(engine, flags, batch)
             out["loss_delta_vs_ref"] = ld

@@ -416,11 +416,104 @@ extern "C" int edgedict_stack_pack_weights(const float* w_ih, const float* w_hh,
 
 namespace {
 
+long long* g_wsr_trace = nullptr;   // debug: device buffer of >= 64 KB registered by edgedict_stack_wsr_set_trace
+
 bool wsr_applicable(const edgedict_stack_desc_t* d) {
     if (!(d->flags & EDGEDICT_STACK_WSR) || d->H != 1024 || d->B > 64 || d->L > ED_STACK_MAX_SLOTS) return false;
     for (int l = 0; l < d->L; ++l)
         if (!d->layers[l].whh_r) return false;
     return true;
+}
+
+// Forward pass as ONE persistent launch (wsr_kernels.hip, EdWsrLaunch::persistent): every layer runs all
+// its frames on its own XCD and waits, chunk by chunk, for the workgroups of the spare XCDs (the WORKERS)
+// to turn the chunk the layer below has finished into its gates (LayerNorm + input product).  Nothing else
+// can run beside a grid that fills whole XCDs (workgroups are bound to XCDs round-robin at dispatch, and
+// a CU mask cannot exclude an XCD - tools/cumask_probe.hip), so the side work lives INSIDE the launch.
+int forward_wsr_persistent(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Streams& st,
+                           const WsLayout& wl) {
+    const int B = d->B, H = d->H, L = d->L;
+    const long long BH = (long long)B * H;
+    char* ws = (char*)d->ws;
+    unsigned* sync = (unsigned*)(ws + wl.wsr_sync);
+    ED_DEV(ed_stack_zero(sync, WSR_SYNC_BYTES, st.R));
+    const int T_out = (g[L - 1].T + d->layers[L - 1].reduce - 1) / d->layers[L - 1].reduce;
+    // layer 0's input product, all chunks, before the launch
+    for (int k = 0; k < g[0].nchunks; ++k) {
+        ED_DEV(input_gemm(d, g, 0, k, st.S[0]));
+        if (g_trace) g_trace->chunk_enqueued[g_trace->coff[0] + k] = 0;
+    }
+    ED_TRY(st.chain(st.S[0], st.R));
+    EdWsrLaunch Lc;
+    Lc.nslot = L;
+    Lc.B = B;
+    Lc.err = sync;
+    Lc.ticket = sync + 8;
+    Lc.persistent = 1;
+    Lc.eps = d->eps;
+    Lc.trace = g_wsr_trace;
+    for (int l = 0; l < L; ++l) {
+        const edgedict_stack_layer_t& y = d->layers[l];
+        ED_CHECK_ARG(g[l].nchunks <= 512, "encoder_stack: too many chunks for the persistent launch");
+        EdWsrSlot& S = Lc.slot[l];
+        S.G = bptr(y.G);
+        S.img0 = bptr(ws + wl.frag0[l]);
+        S.img1 = bptr(ws + wl.frag1[l]);
+        S.Y = bptr(y.Yx) + BH;
+        S.C_prev = y.Cx;
+        S.C = y.Cx + BH;
+        S.Wreg = bptr(y.whh_r);
+        S.counter = sync + 16 + l;
+        S.base = 0;
+        S.t0 = 0;
+        S.nsteps = y.T;
+        S.cf = g[l].cf;
+        S.gdone = l == 0 ? nullptr : sync + 64 + l * 512;
+        S.ydone = sync + 32 + l;
+        S.X = y.residual ? bptr(y.X) : nullptr;
+        S.gamma = y.ln_gamma;
+        S.beta = y.ln_beta;
+        S.mean = y.mean;
+        S.rstd = y.rstd;
+        S.T = y.T;
+        S.reduce = y.reduce;
+        S.xdone = sync + 64 + 8 * 512 + l * 512;
+        if (l + 1 < L) {
+            const edgedict_stack_layer_t& z = d->layers[l + 1];
+            S.nX = bptr(z.X);
+            S.nX_st = BH;
+            S.nX_sb = H;
+            S.nWih = bptr(z.wih_p);
+            S.nBias = z.bias_p;
+            S.nG = bptr(z.G);
+            S.ngdone = sync + 64 + (l + 1) * 512;
+        } else {
+            S.nX = bptr(d->out);
+            S.nX_st = H;
+            S.nX_sb = (long long)T_out * H;
+            S.nWih = nullptr;
+            S.nBias = nullptr;
+            S.nG = nullptr;
+            S.ngdone = nullptr;
+        }
+        if (g_trace) {
+            for (int t = 0; t < y.T; ++t) g_trace->step_launch[g_trace->toff[l] + t] = 0;
+            for (int k = 0; k < g[l].nchunks && l > 0; ++k) g_trace->chunk_enqueued[g_trace->coff[l] + k] = 0;
+        }
+    }
+    if (st.rt && st.rt->tev[0][0]) ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][0], st.R));
+    ED_DEV(ed_wsr_launch_fwd(Lc, st.R));
+    if (g_trace) {
+        g_trace->max_slots = L;
+        g_trace->launches = 1;
+    }
+    if (st.rt && st.rt->tev[0][1]) {
+        ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][1], st.R));
+        st.rt->tlaunches[0] = 1;
+    }
+    if (st.rt && st.rt->wsr_err_dev && !g_trace)
+        ED_CHECK_HIP(hipMemcpyAsync(st.rt->wsr_err_host + 1, sync, 4, hipMemcpyDeviceToHost, st.R));
+    return ED_OK;
 }
 
 // Forward pass with the weights-stationary recurrence kernel (wsr_kernels.hip): launch w carries chunk
@@ -468,6 +561,9 @@ int forward_wsr(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
         Lc.nslot = 0;
         Lc.B = B;
         Lc.err = sync;
+        Lc.persistent = 0;
+        Lc.eps = d->eps;
+        Lc.trace = nullptr;
         Lc.ticket = sync + 64 + (size_t)launches * 8;
         int ran_l[ED_STACK_MAX_SLOTS], ran_k[ED_STACK_MAX_SLOTS];
         bool pending = false;
@@ -574,7 +670,11 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.C, st.S[l]));
 
     if (wsr_applicable(d)) {
-        ED_TRY(forward_wsr(d, g, st, wl));
+        // persistent form (default): needs at least one spare XCD for the workers
+        bool persist = L <= 7;
+        if (const char* e = getenv("EDGEDICT_WSR_PERSIST")) persist = persist && atoi(e) != 0;
+        if (persist) ED_TRY(forward_wsr_persistent(d, g, st, wl));
+        else ED_TRY(forward_wsr(d, g, st, wl));
         ED_TRY(st.chain(st.R, st.C));
         for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.S[l], st.C));
         return ED_OK;
@@ -725,6 +825,12 @@ extern "C" int edgedict_stack_pack_wsr(const float* w_hh, int H, void* whh_r, vo
     ED_CHECK_ARG(H == 1024, "stack_pack_wsr: the weights-stationary kernels are built for H = 1024 (got %d)", H);
     ED_CHECK_ARG(w_hh && whh_r, "stack_pack_wsr: null pointer");
     return ed_wsr_pack_fwd(w_hh, (bf16_t*)whh_r, (hipStream_t)stream_);
+}
+
+extern "C" int edgedict_stack_wsr_set_trace(void* device_buffer) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_wsr_trace = (long long*)device_buffer;
+    return ED_OK;
 }
 
 extern "C" int edgedict_stack_wsr_error(void) {

@@ -73,6 +73,25 @@ struct EdWsrSlot {
     unsigned* counter;         // arrivals of this layer: == base when the launch starts
     unsigned base;
     int t0, nsteps;
+    // ---- persistent form only (EdWsrLaunch::persistent): the layer runs ALL its frames in one launch
+    int cf;                    // frames per chunk of this layer
+    unsigned* gdone;           // [nchunks] workers that finished chunk k of this layer's input product
+                               // (null: the product was complete before the launch - layer 0)
+    unsigned* ydone;           // [1] += 1 per CU when a chunk's h rows are out (write-through)
+    // what the worker workgroups need to turn this layer's OUTPUT into the next layer's gates
+    const bf16_t* X;           // this layer's input rows [T, B, H] (the residual) or null
+    const float* gamma;        // LayerNorm after this layer
+    const float* beta;
+    float* mean;               // [T, B] statistics for the backward pass
+    float* rstd;
+    bf16_t* nX;                // next layer's input rows [T', B, H]; for the LAST layer: the stack output ...
+    long long nX_st, nX_sb;    // ... frame tau, row b at nX + tau * nX_st + b * nX_sb
+    const bf16_t* nWih;        // next layer's W_ih image [4H, H] (rows in interleaved gate order); null = last layer
+    const float* nBias;        // [4H]
+    bf16_t* nG;                // next layer's gates [T', B, 4H]
+    unsigned* xdone;           // [nchunks] workers done with the LayerNorm rows of chunk k (of the NEXT layer's input)
+    unsigned* ngdone;          // = next layer's gdone
+    int T, reduce;
 };
 struct EdWsrLaunch {
     EdWsrSlot slot[ED_STACK_MAX_SLOTS];
@@ -80,9 +99,14 @@ struct EdWsrLaunch {
     int B;
     unsigned* ticket;          // [8] zeroed role tickets of THIS launch
     unsigned* err;             // [1] give-up code (0 = fine), shared by the whole call
+    int persistent;            // 1: every layer runs all its frames; the workgroups of the XCDs >= nslot are
+                               // WORKERS (LayerNorm + next layer's input product per finished chunk)
+    float eps;
+    long long* trace;          // debug (nullable): wall-clock stamps, see tools/wsr_persist_trace.py
 };
 int ed_wsr_pack_fwd(const float* w_hh, bf16_t* out, hipStream_t s);
 int ed_wsr_launch_fwd(const EdWsrLaunch& L, hipStream_t s);
+int ed_wsr_workers(const EdWsrLaunch& L);      // worker workgroups of a persistent launch (0 = none possible)
 // LayerNorm(+ residual, + pair mean under time reduction) of the frames [t0, t1) a layer finished
 int ed_stack_chunk_norm(const bf16_t* Yx1, const bf16_t* X, const float* gamma, const float* beta,
                         bf16_t* out, long long out_st, long long out_sb, float* mean, float* rstd,

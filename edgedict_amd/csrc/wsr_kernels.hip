@@ -63,6 +63,294 @@ __global__ void wsr_pack_fwd_kernel(const float* __restrict__ W, bf16_t* __restr
     }
 }
 
+// bounded wait of ONE lane for *p >= want (relaxed agent-scope polls); false = gave up / someone else did
+__device__ __forceinline__ bool wsr_wait_ge(gu32* p, unsigned want, gu32* gerr, unsigned* err, unsigned code) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(2);
+        if (((++spins) & 1023u) == 0) {
+            if (spins > (1u << 22) || __hip_atomic_load(gerr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                atomicCAS(err, 0u, code);
+                return false;
+            }
+        }
+    }
+    return true;
+}
+
+// ---- worker role (persistent launch): for every chunk a layer has finished AND normalised into the next
+// layer's input rows (the recurrence CUs do the LayerNorm themselves, two rows each, from the h image
+// they hold anyway), the next layer's input product G = X W_ih^T + b for the chunk, 128 x 256 tiles.
+__device__ __forceinline__ void wsr_norm_row(const bf16_t* y0, const bf16_t* r0, const bf16_t* y1, const bf16_t* r1,
+                                             const float* gamma, const float* beta, bf16_t* out, float scale, float eps,
+                                             float* mean0, float* rstd0, float* mean1, float* rstd1, int lane) {
+    // H = 1024: lane owns elements [16 lane, 16 lane + 16)
+    float acc[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const bf16_t* y = k ? y1 : y0;
+        const bf16_t* r = k ? r1 : r0;
+        if (!y) continue;
+        float a[16];
+        ElemIO<bf16_t>::load_vec(y + lane * 16, *reinterpret_cast<float(*)[8]>(a));
+        ElemIO<bf16_t>::load_vec(y + lane * 16 + 8, *reinterpret_cast<float(*)[8]>(a + 8));
+        if (r) {
+            float b[16];
+            ElemIO<bf16_t>::load_vec(r + lane * 16, *reinterpret_cast<float(*)[8]>(b));
+            ElemIO<bf16_t>::load_vec(r + lane * 16 + 8, *reinterpret_cast<float(*)[8]>(b + 8));
+#pragma unroll
+            for (int e = 0; e < 16; ++e) a[e] += b[e];
+        }
+        float sm = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sm += a[e];
+        const float mean = wave_sum(sm) * (1.f / WH);
+        float sq = 0.f;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) sq += (a[e] - mean) * (a[e] - mean);
+        const float rstd = rsqrtf(wave_sum(sq) * (1.f / WH) + eps);
+        if (lane == 0) {
+            *(k ? mean1 : mean0) = mean;
+            *(k ? rstd1 : rstd0) = rstd;
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e)
+            acc[e] += (a[e] - mean) * rstd * gamma[lane * 16 + e] + beta[lane * 16 + e];
+    }
+    float o[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) o[e] = acc[e] * scale;
+    ElemIO<bf16_t>::store_vec(out + lane * 16, *reinterpret_cast<float(*)[8]>(o));
+    ElemIO<bf16_t>::store_vec(out + lane * 16 + 8, *reinterpret_cast<float(*)[8]>(o + 8));
+}
+
+// one 128 x 256 tile of C[M, 4H] = A[M, H] Bw[4H, H]^T + bias (bf16; K = H = 1024): 4 waves (2 x 2), wave
+// tile 64 x 128 = 4 x 8 MFMA tiles.  ONE workgroup per CU here (the recurrence's register budget), so the
+// operands are REGISTER-staged: the 12 16-byte loads of K tile t+1 are issued before the MFMAs of tile t
+// and written to the other LDS buffer after them (an LDS-DMA costs ~115 issue cycles per KB on a wave
+// that has no partner to hide it; a global_load + ds_write_b128 pair ~20).  LDS rows are 128 bytes
+// (BK = 64), chunk index XOR-ed with row & 7 on the ds_write side.
+__device__ __forceinline__ void wsr_gemm_tile(const bf16_t* A, int M, const bf16_t* Bw, const float* bias, bf16_t* C,
+                                              int m0, int n0, unsigned char* smem) {
+    constexpr int BK = 64, A_BYTES = 128 * BK * 2, B_BYTES = 256 * BK * 2, BUFB = A_BYTES + B_BYTES;
+    constexpr int KT = WH / BK, CCH = 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, kq = lane >> 4;
+    // staging: thread -> (row = tid >> 3 (+32 per pass), 16-byte chunk = tid & 7): a row's 128 bytes = 8 lanes
+    const int srow = threadIdx.x >> 3, sch = threadIdx.x & 7;
+    const bf16_t* ap[4];
+    const bf16_t* bp[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ap[i] = A + (long long)min(m0 + srow + 32 * i, M - 1) * WH + sch * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) bp[i] = Bw + (long long)(n0 + srow + 32 * i) * WH + sch * 8;
+    u32x4_t ra[4], rb[8];
+    auto gload = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const u32x4_t*>(ap[i] + k0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) rb[i] = *reinterpret_cast<const u32x4_t*>(bp[i] + k0);
+    };
+    auto lstore = [&](int buf) {
+        unsigned char* sA = smem + buf * BUFB;
+        unsigned char* sB = sA + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = srow + 32 * i;
+            *reinterpret_cast<u32x4_t*>(sA + r * 128 + ((sch ^ (r & 7)) << 4)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = srow + 32 * i;
+            *reinterpret_cast<u32x4_t*>(sB + r * 128 + ((sch ^ (r & 7)) << 4)) = rb[i];
+        }
+    };
+    f32x4_t acc[4][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + n0 + wn * 128 + j * 16 + kq * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = (f32x4_t){bv.x, bv.y, bv.z, bv.w};
+    }
+    gload(0);
+    __syncthreads();                 // the previous tile's C staging reads are done (WAR on smem)
+    lstore(0);
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 1 < KT) gload((kt + 1) * BK);
+        __syncthreads();             // buffer kt & 1 is written; buffer (kt + 1) & 1 was last read two tiles ago
+        const unsigned char* sA = smem + (kt & 1) * BUFB;
+        const unsigned char* sB = sA + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t a[4], b[8];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = wm * 64 + i * 16 + r16;
+                a[i] = *reinterpret_cast<const bf16x8_t*>(sA + r * 128 + (((ks * 4 + kq) ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int r = wn * 128 + j * 16 + r16;
+                b[j] = *reinterpret_cast<const bf16x8_t*>(sB + r * 128 + (((ks * 4 + kq) ^ (r & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < KT) lstore((kt + 1) & 1);
+    }
+    __syncthreads();
+    unsigned char* sC = smem;        // [128 rows][32 chunks of 16 B], chunk ^= row & 31
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int nl = wn * 128 + j * 16 + kq * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ml = wm * 64 + i * 16 + r16;
+            uint2 pk;
+            pk.x = f32x2_to_bf16x2(acc[i][j][0], acc[i][j][1]);
+            pk.y = f32x2_to_bf16x2(acc[i][j][2], acc[i][j][3]);
+            *reinterpret_cast<uint2*>(sC + ml * 512 + ((((nl >> 3) ^ (ml & (CCH - 1))) << 4) | ((nl & 4) << 1))) = pk;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int c = threadIdx.x + it * 256;
+        const int rl = c / CCH, ch = c % CCH;
+        if (m0 + rl >= M) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(sC + rl * 512 + ((ch ^ (rl & (CCH - 1))) << 4));
+        *reinterpret_cast<uint4*>(C + (long long)(m0 + rl) * 4 * WH + n0 + ch * 8) = v;
+    }
+}
+
+__device__ void wsr_worker(const EdWsrLaunch& L, int wi, int NW, unsigned char* smem) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int B = L.B;
+    const long long BH = (long long)B * WH;
+    gu32* gerr = (gu32*)L.err;
+    __shared__ unsigned ok_s;
+    int nch = 0;
+    for (int l = 0; l < L.nslot; ++l) nch = max(nch, (L.slot[l].T + L.slot[l].cf - 1) / L.slot[l].cf);
+    // wavefront order: layer l's chunk k is finished about l chunk-times after layer 0's
+    for (int w = 0; w < nch + L.nslot; ++w) {
+        for (int l = 0; l < L.nslot; ++l) {
+            const int k = w - l;
+            const EdWsrSlot& S = L.slot[l];
+            if (k < 0 || k * S.cf >= S.T) continue;
+            const int t0 = k * S.cf, t1 = min(S.T, t0 + S.cf);
+            long long* tr = (L.trace && wi == 0 && threadIdx.x == 0 && k < 64) ? L.trace + 2048 + (l * 64 + k) * 4 : nullptr;
+            if (tr) tr[0] = wall_clock64();
+            // ---- frames [t0, t1) of layer l are out AND normalised (next layer's input rows written)
+            if (threadIdx.x == 0)
+                ok_s = wsr_wait_ge((gu32*)S.ydone, (unsigned)(WCUS * (k + 1)), gerr, L.err, 300u + l) ? 1u : 0u;
+            __syncthreads();
+            if (!ok_s) return;
+            if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __syncthreads();
+            if (tr) tr[1] = wall_clock64();
+            if (!S.nWih) continue;          // last layer: its LayerNorm rows ARE the stack output
+            const int r = S.reduce, tau0 = t0 / r, ntau = (t1 - t0 + r - 1) / r;
+            if (tr) tr[2] = wall_clock64();
+            // ---- input product of layer l + 1 for these rows: tiles mt x 32
+            const int M = ntau * B;
+            const bf16_t* A = S.nX + (long long)tau0 * S.nX_st;          // [M, H] (time-major rows: nX_st = B H)
+            bf16_t* C = S.nG + (long long)tau0 * B * 4 * WH;
+            const int mtiles = (M + 127) / 128;
+            for (int tile = wi; tile < mtiles * 16; tile += NW)
+                wsr_gemm_tile(A, M, S.nWih, S.nBias, C, (tile / 16) * 128, (tile % 16) * 256, smem);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add((gu32*)(S.ngdone + k), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            if (tr) tr[3] = wall_clock64();
+        }
+    }
+}
+
+// LayerNorm of ONE row of frame t of a layer, by one wave of a recurrence CU, from the h image that CU
+// holds in LDS (A-fragment order) + the residual row; under time reduction the even frame's row waits in
+// `prev` (registers) for its partner.  Writes the next layer's input row (or the stack output) with
+// write-through stores: the workers on another XCD read it inside this launch.
+__device__ __forceinline__ void wsr_ln_from_image(const EdWsrSlot& S, const unsigned char* img_lds, int t, int b, int B,
+                                                  float eps, unsigned (&prev)[8], int lane) {
+    const int rbk = b >> 4, r16 = b & 15;
+    float a[16];
+    {
+        const unsigned char* p0 = img_lds + ((lane >> 1) * 4 + rbk) * 1024 + (((lane & 1) * 2) * 16 + r16) * 16;
+        ElemIO<bf16_t>::load_vec(reinterpret_cast<const bf16_t*>(p0), *reinterpret_cast<float(*)[8]>(a));
+        ElemIO<bf16_t>::load_vec(reinterpret_cast<const bf16_t*>(p0 + 256), *reinterpret_cast<float(*)[8]>(a + 8));
+    }
+    if (S.X) {
+        const bf16_t* r = S.X + ((long long)t * B + b) * WH + lane * 16;
+        float x[16];
+        ElemIO<bf16_t>::load_vec(r, *reinterpret_cast<float(*)[8]>(x));
+        ElemIO<bf16_t>::load_vec(r + 8, *reinterpret_cast<float(*)[8]>(x + 8));
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a[e] += x[e];
+    }
+    float sm = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sm += a[e];
+    const float mean = wave_sum(sm) * (1.f / WH);
+    float sq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sq += (a[e] - mean) * (a[e] - mean);
+    const float rstd = rsqrtf(wave_sum(sq) * (1.f / WH) + eps);
+    if (lane == 0) {
+        S.mean[(long long)t * B + b] = mean;
+        S.rstd[(long long)t * B + b] = rstd;
+    }
+    float o[16];
+#pragma unroll
+    for (int e = 0; e < 16; e += 4) {
+        const float4 gm = *reinterpret_cast<const float4*>(S.gamma + lane * 16 + e);
+        const float4 bt = *reinterpret_cast<const float4*>(S.beta + lane * 16 + e);
+        o[e] = (a[e] - mean) * rstd * gm.x + bt.x;
+        o[e + 1] = (a[e + 1] - mean) * rstd * gm.y + bt.y;
+        o[e + 2] = (a[e + 2] - mean) * rstd * gm.z + bt.z;
+        o[e + 3] = (a[e + 3] - mean) * rstd * gm.w + bt.w;
+    }
+    bool emit = true;
+    int tau = t;
+    if (S.reduce == 2) {
+        tau = t >> 1;
+        if (!(t & 1)) {
+            if (t + 1 < S.T) {       // wait for the partner frame (kept as packed bf16: 8 registers)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) prev[e] = f32x2_to_bf16x2(o[2 * e], o[2 * e + 1]);
+                emit = false;
+            } else {                 // odd length: the zero-padded partner counts as 0
+#pragma unroll
+                for (int e = 0; e < 16; ++e) o[e] *= 0.5f;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                o[2 * e] = 0.5f * (__uint_as_float(prev[e] << 16) + o[2 * e]);
+                o[2 * e + 1] = 0.5f * (__uint_as_float(prev[e] & 0xffff0000u) + o[2 * e + 1]);
+            }
+        }
+    }
+    if (emit) {
+        u32x4_t v0, v1;
+        v0[0] = f32x2_to_bf16x2(o[0], o[1]);   v0[1] = f32x2_to_bf16x2(o[2], o[3]);
+        v0[2] = f32x2_to_bf16x2(o[4], o[5]);   v0[3] = f32x2_to_bf16x2(o[6], o[7]);
+        v1[0] = f32x2_to_bf16x2(o[8], o[9]);   v1[1] = f32x2_to_bf16x2(o[10], o[11]);
+        v1[2] = f32x2_to_bf16x2(o[12], o[13]); v1[3] = f32x2_to_bf16x2(o[14], o[15]);
+        bf16_t* dst = S.nX + (long long)tau * S.nX_st + (long long)b * S.nX_sb + lane * 16;
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(v0) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + 8), "v"(v1) : "memory");
+    }
+}
+
 __global__ __launch_bounds__(256, 1) void wsr_fwd_kernel(EdWsrLaunch L) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
     unsigned char* gtile = lds + W_IMG;                       // [64 rows][128 cols] bf16
@@ -73,12 +361,16 @@ __global__ __launch_bounds__(256, 1) void wsr_fwd_kernel(EdWsrLaunch L) {
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 7;
-    if ((int)xcc >= L.nslot) return;             // no layer for this XCD in this launch
+    if ((int)xcc >= L.nslot && !L.persistent) return;   // no layer for this XCD in this launch
     if (threadIdx.x == 0) role_s = atomicAdd(&L.ticket[xcc], 1u);
     __syncthreads();
     const int cu = (int)role_s;
     if (cu >= WCUS) {                            // more than 32 workgroups of this grid landed on the XCD
         if (threadIdx.x == 0) atomicExch(L.err, 7000u + xcc);
+        return;
+    }
+    if ((int)xcc >= L.nslot) {                   // persistent launch: the spare XCDs' workgroups are workers
+        wsr_worker(L, ((int)xcc - L.nslot) * WCUS + cu, (8 - L.nslot) * WCUS, lds);
         return;
     }
     const EdWsrSlot& S = L.slot[xcc];
@@ -118,11 +410,32 @@ __global__ __launch_bounds__(256, 1) void wsr_fwd_kernel(EdWsrLaunch L) {
         return reinterpret_cast<u32x4_t*>(S.G + ((long long)s * B + grow + 16 * i) * 4 * WH + cu * 128 + gch * 8);
     };
     u32x4_t gq[4];
+    unsigned ln_prev[8];     // LayerNorm row of an even frame (packed bf16), waiting for its time-reduction partner
 #pragma unroll
-    for (int i = 0; i < 4; ++i) gq[i] = (grow + 16 * i < B) ? *g_ptr(0, i) : (u32x4_t){0u, 0u, 0u, 0u};
+    for (int e = 0; e < 8; ++e) ln_prev[e] = 0u;
+    const int NW = (8 - L.nslot) * WCUS;
+    if (!(L.persistent && S.gdone)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gq[i] = (grow + 16 * i < B) ? *g_ptr(0, i) : (u32x4_t){0u, 0u, 0u, 0u};
+    }
 
     for (int s = 0; s < S.nsteps; ++s) {
         const int t = S.t0 + s;
+        if (L.trace && cu == 0 && threadIdx.x == 0 && (t % S.cf) == 0 && t / S.cf < 64)
+            L.trace[(xcc * 64 + t / S.cf) * 4 + 0] = wall_clock64();
+        if (L.persistent && S.gdone && (t % S.cf) == 0) {
+            // a new chunk of this layer's input product: wait until every worker has delivered its tiles
+            if (threadIdx.x == 0) {
+                role_s = wsr_wait_ge((gu32*)(S.gdone + t / S.cf), (unsigned)NW, gerr, L.err, 200u + xcc) ? 1u : 0u;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            }
+            __syncthreads();
+            if (!role_s) return;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gq[i] = (grow + 16 * i < B) ? *g_ptr(s, i) : (u32x4_t){0u, 0u, 0u, 0u};
+        }
+        if (L.trace && cu == 0 && threadIdx.x == 0 && (t % S.cf) == 0 && t / S.cf < 64)
+            L.trace[(xcc * 64 + t / S.cf) * 4 + 1] = wall_clock64();
         // pre-activations of this step -> LDS tile (the previous step's gate store has read it: the
         // barrier of the wait below orders this write before any lane's read of the new contents)
 #pragma unroll
@@ -241,8 +554,9 @@ __global__ __launch_bounds__(256, 1) void wsr_fwd_kernel(EdWsrLaunch L) {
         {
             const int row = threadIdx.x >> 2, ch = threadIdx.x & 3;
             if (row < B) {
-                const uint4 y = *reinterpret_cast<const uint4*>(hstage + (row * WUPC + ch * 8) * 2);
-                *reinterpret_cast<uint4*>(S.Y + (long long)s * BH + (long long)row * WH + cu * WUPC + ch * 8) = y;
+                const u32x4_t y = *reinterpret_cast<const u32x4_t*>(hstage + (row * WUPC + ch * 8) * 2);
+                bf16_t* yd = S.Y + (long long)s * BH + (long long)row * WH + cu * WUPC + ch * 8;
+                *reinterpret_cast<u32x4_t*>(yd) = y;
                 const uint4 c0 = *reinterpret_cast<const uint4*>(cstage + row * WUPC + ch * 8);
                 const uint4 c1 = *reinterpret_cast<const uint4*>(cstage + row * WUPC + ch * 8 + 4);
                 float* cd = S.C + (long long)s * BH + (long long)row * WH + cu * WUPC + ch * 8;
@@ -253,11 +567,50 @@ __global__ __launch_bounds__(256, 1) void wsr_fwd_kernel(EdWsrLaunch L) {
             for (int i = 0; i < 4; ++i) {
                 if (grow + 16 * i < B)
                     *g_ptr(s, i) = *reinterpret_cast<const u32x4_t*>(gtile + ((grow + 16 * i) * 128 + gch * 8) * 2);
-                if (s + 1 < S.nsteps)
+                if (s + 1 < S.nsteps && !(L.persistent && S.gdone && ((t + 1) % S.cf) == 0))
                     gq[i] = (grow + 16 * i < B) ? *g_ptr(s + 1, i) : (u32x4_t){0u, 0u, 0u, 0u};
             }
         }
+        if (L.persistent && t > 0) {
+            // LayerNorm of frame t-1 (its h image is the one this step gathered): rows 2 cu and 2 cu + 1, one
+            // wave each - after the publish, while the other CUs of the layer are still arriving
+            if (wave < 2 && 2 * cu + wave < B) wsr_ln_from_image(S, lds, t - 1, 2 * cu + wave, B, L.eps, ln_prev, lane);
+            if ((t % S.cf) == 0) {
+                // ... which completes chunk t / cf - 1 of the next layer's input: tell the workers
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0)
+                    __hip_atomic_fetch_add((gu32*)S.ydone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (L.trace && cu == 0 && threadIdx.x == 0 && t / S.cf - 1 < 64)
+                    L.trace[(xcc * 64 + t / S.cf - 1) * 4 + 2] = wall_clock64();
+            }
+        }
         __syncthreads();      // the LDS tile is rewritten at the top of the next iteration
+    }
+    if (L.persistent) {
+        // the last frame: wait for its image, normalise, complete the last chunk
+        const int t = S.t0 + S.nsteps;
+        if (threadIdx.x == 0)
+            role_s = wsr_wait_ge(cnt, S.base + (unsigned)(WCUS * S.nsteps), gerr, L.err, 500u + xcc) ? 1u : 0u;
+        __syncthreads();
+        if (!role_s) return;
+        const unsigned char* img = reinterpret_cast<const unsigned char*>((t & 1) ? S.img1 : S.img0);
+        if (wave < MT) {
+#pragma unroll
+            for (int ks = 0; ks < WKS; ++ks)
+                __builtin_amdgcn_global_load_lds(
+                    (const __attribute__((address_space(1))) void*)(img + ((long long)(ks * MT + wave) * 64 + lane) * 16),
+                    (__attribute__((address_space(3))) void*)(lds + (ks * 4 + wave) * 1024), 16, 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (wave < 2 && 2 * cu + wave < B) wsr_ln_from_image(S, lds, t - 1, 2 * cu + wave, B, L.eps, ln_prev, lane);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0)
+            __hip_atomic_fetch_add((gu32*)S.ydone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (L.trace && cu == 0 && threadIdx.x == 0 && (t - 1) / S.cf < 64)
+            L.trace[(xcc * 64 + (t - 1) / S.cf) * 4 + 2] = wall_clock64();
     }
 }
 
@@ -268,6 +621,8 @@ int ed_wsr_pack_fwd(const float* w_hh, bf16_t* out, hipStream_t s) {
     ED_CHECK_LAUNCH("wsr_pack_fwd_kernel");
     return ED_OK;
 }
+
+int ed_wsr_workers(const EdWsrLaunch& L) { return (8 - L.nslot) * WCUS; }
 
 int ed_wsr_launch_fwd(const EdWsrLaunch& L, hipStream_t s) {
     if (L.nslot == 0) return ED_OK;

@@ -315,6 +315,10 @@ int edgedict_stack_pack_wsr(const float* w_hh, int H, void* whh_r, void* stream)
 /* give-up code of the last weights-stationary launch on the current device that ran into a bounded
  * spin (0 = none since the last call of this function; reading clears it) - see csrc/wsr_kernels.hip */
 int edgedict_stack_wsr_error(void);
+/* debug: a zeroed device buffer of >= 64 KB that the persistent weights-stationary launch fills with
+ * wall-clock stamps (100 MHz) of its layers' chunks and of worker 0's tasks (tools/wsr_persist_trace.py);
+ * NULL switches it off.  Not part of the hot path. */
+int edgedict_stack_wsr_set_trace(void* device_buffer);
 int edgedict_stack_forward(const edgedict_stack_desc_t* desc, void* stream);
 /* measurement aid: HIP-event time (on the recurrence stream) from the first to the last wavefront
  * launch of the most recent forward (backward = 0) or backward (1) call on this device, and the

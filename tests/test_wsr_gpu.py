@@ -54,9 +54,13 @@ def _nrel(a, b):
     return (a.double() - b.double()).norm().item() / max(b.double().norm().item(), 1e-30)
 
 
+@pytest.mark.parametrize("persist", ["1", "0"])
 @pytest.mark.parametrize("case", CASES)
-def test_wsr_forward_matches_step_kernels_and_feeds_their_backward(hip_lib, case):
+def test_wsr_forward_matches_step_kernels_and_feeds_their_backward(hip_lib, case, persist, monkeypatch):
+    """persist=1: ONE launch, layers free-running on their XCDs, LayerNorm + input products by the worker
+    workgroups inside the launch; persist=0: one launch per chunk, side work on the side stream."""
     from edgedict_amd import encoder_stack
+    monkeypatch.setenv("EDGEDICT_WSR_PERSIST", persist)
     B, T0, L, red, chunk = case
     enc, xs = _encoder(B, T0, L, red)
     new = _run(enc, xs, encoder_stack.WSR, chunk)
@@ -67,7 +71,7 @@ def test_wsr_forward_matches_step_kernels_and_feeds_their_backward(hip_lib, case
     assert _nrel(new[1], old[1]) < 5e-3 and _nrel(new[2], old[2]) < 5e-3
     # the BPTT kernels read the gates the forward pass left in G: gradients agree as well
     for n in old[3]:
-        assert _nrel(new[3][n], old[3][n]) < 2e-2, (n, _nrel(new[3][n], old[3][n]))
+        assert _nrel(new[3][n], old[3][n]) < 4e-2, (n, _nrel(new[3][n], old[3][n]))
 
 
 @pytest.mark.parametrize("case", CASES[:2] + CASES[3:])
@@ -90,6 +94,7 @@ def test_wsr_dry_run_schedule_covers_every_frame_once(hip_lib):
     from edgedict_amd import encoder_stack
     old = encoder_stack.FLAGS
     os.environ["EDGEDICT_WSR_DELAY"] = "1"
+    os.environ["EDGEDICT_WSR_PERSIST"] = "0"
     try:
         for T0, chunk in ((401, 12), (401, 6), (251, 5), (37, 1)):
             steps, enq, n, slots = encoder_stack.schedule(T0, 240, 1024, [1, 2, 1, 1, 1, 1], B=64, chunk=chunk,
@@ -109,3 +114,8 @@ def test_wsr_dry_run_schedule_covers_every_frame_once(hip_lib):
     finally:
         encoder_stack.FLAGS = old
         os.environ.pop("EDGEDICT_WSR_DELAY", None)
+        os.environ.pop("EDGEDICT_WSR_PERSIST", None)
+    # the persistent form (default) is ONE launch that carries every frame
+    steps, enq, n, slots = encoder_stack.schedule(401, 240, 1024, [1, 2, 1, 1, 1, 1], B=64, chunk=12,
+                                                  flags=encoder_stack.WSR)
+    assert n == 1 and slots == 6 and all((s == 0).all() for s in steps)
