@@ -38,6 +38,10 @@ constexpr int W_GT = 64 * 128 * 2;            // 16 KB: this CU's gate columns o
 constexpr int W_HS = 64 * WUPC * 2;           // 4 KB
 constexpr int W_CS = 64 * WUPC * 4;           // 8 KB
 constexpr int W_LDS = W_IMG + W_GT + W_HS + W_CS;
+#ifndef WSR_LN_IN_RECURRENCE
+#define WSR_LN_IN_RECURRENCE 0   // 1: the recurrence CUs normalise their layer's frames (two rows each, from the
+#endif                           // h image in LDS); 0: the workers do, before the product (measured faster: the
+                                 // residual row's HBM latency lands on the recurrence's critical path otherwise)
 
 __device__ __forceinline__ float wsigm(float x) {
     return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
@@ -127,44 +131,36 @@ __device__ __forceinline__ void wsr_norm_row(const bf16_t* y0, const bf16_t* r0,
 }
 
 // one 128 x 256 tile of C[M, 4H] = A[M, H] Bw[4H, H]^T + bias (bf16; K = H = 1024): 4 waves (2 x 2), wave
-// tile 64 x 128 = 4 x 8 MFMA tiles.  ONE workgroup per CU here (the recurrence's register budget), so the
-// operands are REGISTER-staged: the 12 16-byte loads of K tile t+1 are issued before the MFMAs of tile t
-// and written to the other LDS buffer after them (an LDS-DMA costs ~115 issue cycles per KB on a wave
-// that has no partner to hide it; a global_load + ds_write_b128 pair ~20).  LDS rows are 128 bytes
-// (BK = 64), chunk index XOR-ed with row & 7 on the ds_write side.
+// tile 64 x 128 = 4 x 8 MFMA tiles.  ONE workgroup per CU here, and the operands come from MALL/HBM (40 MB
+// of W_ih cycle through two 4 MB L2s): a K tile per memory round trip is latency-bound (measured 28 us
+// per tile with one K tile in flight).  Three LDS stages of 48 KB filled by LDS-DMA, TWO K tiles in flight:
+// `s_waitcnt vmcnt(12)` retires the oldest stage's 12 DMA instructions of this wave, a raw s_barrier
+// publishes everybody's, then stage kt+2 is issued into the buffer all waves left two barriers ago.
+// 128-byte LDS rows, 16-byte chunk index XOR-ed with row & 7 on the SOURCE address (gemm_nt.hip).
 __device__ __forceinline__ void wsr_gemm_tile(const bf16_t* A, int M, const bf16_t* Bw, const float* bias, bf16_t* C,
                                               int m0, int n0, unsigned char* smem) {
     constexpr int BK = 64, A_BYTES = 128 * BK * 2, B_BYTES = 256 * BK * 2, BUFB = A_BYTES + B_BYTES;
     constexpr int KT = WH / BK, CCH = 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, kq = lane >> 4;
-    // staging: thread -> (row = tid >> 3 (+32 per pass), 16-byte chunk = tid & 7): a row's 128 bytes = 8 lanes
-    const int srow = threadIdx.x >> 3, sch = threadIdx.x & 7;
-    const bf16_t* ap[4];
-    const bf16_t* bp[8];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) ap[i] = A + (long long)min(m0 + srow + 32 * i, M - 1) * WH + sch * 8;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) bp[i] = Bw + (long long)(n0 + srow + 32 * i) * WH + sch * 8;
-    u32x4_t ra[4], rb[8];
-    auto gload = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = *reinterpret_cast<const u32x4_t*>(ap[i] + k0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) rb[i] = *reinterpret_cast<const u32x4_t*>(bp[i] + k0);
-    };
-    auto lstore = [&](int buf) {
-        unsigned char* sA = smem + buf * BUFB;
-        unsigned char* sB = sA + A_BYTES;
+    const int prow = lane >> 3, chunk = (lane & 7) ^ prow;
+    // pieces of 8 rows x 128 B: A has 16 (wave w: 4 i + w), B has 32 (wave w: 4 i + w, i < 8)
+    auto issue = [&](int kt) {
+        unsigned char* base = smem + (kt % 3) * BUFB;
+        const int k0 = kt * BK;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = srow + 32 * i;
-            *reinterpret_cast<u32x4_t*>(sA + r * 128 + ((sch ^ (r & 7)) << 4)) = ra[i];
+            const int p = i * 4 + wave;
+            const bf16_t* src = A + (long long)min(m0 + p * 8 + prow, M - 1) * WH + chunk * 8 + k0;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(base + p * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const int r = srow + 32 * i;
-            *reinterpret_cast<u32x4_t*>(sB + r * 128 + ((sch ^ (r & 7)) << 4)) = rb[i];
+            const int p = i * 4 + wave;
+            const bf16_t* src = Bw + (long long)(n0 + p * 8 + prow) * WH + chunk * 8 + k0;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)(base + A_BYTES + p * 1024), 16, 0, 0);
         }
     };
     f32x4_t acc[4][8];
@@ -174,13 +170,16 @@ __device__ __forceinline__ void wsr_gemm_tile(const bf16_t* A, int M, const bf16
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i][j] = (f32x4_t){bv.x, bv.y, bv.z, bv.w};
     }
-    gload(0);
-    __syncthreads();                 // the previous tile's C staging reads are done (WAR on smem)
-    lstore(0);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");     // the previous tile's C staging reads are done (WAR on smem)
+    issue(0);
+    issue(1);
     for (int kt = 0; kt < KT; ++kt) {
-        if (kt + 1 < KT) gload((kt + 1) * BK);
-        __syncthreads();             // buffer kt & 1 is written; buffer (kt + 1) & 1 was last read two tiles ago
-        const unsigned char* sA = smem + (kt & 1) * BUFB;
+        if (kt + 1 < KT) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");
+        if (kt + 2 < KT) issue(kt + 2);
+        const unsigned char* sA = smem + (kt % 3) * BUFB;
         const unsigned char* sB = sA + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
@@ -201,9 +200,9 @@ __device__ __forceinline__ void wsr_gemm_tile(const bf16_t* A, int M, const bf16
                 for (int j = 0; j < 8; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < KT) lstore((kt + 1) & 1);
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
     unsigned char* sC = smem;        // [128 rows][32 chunks of 16 B], chunk ^= row & 31
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -217,7 +216,8 @@ __device__ __forceinline__ void wsr_gemm_tile(const bf16_t* A, int M, const bf16
             *reinterpret_cast<uint2*>(sC + ml * 512 + ((((nl >> 3) ^ (ml & (CCH - 1))) << 4) | ((nl & 4) << 1))) = pk;
         }
     }
-    __syncthreads();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    asm volatile("s_barrier" ::: "memory");
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int c = threadIdx.x + it * 256;
@@ -228,6 +228,88 @@ __device__ __forceinline__ void wsr_gemm_tile(const bf16_t* A, int M, const bf16
     }
 }
 
+// one 128 x 128 tile of the same product for the separate WORKER KERNEL (256 threads, <= 128 registers, 64 KB of
+// LDS: two workgroups per CU, as gemm_nt.hip runs): double-buffered LDS-DMA, one barrier per K tile.
+__device__ __forceinline__ void wsr_gemm_tile128(const bf16_t* A, int M, const bf16_t* Bw, const float* bias, bf16_t* C,
+                                                 int m0, int n0, unsigned char* smem) {
+    constexpr int BK = 64, A_BYTES = 128 * BK * 2, BUFB = 2 * A_BYTES, KT = WH / BK, CCH = 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, kq = lane >> 4;
+    const int prow = lane >> 3, chunk = (lane & 7) ^ prow;
+    const bf16_t* asrc[4];
+    const bf16_t* bsrc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        asrc[i] = A + (long long)min(m0 + (i * 4 + wave) * 8 + prow, M - 1) * WH + chunk * 8;
+        bsrc[i] = Bw + (long long)(n0 + (i * 4 + wave) * 8 + prow) * WH + chunk * 8;
+    }
+    auto issue = [&](int buf, int k0) {
+        unsigned char* base = smem + buf * BUFB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(base + (i * 4 + wave) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + k0),
+                                             (__attribute__((address_space(3))) void*)(base + A_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
+        }
+    };
+    f32x4_t acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float4 bv = *reinterpret_cast<const float4*>(bias + n0 + wn * 64 + j * 16 + kq * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i][j] = (f32x4_t){bv.x, bv.y, bv.z, bv.w};
+    }
+    __syncthreads();                 // the previous tile's C staging reads are done (WAR on smem)
+    issue(0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+        __syncthreads();             // vmcnt(0) + barrier: this K tile landed everywhere, the other buffer is free
+        if (kt + 1 < KT) issue((kt + 1) & 1, (kt + 1) * BK);
+        const unsigned char* sA = smem + (kt & 1) * BUFB;
+        const unsigned char* sB = sA + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ra = wm * 64 + i * 16 + r16;
+                a[i] = *reinterpret_cast<const bf16x8_t*>(sA + ra * 128 + (((ks * 4 + kq) ^ (ra & 7)) << 4));
+                const int rb = wn * 64 + i * 16 + r16;
+                b[i] = *reinterpret_cast<const bf16x8_t*>(sB + rb * 128 + (((ks * 4 + kq) ^ (rb & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    unsigned char* sC = smem;        // [128 rows][16 chunks of 16 B], chunk ^= row & 15
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int nl = wn * 64 + j * 16 + kq * 4;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ml = wm * 64 + i * 16 + r16;
+            uint2 pk;
+            pk.x = f32x2_to_bf16x2(acc[i][j][0], acc[i][j][1]);
+            pk.y = f32x2_to_bf16x2(acc[i][j][2], acc[i][j][3]);
+            *reinterpret_cast<uint2*>(sC + ml * 256 + ((((nl >> 3) ^ (ml & (CCH - 1))) << 4) | ((nl & 4) << 1))) = pk;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int c = threadIdx.x + it * 256;
+        const int rl = c / CCH, ch = c % CCH;
+        if (m0 + rl >= M) continue;
+        const uint4 v = *reinterpret_cast<const uint4*>(sC + rl * 256 + ((ch ^ (rl & (CCH - 1))) << 4));
+        *reinterpret_cast<uint4*>(C + (long long)(m0 + rl) * 4 * WH + n0 + ch * 8) = v;
+    }
+}
+
+template <bool LIGHT>
 __device__ void wsr_worker(const EdWsrLaunch& L, int wi, int NW, unsigned char* smem) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int B = L.B;
@@ -253,16 +335,49 @@ __device__ void wsr_worker(const EdWsrLaunch& L, int wi, int NW, unsigned char* 
             if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
             __syncthreads();
             if (tr) tr[1] = wall_clock64();
-            if (!S.nWih) continue;          // last layer: its LayerNorm rows ARE the stack output
             const int r = S.reduce, tau0 = t0 / r, ntau = (t1 - t0 + r - 1) / r;
+            if (!WSR_LN_IN_RECURRENCE) {
+                // ---- LayerNorm rows: output frames tau in [tau0, tau0 + ntau), one wave per (tau, b)
+                for (int row = wi * 4 + wave; row < ntau * B; row += NW * 4) {
+                    const int tau = tau0 + row / B, b = row % B;
+                    const int ta = tau * r, tb = (r == 2 && ta + 1 < S.T) ? ta + 1 : -1;
+                    const bf16_t* y0 = S.Y + (long long)(ta - S.t0) * BH + (long long)b * WH;
+                    const bf16_t* y1 = tb >= 0 ? S.Y + (long long)(tb - S.t0) * BH + (long long)b * WH : nullptr;
+                    const bf16_t* r0 = S.X ? S.X + (long long)ta * BH + (long long)b * WH : nullptr;
+                    const bf16_t* r1 = (tb >= 0 && S.X) ? S.X + (long long)tb * BH + (long long)b * WH : nullptr;
+                    wsr_norm_row(y0, r0, y1, r1, S.gamma, S.beta, S.nX + (long long)tau * S.nX_st + (long long)b * S.nX_sb,
+                                 r == 1 ? 1.f : 0.5f, L.eps, S.mean + (long long)ta * B + b, S.rstd + (long long)ta * B + b,
+                                 tb >= 0 ? S.mean + (long long)tb * B + b : nullptr,
+                                 tb >= 0 ? S.rstd + (long long)tb * B + b : nullptr, lane);
+                }
+                if (!S.nWih) continue;      // last layer: the rows above ARE the stack output
+                // publish the rows, wait for every worker's
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __hip_atomic_fetch_add((gu32*)(S.xdone + k), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok_s = wsr_wait_ge((gu32*)(S.xdone + k), (unsigned)NW, gerr, L.err, 400u + l) ? 1u : 0u;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                }
+                __syncthreads();
+                if (!ok_s) return;
+            }
+            if (!S.nWih) continue;          // last layer: its LayerNorm rows ARE the stack output
             if (tr) tr[2] = wall_clock64();
             // ---- input product of layer l + 1 for these rows: tiles mt x 32
             const int M = ntau * B;
             const bf16_t* A = S.nX + (long long)tau0 * S.nX_st;          // [M, H] (time-major rows: nX_st = B H)
             bf16_t* C = S.nG + (long long)tau0 * B * 4 * WH;
             const int mtiles = (M + 127) / 128;
-            for (int tile = wi; tile < mtiles * 16; tile += NW)
-                wsr_gemm_tile(A, M, S.nWih, S.nBias, C, (tile / 16) * 128, (tile % 16) * 256, smem);
+            if (LIGHT) {
+                for (int tile = wi; tile < mtiles * 32; tile += NW)
+                    wsr_gemm_tile128(A, M, S.nWih, S.nBias, C, (tile / 32) * 128, (tile % 32) * 128, smem);
+            } else {
+                for (int tile = wi; tile < mtiles * 16; tile += NW)
+                    wsr_gemm_tile(A, M, S.nWih, S.nBias, C, (tile / 16) * 128, (tile % 16) * 256, smem);
+            }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0) {
@@ -370,8 +485,8 @@ __global__ __launch_bounds__(256, 1) void wsr_fwd_kernel(EdWsrLaunch L) {
         return;
     }
     if ((int)xcc >= L.nslot) {                   // persistent launch: the spare XCDs' workgroups are workers
-        wsr_worker(L, ((int)xcc - L.nslot) * WCUS + cu, (8 - L.nslot) * WCUS, lds);
-        return;
+        if (L.persistent == 1) wsr_worker<false>(L, ((int)xcc - L.nslot) * WCUS + cu, (8 - L.nslot) * WCUS, lds);
+        return;                                  // persistent == 2: the workers are a separate kernel
     }
     const EdWsrSlot& S = L.slot[xcc];
     const int B = L.B, MT = (B + 15) >> 4;
@@ -413,7 +528,7 @@ __global__ __launch_bounds__(256, 1) void wsr_fwd_kernel(EdWsrLaunch L) {
     unsigned ln_prev[8];     // LayerNorm row of an even frame (packed bf16), waiting for its time-reduction partner
 #pragma unroll
     for (int e = 0; e < 8; ++e) ln_prev[e] = 0u;
-    const int NW = (8 - L.nslot) * WCUS;
+    const int NW = (8 - L.nslot) * WCUS * (L.persistent == 2 ? 2 : 1);
     if (!(L.persistent && S.gdone)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) gq[i] = (grow + 16 * i < B) ? *g_ptr(0, i) : (u32x4_t){0u, 0u, 0u, 0u};
@@ -556,7 +671,10 @@ __global__ __launch_bounds__(256, 1) void wsr_fwd_kernel(EdWsrLaunch L) {
             if (row < B) {
                 const u32x4_t y = *reinterpret_cast<const u32x4_t*>(hstage + (row * WUPC + ch * 8) * 2);
                 bf16_t* yd = S.Y + (long long)s * BH + (long long)row * WH + cu * WUPC + ch * 8;
-                *reinterpret_cast<u32x4_t*>(yd) = y;
+                if (L.persistent && !WSR_LN_IN_RECURRENCE)   // read by the workers inside this launch: write-through
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(yd), "v"(y) : "memory");
+                else
+                    *reinterpret_cast<u32x4_t*>(yd) = y;
                 const uint4 c0 = *reinterpret_cast<const uint4*>(cstage + row * WUPC + ch * 8);
                 const uint4 c1 = *reinterpret_cast<const uint4*>(cstage + row * WUPC + ch * 8 + 4);
                 float* cd = S.C + (long long)s * BH + (long long)row * WH + cu * WUPC + ch * 8;
@@ -571,7 +689,17 @@ __global__ __launch_bounds__(256, 1) void wsr_fwd_kernel(EdWsrLaunch L) {
                     gq[i] = (grow + 16 * i < B) ? *g_ptr(s + 1, i) : (u32x4_t){0u, 0u, 0u, 0u};
             }
         }
-        if (L.persistent && t > 0) {
+        if (L.persistent && !WSR_LN_IN_RECURRENCE && (((t + 1) % S.cf) == 0 || s + 1 == S.nsteps)) {
+            // a chunk of this layer is complete: its h rows (write-through stores) are out once every wave
+            // has drained; tell the workers
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (threadIdx.x == 0)
+                __hip_atomic_fetch_add((gu32*)S.ydone, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (L.trace && cu == 0 && threadIdx.x == 0 && t / S.cf < 64)
+                L.trace[(xcc * 64 + t / S.cf) * 4 + 2] = wall_clock64();
+        }
+        if (L.persistent && WSR_LN_IN_RECURRENCE && t > 0) {
             // LayerNorm of frame t-1 (its h image is the one this step gathered): rows 2 cu and 2 cu + 1, one
             // wave each - after the publish, while the other CUs of the layer are still arriving
             if (wave < 2 && 2 * cu + wave < B) wsr_ln_from_image(S, lds, t - 1, 2 * cu + wave, B, L.eps, ln_prev, lane);
@@ -587,7 +715,7 @@ __global__ __launch_bounds__(256, 1) void wsr_fwd_kernel(EdWsrLaunch L) {
         }
         __syncthreads();      // the LDS tile is rewritten at the top of the next iteration
     }
-    if (L.persistent) {
+    if (L.persistent && WSR_LN_IN_RECURRENCE) {
         // the last frame: wait for its image, normalise, complete the last chunk
         const int t = S.t0 + S.nsteps;
         if (threadIdx.x == 0)
@@ -619,6 +747,33 @@ __global__ __launch_bounds__(256, 1) void wsr_fwd_kernel(EdWsrLaunch L) {
 int ed_wsr_pack_fwd(const float* w_hh, bf16_t* out, hipStream_t s) {
     hipLaunchKernelGGL(wsr_pack_fwd_kernel, dim3(4096), dim3(256), 0, s, w_hh, out);
     ED_CHECK_LAUNCH("wsr_pack_fwd_kernel");
+    return ED_OK;
+}
+
+// The workers as their OWN kernel (EdWsrLaunch::persistent == 2), launched on another stream beside
+// wsr_fwd_kernel: 64 workgroups per XCD, two per CU (128 registers, 64 KB LDS) - twice the waves per SIMD the
+// recurrence's 512-register workgroups allow.  A grid's workgroups are bound to XCDs round-robin: the ones
+// bound to a layer's XCD find no room until the recurrence kernel ends, then exit at once; the ones on the
+// spare XCDs take tickets and do all the work.  (If the spare XCDs' recurrence workgroups - which only exit -
+// arrive after the workers have filled those CUs, they wait for the workers to finish; nothing depends on them.)
+__global__ __launch_bounds__(256, 2) void wsr_worker_kernel(EdWsrLaunch L) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+    __shared__ unsigned role_s;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7;
+    if ((int)xcc < L.nslot) return;
+    if (threadIdx.x == 0) role_s = atomicAdd(&L.wticket[xcc], 1u);
+    __syncthreads();
+    const int per = 2 * WCUS, id = (int)role_s;
+    if (id >= per) return;
+    wsr_worker<true>(L, ((int)xcc - L.nslot) * per + id, (8 - L.nslot) * per, lds);
+}
+
+int ed_wsr_launch_workers(const EdWsrLaunch& L, hipStream_t s) {
+    ED_CHECK_HIP(hipFuncSetAttribute((const void*)wsr_worker_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
+    hipLaunchKernelGGL(wsr_worker_kernel, dim3(512), dim3(256), 65536, s, L);
+    ED_CHECK_LAUNCH("wsr_worker_kernel");
     return ED_OK;
 }
 
