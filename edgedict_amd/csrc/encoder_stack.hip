@@ -449,9 +449,7 @@ int forward_wsr_persistent(const edgedict_stack_desc_t* d, const std::vector<Geo
     Lc.B = B;
     Lc.err = sync;
     Lc.ticket = sync + 8;
-    Lc.persistent = 2;     // workers as their own kernel (two workgroups per CU); 1 = inside the launch
-    if (const char* e = getenv("EDGEDICT_WSR_WORKERS")) Lc.persistent = atoi(e) == 1 ? 1 : 2;
-    Lc.wticket = sync + 48;
+    Lc.persistent = 1;
     Lc.eps = d->eps;
     Lc.trace = g_wsr_trace;
     for (int l = 0; l < L; ++l) {
@@ -504,9 +502,7 @@ int forward_wsr_persistent(const edgedict_stack_desc_t* d, const std::vector<Geo
         }
     }
     if (st.rt && st.rt->tev[0][0]) ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][0], st.R));
-    if (Lc.persistent == 2) ED_TRY(st.chain(st.R, st.S[0]));   // the sync words are zeroed, layer 0's gates exist
     ED_DEV(ed_wsr_launch_fwd(Lc, st.R));
-    if (Lc.persistent == 2) ED_DEV(ed_wsr_launch_workers(Lc, st.S[0]));
     if (g_trace) {
         g_trace->max_slots = L;
         g_trace->launches = 1;
@@ -566,7 +562,6 @@ int forward_wsr(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
         Lc.B = B;
         Lc.err = sync;
         Lc.persistent = 0;
-        Lc.wticket = nullptr;
         Lc.eps = d->eps;
         Lc.trace = nullptr;
         Lc.ticket = sync + 64 + (size_t)launches * 8;

@@ -100,15 +100,12 @@ struct EdWsrLaunch {
     unsigned* ticket;          // [8] zeroed role tickets of THIS launch
     unsigned* err;             // [1] give-up code (0 = fine), shared by the whole call
     int persistent;            // 1: every layer runs all its frames; the workgroups of the XCDs >= nslot are
-                               // WORKERS (LayerNorm + next layer's input product per finished chunk);
-                               // 2: the same with the workers as a separate kernel (ed_wsr_launch_workers)
-    unsigned* wticket;         // persistent == 2: [8] zeroed tickets of the worker kernel
+                               // WORKERS (LayerNorm + next layer's input product per finished chunk)
     float eps;
     long long* trace;          // debug (nullable): wall-clock stamps, see tools/wsr_persist_trace.py
 };
 int ed_wsr_pack_fwd(const float* w_hh, bf16_t* out, hipStream_t s);
 int ed_wsr_launch_fwd(const EdWsrLaunch& L, hipStream_t s);
-int ed_wsr_launch_workers(const EdWsrLaunch& L, hipStream_t s);   // persistent == 2: the workers' own kernel
 int ed_wsr_workers(const EdWsrLaunch& L);      // worker workgroups of a persistent launch (0 = none possible)
 // LayerNorm(+ residual, + pair mean under time reduction) of the frames [t0, t1) a layer finished
 int ed_stack_chunk_norm(const bf16_t* Yx1, const bf16_t* X, const float* gamma, const float* beta,

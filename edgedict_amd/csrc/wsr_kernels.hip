@@ -228,88 +228,6 @@ __device__ __forceinline__ void wsr_gemm_tile(const bf16_t* A, int M, const bf16
     }
 }
 
-// one 128 x 128 tile of the same product for the separate WORKER KERNEL (256 threads, <= 128 registers, 64 KB of
-// LDS: two workgroups per CU, as gemm_nt.hip runs): double-buffered LDS-DMA, one barrier per K tile.
-__device__ __forceinline__ void wsr_gemm_tile128(const bf16_t* A, int M, const bf16_t* Bw, const float* bias, bf16_t* C,
-                                                 int m0, int n0, unsigned char* smem) {
-    constexpr int BK = 64, A_BYTES = 128 * BK * 2, BUFB = 2 * A_BYTES, KT = WH / BK, CCH = 16;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, kq = lane >> 4;
-    const int prow = lane >> 3, chunk = (lane & 7) ^ prow;
-    const bf16_t* asrc[4];
-    const bf16_t* bsrc[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        asrc[i] = A + (long long)min(m0 + (i * 4 + wave) * 8 + prow, M - 1) * WH + chunk * 8;
-        bsrc[i] = Bw + (long long)(n0 + (i * 4 + wave) * 8 + prow) * WH + chunk * 8;
-    }
-    auto issue = [&](int buf, int k0) {
-        unsigned char* base = smem + buf * BUFB;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(base + (i * 4 + wave) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(bsrc[i] + k0),
-                                             (__attribute__((address_space(3))) void*)(base + A_BYTES + (i * 4 + wave) * 1024), 16, 0, 0);
-        }
-    };
-    f32x4_t acc[4][4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float4 bv = *reinterpret_cast<const float4*>(bias + n0 + wn * 64 + j * 16 + kq * 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) acc[i][j] = (f32x4_t){bv.x, bv.y, bv.z, bv.w};
-    }
-    __syncthreads();                 // the previous tile's C staging reads are done (WAR on smem)
-    issue(0, 0);
-    for (int kt = 0; kt < KT; ++kt) {
-        __syncthreads();             // vmcnt(0) + barrier: this K tile landed everywhere, the other buffer is free
-        if (kt + 1 < KT) issue((kt + 1) & 1, (kt + 1) * BK);
-        const unsigned char* sA = smem + (kt & 1) * BUFB;
-        const unsigned char* sB = sA + A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8_t a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ra = wm * 64 + i * 16 + r16;
-                a[i] = *reinterpret_cast<const bf16x8_t*>(sA + ra * 128 + (((ks * 4 + kq) ^ (ra & 7)) << 4));
-                const int rb = wn * 64 + i * 16 + r16;
-                b[i] = *reinterpret_cast<const bf16x8_t*>(sB + rb * 128 + (((ks * 4 + kq) ^ (rb & 7)) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
-        }
-    }
-    __syncthreads();
-    unsigned char* sC = smem;        // [128 rows][16 chunks of 16 B], chunk ^= row & 15
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int nl = wn * 64 + j * 16 + kq * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ml = wm * 64 + i * 16 + r16;
-            uint2 pk;
-            pk.x = f32x2_to_bf16x2(acc[i][j][0], acc[i][j][1]);
-            pk.y = f32x2_to_bf16x2(acc[i][j][2], acc[i][j][3]);
-            *reinterpret_cast<uint2*>(sC + ml * 256 + ((((nl >> 3) ^ (ml & (CCH - 1))) << 4) | ((nl & 4) << 1))) = pk;
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 8; ++it) {
-        const int c = threadIdx.x + it * 256;
-        const int rl = c / CCH, ch = c % CCH;
-        if (m0 + rl >= M) continue;
-        const uint4 v = *reinterpret_cast<const uint4*>(sC + rl * 256 + ((ch ^ (rl & (CCH - 1))) << 4));
-        *reinterpret_cast<uint4*>(C + (long long)(m0 + rl) * 4 * WH + n0 + ch * 8) = v;
-    }
-}
-
-template <bool LIGHT>
 __device__ void wsr_worker(const EdWsrLaunch& L, int wi, int NW, unsigned char* smem) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int B = L.B;
@@ -371,13 +289,8 @@ __device__ void wsr_worker(const EdWsrLaunch& L, int wi, int NW, unsigned char* 
             const bf16_t* A = S.nX + (long long)tau0 * S.nX_st;          // [M, H] (time-major rows: nX_st = B H)
             bf16_t* C = S.nG + (long long)tau0 * B * 4 * WH;
             const int mtiles = (M + 127) / 128;
-            if (LIGHT) {
-                for (int tile = wi; tile < mtiles * 32; tile += NW)
-                    wsr_gemm_tile128(A, M, S.nWih, S.nBias, C, (tile / 32) * 128, (tile % 32) * 128, smem);
-            } else {
-                for (int tile = wi; tile < mtiles * 16; tile += NW)
-                    wsr_gemm_tile(A, M, S.nWih, S.nBias, C, (tile / 16) * 128, (tile % 16) * 256, smem);
-            }
+            for (int tile = wi; tile < mtiles * 16; tile += NW)
+                wsr_gemm_tile(A, M, S.nWih, S.nBias, C, (tile / 16) * 128, (tile % 16) * 256, smem);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (threadIdx.x == 0) {
@@ -485,8 +398,8 @@ __global__ __launch_bounds__(256, 1) void wsr_fwd_kernel(EdWsrLaunch L) {
         return;
     }
     if ((int)xcc >= L.nslot) {                   // persistent launch: the spare XCDs' workgroups are workers
-        if (L.persistent == 1) wsr_worker<false>(L, ((int)xcc - L.nslot) * WCUS + cu, (8 - L.nslot) * WCUS, lds);
-        return;                                  // persistent == 2: the workers are a separate kernel
+        wsr_worker(L, ((int)xcc - L.nslot) * WCUS + cu, (8 - L.nslot) * WCUS, lds);
+        return;
     }
     const EdWsrSlot& S = L.slot[xcc];
     const int B = L.B, MT = (B + 15) >> 4;
@@ -528,7 +441,7 @@ __global__ __launch_bounds__(256, 1) void wsr_fwd_kernel(EdWsrLaunch L) {
     unsigned ln_prev[8];     // LayerNorm row of an even frame (packed bf16), waiting for its time-reduction partner
 #pragma unroll
     for (int e = 0; e < 8; ++e) ln_prev[e] = 0u;
-    const int NW = (8 - L.nslot) * WCUS * (L.persistent == 2 ? 2 : 1);
+    const int NW = (8 - L.nslot) * WCUS;
     if (!(L.persistent && S.gdone)) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) gq[i] = (grow + 16 * i < B) ? *g_ptr(0, i) : (u32x4_t){0u, 0u, 0u, 0u};
@@ -747,33 +660,6 @@ __global__ __launch_bounds__(256, 1) void wsr_fwd_kernel(EdWsrLaunch L) {
 int ed_wsr_pack_fwd(const float* w_hh, bf16_t* out, hipStream_t s) {
     hipLaunchKernelGGL(wsr_pack_fwd_kernel, dim3(4096), dim3(256), 0, s, w_hh, out);
     ED_CHECK_LAUNCH("wsr_pack_fwd_kernel");
-    return ED_OK;
-}
-
-// The workers as their OWN kernel (EdWsrLaunch::persistent == 2), launched on another stream beside
-// wsr_fwd_kernel: 64 workgroups per XCD, two per CU (128 registers, 64 KB LDS) - twice the waves per SIMD the
-// recurrence's 512-register workgroups allow.  A grid's workgroups are bound to XCDs round-robin: the ones
-// bound to a layer's XCD find no room until the recurrence kernel ends, then exit at once; the ones on the
-// spare XCDs take tickets and do all the work.  (If the spare XCDs' recurrence workgroups - which only exit -
-// arrive after the workers have filled those CUs, they wait for the workers to finish; nothing depends on them.)
-__global__ __launch_bounds__(256, 2) void wsr_worker_kernel(EdWsrLaunch L) {
-    extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-    __shared__ unsigned role_s;
-    unsigned xcc;
-    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= 7;
-    if ((int)xcc < L.nslot) return;
-    if (threadIdx.x == 0) role_s = atomicAdd(&L.wticket[xcc], 1u);
-    __syncthreads();
-    const int per = 2 * WCUS, id = (int)role_s;
-    if (id >= per) return;
-    wsr_worker<true>(L, ((int)xcc - L.nslot) * per + id, (8 - L.nslot) * per, lds);
-}
-
-int ed_wsr_launch_workers(const EdWsrLaunch& L, hipStream_t s) {
-    ED_CHECK_HIP(hipFuncSetAttribute((const void*)wsr_worker_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 65536));
-    hipLaunchKernelGGL(wsr_worker_kernel, dim3(512), dim3(256), 65536, s, L);
-    ED_CHECK_LAUNCH("wsr_worker_kernel");
     return ED_OK;
 }
 
