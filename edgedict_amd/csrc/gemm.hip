@@ -550,16 +550,23 @@ static int gemm_impl(int dtype_in, int dtype_out, const void* A, long long lda, 
 int ed_gemm_quiet_partials(int dtype_in, const void* A, long long lda, int a_kmajor, const void* B,
                            long long ldb, int b_kmajor, int M, int N, int K, int split_k,
                            int max_wg_per_cu, float* partials, int* slices, hipStream_t stream) {
-    // large bf16 weight-gradient products: the vendor kernel's 256x256 tiles pull half the bytes per
-    // flop through the CU fetch path that the recurrence beside it is bound by (blaslt.cpp)
+    int p2 = 1;
+    while (p2 < split_k && p2 < 8) p2 *= 2;
+    // large bf16 weight-gradient products: 256-row tiles pull fewer bytes per flop through the CU fetch
+    // path that the recurrence beside them is bound by - the own kernel (gemm_tn256.hip), else the vendor's
+    if (dtype_in == ED_BF16 && !a_kmajor && !b_kmajor && (long long)M * N >= (1ll << 18) && K >= 1024 &&
+        ed_gemm_tn256_ok(A, lda, B, ldb, M, N, K)) {
+        // (every caller's partials buffer holds 8 slices: encoder_stack.hip tmpW)
+        const int S = ed_gemm_tn256_slices(M, N, K, 8);
+        *slices = S;
+        return ed_gemm_tn256_partials(A, lda, B, ldb, partials, M, N, K, S, 0, stream);
+    }
     if (dtype_in == ED_BF16 && !a_kmajor && !b_kmajor && (long long)M * N >= (1ll << 18) && K >= 4096 &&
         lda % 8 == 0 && ldb % 8 == 0 && N % 4 == 0 &&
         ed_blaslt_tn_f32(A, lda, B, ldb, partials, N, M, N, K, 0, stream)) {
         *slices = 1;
         return ED_OK;
     }
-    int p2 = 1;
-    while (p2 < split_k && p2 < 8) p2 *= 2;
     const int bk = dtype_in == ED_F32 ? 16 : 64;
     const int ktiles = (K + bk - 1) / bk;
     if (p2 > ktiles) p2 = ktiles > 0 ? ktiles : 1;
@@ -595,6 +602,21 @@ extern "C" int edgedict_gemm_bg(int dtype_in, int dtype_out, const void* A, long
     ED_CHECK_ARG(max_wg_per_cu >= 1 && max_wg_per_cu <= 8, "gemm_bg: max_wg_per_cu must be 1..8");
     ED_CHECK_ARG(!partials || dtype_out == ED_F32, "gemm_bg: the quiet (partials) form needs an fp32 output");
     ED_CHECK_ARG(!partials || (!bias1 && !bias2), "gemm_bg: the quiet (partials) form takes no bias");
+    // weight gradients (both operands row-major over the reduction) with a partials buffer: own 256 x 128
+    // quiet kernel + the reduce pass
+    if (partials && dtype_in == ED_BF16 && dtype_out == ED_F32 && !a_kmajor && !b_kmajor && A && B && C &&
+        (long long)M * N >= (1ll << 18) && K >= 1024 && ed_gemm_tn256_ok(A, lda, B, ldb, M, N, K)) {
+        int p2 = 1;      // the caller's buffer holds the next power of two >= split_k (<= 8) slices
+        while (p2 < split_k && p2 < 8) p2 *= 2;
+        p2 = ed_gemm_tn256_slices(M, N, K, p2);
+        const int rc = ed_gemm_tn256_partials(A, lda, B, ldb, partials, M, N, K, p2, 0, (hipStream_t)stream_);
+        if (rc != ED_OK) return rc;
+        hipLaunchKernelGGL(reduce_partials_kernel, dim3(ed_grid_for((long long)M * N, 256, 2048)), dim3(256), 0,
+                           (hipStream_t)stream_, partials, (long long)M * N, p2, (float*)C, ldc, (long long)M, N,
+                           accumulate);
+        ED_CHECK_LAUNCH("gemm reduce_partials");
+        return ED_OK;
+    }
     if (dtype_in == ED_BF16 && dtype_out == ED_F32 && !a_kmajor && !b_kmajor && !bias1 && !bias2 && A && B && C &&
         (long long)M * N >= (1ll << 18) && K >= 4096 && lda % 8 == 0 && ldb % 8 == 0 && ldc % 4 == 0 &&
         ed_blaslt_tn_f32(A, lda, B, ldb, (float*)C, ldc, M, N, K, accumulate, (hipStream_t)stream_))

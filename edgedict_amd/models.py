@@ -399,7 +399,7 @@ class _JointFn(torch.autograd.Function):
             # enqueued AFTER the critical-path products above: the auxiliary stream starts when
             # they are done and its MFMA work runs under the latency-bound recurrences that follow
             with side.deferred(dl.device, dl, hid, dE1c, dD1c, dD1, enc2, dec2):
-                ops.gemm(dl.t(), hid2.t(), out=w2.grad, accumulate=True, split_k=4,
+                ops.gemm(dl.t(), hid2.t(), out=w2.grad, accumulate=True, split_k=8,
                          max_wg_per_cu=2)
                 ops.colsum(dl, out=ctx.b2.grad)
                 g1 = w1.grad
@@ -511,7 +511,7 @@ class _JointLossFn(torch.autograd.Function):
         ddec = ops.gemm(dD1c, w1c[:, P:].t()).view(B, U1, P2)
         if defer:
             with side.deferred(dl.device, dl, hid, dE1c, dD1c, dD1, enc2, dec2):
-                ops.gemm(dl.t(), hid.t(), out=w2.grad, accumulate=True, split_k=4, max_wg_per_cu=2)
+                ops.gemm(dl.t(), hid.t(), out=w2.grad, accumulate=True, split_k=8, max_wg_per_cu=2)
                 ops.colsum(dl, out=ctx.b2.grad)
                 g1 = w1.grad
                 ops.gemm(dE1c.t(), enc2.t(), out=g1[:, :P], accumulate=True,

@@ -129,3 +129,25 @@ def test_gemm_nt256_macro_tile_path(hip_lib, M, N, K):
         small = ops.gemm(a[r0:r0 + 300], b, bias=b1, bias2=b2)        # 128 x 128 kernel
         assert ((out[r0:r0 + 300].float() - small.float()).abs() <= 2.0 ** -7 * small.float().abs() + 0.03).all()
     assert torch.isfinite(out.float()).all()
+
+
+@pytest.mark.parametrize("M,N,K,split", [(512, 256, 4096, 2), (1024, 240, 5003, 4), (264, 648, 1111, 1),
+                                         (2048, 640, 9000, 4)])
+def test_gemm_tn256_weight_gradient_path(hip_lib, M, N, K, split):
+    """Background weight-gradient products (dW = dY^T X, both operands row-major over the reduction) run
+    gemm_tn256.hip: 256 x 128 tiles, transpose reads out of LDS, fp32 K-slice partials written once and summed
+    by the reduce pass.  Ragged M / N edges, K not a multiple of the K tile or of the slice count, strided
+    operands, accumulate into an existing gradient - against fp64 (bf16 products are exact in fp32, only
+    the summation order differs)."""
+    from edgedict_amd import ops
+    dy_full = _mk((K, M + 8), torch.bfloat16, 41)
+    dy = dy_full[:, 8:]                       # [K, M], row stride M + 8
+    x = _mk((K, N), torch.bfloat16, 42)
+    grad = torch.randn(M, N, generator=torch.Generator().manual_seed(6)).cuda()
+    want = grad.double() + dy.double().t() @ x.double()
+    ops.gemm(dy.t(), x.t(), out=grad, accumulate=True, split_k=split, max_wg_per_cu=2)
+    tol = 3e-5 * (K ** 0.5) * max(1.0, want.abs().max().item() / 10)
+    assert (grad.double() - want).abs().max().item() <= tol
+    # and without accumulate, fresh output
+    out = ops.gemm(dy.t(), x.t(), out_dtype=torch.float32, split_k=split, max_wg_per_cu=1)
+    assert (out.double() - dy.double().t() @ x.double()).abs().max().item() <= tol
