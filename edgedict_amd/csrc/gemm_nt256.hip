@@ -46,6 +46,7 @@ struct Nt256Args {
     long long lda, ldb, ldc;
     int M, N, K;
     int n_tiles, tiles;
+    int dbg;            // EDGEDICT_NT256_DEBUG ablation bits (tools/nt256_ablate.py): 1 no lse, 2 no C store, 4 no MFMA, 8 no C staging
     float2* lse_part;   // optional [M][lse_slots] (max, sum exp(x - max)) over 64-column slots of each C row
     int lse_slots;
 };
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(Nt256Args g) {
                 asm volatile("s_barrier" ::: "memory");
                 // ---- MFMA block
                 __builtin_amdgcn_s_setprio(1);
+                if (!(g.dbg & 4))
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -173,6 +175,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(Nt256Args g) {
     asm volatile("s_barrier" ::: "memory");
     constexpr int CCH = TN / 8;      // 16-byte chunks per staged C row
     unsigned char* sC = smem;        // [256 rows][32 chunks], chunk ^= row & 31
+    if (!(g.dbg & 8))
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int nl = wn * 64 + j * 16 + kq * 4;          // 4 consecutive columns nl .. nl+3
@@ -190,7 +193,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(Nt256Args g) {
     // columns, computed from the bf16-ROUNDED values (exactly what a later pass over the stored logits
     // would see), reduced over the 4 lanes that share a row, one 8-byte store per (row, slot).  The
     // denominators are then finished from M x N/64 pairs instead of a second pass over M x N logits.
-    if (g.lse_part) {
+    if (g.lse_part && !(g.dbg & 1)) {
+        constexpr float LOG2E = 1.4426950408889634f;
+        const bool ragged = n0 + TN > g.N;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             float v[16];
@@ -200,14 +205,18 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(Nt256Args g) {
                 const int nc = n0 + wn * 64 + j * 16 + kq * 4;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float x = bf16_to_f32(f32_to_bf16(acc[i][j][q]));
-                    v[j * 4 + q] = (nc + q < g.N) ? x : -INFINITY;
-                    mx = fmaxf(mx, v[j * 4 + q]);
+                    float x = bf16_to_f32(f32_to_bf16(acc[i][j][q]));
+                    if (ragged && nc + q >= g.N) x = -INFINITY;
+                    v[j * 4 + q] = x;
+                    mx = fmaxf(mx, x);
                 }
             }
+            // sum exp(x - mx) = sum exp2(x * log2e - mx * log2e): one fma + one v_exp_f32 per value; a row of
+            // -inf only (ragged edge) sums to 0
+            const float mb = (mx == -INFINITY) ? 0.f : mx * LOG2E;
             float sm = 0.f;
 #pragma unroll
-            for (int e = 0; e < 16; ++e) sm += (v[e] == -INFINITY) ? 0.f : __expf(v[e] - mx);
+            for (int e = 0; e < 16; ++e) sm += __builtin_amdgcn_exp2f(fmaf(v[e], LOG2E, -mb));
 #pragma unroll
             for (int off = 16; off <= 32; off <<= 1) {
                 const float om = __shfl_xor(mx, off, 64), os = __shfl_xor(sm, off, 64);
@@ -223,6 +232,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(Nt256Args g) {
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
+    if (!(g.dbg & 2))
 #pragma unroll 4
     for (int it = 0; it < TM * TN / 8 / 512; ++it) {
         const int c = threadIdx.x + it * 512;
@@ -256,6 +266,8 @@ int ed_gemm_nt256_launch(const void* A, long long lda, const void* B, long long 
     g.lda = lda; g.ldb = ldb; g.ldc = ldc;
     g.M = M; g.N = N; g.K = K;
     g.lse_part = (float2*)lse_part;
+    static const int dbg = [] { const char* e = getenv("EDGEDICT_NT256_DEBUG"); return e ? atoi(e) : 0; }();
+    g.dbg = dbg;
     g.lse_slots = (N + 63) / 64;
     g.n_tiles = (N + TN - 1) / TN;
     const long long tiles = (long long)((M + TM - 1) / TM) * g.n_tiles;
