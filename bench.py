@@ -269,6 +269,26 @@ def main():
         if joined != args.gpus or any(i < 0 for i in devices):
             raise SystemExit("bench.py: %d ranks joined, --gpus %d" % (joined, args.gpus))
 
+    # ---- the dominant kernel's own duration, live (outside the timed region): first the span of the last
+    # timed backward call's launch sequence, then two more steps with a HIP-event pair around EVERY
+    # wavefront launch (edgedict_stack_time_launches) - on all ranks, the steps contain the exchange
+    import ctypes
+    from edgedict_amd import _lib as _edlib
+    span_ms, span_n = ctypes.c_float(0), ctypes.c_int(0)
+    have_span = _edlib.load().edgedict_stack_last_timing(1, ctypes.byref(span_ms), ctypes.byref(span_n)) == 0
+    kern = {}
+    if have_span and span_n.value:
+        _edlib.load().edgedict_stack_time_launches(1)
+        for _ in range(2):
+            engine.train_step(*batch)
+        torch.cuda.synchronize()
+        for name, bw in (("fwd", 0), ("bwd", 1)):
+            ms_k, n_k = ctypes.c_float(0), ctypes.c_int(0)
+            if _edlib.load().edgedict_stack_launch_times(bw, ctypes.byref(ms_k), ctypes.byref(n_k)) == 0 and n_k.value:
+                kern[name] = (1e3 * ms_k.value / n_k.value, n_k.value)
+        _edlib.load().edgedict_stack_time_launches(0)
+    barrier()
+
     if rank == 0:
         # dominant kernel: the joint's second Linear, logits = hid[B*T'*U1, J] x W2[V, J]^T
         xs_frames = engine.features.output_frames(batch[0].shape[1])
@@ -310,11 +330,14 @@ def main():
         rd = 4 * H * H * 2 + Bq * 4 * H * 2 * 2 + 3 * Bq * H * 4 + Bq * H * 2   # W^T, dG image, gates, c_t, c_{t-1}, dC, dY
         wr = Bq * 4 * H * 2 * 2 + Bq * H * 4                                     # dG (plain + image), dC
         layer_steps = xs_frames * 2 + Tp * (L - 2)          # layers 0,1 at T0, the rest behind the 2x reduction
-        ms_b, n_b = ctypes.c_float(0), ctypes.c_int(0)
+        ms_b, n_b = span_ms, span_n
         stack = None
-        if _lib.load().edgedict_stack_last_timing(1, ctypes.byref(ms_b), ctypes.byref(n_b)) == 0 and n_b.value:
+        if have_span and n_b.value:
             per_launch = (rd + wr) * layer_steps / n_b.value
             period_us = 1e3 * ms_b.value / n_b.value
+            # the kernel's average duration: event pair around every launch (two extra steps after the timed
+            # region); the period also contains the gaps between dependent launches
+            kernel_us = kern["bwd"][0] if "bwd" in kern else period_us
             tr = None
             try:
                 ent = pmc.get("stack_bwd_kernel")
@@ -324,12 +347,16 @@ def main():
             stack = {
                 "kernel": "stack_bwd_kernel (BPTT wavefront launch: one time step of every runnable "
                           "layer; %d launches carry %d layer-steps)" % (n_b.value, layer_steps),
-                "bound": "hbm", "achieved": per_launch / (period_us * 1e-6) / 1e9,
+                "bound": "hbm", "achieved": per_launch / (kernel_us * 1e-6) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": per_launch / (period_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": tr,
-                "algorithmic_bytes": per_launch, "launch_us": period_us, "launches_timed": n_b.value,
-                "note": "launch_us = HIP-event span of the launch sequence on the recurrence stream "
-                        "/ launches (includes inter-launch gaps and waits for the chunk-GEMM stream)",
+                "frac": per_launch / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": tr,
+                "algorithmic_bytes": per_launch, "kernel_us": kernel_us, "launch_period_us": period_us,
+                "launches_timed": kern["bwd"][1] if "bwd" in kern else n_b.value,
+                "fwd_kernel_us": kern["fwd"][0] if "fwd" in kern else None,
+                "note": "kernel_us = mean of HIP-event pairs around every launch (recurrence stream, two steps "
+                        "after the timed region; compare the rocprofv3 average in profiles/); "
+                        "launch_period_us = span of the timed launch sequence / launches (adds the gaps "
+                        "between dependent launches and waits for the chunk-GEMM stream)",
             }
         out = {
             "metric": "utterances/sec (E6D2, 15 s audio)",
@@ -379,10 +406,14 @@ def main():
         }
         out["roofline"] = stack if stack is not None else out["roofline_mfma"]
         out["vendor_gemm_calls"] = int(_edlib.load().edgedict_blaslt_calls())
-        if world == 1 and not args.own_kernels_only and not args.no_own_kernels_run:
-            # the same step with EVERY product on the hand-written kernels (the default run leaves the
-            # encoder's background weight-gradient products and the small chunk dX products to hipBLASLt,
-            # DESIGN.md 4.2): a second, shorter run in a fresh process
+        if out["vendor_gemm_calls"] == 0:
+            # the default build routes nothing to hipBLASLt (the bridge is opt-in: EDGEDICT_BLASLT=1)
+            out["value_own_kernels"] = out["value"]
+            out["ms_per_step_own_kernels"] = out["ms_per_step"]
+            out["own_kernels_vendor_gemm_calls"] = 0
+        elif world == 1 and not args.own_kernels_only and not args.no_own_kernels_run:
+            # vendor routes were switched on (EDGEDICT_BLASLT=1): the same step with EVERY product on the
+            # hand-written kernels, a second, shorter run in a fresh process
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), "--own-kernels-only", "--no-cpu-baseline",
                    "--no-loss-delta", "--steps", str(min(args.steps, 12)), "--warmup", "3",

@@ -42,8 +42,10 @@ struct Api {
 const Api& api() {
     static const Api a = [] {
         Api x;
+        // OPT-IN since round 2 (EDGEDICT_BLASLT=1): every product of the training step has an own kernel
+        // that is at least as fast inside the step (gemm_nt256 / gemm_tn256 / the ring kernel of gemm_nt.hip)
         const char* e = getenv("EDGEDICT_BLASLT");
-        if (e && e[0] == '0') return x;
+        if (!e || e[0] == '0') return x;
         void* h = dlopen("libhipblaslt.so.1", RTLD_NOW | RTLD_LOCAL);
         if (!h) h = dlopen("libhipblaslt.so", RTLD_NOW | RTLD_LOCAL);
         if (!h) return x;

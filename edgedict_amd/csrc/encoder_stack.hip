@@ -108,6 +108,26 @@ struct Runtime {
     // timing of the recurrence stream's launch sequence of the last forward / backward call
     hipEvent_t tev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     int tlaunches[2] = {0, 0};
+    // opt-in (edgedict_stack_time_launches): every wavefront launch of a call stamps its first workgroup's
+    // start and its last workgroup's end (100 MHz clock) into its own slot of a device buffer - the kernels'
+    // own durations, without the gaps between launches that the span above includes
+    bool time_each = false;
+    static constexpr int STAMP_SLOTS = 4096;
+    unsigned long long* stamps[2] = {nullptr, nullptr};   // [STAMP_SLOTS][2] per direction
+    int stamp_used[2] = {0, 0};
+    unsigned long long* stamp_slot(int i, hipStream_t s) {
+        if (!time_each) return nullptr;
+        if (!stamps[i] && hipMalloc((void**)&stamps[i], (size_t)STAMP_SLOTS * 16) != hipSuccess) {
+            stamps[i] = nullptr;
+            return nullptr;
+        }
+        if (stamp_used[i] == 0) {   // start-of-call: min slots to all-ones, max slots to zero
+            if (hipMemsetAsync(stamps[i], 0, (size_t)STAMP_SLOTS * 16, s) != hipSuccess) return nullptr;
+            if (hipMemset2DAsync(stamps[i], 16, 0xff, 8, STAMP_SLOTS, s) != hipSuccess) return nullptr;
+        }
+        if (stamp_used[i] >= STAMP_SLOTS) return nullptr;
+        return stamps[i] + 2 * (size_t)stamp_used[i]++;
+    }
     // give-up code of the weights-stationary kernels: pinned host word the device writes on failure
     unsigned* wsr_err_host = nullptr;
     unsigned* wsr_err_dev = nullptr;
@@ -501,6 +521,7 @@ int forward_wsr_persistent(const edgedict_stack_desc_t* d, const std::vector<Geo
             for (int k = 0; k < g[l].nchunks && l > 0; ++k) g_trace->chunk_enqueued[g_trace->coff[l] + k] = 0;
         }
     }
+    if (st.rt) st.rt->stamp_used[0] = 0;
     if (st.rt && st.rt->tev[0][0]) ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][0], st.R));
     ED_DEV(ed_wsr_launch_fwd(Lc, st.R));
     if (g_trace) {
@@ -554,6 +575,7 @@ int forward_wsr(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
     std::vector<std::vector<int>> ready_at(L);
     for (int l = 0; l < L; ++l) ready_at[l].assign(g[l].nchunks, 0);
     int launches = 0;
+    if (st.rt) st.rt->stamp_used[0] = 0;
     if (st.rt && st.rt->tev[0][0]) ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][0], st.R));
     const size_t max_launches = (WSR_SYNC_BYTES / 4 - 64) / 8;
     for (;;) {
@@ -703,6 +725,7 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     std::vector<std::vector<int>> ready_w(L);
     for (int l = 0; l < L; ++l) ready_w[l].assign(g[l].nchunks, l == 0 ? 0 : 0x3fffffff);
     int launches = 0, idle = 0;
+    if (st.rt) st.rt->stamp_used[0] = 0;
     if (st.rt && st.rt->tev[0][0]) ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][0], st.R));
     const int T_out = (g[L - 1].T + d->layers[L - 1].reduce - 1) / d->layers[L - 1].reduce;
     struct Done { int l, k; };
@@ -794,6 +817,8 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
         }
         idle = 0;
         ++launches;
+        Lcs[0].stamp = st.rt ? st.rt->stamp_slot(0, st.R) : nullptr;
+        Lcs[1].stamp = nullptr;
         ED_DEV(ed_stack_launch_fwd(Lcs[0], st.R));
         if (st.split < L) ED_DEV(ed_stack_launch_fwd(Lcs[1], st.R2));
         if (g_trace) {
@@ -880,6 +905,38 @@ extern "C" int edgedict_stack_last_timing(int backward, float* ms, int* launches
     ED_CHECK_HIP(hipEventSynchronize(r->tev[i][1]));
     ED_CHECK_HIP(hipEventElapsedTime(ms, r->tev[i][0], r->tev[i][1]));
     *launches = r->tlaunches[i];
+    return ED_OK;
+}
+
+extern "C" int edgedict_stack_time_launches(int on) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    Runtime* r = runtime_for_current_device();
+    ED_CHECK_ARG(r, "stack_time_launches: no device runtime");
+    r->time_each = on != 0;
+    return ED_OK;
+}
+
+extern "C" int edgedict_stack_launch_times(int backward, float* sum_ms, int* launches) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    ED_CHECK_ARG(sum_ms && launches, "stack_launch_times: null pointer");
+    Runtime* r = runtime_for_current_device();
+    const int i = backward ? 1 : 0;
+    ED_CHECK_ARG(r && r->stamps[i] && r->stamp_used[i] > 0,
+                 "stack_launch_times: nothing recorded (edgedict_stack_time_launches(1) first)");
+    const int n = r->stamp_used[i];
+    std::vector<unsigned long long> h(2 * (size_t)n);
+    ED_CHECK_HIP(hipStreamSynchronize(r->R));
+    ED_CHECK_HIP(hipMemcpy(h.data(), r->stamps[i], h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    double ticks = 0.0;
+    int ok = 0;
+    for (int k = 0; k < n; ++k)
+        if (h[2 * k + 1] > h[2 * k]) {
+            ticks += (double)(h[2 * k + 1] - h[2 * k]);
+            ++ok;
+        }
+    ED_CHECK_ARG(ok > 0, "stack_launch_times: no launch stamped");
+    *sum_ms = (float)(ticks * 1e-5);      // 100 MHz ticks -> ms
+    *launches = ok;
     return ED_OK;
 }
 
@@ -974,6 +1031,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     std::vector<std::vector<int>> ready_w(L);
     for (int l = 0; l < L; ++l) ready_w[l].assign(g[l].nchunks, l == L - 1 ? 0 : 0x3fffffff);
     int launches = 0, idle = 0;
+    if (st.rt) st.rt->stamp_used[1] = 0;
     if (st.rt && st.rt->tev[1][0]) ED_CHECK_HIP(hipEventRecord(st.rt->tev[1][0], st.R));
     struct Done { int l, k, t; };
     for (int w = 0;; ++w) {
@@ -1024,6 +1082,8 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
         }
         idle = 0;
         ++launches;
+        Lcs[0].stamp = st.rt ? st.rt->stamp_slot(1, st.R) : nullptr;
+        Lcs[1].stamp = nullptr;
         ED_DEV(ed_stack_launch_bwd(Lcs[0], st.R));
         if (st.split < L) ED_DEV(ed_stack_launch_bwd(Lcs[1], st.R2));
         if (g_trace) {

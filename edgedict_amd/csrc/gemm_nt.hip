@@ -202,6 +202,126 @@ void gemm_nt_kernel(NtArgs g) {
     }
 }
 
+// Small-M, long-K products - the encoder stack's per-chunk dX = dG x W_ih ([768..1536 x 1024 x 4096],
+// accumulated in place on the side stream under the BPTT): 64 x 64 tiles so that every CU has one, and then
+// the whole product is 64 K steps of 16 KB per workgroup - a latency chain.  The double-buffered kernel above
+// drains its DMA queue at every step (0.5 us per step, 32 us per product); this one keeps a ring of three
+// K stages with COUNTED waits (one stage always in flight across the barrier).  Three, not four: with four
+// (64 KB) two of these workgroups fill a CU's LDS and the BPTT's own workgroups (37 KB) queue behind them -
+// 23.7 us per product alone, but the training step got 0.8 ms SLOWER than with the drained kernel.
+__global__ __launch_bounds__(256, 2) void gemm_nt_ring64_kernel(NtArgs g) {
+    constexpr int TM = 64, TN = 64, WT = 32, WAVES = 4, THREADS = 256, NS = 3;   // 48 KB: see below
+    constexpr int MI = 2, NJ = 2, PIECES = 2;
+    constexpr int A_BYTES = TM * BK * 2, BUF_BYTES = 2 * A_BYTES;      // 16 KB per stage
+    constexpr int CCH = TN / 8;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * BUF_BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int KT = g.K / BK;
+    int tile = blockIdx.x;
+    {
+        const int nx = 8, q = g.tiles / nx, r = g.tiles % nx, x = tile % nx, i = tile / nx;
+        tile = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + i;
+    }
+    const int m0 = (tile / g.n_tiles) * TM, n0 = (tile % g.n_tiles) * TN;
+    const int prow = lane >> 3;
+    const int chunk = (lane & 7) ^ prow;
+    const bf16_t* asrc[PIECES];
+    const bf16_t* bsrc[PIECES];
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) {
+        asrc[i] = g.A + (long long)min(m0 + (i * WAVES + wave) * 8 + prow, g.M - 1) * g.lda + chunk * 8;
+        bsrc[i] = g.B + (long long)min(n0 + (i * WAVES + wave) * 8 + prow, g.N - 1) * g.ldb + chunk * 8;
+    }
+    auto issue = [&](int q) {
+        unsigned char* base = smem + (q % NS) * BUF_BYTES;
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) glds16(asrc[i] + q * BK, base + (i * WAVES + wave) * 1024);
+#pragma unroll
+        for (int i = 0; i < PIECES; ++i) glds16(bsrc[i] + q * BK, base + A_BYTES + (i * WAVES + wave) * 1024);
+    };
+    f32x4_t acc[MI][NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int nc = n0 + wn * WT + j * 16 + kq * 4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (nc < g.N) {
+            if (g.bias1) bv = *reinterpret_cast<const float4*>(g.bias1 + nc);
+            if (g.bias2) {
+                const float4 v = *reinterpret_cast<const float4*>(g.bias2 + nc);
+                bv.x += v.x; bv.y += v.y; bv.z += v.z; bv.w += v.w;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) acc[i][j] = (f32x4_t){bv.x, bv.y, bv.z, bv.w};
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // ordinary loads done before the DMA counting starts
+    issue(0);
+    issue(1);
+    for (int q = 0; q < KT; ++q) {
+        if (q + 1 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");          // stage q landed everywhere; stage q - 1 is read out
+        if (q + 2 < KT) issue(q + 2);
+        const unsigned char* sA = smem + (q % NS) * BUF_BYTES;
+        const unsigned char* sB = sA + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BK / 32; ++ks) {
+            bf16x8_t a[MI], b[NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int ra = wm * WT + i * 16 + r16;
+                a[i] = *reinterpret_cast<const bf16x8_t*>(sA + ra * 128 + (((ks * 4 + kq) ^ (ra & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < NJ; ++i) {
+                const int rb = wn * WT + i * 16 + r16;
+                b[i] = *reinterpret_cast<const bf16x8_t*>(sB + rb * 128 + (((ks * 4 + kq) ^ (rb & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    unsigned char* sC = smem;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int nl = wn * WT + j * 16 + kq * 4;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int ml = wm * WT + i * 16 + r16;
+            uint2 pk;
+            pk.x = f32x2_to_bf16x2(acc[i][j][0], acc[i][j][1]);
+            pk.y = f32x2_to_bf16x2(acc[i][j][2], acc[i][j][3]);
+            *reinterpret_cast<uint2*>(sC + ml * (TN * 2) + ((((nl >> 3) ^ (ml & (CCH - 1))) << 4) | ((nl & 4) << 1))) = pk;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < TM * TN / 8 / THREADS; ++it) {
+        const int c = threadIdx.x + it * THREADS;
+        const int rl = c / CCH, ch = c % CCH;
+        const int row = m0 + rl, col = n0 + ch * 8;
+        if (row >= g.M || col >= g.N) continue;
+        uint4 v = *reinterpret_cast<const uint4*>(sC + rl * (TN * 2) + ((ch ^ (rl & (CCH - 1))) << 4));
+        bf16_t* dst = g.C + (long long)row * g.ldc + col;
+        if (g.accumulate) {
+            float x[8], y[8];
+            ElemIO<bf16_t>::load_vec(dst, x);
+            ElemIO<bf16_t>::load_vec(reinterpret_cast<const bf16_t*>(&v), y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] += y[e];
+            ElemIO<bf16_t>::store_vec(dst, x);
+        } else {
+            *reinterpret_cast<uint4*>(dst) = v;
+        }
+    }
+}
+
 }  // namespace
 
 bool ed_gemm_nt_ok(int dtype_in, int dtype_out, const void* A, long long lda, int a_kmajor,
@@ -234,7 +354,10 @@ int ed_gemm_nt_launch(const void* A, long long lda, const void* B, long long ldb
     const long long tiles = (long long)((M + tm - 1) / tm) * g.n_tiles;
     ED_CHECK_ARG(tiles < (1ll << 31), "gemm: too many tiles");
     g.tiles = (int)tiles;
-    if (tm == 64) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 32>), dim3((unsigned)tiles), dim3(256), lds_pad, s, g);
+    static const int ring = [] { const char* e = getenv("EDGEDICT_GEMM_NT_RING"); return e ? atoi(e) : 1; }();
+    if (tm == 64 && ring && K >= 1024 && lds_pad == 0 && !g.debug)
+        hipLaunchKernelGGL(gemm_nt_ring64_kernel, dim3((unsigned)tiles), dim3(256), 0, s, g);
+    else if (tm == 64) hipLaunchKernelGGL((gemm_nt_kernel<64, 64, 32>), dim3((unsigned)tiles), dim3(256), lds_pad, s, g);
     else if (tm == 256) hipLaunchKernelGGL((gemm_nt_kernel<256, 128, 64>), dim3((unsigned)tiles), dim3(512), lds_pad, s, g);
     else hipLaunchKernelGGL((gemm_nt_kernel<128, 128, 64>), dim3((unsigned)tiles), dim3(256), lds_pad, s, g);
     ED_CHECK_LAUNCH("gemm_nt");

@@ -323,6 +323,9 @@ __device__ __forceinline__ void fwd_norm_role(const EdFwdNorm& p, int rb, int B,
 
 __global__ __launch_bounds__(256, ED_FWD_OCC) void stack_fwd_kernel(EdFwdLaunch L) {
     __shared__ FwdShared sh;
+    // measurement mode (edgedict_stack_time_launches): first workgroup start / last workgroup end of this
+    // launch on the constant 100 MHz clock - the kernel's own duration, as a profiler's begin/end sees it
+    if (L.stamp && threadIdx.x == 0) atomicMin(&L.stamp[0], wall_clock64());
     const int UB = L.H >> 4, RG = (L.B + 63) >> 6;
     const int nsb = L.nstep * UB * RG;
     int bid = blockIdx.x;
@@ -333,6 +336,10 @@ __global__ __launch_bounds__(256, ED_FWD_OCC) void stack_fwd_kernel(EdFwdLaunch 
         bid -= nsb;
         const int RB = (L.B + 3) >> 2;
         fwd_norm_role(L.norm[bid / RB], bid % RB, L.B, L.H, L.eps);
+    }
+    if (L.stamp) {
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(&L.stamp[1], wall_clock64());
     }
 }
 
@@ -555,10 +562,15 @@ __device__ __forceinline__ void bwd_step_role(const EdBwdStep& p, int nb, int rg
 
 __global__ __launch_bounds__(256, ED_BWD_OCC) void stack_bwd_kernel(EdBwdLaunch L) {
     __shared__ BwdShared sh;
+    if (L.stamp && threadIdx.x == 0) atomicMin(&L.stamp[0], wall_clock64());   // see stack_fwd_kernel
     const int NB = L.H >> 5, RG = (L.B + 31) >> 5;
     const int bid = blockIdx.x;
     const int slot = bid / (NB * RG), rem = bid - slot * NB * RG;
     bwd_step_role(L.step[slot], rem % NB, rem / NB, L.B, L.H, sh);
+    if (L.stamp) {
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(&L.stamp[1], wall_clock64());
+    }
 }
 
 // =====================================================================================

@@ -41,6 +41,7 @@ struct EdFwdLaunch {
     int nstep, nnorm;
     int B, H;
     float eps;
+    unsigned long long* stamp;   // measurement mode only (else null): [0] min start, [1] max end, 100 MHz ticks
 };
 
 struct EdBwdStep {             // one BPTT step of one layer, all batch rows
@@ -58,6 +59,7 @@ struct EdBwdLaunch {
     EdBwdStep step[ED_STACK_MAX_SLOTS];
     int nstep;
     int B, H;
+    unsigned long long* stamp;   // as EdFwdLaunch::stamp
 };
 
 // ---- weights-stationary recurrence (wsr_kernels.hip): ONE launch carries a chunk of frames of every

@@ -324,6 +324,15 @@ int edgedict_stack_forward(const edgedict_stack_desc_t* desc, void* stream);
  * launch of the most recent forward (backward = 0) or backward (1) call on this device, and the
  * number of launches in it; blocks until that call's launches have executed. */
 int edgedict_stack_last_timing(int backward, float* ms, int* launches);
+/* measurement aid, opt-in: with on != 0 every wavefront launch of the following forward / backward calls on
+ * this device stamps its first workgroup's start and its last workgroup's end (constant 100 MHz clock) into
+ * an internal device buffer (64 KB per direction, allocated on first use).  edgedict_stack_launch_times then
+ * returns the SUM of the launches' own durations of the most recent call and their number: the kernels'
+ * average duration as a profiler's begin/end timestamps see it, without the gaps between dependent launches
+ * that edgedict_stack_last_timing's span includes.  The two atomics per workgroup cost time: switch it off
+ * for timed runs. */
+int edgedict_stack_time_launches(int on);
+int edgedict_stack_launch_times(int backward, float* sum_ms, int* launches);
 /* Dry run of the scheduler (no device needed, nothing is launched; buffer pointers in the descriptor
  * only have to be non-NULL): the launch index that carries every layer-step and the number of
  * launches issued when each chunk's side-stream product was enqueued.

@@ -151,3 +151,21 @@ def test_gemm_tn256_weight_gradient_path(hip_lib, M, N, K, split):
     # and without accumulate, fresh output
     out = ops.gemm(dy.t(), x.t(), out_dtype=torch.float32, split_k=split, max_wg_per_cu=1)
     assert (out.double() - dy.double().t() @ x.double()).abs().max().item() <= tol
+
+
+@pytest.mark.parametrize("M,N,K", [(768, 1024, 4096), (1000, 1000, 1024), (1536, 1024, 4096), (70, 200, 2048)])
+def test_gemm_nt_small_long_k_ring_path(hip_lib, M, N, K):
+    """Small-M long-K bf16 NT products with in-place accumulation (the encoder stack's per-chunk
+    dX = dG x W_ih under the BPTT) run the 64 x 64-tile ring kernel of gemm_nt.hip (four K stages, counted
+    waits): ragged edges, accumulate and plain store, against fp64 with bf16 output rounding."""
+    from edgedict_amd import ops
+    a = _mk((M, K), torch.bfloat16, 51)
+    b = _mk((N, K), torch.bfloat16, 52)
+    c0 = _mk((M, N), torch.bfloat16, 53)
+    prod = a.double() @ b.double().t()
+    out = ops.gemm(a, b)
+    assert ((out.double() - prod).abs() <= 2.0 ** -7 * prod.abs() + 1e-3 * (K ** 0.5)).all()
+    acc = c0.clone()
+    ops.gemm(a, b, out=acc, accumulate=True)
+    want = c0.double() + out.double()         # the kernel adds its bf16-rounded tile to the bf16 C
+    assert ((acc.double() - want).abs() <= 2.0 ** -6 * want.abs() + 1e-2).all()
