@@ -323,8 +323,9 @@ thread_local ScheduleTrace* g_trace = nullptr;
 
 struct Streams {
     hipStream_t C, R, R2, W;
-    int split;   // layers >= split run their recurrence on R2 (experiment; L = never)
-    hipStream_t RS(int l) const { return l >= split ? R2 : R; }
+    int split;   // layers >= split run their recurrence on R2 (L = never)
+    int which(int l) const { return l >= split ? 1 : 0; }
+    hipStream_t RS(int l) const { return which(l) ? R2 : R; }
     hipStream_t S[ED_STACK_MAX_SLOTS];
     bool serial;
     Runtime* rt;
@@ -671,6 +672,16 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     char* ws = (char*)d->ws;
     Streams st;
     ED_TRY(open_streams(d, stream_, st));
+    // TWO recurrence streams: the layers behind the time reduction run their launches on the CALLER's stream,
+    // which is otherwise idle until this call's join - the 3.4 us between two dependent launches of one
+    // stream (12.5 us kernel, 15.9 us period) are then covered by the other stream's kernel.  Per-layer state
+    // stays on one stream, layers meet through the chunk events only.  Measured: forward 7.73 -> 7.18 ms,
+    // step 26.5 -> 25.9 ms (EDGEDICT_STACK_FWD_R2=0 for one stream).  The auxiliary stream is NOT a
+    // candidate (the prediction network runs there: 7.20 ms forward but a slower step), a fifth stream
+    // neither (hardware queues), and splitting the layers by parity instead of by rate is slower
+    // (7.4 ms) and lets adjacent layers of one launch race.
+    static const int fwd_r2 = [] { const char* e = getenv("EDGEDICT_STACK_FWD_R2"); return e ? atoi(e) : 1; }();
+    if (fwd_r2 && !st.serial && st.R2 == st.R) st.R2 = st.C;
     st.split = L;
     if (st.R2 != st.R) {   // full-rate layers (up to the first time reduction) vs the rest
         st.split = L / 2;
@@ -742,7 +753,7 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
         int ndone = 0;
         for (int l = 0; l < L; ++l) {
             const edgedict_stack_layer_t& y = d->layers[l];
-            EdFwdLaunch& Lc = Lcs[l >= st.split ? 1 : 0];
+            EdFwdLaunch& Lc = Lcs[st.which(l)];
             // ---- LayerNorm of the frame the previous launch finished (before the step below
             // advances next_t)
             if (stepped_w[l] == w - 1) {
@@ -820,7 +831,7 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
         Lcs[0].stamp = st.rt ? st.rt->stamp_slot(0, st.R) : nullptr;
         Lcs[1].stamp = nullptr;
         ED_DEV(ed_stack_launch_fwd(Lcs[0], st.R));
-        if (st.split < L) ED_DEV(ed_stack_launch_fwd(Lcs[1], st.R2));
+        if (st.R2 != st.R) ED_DEV(ed_stack_launch_fwd(Lcs[1], st.R2));
         if (g_trace) {
             g_trace->max_slots = max(g_trace->max_slots, max(Lcs[0].nstep + Lcs[1].nstep, Lcs[0].nnorm + Lcs[1].nnorm));
             ++g_trace->launches;
@@ -951,6 +962,8 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     char* ws = (char*)d->ws;
     Streams st;
     ED_TRY(open_streams(d, stream_, st));
+    static const int bwd_r2 = [] { const char* e = getenv("EDGEDICT_STACK_BWD_R2"); return e ? atoi(e) : 0; }();
+    if (bwd_r2 && !st.serial && st.R2 == st.R) st.R2 = st.C;   // as in the forward pass (measured: 25.92 -> 25.85 ms, within noise)
     st.split = L;
     if (st.R2 != st.R) {   // full-rate layers (up to the first time reduction) vs the rest
         st.split = L / 2;
@@ -1057,7 +1070,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                 if (next_t[j] > 0 && next_t[j] < g[j].T) m_min = min(m_min, g[j].m);
             if (!Pace::allows(w, l, g[l].m, m_min)) continue;
             if (opens) ED_TRY(st.wait(st.RS(l), Eb[l][k]));
-            EdBwdLaunch& Lc = Lcs[l >= st.split ? 1 : 0];
+            EdBwdLaunch& Lc = Lcs[st.which(l)];
             EdBwdStep& sl = Lc.step[Lc.nstep++];
             bf16_t* f0 = bptr(ws + wl.frag0[l]);
             bf16_t* f1 = bptr(ws + wl.frag1[l]);
@@ -1085,7 +1098,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
         Lcs[0].stamp = st.rt ? st.rt->stamp_slot(1, st.R) : nullptr;
         Lcs[1].stamp = nullptr;
         ED_DEV(ed_stack_launch_bwd(Lcs[0], st.R));
-        if (st.split < L) ED_DEV(ed_stack_launch_bwd(Lcs[1], st.R2));
+        if (st.R2 != st.R) ED_DEV(ed_stack_launch_bwd(Lcs[1], st.R2));
         if (g_trace) {
             g_trace->max_slots = max(g_trace->max_slots, Lcs[0].nstep + Lcs[1].nstep);
             ++g_trace->launches;
