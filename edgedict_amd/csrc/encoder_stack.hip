@@ -181,7 +181,7 @@ Runtime* runtime_for_current_device() {
             for (int j = 0; j < 2; ++j)
                 if (hipEventCreate(&r->tev[i][j]) != hipSuccess) r->tev[i][j] = nullptr;
         if (hipHostMalloc((void**)&r->wsr_err_host, 64, hipHostMallocMapped) == hipSuccess) {
-            r->wsr_err_host[0] = 0;
+            r->wsr_err_host[0] = r->wsr_err_host[1] = r->wsr_err_host[2] = 0;
             if (hipHostGetDevicePointer((void**)&r->wsr_err_dev, r->wsr_err_host, 0) != hipSuccess)
                 r->wsr_err_dev = nullptr;
         }
@@ -296,6 +296,9 @@ int margin_launches(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, 
     // LayerNorm backward); margins of 2 / 3 lose 1 ms.
     const int P = d->chunk * g[0].f;
     if (d->lag > 0) return max(1, d->lag - P + (backward ? 1 : 0));
+    static const int mf = [] { const char* e = getenv("EDGEDICT_STACK_MARGIN_F"); return e ? atoi(e) : 0; }();
+    static const int mb = [] { const char* e = getenv("EDGEDICT_STACK_MARGIN_B"); return e ? atoi(e) : 0; }();
+    if (backward ? mb > 0 : mf > 0) return backward ? mb : mf;
     return backward ? 6 : 3;
 }
 
@@ -713,6 +716,19 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
         return ED_OK;
     }
 
+    // flag waits instead of stream waits on the recurrence streams (stack_kernels.hip soft_wait): one word per
+    // (layer, chunk) in the workspace's sync region, zeroed before the streams fork
+    static const int soft_env = [] { const char* e = getenv("EDGEDICT_STACK_SOFT_WAIT"); return e ? atoi(e) : 1; }();
+    const bool soft = soft_env && !st.serial && L <= 8;
+    unsigned* fflag = reinterpret_cast<unsigned*>(ws + wl.wsr_sync);           // [8][512]
+    unsigned* gerr = (st.rt && st.rt->wsr_err_dev) ? st.rt->wsr_err_dev + 2 : nullptr;
+    if (soft) {
+        for (int l = 0; l < L; ++l) ED_CHECK_ARG(g[l].nchunks <= 512, "encoder_stack: too many chunks for the flag table");
+        ED_DEV(ed_stack_zero(fflag, (size_t)8 * 512 * sizeof(unsigned), st.C));
+        ED_TRY(st.chain(st.C, st.R));
+        if (st.R2 != st.R) ED_TRY(st.chain(st.C, st.R2));
+        for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.C, st.S[l]));
+    }
     std::vector<std::vector<hipEvent_t>> Eg(L);
     std::vector<std::vector<char>> queued(L);   // schedule self-check: producer enqueued before consumer
     for (int l = 0; l < L; ++l) {
@@ -724,7 +740,8 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
         for (; next_g0 < g[0].nchunks && next_g0 <= upto; ++next_g0) {
             ED_DEV(input_gemm(d, g, 0, next_g0, st.S[0]));
             if (g_trace) g_trace->chunk_enqueued[g_trace->coff[0] + next_g0] = g_trace->launches;
-            ED_TRY(st.record(Eg[0][next_g0], st.S[0]));
+            if (soft) ED_DEV(ed_stack_set_flag(fflag + next_g0, st.S[0]));
+            else ED_TRY(st.record(Eg[0][next_g0], st.S[0]));
             queued[0][next_g0] = 1;
         }
         return ED_OK;
@@ -805,9 +822,10 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
             if (opens) {
                 if (l == 0) ED_TRY(feed_layer0(k + 2));
                 ED_CHECK_ARG(queued[l][k], "encoder_stack: schedule violated (layer %d chunk %d)", l, k);
-                ED_TRY(st.wait(st.RS(l), Eg[l][k]));
+                if (!soft) ED_TRY(st.wait(st.RS(l), Eg[l][k]));
             }
             EdFwdStep& sl = Lc.step[Lc.nstep++];
+            sl.wait_flag = (soft && opens) ? fflag + l * 512 + k : nullptr;
             bf16_t* f0 = bptr(ws + wl.frag0[l]);
             bf16_t* f1 = bptr(ws + wl.frag1[l]);
             sl.G_t = bptr(y.G) + (long long)t * B * 4 * H;
@@ -830,6 +848,7 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
         ++launches;
         Lcs[0].stamp = st.rt ? st.rt->stamp_slot(0, st.R) : nullptr;
         Lcs[1].stamp = nullptr;
+        Lcs[0].err = Lcs[1].err = gerr;
         ED_DEV(ed_stack_launch_fwd(Lcs[0], st.R));
         if (st.R2 != st.R) ED_DEV(ed_stack_launch_fwd(Lcs[1], st.R2));
         if (g_trace) {
@@ -841,7 +860,8 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
             ED_TRY(st.chain(st.RS(done[i].l), st.S[l]));
             ED_DEV(input_gemm(d, g, l, k, st.S[l]));
             if (g_trace) g_trace->chunk_enqueued[g_trace->coff[l] + k] = g_trace->launches;
-            ED_TRY(st.record(Eg[l][k], st.S[l]));
+            if (soft) ED_DEV(ed_stack_set_flag(fflag + l * 512 + k, st.S[l]));
+            else ED_TRY(st.record(Eg[l][k], st.S[l]));
             queued[l][k] = 1;
             ready_w[l][k] = w + margin;
         }
@@ -874,9 +894,10 @@ extern "C" int edgedict_stack_wsr_error(void) {
     Runtime* r = runtime_for_current_device();
     if (!r || !r->wsr_err_host) return 0;
     volatile unsigned* p = r->wsr_err_host;
-    const unsigned code = p[1] ? p[1] : p[0];
+    const unsigned code = p[2] ? p[2] : (p[1] ? p[1] : p[0]);   // [2]: flag waits of the step kernels
     p[0] = 0;
     p[1] = 0;
+    p[2] = 0;
     return (int)code;
 }
 
@@ -973,6 +994,14 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     }
     const int T_out = (g[L - 1].T + d->layers[L - 1].reduce - 1) / d->layers[L - 1].reduce;
 
+    static const int soft_env = [] { const char* e = getenv("EDGEDICT_STACK_SOFT_WAIT"); return e ? atoi(e) : 1; }();
+    const bool soft = soft_env && !st.serial && L <= 8;       // flag waits, as in the forward pass
+    unsigned* bflag = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + 8 * 512;   // [8][512], after the forward's
+    unsigned* gerr = (st.rt && st.rt->wsr_err_dev) ? st.rt->wsr_err_dev + 2 : nullptr;
+    if (soft) {
+        for (int l = 0; l < L; ++l) ED_CHECK_ARG(g[l].nchunks <= 512, "encoder_stack: too many chunks for the flag table");
+        ED_DEV(ed_stack_zero(bflag, (size_t)8 * 512 * sizeof(unsigned), st.C));
+    }
     // ---- prologue: running dL/dc = 0, LayerNorm backward of the top layer (all frames)
     for (int l = 0; l < L; ++l) ED_DEV(ed_stack_zero(ws + wl.dC[l], (size_t)BH * sizeof(float), st.C));
     {
@@ -1069,9 +1098,10 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
             for (int j = 0; j < l; ++j)
                 if (next_t[j] > 0 && next_t[j] < g[j].T) m_min = min(m_min, g[j].m);
             if (!Pace::allows(w, l, g[l].m, m_min)) continue;
-            if (opens) ED_TRY(st.wait(st.RS(l), Eb[l][k]));
+            if (opens && !soft) ED_TRY(st.wait(st.RS(l), Eb[l][k]));
             EdBwdLaunch& Lc = Lcs[st.which(l)];
             EdBwdStep& sl = Lc.step[Lc.nstep++];
+            sl.wait_flag = (soft && opens && l < L - 1) ? bflag + l * 512 + k : nullptr;
             bf16_t* f0 = bptr(ws + wl.frag0[l]);
             bf16_t* f1 = bptr(ws + wl.frag1[l]);
             sl.G_t = bptr(y.G) + (long long)t * B * 4 * H;
@@ -1097,6 +1127,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
         ++launches;
         Lcs[0].stamp = st.rt ? st.rt->stamp_slot(1, st.R) : nullptr;
         Lcs[1].stamp = nullptr;
+        Lcs[0].err = Lcs[1].err = gerr;
         ED_DEV(ed_stack_launch_bwd(Lcs[0], st.R));
         if (st.R2 != st.R) ED_DEV(ed_stack_launch_bwd(Lcs[1], st.R2));
         if (g_trace) {
@@ -1122,7 +1153,8 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                                        z.residual ? bptr(z.X) : nullptr, z.ln_gamma, z.mean, z.rstd,
                                        bptr(z.dZ), (float*)(ws + wl.lnpart[l - 1]) + (size_t)k * LNB_GRID * 2 * H,
                                        LNB_GRID, B, H, u0, u1, z.reduce, S));
-                ED_TRY(st.record(Eb[l - 1][k], S));
+                if (soft) ED_DEV(ed_stack_set_flag(bflag + (l - 1) * 512 + k, S));
+                else ED_TRY(st.record(Eb[l - 1][k], S));
                 queued[l - 1][k] = 1;
                 ready_w[l - 1][k] = w + margin;
                 if (g_trace) g_trace->chunk_enqueued[g_trace->coff[l - 1] + k] = g_trace->launches;

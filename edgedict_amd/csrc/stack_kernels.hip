@@ -321,6 +321,33 @@ __device__ __forceinline__ void fwd_norm_role(const EdFwdNorm& p, int rb, int B,
     }
 }
 
+// ---- flag wait instead of a stream wait.  A step that opens a chunk needs the chunk's side-stream product.
+// Ordering the recurrence stream behind it with hipStreamWaitEvent costs that stream 5-15 us per wait even
+// when the event is long complete (~135 waits per pass); instead the side stream sets a word
+// after the product (ed_stack_set_flag) and the workgroups of that one slot poll it - satisfied on the first
+// poll in the normal case, because the scheduler opens a chunk only `margin` launches after its product
+// was enqueued.  The producer's results were written back at ITS kernel end, before the flag kernel ran;
+// this kernel has not touched those lines before the poll succeeds (caches are invalidated at kernel
+// start), and the acquire fence covers the rest.  Bounded: a give-up code goes to the host-visible word.
+__device__ __forceinline__ void soft_wait(const unsigned* flag, unsigned* err, unsigned code) {
+    if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1u << 22)) {            // ~ seconds
+                if (err) atomicCAS(err, 0u, code);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
+__global__ void stack_set_flag_kernel(unsigned* flag) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __global__ __launch_bounds__(256, ED_FWD_OCC) void stack_fwd_kernel(EdFwdLaunch L) {
     __shared__ FwdShared sh;
     // measurement mode (edgedict_stack_time_launches): first workgroup start / last workgroup end of this
@@ -331,6 +358,7 @@ __global__ __launch_bounds__(256, ED_FWD_OCC) void stack_fwd_kernel(EdFwdLaunch 
     int bid = blockIdx.x;
     if (bid < nsb) {
         const int slot = bid / (UB * RG), rem = bid - slot * UB * RG;
+        if (L.step[slot].wait_flag) soft_wait(L.step[slot].wait_flag, L.err, 500u + slot);
         fwd_step_role(L.step[slot], rem % UB, rem / UB, L.B, L.H, sh);
     } else {
         bid -= nsb;
@@ -566,6 +594,7 @@ __global__ __launch_bounds__(256, ED_BWD_OCC) void stack_bwd_kernel(EdBwdLaunch 
     const int NB = L.H >> 5, RG = (L.B + 31) >> 5;
     const int bid = blockIdx.x;
     const int slot = bid / (NB * RG), rem = bid - slot * NB * RG;
+    if (L.step[slot].wait_flag) soft_wait(L.step[slot].wait_flag, L.err, 600u + slot);
     bwd_step_role(L.step[slot], rem % NB, rem / NB, L.B, L.H, sh);
     if (L.stamp) {
         __syncthreads();
@@ -802,6 +831,12 @@ int ed_stack_chunk_norm(const bf16_t* Yx1, const bf16_t* X, const float* gamma, 
     const int frames_out = reduce == 1 ? t1 - t0 : (t1 - t0 + 1) / 2;
     hipLaunchKernelGGL(stack_chunk_norm_kernel, dim3(frames_out * ((B + 3) >> 2)), dim3(256), 0, s, a);
     ED_CHECK_LAUNCH("stack_chunk_norm_kernel");
+    return ED_OK;
+}
+
+int ed_stack_set_flag(unsigned* flag, hipStream_t s) {
+    hipLaunchKernelGGL(stack_set_flag_kernel, dim3(1), dim3(64), 0, s, flag);
+    ED_CHECK_LAUNCH("stack_set_flag_kernel");
     return ED_OK;
 }
 

@@ -19,6 +19,7 @@ struct EdFwdStep {             // one LSTM time step of one layer, all batch row
     const float* C_prev;       // [B, H] c_{t-1}
     float* C_t;                // [B, H] c_t
     const bf16_t* Wfrag;       // W_hh B-fragment image [H/16][H/32][4 gates][64][8]
+    const unsigned* wait_flag; // null, or: G_t's chunk product (side stream) is done when *wait_flag != 0
 };
 
 struct EdFwdNorm {             // LayerNorm(y + r) of one frame, or the pair mean of two frames
@@ -42,6 +43,7 @@ struct EdFwdLaunch {
     int B, H;
     float eps;
     unsigned long long* stamp;   // measurement mode only (else null): [0] min start, [1] max end, 100 MHz ticks
+    unsigned* err;               // host-visible give-up word of the bounded flag waits (may be null)
 };
 
 struct EdBwdStep {             // one BPTT step of one layer, all batch rows
@@ -53,6 +55,8 @@ struct EdBwdStep {             // one BPTT step of one layer, all batch rows
     const float* C_prev;       // [B, H]
     float* dC;                 // [B, H] running dL/dc, in/out
     const bf16_t* WTfrag;      // W_hh^T B-fragment image [H/32][4H/32][2][64][8], K interleaved
+    const unsigned* wait_flag; // null, or: dY_t's chunk (dX product + LayerNorm backward on the side stream) is
+                               // done when *wait_flag != 0
 };
 
 struct EdBwdLaunch {
@@ -60,6 +64,7 @@ struct EdBwdLaunch {
     int nstep;
     int B, H;
     unsigned long long* stamp;   // as EdFwdLaunch::stamp
+    unsigned* err;               // as EdFwdLaunch::err
 };
 
 // ---- weights-stationary recurrence (wsr_kernels.hip): ONE launch carries a chunk of frames of every
@@ -116,6 +121,7 @@ int ed_stack_chunk_norm(const bf16_t* Yx1, const bf16_t* X, const float* gamma, 
 
 // kernels / launchers implemented in stack_kernels.hip
 int ed_stack_launch_fwd(const EdFwdLaunch& L, hipStream_t s);
+int ed_stack_set_flag(unsigned* flag, hipStream_t s);   // *flag = 1 once the stream reaches this point
 int ed_stack_launch_bwd(const EdBwdLaunch& L, hipStream_t s);
 // time-major LayerNorm backward over frames [t0, t1) of one layer; workgroup j writes its
 // dgamma/dbeta partial sums to part[j][2][H] (grid rows), summed later by ed_stack_sum_parts

@@ -73,6 +73,9 @@ class BucketedAllReduce:
         self._ready_calls = 0
         self._hooks = []
         self.armed = True   # disarm while accumulating sub-batches; arm for the last backward
+        # EDGEDICT_DP_OVERLAP=0: every bucket leaves from finish(), after the backward pass (to weigh the
+        # overlap against what RCCL's kernels cost the BPTT beside them, on a multi-GPU box)
+        self.overlap = os.environ.get("EDGEDICT_DP_OVERLAP", "1") != "0"
         if self.world > 1:
             for p in flat.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
@@ -101,13 +104,13 @@ class BucketedAllReduce:
                     self._issue(b)
 
     def _on_grad(self, p):
-        if self.armed and self.world > 1:
+        if self.armed and self.overlap and self.world > 1:
             self._done(p)
 
     def ready(self, params, stream=None):
         """``params`` were accumulated in place (no autograd hook fires for them) by work enqueued
         on ``stream`` (None = the current stream) up to this moment."""
-        if not self.armed or self.world <= 1:
+        if not self.armed or not self.overlap or self.world <= 1:
             return
         self._ready_calls += 1
         for p in params:

@@ -27,7 +27,7 @@ int main() {
             for (int rep = 0; rep < 2; ++rep) {
                 hipEventRecord(a, st);
                 for (int t = 0; t < T; ++t) {
-                    EdFwdLaunch L; L.nstep = ns; L.nnorm = 0; L.B = B; L.H = H; L.eps = 1e-5f; L.stamp = nullptr;
+                    EdFwdLaunch L; L.nstep = ns; L.nnorm = 0; L.B = B; L.H = H; L.eps = 1e-5f; L.stamp = nullptr; L.err = nullptr;
                     for (int i = 0; i < ns; ++i) {
                         EdFwdStep& s = L.step[i];
                         s.G_t = sl[i].G + (size_t)t * B * 4 * H;
@@ -37,6 +37,7 @@ int main() {
                         s.C_prev = sl[i].C + (size_t)t * B * H;
                         s.C_t = sl[i].C + (size_t)(t + 1) * B * H;
                         s.Wfrag = shared ? sl[0].W : sl[i].W;
+                        s.wait_flag = nullptr;
                     }
                     ed_stack_launch_fwd(L, st);
                 }
