@@ -270,8 +270,8 @@ def main():
             raise SystemExit("bench.py: %d ranks joined, --gpus %d" % (joined, args.gpus))
 
     # ---- the dominant kernel's own duration, live (outside the timed region): first the span of the last
-    # timed backward call's launch sequence, then two more steps with a HIP-event pair around EVERY
-    # wavefront launch (edgedict_stack_time_launches) - on all ranks, the steps contain the exchange
+    # timed backward call's launch sequence, then two more steps in which EVERY wavefront launch stamps its
+    # begin and end in-kernel (edgedict_stack_time_launches) - on all ranks, the steps contain the exchange
     import ctypes
     from edgedict_amd import _lib as _edlib
     span_ms, span_n = ctypes.c_float(0), ctypes.c_int(0)
@@ -335,8 +335,8 @@ def main():
         if have_span and n_b.value:
             per_launch = (rd + wr) * layer_steps / n_b.value
             period_us = 1e3 * ms_b.value / n_b.value
-            # the kernel's average duration: event pair around every launch (two extra steps after the timed
-            # region); the period also contains the gaps between dependent launches
+            # the kernel's average duration: in-kernel begin/end stamps of every launch (two extra steps after
+            # the timed region); the period also contains the gaps between dependent launches
             kernel_us = kern["bwd"][0] if "bwd" in kern else period_us
             tr = None
             try:
@@ -353,8 +353,9 @@ def main():
                 "algorithmic_bytes": per_launch, "kernel_us": kernel_us, "launch_period_us": period_us,
                 "launches_timed": kern["bwd"][1] if "bwd" in kern else n_b.value,
                 "fwd_kernel_us": kern["fwd"][0] if "fwd" in kern else None,
-                "note": "kernel_us = mean of HIP-event pairs around every launch (recurrence stream, two steps "
-                        "after the timed region; compare the rocprofv3 average in profiles/); "
+                "note": "kernel_us = mean over the launches of (last workgroup's end - first workgroup's start), "
+                        "stamped in-kernel on the 100 MHz clock during two steps after the timed region "
+                        "(edgedict_stack_time_launches; compare the rocprofv3 average in profiles/); "
                         "launch_period_us = span of the timed launch sequence / launches (adds the gaps "
                         "between dependent launches and waits for the chunk-GEMM stream)",
             }
