@@ -8,9 +8,12 @@
  *     code) owns every tensor and workspace it passes in,
  *   - keeps exactly this per-DEVICE state, created lazily under a mutex and never exposed: three
  *     internal HIP streams + an event pool for the encoder-stack scheduler (edgedict_aux_stream,
- *     edgedict_stack_*), the timing record read by edgedict_stack_last_timing, and - only when a
- *     product is routed to the vendor library - one hipBLASLt handle per device with a 64 MiB
- *     workspace per (device, stream).  Entry points are re-entrant per device; calls that touch
+ *     edgedict_stack_*), a pinned host word for the give-up codes of bounded in-kernel waits
+ *     (edgedict_stack_wsr_error), the timing record read by edgedict_stack_last_timing /
+ *     edgedict_stack_launch_times (two 64 KB device buffers, allocated only once
+ *     edgedict_stack_time_launches(1) was called), and - only with EDGEDICT_BLASLT=1 in the
+ *     environment, when a product is routed to the vendor library - one hipBLASLt handle per device
+ *     with a 64 MiB workspace per (device, stream).  Entry points are re-entrant per device; calls that touch
  *     the same device from several host threads must be serialised by the caller
  *     (nn.DataParallel's one-thread-per-GPU pattern is fine: different devices),
  *   - never aborts: it returns ED_OK or a negative status and leaves a message in
