@@ -93,9 +93,11 @@ _PACKED = {}
 def packed_weights(w_ih, w_hh, b_ih, b_hh):
     ent = _PACKED.get(id(w_hh))
     if ent is None or ent.ref() is not w_hh:     # ids are recycled: the entry must be this tensor's
+        for k in [k for k, v in _PACKED.items() if v.ref() is None]:
+            del _PACKED[k]                       # images of parameters that no longer exist
         ent = _PACKED[id(w_hh)] = _PackedLayer(w_hh)
     key = (w_ih.data_ptr(), w_hh.data_ptr(), w_ih._version, w_hh._version, b_ih._version,
-           b_hh._version, config.param_epoch())
+           b_hh._version, config.param_epoch(), bool(FLAGS & WSR))
     if ent.key != key:
         H4, I = w_ih.shape
         H = H4 // 4
@@ -105,7 +107,7 @@ def packed_weights(w_ih, w_hh, b_ih, b_hh):
         ent.bias_p = torch.empty(H4, dtype=F32, device=dev)
         ent.whh_f = torch.empty(H4 * H, dtype=BF16, device=dev)
         ent.whh_b = torch.empty(H4 * H, dtype=BF16, device=dev)
-        ent.whh_r = torch.empty(H4 * H, dtype=BF16, device=dev) if H == 1024 else None
+        ent.whh_r = torch.empty(H4 * H, dtype=BF16, device=dev) if (H == 1024 and FLAGS & WSR) else None
         srcs = [t.detach().contiguous() for t in (w_ih, w_hh, b_ih, b_hh)]
         for t in srcs:
             if t.dtype != F32:

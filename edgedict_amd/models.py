@@ -51,6 +51,11 @@ class _WeightCache:
         # THIS tensor object, not to a dead one that happened to share id, address and version
         if hit is not None and hit[0] == ver and hit[2]() is p:
             return hit[1]
+        # a miss: drop the copies of parameters that no longer exist (replicas of nn.DataParallel,
+        # rebuilt models) - each holds a device tensor
+        dead = [k for k, v in self._store.items() if v[2]() is None]
+        for k in dead:
+            del self._store[k]
         src = p.detach()
         if not src.is_contiguous():
             src = src.contiguous()
@@ -64,6 +69,13 @@ class _WeightCache:
             t = src
         else:
             t = ops.cast(src, dtype)
+        if t is not src and t.is_cuda:
+            # the copy is made on whichever stream asked first and read from the other one too (caller's /
+            # auxiliary): its block must not be recycled under a reader when the entry is replaced
+            from . import side
+            for s in (torch.cuda.current_stream(t.device), side.peek(t.device)):
+                if s is not None:
+                    t.record_stream(s)
         self._store[key] = (ver, t, weakref.ref(p))
         return t
 

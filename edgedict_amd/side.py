@@ -33,6 +33,13 @@ def stream(device):
     return s
 
 
+def peek(device):
+    """The auxiliary stream of ``device`` if it has been created already, else None."""
+    dev = torch.device(device)
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    return _streams.get(idx)
+
+
 def _join(idx):
     def cb():
         torch.cuda.current_stream(idx).wait_stream(_streams[idx])

@@ -126,7 +126,7 @@ class TrainEngine:
             self.reducer.armed = (s == starts[-1])   # exchange once, after the last accumulation
             xs, xlen = self.features(wave[s:e], None if wave_len is None else wave_len[s:e])
             if self.spec_augment is not None:
-                xs = self.spec_augment(xs)
+                xs = self.spec_augment(xs, xlen)
             loss = self.model(xs, ys[s:e], xlen, ylen[s:e])
             loss = loss / len(starts)
             ops.mark("backward:enter")

@@ -53,7 +53,7 @@ class _FusedFbankDownsample(torch.nn.Module):
         lengths on the host when they came from the host."""
         xs, xlen = self.inner(x, lengths)
         if self.augment is not None:
-            xs = self.augment(xs)
+            xs = self.augment(xs, xlen if lengths is not None else None)
         if lengths is None:
             return xs.transpose(1, 2)
         return xs, xlen
@@ -74,15 +74,18 @@ class SpecAugment(torch.nn.Module):
         self.T_mask, self.T_num_mask = T_mask, T_num_mask
         self.F_mask, self.F_num_mask = F_mask, F_num_mask
 
-    def draw(self, B, T0, F):
-        """Half-open [start, end) intervals, int32 CPU tensors [B, n, 2] (or None)."""
+    def draw(self, B, T0, F, xlen=None):
+        """Half-open [start, end) intervals, int32 CPU tensors [B, n, 2] (or None).  ``xlen`` (host
+        integers, one per row): each row's time masks start inside ITS frames, as in the reference, which
+        masks every utterance on its own length before the batch is padded (rnnt/dataset.py:98-104)."""
         import random
         t_iv = f_iv = None
         if self.T_mask > 0 and self.T_num_mask > 0:
             rows = []
-            for _ in range(B):
+            for b in range(B):
+                Tb = T0 if xlen is None else max(1, min(T0, int(xlen[b])))
                 for _ in range(self.T_num_mask):
-                    start = random.randrange(0, T0)
+                    start = random.randrange(0, Tb)
                     rows.append((start, start + random.randrange(0, self.T_mask)))
             t_iv = torch.tensor(rows, dtype=torch.int32).view(B, self.T_num_mask, 2)
         if self.F_mask > 0 and self.F_num_mask > 0:
@@ -95,10 +98,12 @@ class SpecAugment(torch.nn.Module):
         return t_iv, f_iv
 
     @torch.no_grad()
-    def forward(self, xs):
+    def forward(self, xs, xlen=None):
         from . import ops
         B, T0, F = xs.shape
-        t_iv, f_iv = self.draw(B, T0, F)
+        if xlen is not None and getattr(xlen, "is_cuda", False):
+            xlen = None              # lengths on the device: no sync for them, whole-batch frame count
+        t_iv, f_iv = self.draw(B, T0, F, None if xlen is None else [int(v) for v in xlen])
         if t_iv is None and f_iv is None:
             return xs
         dev = xs.device
