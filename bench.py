@@ -252,6 +252,8 @@ def main():
     dt = time.perf_counter() - t0
     timers = ops.timer_summary()
     ops.TIMERS = None
+    from edgedict_amd import encoder_stack as _es
+    _es.check_wsr_error()        # no bounded in-kernel wait gave up during the timed steps (host word, after the sync)
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

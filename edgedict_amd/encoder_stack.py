@@ -127,11 +127,17 @@ def clear_cache():
 
 
 def check_wsr_error():
-    """Raise if a weights-stationary launch on this device ran into one of its bounded spins (its
-    workgroups could not all become resident, or a peer never arrived): the results of that call are
+    """Raise if a launch on this device ran into one of its bounded in-kernel waits - a weights-stationary
+    launch whose workgroups could not all become resident or whose peer never arrived, or a step kernel whose
+    chunk product never signalled (flag waits, csrc/stack_kernels.hip soft_wait): the results of that call are
     garbage.  The code is a pinned host word the library copies at the end of each call; reading it
     costs nothing and clears it.  Call after a synchronize for an up-to-date answer."""
     code = _lib.load().edgedict_stack_wsr_error()
+    if code >= 500:
+        raise RuntimeError("edgedict_amd: a step kernel of the encoder stack gave up waiting for a chunk product "
+                           "of the side stream (code %d: %s pass, launch slot %d); the results of that call are "
+                           "garbage. EDGEDICT_STACK_SOFT_WAIT=0 orders the streams with events instead"
+                           % (code, "forward" if code < 600 else "backward", code % 100))
     if code:
         raise RuntimeError("edgedict_amd: a weights-stationary encoder launch gave up (code %d); set "
                            "EDGEDICT_STACK_WSR=0 to use the launch-per-step kernels" % code)
