@@ -39,6 +39,15 @@ class BucketedAllReduce:
         self.flat = flat
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # tools/overlap_probe.py: exercise the whole issue path on ONE rank (a 1-rank communicator)
+        self.force = os.environ.get("EDGEDICT_DP_FORCE", "0") == "1" and dist.is_initialized()
+        # how a bucket is issued: "stream" = async_op=False, which ProcessGroupNCCL enqueues on the CURRENT
+        # stream - the one that accumulated the gradients (auxiliary stream for the in-place accumulated ones,
+        # the caller's for hooks and finish()); "async" = async_op=True on the process group's own stream,
+        # ordered behind the current one by an event.  "async" puts a FIFTH active stream beside the engine's
+        # four, and HIP has four hardware queues: measured on one rank (tools/overlap_probe.py nccl) 36-40 ms
+        # per step instead of 26, even when every bucket leaves after the backward pass.
+        self.early_mode = os.environ.get("EDGEDICT_DP_EARLY", "stream")
         per = max(1, bucket_bytes // 4)
         lo_min = max(1, (MIN_BUCKET_BYTES if min_bytes is None else min_bytes) // 4)
         starts = {id(p) for p in boundaries}
@@ -76,13 +85,18 @@ class BucketedAllReduce:
         # EDGEDICT_DP_OVERLAP=0: every bucket leaves from finish(), after the backward pass (to weigh the
         # overlap against what RCCL's kernels cost the BPTT beside them, on a multi-GPU box)
         self.overlap = os.environ.get("EDGEDICT_DP_OVERLAP", "1") != "0"
-        if self.world > 1:
+        if self.world > 1 or self.force:
             for p in flat.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
     def _issue(self, b):
         lo, hi = self.bounds[b]
         self.issued[b] = True
+        if self.early_mode == "stream":
+            # async_op=False: ProcessGroupNCCL enqueues the collective on the CURRENT stream (no stream of its
+            # own, no cross-stream wait); nothing to wait for later - consumers are ordered by that stream
+            dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=False)
+            return
         self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM,
                                             group=self.group, async_op=True))
 
@@ -98,19 +112,18 @@ class BucketedAllReduce:
             if stream is None:
                 self._issue(b)
             else:
-                # the collective waits for the current stream's position: make that the stream the
-                # gradients were accumulated on
+                # the collective is ordered behind the stream the gradients were accumulated on
                 with torch.cuda.stream(stream):
                     self._issue(b)
 
     def _on_grad(self, p):
-        if self.armed and self.overlap and self.world > 1:
+        if self.armed and self.overlap and (self.world > 1 or self.force):
             self._done(p)
 
     def ready(self, params, stream=None):
         """``params`` were accumulated in place (no autograd hook fires for them) by work enqueued
         on ``stream`` (None = the current stream) up to this moment."""
-        if not self.armed or not self.overlap or self.world <= 1:
+        if not self.armed or not self.overlap or (self.world <= 1 and not self.force):
             return
         self._ready_calls += 1
         for p in params:
@@ -119,7 +132,7 @@ class BucketedAllReduce:
     def finish(self):
         """Flush the buckets that are not out yet (parameters finalised at the very end of the
         backward pass, unused parameters), then wait for every bucket."""
-        if self.world > 1:
+        if self.world > 1 or self.force:
             for b in range(len(self.bounds)):
                 if not self.issued[b]:
                     self._issue(b)

@@ -68,7 +68,7 @@ class TrainEngine:
         if hasattr(enc.lstm, "lstms"):
             cuts += [m.layer(0)[0] for m in enc.lstm.lstms] + [enc.lstm.projs[0][0].weight]
         self.reducer = BucketedAllReduce(self.flat, process_group, boundaries=cuts)
-        if self.world > 1:
+        if self.world > 1 or self.reducer.force:
             from . import dp
             dp.READY_HOOK = self.reducer.ready     # in-place accumulated gradients report here
         self.sub_batch_size = getattr(flags, "sub_batch_size", None)
