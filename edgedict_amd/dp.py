@@ -100,6 +100,16 @@ class BucketedAllReduce:
         self.handles.append(dist.all_reduce(self.flat.grad[lo:hi], op=dist.ReduceOp.SUM,
                                             group=self.group, async_op=True))
 
+    def _exchange_stream(self):
+        """Stream mode: every collective issued DURING the backward pass goes onto ONE stream, the engine's
+        auxiliary stream.  A communicator orders its collectives globally - one issued on the caller's stream
+        would wait there for the earlier ones still queued behind weight-gradient products on the auxiliary
+        stream, and the caller's stream is where the backward pass itself is enqueued."""
+        if not self.flat.grad.is_cuda:
+            return None
+        from . import side
+        return side.peek(self.flat.grad.device)
+
     def _done(self, p, stream=None):
         b = self.param_bucket.get(id(p))
         if b is None or self.issued[b]:
@@ -109,7 +119,14 @@ class BucketedAllReduce:
             self.issued_early += 1
             self.early_buckets.append(b)
             self.early_by.append("ready" if stream is not None else "hook")
-            if stream is None:
+            ex = self._exchange_stream() if self.early_mode == "stream" else None
+            if ex is not None:
+                src = stream if stream is not None else torch.cuda.current_stream(self.flat.grad.device)
+                if src != ex:
+                    ex.wait_stream(src)          # the gradients were produced up to here on `src`
+                with torch.cuda.stream(ex):
+                    self._issue(b)
+            elif stream is None:
                 self._issue(b)
             else:
                 # the collective is ordered behind the stream the gradients were accumulated on
@@ -133,6 +150,11 @@ class BucketedAllReduce:
         """Flush the buckets that are not out yet (parameters finalised at the very end of the
         backward pass, unused parameters), then wait for every bucket."""
         if self.world > 1 or self.force:
+            ex = self._exchange_stream() if self.early_mode == "stream" else None
+            if ex is not None:
+                # the early collectives (and the gradients accumulated on that stream) first; the rest follows
+                # on the caller's stream, where the optimiser step is enqueued next
+                torch.cuda.current_stream(self.flat.grad.device).wait_stream(ex)
             for b in range(len(self.bounds)):
                 if not self.issued[b]:
                     self._issue(b)
