@@ -1002,15 +1002,8 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
         for (int l = 0; l < L; ++l) ED_CHECK_ARG(g[l].nchunks <= 512, "encoder_stack: too many chunks for the flag table");
         ED_DEV(ed_stack_zero(bflag, (size_t)8 * 512 * sizeof(unsigned), st.C));
     }
-    // ---- prologue: running dL/dc = 0, LayerNorm backward of the top layer (all frames)
+    // ---- prologue: running dL/dc = 0
     for (int l = 0; l < L; ++l) ED_DEV(ed_stack_zero(ws + wl.dC[l], (size_t)BH * sizeof(float), st.C));
-    {
-        const edgedict_stack_layer_t& y = d->layers[L - 1];
-        ED_DEV(ed_stack_ln_bwd(bptr(d->dout), H, (long long)T_out * H, bptr(y.Yx) + BH,
-                               y.residual ? bptr(y.X) : nullptr, y.ln_gamma, y.mean, y.rstd,
-                               bptr(y.dZ), (float*)(ws + wl.lnpart[L - 1]) + (size_t)g[L - 1].nchunks * LNB_GRID * 2 * H,
-                               LNB_GRID_TOP, B, H, 0, y.T, y.reduce, st.C));
-    }
     ED_TRY(st.chain(st.C, st.R));
     if (st.R2 != st.R) ED_TRY(st.chain(st.C, st.R2));
     for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.C, st.S[l]));
@@ -1021,6 +1014,22 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     for (int l = 0; l < L; ++l) {
         Eb[l].assign(g[l].nchunks, nullptr);
         queued[l].assign(g[l].nchunks, l == L - 1 ? 1 : 0);
+    }
+    // ---- LayerNorm backward of the TOP layer, chunk by chunk on the side stream, last chunk first: the
+    // BPTT starts after ONE chunk's kernel (~10 us) instead of after all frames' (150 us on the caller's
+    // stream, with nothing beside it)
+    {
+        const edgedict_stack_layer_t& y = d->layers[L - 1];
+        hipStream_t S = st.S[L - 1];
+        for (int k = g[L - 1].nchunks - 1; k >= 0; --k) {
+            const int t0 = k * g[L - 1].cf, t1 = min(y.T, t0 + g[L - 1].cf);
+            ED_DEV(ed_stack_ln_bwd(bptr(d->dout), H, (long long)T_out * H, bptr(y.Yx) + BH,
+                                   y.residual ? bptr(y.X) : nullptr, y.ln_gamma, y.mean, y.rstd, bptr(y.dZ),
+                                   (float*)(ws + wl.lnpart[L - 1]) + (size_t)k * LNB_GRID * 2 * H, LNB_GRID, B, H,
+                                   t0, t1, y.reduce, S));
+            if (soft) ED_DEV(ed_stack_set_flag(bflag + (L - 1) * 512 + k, S));
+            else ED_TRY(st.record(Eb[L - 1][k], S));
+        }
     }
     std::vector<int> deferred;   // layers whose weight gradients run after the BPTT (DW_AT_END)
 
@@ -1101,7 +1110,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
             if (opens && !soft) ED_TRY(st.wait(st.RS(l), Eb[l][k]));
             EdBwdLaunch& Lc = Lcs[st.which(l)];
             EdBwdStep& sl = Lc.step[Lc.nstep++];
-            sl.wait_flag = (soft && opens && l < L - 1) ? bflag + l * 512 + k : nullptr;
+            sl.wait_flag = (soft && opens) ? bflag + l * 512 + k : nullptr;
             bf16_t* f0 = bptr(ws + wl.frag0[l]);
             bf16_t* f1 = bptr(ws + wl.frag1[l]);
             sl.G_t = bptr(y.G) + (long long)t * B * 4 * H;
@@ -1207,10 +1216,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
         for (int l = 0; l < L; ++l) {
             const edgedict_stack_layer_t& z = d->layers[l];
             const float* part = (const float*)(ws + wl.lnpart[l]);
-            if (l == L - 1)   // only the top layer's all-frames call (it ran on the caller's stream)
-                ED_DEV(ed_stack_sum_parts(part + (size_t)g[l].nchunks * LNB_GRID * 2 * H, LNB_GRID_TOP, H, z.dgamma, z.dbeta, st.S[0]));
-            else
-                ED_DEV(ed_stack_sum_parts(part, g[l].nchunks * LNB_GRID, H, z.dgamma, z.dbeta, st.S[0]));
+            ED_DEV(ed_stack_sum_parts(part, g[l].nchunks * LNB_GRID, H, z.dgamma, z.dbeta, st.S[0]));
         }
     }
     if (!deferred.empty()) {
