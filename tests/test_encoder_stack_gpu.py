@@ -145,3 +145,36 @@ def test_e6d2_full_size_schedule_is_bit_exact_and_finite(hip_lib):
             assert torch.equal(a[3][n], b[3][n]), n
     # the carried cell state stays inside the range |c| <= T that the recurrence allows
     assert a[2].abs().max().item() < 401
+
+
+def test_launch_timing_entry_points_and_results_unchanged_by_stamping(hip_lib):
+    """edgedict_stack_last_timing (span of the launch sequence) and, with edgedict_stack_time_launches(1), the
+    in-kernel begin/end stamps of every wavefront launch (edgedict_stack_launch_times): sane numbers - a
+    launch's own duration is positive and their sum does not exceed the span by more than the stamping
+    overhead - and the same results with and without the stamps (bit-identical but for the atomically summed
+    input-norm gradients)."""
+    import ctypes
+    from edgedict_amd import _lib
+    lib = _lib.load()
+    case = (4, 50, 32, 64, 6, [1], 4, 0)
+    enc, xs = _encoder(case)
+    ref = _run(enc, xs, torch.bfloat16, chunk=4)
+    assert lib.edgedict_stack_time_launches(1) == 0
+    try:
+        got = _run(enc, xs, torch.bfloat16, chunk=4)
+        for bw in (0, 1):
+            span, n = ctypes.c_float(0), ctypes.c_int(0)
+            tot, m = ctypes.c_float(0), ctypes.c_int(0)
+            assert lib.edgedict_stack_last_timing(bw, ctypes.byref(span), ctypes.byref(n)) == 0
+            assert lib.edgedict_stack_launch_times(bw, ctypes.byref(tot), ctypes.byref(m)) == 0
+            assert n.value > 0 and 0 < m.value <= n.value
+            assert 0.0 < tot.value <= 1.5 * span.value + 0.5, (bw, tot.value, span.value)
+            assert tot.value / m.value < 1.0          # ms per launch of a tiny geometry
+    finally:
+        assert lib.edgedict_stack_time_launches(0) == 0
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]) and torch.equal(ref[2], got[2])
+    for k in ref[3]:
+        if k.startswith("norm."):     # the input LayerNorm's parameter gradients are summed with fp32 atomics
+            assert torch.allclose(ref[3][k], got[3][k], rtol=1e-4, atol=1e-5), k
+        else:
+            assert torch.equal(ref[3][k], got[3][k]), k
