@@ -192,6 +192,8 @@ def main():
                     help="route NO product to hipBLASLt (EDGEDICT_BLASLT=0, _BG=0, _SMALL=0)")
     ap.add_argument("--no-own-kernels-run", action="store_true",
                     help="skip the second, shorter run that fills value_own_kernels")
+    ap.add_argument("--no-fp32-run", action="store_true",
+                    help="skip the short fp32 parity-mode run that fills the secondary field fp32_parity_mode")
     args = ap.parse_args()
 
     if args.own_kernels_only:                  # read once, when the library first routes a product
@@ -431,6 +433,20 @@ def main():
             except Exception as exc:      # noqa: BLE001 - the headline number must not depend on this
                 out["value_own_kernels"] = None
                 out["own_kernels_error"] = repr(exc)[:200]
+        if world == 1 and args.dtype == "bf16" and not args.no_fp32_run and not args.own_kernels_only:
+            # secondary field: the SAME step in the fp32 parity mode (exact-f32 MFMA, per-layer kernels - the mode
+            # the 1e-3 loss bound is stated for), 3 steps in a fresh process
+            import subprocess
+            cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "fp32", "--steps", "3", "--warmup", "1",
+                   "--no-cpu-baseline", "--no-loss-delta", "--no-own-kernels-run", "--preset", args.preset,
+                   "--batch", str(args.batch), "--seconds", str(args.seconds), "--labels", str(args.labels)]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                sub = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                out["fp32_parity_mode"] = {"value": sub["value"], "unit": sub["unit"], "ms_per_step": sub["ms_per_step"],
+                                           "steps": sub["steps"], "dtype": "fp32"}
+            except Exception as exc:      # noqa: BLE001 - the headline number must not depend on this
+                out["fp32_parity_mode"] = {"error": repr(exc)[:200]}
         if not args.no_loss_delta:
             ld = loss_delta(engine, flags, batch)
             out["loss_delta_vs_ref"] = ld
