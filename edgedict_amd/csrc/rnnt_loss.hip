@@ -149,8 +149,6 @@ __global__ __launch_bounds__(256) void rnnt_lse_from_parts(
         lpl[row] = l;
     }
 }
-    }
-}
 
 // log(exp(a)+exp(b)) with float64 carry: only the add/sub/max are fp64, the correction term
 // log1p(exp(-|a-b|)) in [0, ln 2] is evaluated in fp32 (abs error ~1e-7).
