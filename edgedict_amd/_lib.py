@@ -63,6 +63,7 @@ def load():
         lib.edgedict_stack_workspace_bytes.restype = ctypes.c_size_t
         lib.edgedict_stack_struct_bytes.restype = ctypes.c_size_t
         lib.edgedict_aux_stream.restype = ctypes.c_void_p
+        lib.edgedict_stack_error_words.restype = ctypes.c_void_p
         for name in declared_symbols():
             if not hasattr(lib, name):
                 raise RuntimeError("edgedict_amd: %s lacks symbol %s declared in the header"

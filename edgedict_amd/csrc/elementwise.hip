@@ -332,7 +332,11 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                             float b1, float b2, float omb1, float omb2, float eps, float bc1, float bc2,
                             float weight_decay, float grad_scale_host,
                             const float* __restrict__ grad_scale,
-                            bf16_t* __restrict__ p_bf16) {
+                            bf16_t* __restrict__ p_bf16, const unsigned* skip_words, int n_skip) {
+    // guard (edgedict_adam_step_guarded): a bounded in-kernel wait of this step's encoder stack gave up, so
+    // its gradients are garbage - leave p, m, v untouched; the host raises at its next check of the word
+    for (int k = 0; k < n_skip; ++k)
+        if (__hip_atomic_load(skip_words + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
     const float gs = grad_scale_host * (grad_scale ? *grad_scale : 1.f);
     const float step = lr / bc1;
     const float inv_sqrt_bc2 = rsqrtf(bc2);
@@ -588,13 +592,15 @@ extern "C" int edgedict_joint_hidden_bwd_packed(int dtype, const void* dhid, con
     return joint_hidden_bwd_impl(dtype, dhid, hid, dE1, dD1, B, T, U1, J, act_lens, label_lens, row_offsets, stream_);
 }
 
-extern "C" int edgedict_adam_step(float* p, const float* g, float* m, float* v, long long n,
-                                  float lr, float beta1, float beta2, float eps, int step,
-                                  float weight_decay, float grad_scale_host,
-                                  const float* grad_scale, void* p_bf16, void* stream_) {
+extern "C" int edgedict_adam_step_guarded(float* p, const float* g, float* m, float* v, long long n,
+                                          float lr, float beta1, float beta2, float eps, int step,
+                                          float weight_decay, float grad_scale_host,
+                                          const float* grad_scale, void* p_bf16,
+                                          const unsigned* skip_words, int n_skip, void* stream_) {
     ED_CHECK_ARG(n >= 0 && step >= 1, "adam_step: bad size/step");
     if (n == 0) return ED_OK;
     ED_CHECK_ARG(p && g && m && v, "adam_step: null pointer");
+    ED_CHECK_ARG(n_skip >= 0 && n_skip <= 16 && (n_skip == 0 || skip_words), "adam_step_guarded: bad guard words");
     // torch.optim.Adam works out 1 - beta and 1 - beta^step in DOUBLE from the Python floats and only
     // then rounds to fp32; the betas arrive here as fp32 images of decimal literals, and 1.f - 0.999f
     // differs from (float)(1 - 0.999) by 1.3e-5 relative (it shows in exp_avg_sq).  Recover the decimal
@@ -605,9 +611,17 @@ extern "C" int edgedict_adam_step(float* p, const float* g, float* m, float* v, 
     const float bc2 = (float)(1.0 - pow(b2d, (double)step));
     hipLaunchKernelGGL(adam_kernel, dim3(ed_grid_for(n, 256 * 4, 256 * 8)), dim3(256), 0,
                        (hipStream_t)stream_, p, g, m, v, n, lr, beta1, beta2, omb1, omb2, eps, bc1, bc2,
-                       weight_decay, grad_scale_host, grad_scale, (bf16_t*)p_bf16);
+                       weight_decay, grad_scale_host, grad_scale, (bf16_t*)p_bf16, skip_words, n_skip);
     ED_CHECK_LAUNCH("adam_step");
     return ED_OK;
+}
+
+extern "C" int edgedict_adam_step(float* p, const float* g, float* m, float* v, long long n,
+                                  float lr, float beta1, float beta2, float eps, int step,
+                                  float weight_decay, float grad_scale_host,
+                                  const float* grad_scale, void* p_bf16, void* stream_) {
+    return edgedict_adam_step_guarded(p, g, m, v, n, lr, beta1, beta2, eps, step, weight_decay, grad_scale_host,
+                                      grad_scale, p_bf16, nullptr, 0, stream_);
 }
 
 extern "C" int edgedict_grad_clip_coef(const float* g, long long n, float max_norm,

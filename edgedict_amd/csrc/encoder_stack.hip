@@ -901,6 +901,16 @@ extern "C" int edgedict_stack_wsr_error(void) {
     return (int)code;
 }
 
+extern "C" void* edgedict_stack_error_words(int host) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    Runtime* r = runtime_for_current_device();
+    if (!r || !r->wsr_err_host || !r->wsr_err_dev) {
+        ed_set_error("stack_error_words: no device runtime");
+        return nullptr;
+    }
+    return host ? (void*)r->wsr_err_host : (void*)r->wsr_err_dev;
+}
+
 extern "C" int edgedict_stack_schedule(const edgedict_stack_desc_t* d, int backward, int32_t* step_launch,
                                        int32_t* chunk_enqueued, int32_t* n_launches, int32_t* max_slots) {
     ED_CHECK_ARG(d && step_launch && chunk_enqueued && n_launches && max_slots, "stack_schedule: null pointer");

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void rnnt_lse_from_parts(
     // same as half a wave per row with shuffles: the bound is the 1.09 M scattered 2-byte reads of the blank
     // and label logits (one 64-byte sector each, rows 4 KB apart), not the pairs.
     const int b = blockIdx.y;
-    const int Tb = min(act_lens[b], Tm), Ub = min(label_lens[b], U1 - 1);
+    const int Tb = max(0, min(act_lens[b], Tm)), Ub = max(0, min(label_lens[b], U1 - 1));   // as rnnt_alpha_beta
     const int Wb = Ub + 1, nvalid = Tb * Wb;
     for (int r = blockIdx.x * 256 + threadIdx.x; r < nvalid; r += gridDim.x * 256) {
         const int t = r / Wb, u = r - t * Wb;
@@ -416,6 +416,7 @@ static int loss_forward(const void* acts, int acts_dtype, const int32_t* labels,
     const int vec_ok = ((V * esz) % 16 == 0) && (((uintptr_t)acts & 15) == 0);
     const dim3 grid1(ed_grid_for((long long)T * U1, 4, max(1, 256 * 16 / B)), B);
     if (lse_parts) {
+        ED_CHECK_ARG(((uintptr_t)lse_parts & 15) == 0, "rnnt_loss_forward: lse_parts must be 16-byte aligned");
         ED_CHECK_ARG(acts_dtype == ED_BF16 && pk_off && lse_slots > 0,
                      "rnnt_loss_forward: log-sum-exp partials need bf16 logits on the packed lattice");
         const dim3 gridp(ed_grid_for((long long)T * U1, 256, max(1, 256 * 16 / B)), B);

@@ -34,8 +34,18 @@ MIN_BUCKET_BYTES = int(os.environ.get("EDGEDICT_DP_MIN_BUCKET", str(1 << 20)))
 
 
 class BucketedAllReduce:
-    def __init__(self, flat, process_group=None, bucket_bytes=64 << 20, boundaries=(), min_bytes=None):
-        """``boundaries``: parameters at which a new bucket must start (in parameter order)."""
+    def __init__(self, flat, process_group=None, bucket_bytes=64 << 20, boundaries=(), min_bytes=None,
+                 late=()):
+        """``boundaries``: parameters at which a new bucket must start (in parameter order).
+        ``late``: parameters that are only final at the end of the backward pass; a bucket holding one is
+        issued after every other bucket.
+
+        Buckets leave STRICTLY in ``issue_order`` (buckets from the end of the flat buffer to its start -
+        the order backward finishes them in - with the late ones moved to the end): a bucket that completes
+        before its predecessors is held back.  Which mechanism completes a bucket (autograd hook, the
+        engine's ``ready()`` report, ``finish()``) and when may differ between ranks - e.g. a rank whose
+        batch is too short for the wavefront stack takes the per-layer autograd path - but every rank then
+        still issues the same collectives in the same order (RCCL matches collectives by issue order)."""
         self.flat = flat
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -73,6 +83,10 @@ class BucketedAllReduce:
             self.expected[self.param_bucket[id(p)]] += 1
         self.pending = list(self.expected)
         self.issued = [False] * len(bounds)
+        late_b = {self.param_bucket[id(p)] for p in late if id(p) in self.param_bucket}
+        self.issue_order = [b for b in range(len(bounds)) if b not in late_b] + sorted(late_b)
+        self.complete = [None] * len(bounds)     # None, or the streams the bucket's gradients were produced on
+        self._next = 0                           # position in issue_order of the next bucket to leave
         self.handles = []
         self.issued_early = 0     # buckets that left before finish() in this step ...
         self.last_issued_early = 0   # ... and in the last finished one (reporting / tests)
@@ -112,26 +126,50 @@ class BucketedAllReduce:
 
     def _done(self, p, stream=None):
         b = self.param_bucket.get(id(p))
-        if b is None or self.issued[b]:
+        if b is None or self.issued[b] or self.complete[b] is not None:
             return
         self.pending[b] -= 1
-        if self.pending[b] == 0:
+        if self.pending[b] > 0:
+            return
+        dev = self.flat.grad.device
+        srcs = []
+        if self.flat.grad.is_cuda:
+            # the bucket may mix hook-accumulated parameters (produced on the caller's stream) and in-place
+            # accumulated ones (on `stream`): the collective waits for both
+            srcs = [torch.cuda.current_stream(dev)]
+            if stream is not None and stream != srcs[0]:
+                srcs.append(stream)
+        self.complete[b] = (srcs, "ready" if stream is not None else "hook")
+        self._drain()
+
+    def _drain(self):
+        """Issue, in issue_order, every bucket whose predecessors are out and that is complete."""
+        while self._next < len(self.issue_order):
+            b = self.issue_order[self._next]
+            if self.issued[b]:
+                self._next += 1
+                continue
+            if self.complete[b] is None:
+                return
+            srcs, by = self.complete[b]
             self.issued_early += 1
             self.early_buckets.append(b)
-            self.early_by.append("ready" if stream is not None else "hook")
+            self.early_by.append(by)
             ex = self._exchange_stream() if self.early_mode == "stream" else None
             if ex is not None:
-                src = stream if stream is not None else torch.cuda.current_stream(self.flat.grad.device)
-                if src != ex:
-                    ex.wait_stream(src)          # the gradients were produced up to here on `src`
+                for src in srcs:
+                    if src != ex:
+                        ex.wait_stream(src)          # the gradients were produced up to here on `src`
                 with torch.cuda.stream(ex):
                     self._issue(b)
-            elif stream is None:
+            elif len(srcs) < 2:
                 self._issue(b)
             else:
                 # the collective is ordered behind the stream the gradients were accumulated on
-                with torch.cuda.stream(stream):
+                srcs[1].wait_stream(srcs[0])
+                with torch.cuda.stream(srcs[1]):
                     self._issue(b)
+            self._next += 1
 
     def _on_grad(self, p):
         if self.armed and self.overlap and (self.world > 1 or self.force):
@@ -155,7 +193,7 @@ class BucketedAllReduce:
                 # the early collectives (and the gradients accumulated on that stream) first; the rest follows
                 # on the caller's stream, where the optimiser step is enqueued next
                 torch.cuda.current_stream(self.flat.grad.device).wait_stream(ex)
-            for b in range(len(self.bounds)):
+            for b in self.issue_order:
                 if not self.issued[b]:
                     self._issue(b)
             for h in self.handles:
@@ -163,11 +201,18 @@ class BucketedAllReduce:
         self.handles = []
         self.pending = list(self.expected)
         self.issued = [False] * len(self.bounds)
+        self.complete = [None] * len(self.bounds)
+        self._next = 0
         self.last_issued_early, self.issued_early = self.issued_early, 0
         self.last_early_buckets, self.early_buckets = self.early_buckets, []
         self.last_early_by, self.early_by = self.early_by, []
         self.ready_calls, self._ready_calls = self._ready_calls, 0
         return 1.0 / self.world
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
 
 def shard_batch(tensors, rank, world):

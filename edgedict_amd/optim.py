@@ -6,6 +6,8 @@ Semantics of ``torch.optim.Adam`` as the reference configures it (cli/train.py:1
 gradients into another, so the update is a single streaming kernel over ~51 M elements instead of
 ~60 per-tensor launches, and a data-parallel gradient bucket is just a slice of the flat buffer.
 """
+import ctypes
+
 import torch
 
 from . import config
@@ -65,9 +67,12 @@ class FusedAdam:
     def zero_grad(self):
         self.flat.zero_grad()
 
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, guard=None):
         """``grad_scale`` multiplies every gradient first (1/world_size for data parallelism,
-        1/n_sub for gradient accumulation when the caller did not pre-scale the loss)."""
+        1/n_sub for gradient accumulation when the caller did not pre-scale the loss).
+        ``guard``: device-visible address of 3 words (``edgedict_stack_error_words(0)``); the step is
+        skipped on the device when one of them is non-zero (a bounded in-kernel wait gave up: the
+        gradients are garbage) - no host synchronisation."""
         self.lr = self.param_groups[0]["lr"]
         self.step_count += 1
         coef = None
@@ -75,9 +80,10 @@ class FusedAdam:
             call("grad_clip_coef", self.flat.grad, _ll(self.flat.numel), float(self.max_grad_norm),
                  float(grad_scale), self._sumsq, self._coef, self.grad_norm)
             coef = self._coef
-        call("adam_step", self.flat.data, self.flat.grad, self.m, self.v, _ll(self.flat.numel),
+        call("adam_step_guarded", self.flat.data, self.flat.grad, self.m, self.v, _ll(self.flat.numel),
              float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
-             int(self.step_count), float(self.weight_decay), float(grad_scale), coef, None)
+             int(self.step_count), float(self.weight_decay), float(grad_scale), coef, None,
+             ctypes.c_void_p(guard or 0), 3 if guard else 0)
         config.bump_param_epoch()
 
     def state_dict(self):

@@ -67,10 +67,25 @@ class TrainEngine:
         cuts = [self.model.joint.joint[0].weight, self.model.decoder.embed.weight]
         if hasattr(enc.lstm, "lstms"):
             cuts += [m.layer(0)[0] for m in enc.lstm.lstms] + [enc.lstm.projs[0][0].weight]
-        self.reducer = BucketedAllReduce(self.flat, process_group, boundaries=cuts)
-        if self.world > 1 or self.reducer.force:
-            from . import dp
-            dp.READY_HOOK = self.reducer.ready     # in-place accumulated gradients report here
+        # parameters whose gradients are only final at the very END of the backward pass and that nobody
+        # reports (the stack's LayerNorm gradients are summed from partial rows by its last kernels): their
+        # buckets are issued last on every rank, so the issue order never depends on which mechanism
+        # finalised what (dp.BucketedAllReduce issues strictly in that order)
+        late = [enc.norm.weight, enc.norm.bias]
+        if hasattr(enc.lstm, "projs"):
+            late += [q for m in enc.lstm.projs for q in m.parameters()]
+        self.reducer = BucketedAllReduce(self.flat, process_group, boundaries=cuts, late=late)
+        from . import dp
+        # in-place accumulated gradients report here; set UNCONDITIONALLY so that an engine without an exchange
+        # clears the hook of an earlier one (it would pin that engine's flat buffers)
+        dp.READY_HOOK = self.reducer.ready if (self.world > 1 or self.reducer.force) else None
+        # device-visible give-up words of the encoder stack's bounded in-kernel waits: the Adam kernel skips
+        # its update when one is set (advisor r2: bad gradients were applied before anything raised)
+        self._guard = None
+        if self.device.type == "cuda":
+            from . import _lib
+            with torch.cuda.device(self.device):
+                self._guard = _lib.load().edgedict_stack_error_words(0)
         self.sub_batch_size = getattr(flags, "sub_batch_size", None)
         # learning-rate control of the reference's loop (cli/train.py:142-146,189-191)
         self.warmup = WarmupLR(self.optim, flags.lr, getattr(flags, "warmup_step", 0) or 0)
@@ -103,6 +118,20 @@ class TrainEngine:
             self.sched.load_state_dict(ckpt["sched"])
         self.step_count = int(ckpt.get("step", 0)) if isinstance(ckpt, dict) else 0
 
+    def close(self):
+        """Detach this engine from the process-wide hooks (the in-place gradient report of the encoder
+        stack) and drop its autograd hooks; call before building another engine in the same process."""
+        from . import dp
+        if dp.READY_HOOK == self.reducer.ready:
+            dp.READY_HOOK = None
+        self.reducer.close()
+
+    def check(self):
+        """Raise if a bounded in-kernel wait of an earlier step gave up (its optimiser step was skipped on
+        the device).  Reads a pinned host word: free; call after a synchronize for an up-to-date answer."""
+        from . import encoder_stack
+        encoder_stack.check_wsr_error()
+
     def validation_end(self, val_loss):
         """Call with the validation loss after each evaluation (cli/train.py:182-184,206-208)."""
         if self.sched is not None:
@@ -134,7 +163,7 @@ class TrainEngine:
             ops.mark("backward:exit")
             total = loss.detach() if total is None else total + loss.detach()
         scale = self.reducer.finish()
-        self.optim.step(grad_scale=scale)
+        self.optim.step(grad_scale=scale, guard=self._guard)
         if self.compute_dtype == torch.bfloat16 and config.USE_ENCODER_STACK:
             # next step's weight images, beside its front-end (after Adam in stream order)
             from . import encoder_stack, side

@@ -318,6 +318,10 @@ int edgedict_stack_pack_wsr(const float* w_hh, int H, void* whh_r, void* stream)
 /* give-up code of the last weights-stationary launch on the current device that ran into a bounded
  * spin (0 = none since the last call of this function; reading clears it) - see csrc/wsr_kernels.hip */
 int edgedict_stack_wsr_error(void);
+/* the 3 give-up words behind edgedict_stack_wsr_error of the current device (pinned, mapped host memory):
+ * host = 0 -> the DEVICE-visible address (what edgedict_adam_step_guarded takes as skip_words, n_skip = 3),
+ * host = 1 -> the host address of the same words (tests poke it).  NULL on failure. */
+void* edgedict_stack_error_words(int host);
 /* debug: a zeroed device buffer of >= 64 KB that the persistent weights-stationary launch fills with
  * wall-clock stamps (100 MHz) of its layers' chunks and of worker 0's tasks (tools/wsr_persist_trace.py);
  * NULL switches it off.  Not part of the hot path. */
@@ -406,6 +410,14 @@ int edgedict_joint_hidden_bwd_packed(int dtype, const void* dhid, const void* hi
 int edgedict_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr,
                        float beta1, float beta2, float eps, int step, float weight_decay,
                        float grad_scale_host, const float* grad_scale, void* p_bf16, void* stream);
+/* The same step, skipped entirely (p, m, v untouched) when any of the n_skip (<= 16) device-visible words
+ * at skip_words is non-zero when the kernel starts: the trainer passes edgedict_stack_error_words(), so the
+ * gradients of a step whose encoder stack gave up a bounded in-kernel wait are never applied - without a
+ * host synchronisation; the host raises at its next edgedict_stack_wsr_error(). */
+int edgedict_adam_step_guarded(float* p, const float* g, float* m, float* v, long long n, float lr,
+                               float beta1, float beta2, float eps, int step, float weight_decay,
+                               float grad_scale_host, const float* grad_scale, void* p_bf16,
+                               const unsigned* skip_words, int n_skip, void* stream);
 int edgedict_grad_clip_coef(const float* g, long long n, float max_norm, float pre_scale,
                             float* sumsq_ws, float* coef, float* norm_out, void* stream);
 

@@ -158,3 +158,72 @@ def test_in_place_gradients_report_ready_and_leave_early():
     for r in range(world):
         np.testing.assert_allclose(out[r][1], total, rtol=1e-6, atol=1e-6)
         assert out[r][2:] == (1, 2, 2, 0.5)
+
+
+def _worker_order(rank, world, port, q):
+    """Ranks complete their buckets in DIFFERENT orders (rank 1 the other way round, as a rank on the
+    per-layer autograd path would) and one bucket holds a `late` parameter: every rank must still issue
+    the same collectives in the same order - a bucket that completes early is held back - and the sum
+    must be exact (a mismatched order pairs buffers of different sizes: wrong sums or a hang)."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from edgedict_amd.dp import BucketedAllReduce
+    from edgedict_amd.optim import FlatParams
+    model = _model()
+    flat = FlatParams(model)
+    params = list(model.parameters())
+    red = BucketedAllReduce(flat, bucket_bytes=1 << 30, boundaries=[params[0], params[2], params[4]],
+                            min_bytes=4, late=[params[3]])
+    assert len(red.bounds) == 3
+    # bucket 0 = last Linear, 1 = middle (late: moved to the end), 2 = first
+    assert red.issue_order == [0, 2, 1]
+    issued = []
+    orig = red._issue
+
+    def spy(b):
+        issued.append(b)
+        orig(b)
+    red._issue = spy
+    g = torch.Generator().manual_seed(9 + rank)
+    flat.zero_grad()
+    for p in params:
+        p.grad.copy_(torch.randn(p.shape, generator=g))
+    mine = flat.grad.clone()
+    groups = [params[4:6], params[2:4], params[0:2]]
+    if rank == 1:
+        groups = groups[::-1]
+    held = []
+    for grp in groups:
+        red.ready(grp)
+        held.append(list(issued))
+    scale = red.finish()
+    q.put((rank, mine.numpy(), flat.grad.clone().numpy(), issued, held, scale))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_issue_order_is_rank_invariant():
+    world, port = 2, 33500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_order, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in range(world):
+        r = q.get(timeout=60)
+        out[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    import numpy as np
+    total = out[0][0] + out[1][0]
+    for r in range(world):
+        np.testing.assert_allclose(out[r][1], total, rtol=1e-6, atol=1e-6)
+        assert out[r][2] == [0, 2, 1]                 # the same order on both ranks
+    # rank 0 completes 0, 1 (late: held), 2 -> [0], [0], [0, 2, 1];  rank 1 completes 2 (held behind 0), 1, 0
+    assert out[0][3] == [[0], [0], [0, 2, 1]]
+    assert out[1][3] == [[], [], [0, 2, 1]]

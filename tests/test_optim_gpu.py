@@ -144,3 +144,36 @@ def test_train_step_matches_oracle_gradients_plus_torch_adam(hip_lib, gradclip, 
         assert (du - du_ref).abs().max().item() <= 2.0 * fl.lr * (1 + 1e-3), k
         zero = p.grad == 0                      # e.g. the PAD embedding row: no update at all
         assert (du[zero] == 0).all(), k
+
+
+def test_adam_step_is_skipped_on_the_device_when_a_give_up_word_is_set(hip_lib):
+    """Advisor r2: a step kernel of the encoder stack that gives up its bounded flag wait computes on a chunk
+    product that does not exist yet, and the trainer applied those gradients before anything raised.  The
+    trainer now hands the device-visible give-up words to the Adam kernel (edgedict_adam_step_guarded): with
+    a word set the update is skipped on the device (no host sync), the host raises at its next check and the
+    word is cleared by that read."""
+    import ctypes
+    from edgedict_amd import encoder_stack
+    from edgedict_amd.optim import FusedAdam
+    m = _flat_module([(4099,), (33, 7)], 3).cuda()
+    opt = FusedAdam(m, lr=1e-2)
+    dev_words = hip_lib.edgedict_stack_error_words(0)
+    host_words = hip_lib.edgedict_stack_error_words(1)
+    assert dev_words and host_words
+    encoder_stack.check_wsr_error()              # clear whatever an earlier test left
+    words = (ctypes.c_uint * 3).from_address(host_words)
+    opt.zero_grad()
+    for p in m.parameters():
+        p.grad.fill_(0.5)
+    before = opt.flat.data.clone()
+    words[2] = 503                               # "forward pass, launch slot 3 gave up"
+    opt.step(guard=dev_words)
+    torch.cuda.synchronize()
+    assert torch.equal(opt.flat.data, before)
+    assert float(opt.m.abs().max()) == 0.0 and float(opt.v.abs().max()) == 0.0
+    with pytest.raises(RuntimeError, match="gave up"):
+        encoder_stack.check_wsr_error()
+    assert words[2] == 0
+    opt.step(guard=dev_words)                    # the word is clear again: the update happens
+    torch.cuda.synchronize()
+    assert not torch.equal(opt.flat.data, before)
