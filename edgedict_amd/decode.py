@@ -87,6 +87,10 @@ def greedy_decode_batch(model, xs, xlen):
     state = init_search_state(model, xs.shape[0])
     tokens, score = run_search(model, enc_out.contiguous(), state, unk=-1, want_score=True)
     toks = tokens.cpu().numpy().astype(np.int64)
+    # the copy above synchronised: a bounded in-kernel wait of the encoder stack that gave up during THIS call
+    # has written its code by now (an inference call has no later step that would notice it)
+    from . import encoder_stack
+    encoder_stack.check_wsr_error()
     lens = xlen.cpu().numpy() if torch.is_tensor(xlen) else np.asarray(xlen)
     return [seq[:int(n)] for seq, n in zip(toks, lens)], score
 

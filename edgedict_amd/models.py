@@ -488,6 +488,7 @@ class _JointLossFn(torch.autograd.Function):
                 logits = ops.gemm(hid, w2c, bias=b2.detach())
             _lib.call("rnnt_loss_forward_packed", logits, _lib.dtype_code(cd), labels, al_d, ll_d, off_d,
                       B, T, U1, V, int(blank), costs, reduced, 1.0 / B, ws)
+        ops.LAST["joint_costs"] = costs       # per-utterance costs of the last packed joint + loss ([B], device)
         ctx.save_for_backward(enc2, dec2, w1, w2, hid, logits, labels, al_d, ll_d, off_d, ws)
         ctx.b1, ctx.b2 = b1, b2
         ctx.cfg = (cd, B, T, U1, P, P2, J, V, M, int(blank))

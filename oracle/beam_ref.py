@@ -28,8 +28,14 @@ from (:247); returned tokens exclude it.  Frames: an utterance of a batch uses t
 ``scale_length(T', xlen)`` encoder frames (rnnt/models.py:223-226); batch-1 with a full-length
 ``xlen`` is the reference's loop over every frame.
 
-PARITY STATUS: **unpinned** - the legacy method cannot run on torch 2.x (``volatile=True``
-Variables, the absent ``recurrent`` module) and the reference holds no test or fixture for it.
+PARITY STATUS: **pinned on the reference's own code, executed** (round 3).  oracle/make_golden_beam.py lifts
+``Transducer.beam_search``, ``Sequence`` and ``log_aplusb`` out of /root/reference/models.py:121-224 and
+runs them unmodified on a stub ``self`` backed by the reference's maintained ``rnnt.models`` sub-modules
+(on torch 2.10 ``autograd.Variable(..., volatile=True)`` merely warns; only the module FILE cannot be
+imported, for its absent ``recurrent`` dependency); for W = 1, 2, 4, 10 on the trained tiny model this
+restatement returns the same tokens and the same number of hypothesis expansions, and scores equal to 1e-6
+(``ref_*`` arrays of tests/golden/beam_tiny.npz; tests/test_oracle_beam.py).  The reference holds no
+fixture of its own for this method.
 """
 import numpy as np
 import torch

@@ -1,6 +1,8 @@
-"""GPU: batched beam search (csrc/decode.hip through Transducer.beam_search) against the oracle
-restatement of the reference's legacy beam search (oracle/beam_ref.py) on the committed trained
-tiny model, and on a random-weight model with ragged lengths."""
+"""GPU: batched beam search (csrc/decode.hip through Transducer.beam_search) against the vectors the
+REFERENCE's own legacy beam search returned when executed (``ref_*`` arrays of tests/golden/beam_tiny.npz,
+oracle/make_golden_beam.py: /root/reference/models.py:121-224 lifted and run on the reference's maintained
+sub-modules) on the committed trained tiny model, against the oracle restatement (oracle/beam_ref.py, pinned
+on the same vectors) there and on a random-weight model with ragged lengths."""
 import os
 
 import numpy as np
@@ -44,6 +46,11 @@ def test_beam_matches_committed_oracle_vectors(hip_lib, W):
     # summation order only
     np.testing.assert_allclose(scores.numpy(), G["W%d_score" % W], rtol=2e-4, atol=2e-4)
     assert decode.beam_search_batch.last_expansions == int(G["W%d_expansions" % W][0])
+    # ... and the reference's own code, executed: tokens and pops exactly
+    for b, s in enumerate(seqs):
+        assert np.array_equal(s, G["ref_W%d_seq%d" % (W, b)]), (W, b, s)
+    np.testing.assert_allclose(scores.numpy(), G["ref_W%d_score" % W], rtol=2e-4, atol=2e-4)
+    assert decode.beam_search_batch.last_expansions == int(G["ref_W%d_expansions" % W][0])
 
 
 def test_beam_random_model_ragged_batch_matches_oracle(hip_lib):

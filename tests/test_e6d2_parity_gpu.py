@@ -9,8 +9,16 @@ joint + RNN-T loss - and the fp32 parity mode are compared with
     float64 RNN-T gradient (oracle/rnnt_loss_ref.py) for EVERY parameter gradient.
 
 Tolerances: fp32 mode - loss 1e-5 relative (north-star bound 1e-3), gradients 2e-3 of each tensor's
-max; bf16 mode - loss 5e-3 relative, encoder outputs 2e-2 norm-relative, gradients 6e-2
-norm-relative per tensor (bf16 has 8 mantissa bits; six recurrent layers of 201-401 steps).
+max; bf16 mode - loss 1e-3 relative (the north-star bound; achieved 1e-4 or better), encoder outputs 2e-2
+norm-relative, gradients 6e-2 norm-relative per tensor (bf16 has 8 mantissa bits; six recurrent layers of
+201-401 steps); the achieved errors are printed (pytest -s) and asserted.
+
+`test_benched_geometry_b64_rows_equal_the_pinned_b2_run` pins the EXACT benched geometry (B = 64 x H = 1024:
+all four MFMA row tiles of the step kernels, every row group of the packed joint): the two reference-pinned
+E6D2 utterances are tiled to 64 rows in a shuffled order; every copy must reproduce its original's encoder
+output bit for bit (rows are independent in rnnt/models.py:55-75), its cost must match the golden one, and
+the parameter gradients of the mean loss - 32 copies of each utterance - must equal the B = 2 float64
+reference gradients.
 """
 import os
 
@@ -98,7 +106,7 @@ def test_bf16_benched_path_vs_reference_golden_and_fp64_gradients(hip_lib, name)
     assert any(k.startswith("enc_stack_fwd_T%d" % xs.shape[1]) for k in timers), sorted(timers)
     assert int(ops.LAST["joint_rows"]) == int((g["act_lens"].astype(np.int64) * (ylen.numpy() + 1)).sum())
     rel = abs(loss.item() - float(g["loss_mean"])) / float(g["loss_mean"])
-    assert rel < 5e-3, rel
+    assert rel < 1e-3, rel          # the north-star bound, in the throughput mode
     with torch.no_grad():
         enc, _ = m.encoder(xs.cuda())
     e = enc.float().cpu().numpy()[:, ::5, ::16]
@@ -108,7 +116,61 @@ def test_bf16_benched_path_vs_reference_golden_and_fp64_gradients(hip_lib, name)
     for n, p in m.named_parameters():
         worst[n] = _nrel(p.grad.cpu(), ref_grads[n])
     bad = {n: v for n, v in worst.items() if not v < 6e-2}
+    print("\n[%s bf16] loss rel err %.2e; encoder sample %.2e; gradient norm-relative errors: max %.2e (%s), "
+          "median %.2e" % (name, rel, r, max(worst.values()), max(worst, key=worst.get),
+                           float(np.median(list(worst.values())))))
     assert not bad, bad
+
+
+def test_benched_geometry_b64_rows_equal_the_pinned_b2_run(hip_lib):
+    from edgedict_amd import config, ops
+    cfg, sd, (xs, ys, xlen, ylen), g = _load("E6D2")
+    ref_loss, ref_grads = _fp64_reference("E6D2")
+    B = 64
+    idx = torch.tensor([0, 1] * (B // 2))[torch.randperm(B, generator=torch.Generator().manual_seed(5))]
+    n0 = int((idx == 0).sum())
+    XS, YS, XL, YL = xs[idx].contiguous(), ys[idx].contiguous(), xlen[idx].contiguous(), ylen[idx].contiguous()
+    assert int(XL.max()) == int(xlen.max()) and int(YL.max()) == int(ylen.max())
+    m = _engine(cfg, sd, "bf16")
+    ops.TIMERS = {}
+    try:
+        loss = m(XS.cuda(), YS.cuda(), XL, YL)
+        costs = ops.LAST["joint_costs"].float().cpu().numpy().copy()
+        loss.backward()
+        torch.cuda.synchronize()
+        timers = ops.timer_summary()
+    finally:
+        ops.TIMERS = None
+    assert any(k.startswith("enc_stack_fwd_T%d" % xs.shape[1]) for k in timers), sorted(timers)
+    # every copy's cost against the reference-pinned golden cost of its original
+    gold = g["costs"][idx.numpy()]
+    rel = np.abs(costs - gold) / np.abs(gold)
+    assert rel.max() < 1e-3, (rel.max(), int(rel.argmax()))
+    for u in (0, 1):                                   # copies of one utterance: identical arithmetic, identical cost
+        c = costs[idx.numpy() == u]
+        assert (c == c[0]).all(), (u, c)
+    with torch.no_grad():
+        enc, _ = m.encoder(XS.cuda())
+    enc = enc.float().cpu()
+    for u in (0, 1):
+        rows = torch.nonzero(idx == u).flatten()
+        first = enc[rows[0]]
+        for r in rows[1:]:
+            assert torch.equal(enc[r], first), (u, int(r))      # row tile / wave / LDS slot must not matter
+        e = first.numpy()[::5, ::16]
+        rr = np.linalg.norm(e - g["enc_out_sample"][u]) / np.linalg.norm(g["enc_out_sample"][u])
+        assert rr < 2e-2, (u, rr)
+    # mean over 64 rows = (n0 * cost_0 + (64 - n0) * cost_1) / 64: the gradient is that mix of the two
+    # utterances' gradients; with n0 = 32 it IS the pinned B = 2 gradient of the mean loss
+    assert n0 == B // 2
+    want = (n0 * g["costs"][0] + (B - n0) * g["costs"][1]) / B
+    assert abs(loss.item() - want) / want < 1e-3
+    if n0 == B // 2:
+        worst = {n: _nrel(p.grad.cpu(), ref_grads[n]) for n, p in m.named_parameters()}
+        print("\n[E6D2 B=64 tiled] cost rel err max %.2e; gradient norm-relative errors vs the B=2 float64 "
+              "reference: max %.2e (%s)" % (rel.max(), max(worst.values()), max(worst, key=worst.get)))
+        bad = {n: v for n, v in worst.items() if not v < 6e-2}
+        assert not bad, bad
 
 
 def test_bf16_stack_gradients_h1024_l6_short_sequence_vs_fp64(hip_lib):

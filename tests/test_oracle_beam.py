@@ -1,5 +1,7 @@
-"""CPU: the beam-search oracle (oracle/beam_ref.py) against its committed vectors
-(tests/golden/beam_tiny.npz, oracle/make_golden_beam.py) and structural properties of the search."""
+"""CPU: the beam-search oracle (oracle/beam_ref.py) against the vectors the REFERENCE's own legacy search
+produced when executed (``ref_*`` arrays of tests/golden/beam_tiny.npz: oracle/make_golden_beam.py lifts
+``Transducer.beam_search`` / ``Sequence`` / ``log_aplusb`` out of /root/reference/models.py:121-224 and runs
+them on the reference's maintained sub-modules), and structural properties of the search."""
 import os
 
 import numpy as np
@@ -25,6 +27,18 @@ def test_oracle_reproduces_committed_vectors(W):
         assert np.array_equal(s, G["W%d_seq%d" % (W, b)])
     np.testing.assert_allclose(scores, G["W%d_score" % W], rtol=1e-6)
     assert n == int(G["W%d_expansions" % W][0])
+
+
+@pytest.mark.parametrize("W", WIDTHS)
+def test_oracle_reproduces_the_reference_executed_search(W):
+    """tokens and the number of hypothesis expansions exactly, scores to 1e-6 (fp32 module arithmetic of the
+    reference vs the oracle's functional restatement, summed in fp64 on both sides)."""
+    sd, xs, xlen = load()
+    seqs, scores, n = beam_ref.beam_search(sd, xs, xlen, W=W)
+    for b, s in enumerate(seqs):
+        assert np.array_equal(s, G["ref_W%d_seq%d" % (W, b)])
+    np.testing.assert_allclose(scores, G["ref_W%d_score" % W], rtol=1e-6)
+    assert n == int(G["ref_W%d_expansions" % W][0])
 
 
 def test_score_is_the_log_probability_of_one_alignment():

@@ -61,3 +61,51 @@ def test_grad_rows_sum_to_zero_inside_and_vanish_outside():
     for b in range(acts.shape[0]):
         assert np.all(grads[b, al[b]:] == 0)
         assert np.all(grads[b, :, ll[b] + 1:] == 0)
+
+
+# ---------------------------------------------------------------------------------------------
+# the DP oracle against the DEFINITION of the loss: explicit enumeration of every monotone alignment
+# (oracle/rnnt_loss_bruteforce.py) - nothing of the alpha/beta recursion is shared
+def _tiny_case(seed, B, T, U1, V, blank_bias=0.0):
+    rng = np.random.default_rng(seed)
+    acts = 2.0 * rng.normal(size=(B, T, U1, V))
+    acts[..., 0] += blank_bias
+    labels = rng.integers(1, V, size=(B, max(U1 - 1, 1))).astype(np.int32)[:, :U1 - 1]
+    act_lens = rng.integers(1, T + 1, size=B).astype(np.int32)
+    label_lens = rng.integers(0, U1, size=B).astype(np.int32)
+    act_lens[0] = T
+    label_lens[0] = U1 - 1
+    return acts, labels, act_lens, label_lens
+
+
+def test_alignment_count_is_the_binomial():
+    from math import comb
+    from oracle import rnnt_loss_bruteforce as BF
+    for T in range(1, 6):
+        for U in range(0, 5):
+            assert sum(1 for _ in BF.alignments(T, U)) == comb(T + U - 1, U)
+
+
+def test_dp_oracle_equals_sum_over_all_alignments_cost_and_gradient():
+    from oracle import rnnt_loss_bruteforce as BF
+    n = 0
+    for T in (1, 2, 3, 4):
+        for U1 in (1, 2, 3, 4):
+            for V in (2, 3, 5):
+                for seed in range(2):
+                    acts, labels, al, ll = _tiny_case(100 * T + 10 * U1 + V + 1000 * seed, 3, T, U1, V,
+                                                      blank_bias=(0.0, 2.0)[seed])
+                    c_bf, g_bf = BF.rnnt_loss(acts, labels, al, ll)
+                    c_dp, g_dp = R.rnnt_loss(acts, labels, al, ll)
+                    np.testing.assert_allclose(c_dp, c_bf, rtol=0, atol=1e-11)
+                    np.testing.assert_allclose(g_dp, g_bf, rtol=0, atol=1e-11)
+                    n += 1
+    assert n == 96
+
+
+def test_bruteforce_reproduces_the_upstream_known_answer():
+    from oracle import rnnt_loss_bruteforce as BF
+    ka = R.KNOWN_ANSWER
+    c, g = BF.rnnt_loss(ka["acts"], ka["labels"], ka["act_lens"], ka["label_lens"])
+    assert abs(c[0] - ka["cost"]) < 2e-6
+    np.testing.assert_allclose(g, ka["grads"], atol=5e-7)

@@ -196,3 +196,22 @@ def test_fused_lse_epilogue_matches_separate_pass(hip_lib):
     _lib.call("rnnt_loss_forward_packed", lf.to(torch.bfloat16).cuda(), 1, labels, act_d, lab_d, off_d, B, T, U1,
               V, 0, costs, red, 1.0 / B, ws)
     assert ((costs.cpu() - cf).abs() <= 1e-6 * cf.abs()).all(), (costs.cpu(), cf)
+
+
+def test_hip_loss_equals_the_sum_over_all_alignments(hip_lib):
+    """The HIP kernels against the DEFINITION of the loss (oracle/rnnt_loss_bruteforce.py: every monotone
+    alignment enumerated, -log of the summed path probabilities, autograd gradient) on tiny ragged
+    lattices - no alpha/beta recursion on the checking side."""
+    from oracle import rnnt_loss_bruteforce as BF
+    for T, U1, V, seed in [(1, 1, 2, 0), (2, 3, 5, 1), (3, 2, 3, 2), (4, 4, 5, 3), (4, 3, 2, 4), (3, 4, 4, 5)]:
+        rng = np.random.default_rng(900 + seed)
+        B = 4
+        acts = (2.0 * rng.normal(size=(B, T, U1, V))).astype(np.float32)
+        labels = rng.integers(1, V, size=(B, max(U1 - 1, 1))).astype(np.int32)[:, :U1 - 1]
+        al = rng.integers(1, T + 1, size=B).astype(np.int32)
+        ll = rng.integers(0, U1, size=B).astype(np.int32)
+        al[0], ll[0] = T, U1 - 1
+        c_bf, g_bf = BF.rnnt_loss(acts.astype(np.float64), labels, al, ll)
+        loss, g = _run_hip(acts, np.ascontiguousarray(labels), al, ll, reduction="none")
+        np.testing.assert_allclose(loss, c_bf, rtol=2e-6, atol=2e-6)
+        np.testing.assert_allclose(g, g_bf, rtol=0, atol=5e-6)
