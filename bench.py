@@ -23,6 +23,12 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
+# test switches for the world > 1 body on a box with ONE GPU: EDGEDICT_BENCH_BACKEND=gloo moves the exchange
+# through the host, EDGEDICT_BENCH_SHARE_DEVICE=1 lets every rank drive device 0.  A line measured this way
+# says so ("exchange.backend", "rank_devices"); the driver's runs use neither.
+BACKEND = os.environ.get("EDGEDICT_BENCH_BACKEND", "nccl")
+SHARE_DEVICE = os.environ.get("EDGEDICT_BENCH_SHARE_DEVICE", "0") == "1"
+
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak (not the 2:1 sparse figure)
 MFMA_F32_PEAK_TF = 157.3
@@ -108,17 +114,24 @@ def cpu_baseline(flags, seconds, U, budget_s=25.0):
                       % (iters, B, seconds, U, getattr(flags, "preset_name", "E6D2"), best, ncpu)}
 
 
-def loss_delta(engine, flags, batch, n_utt=4):
-    """'RNN-T loss delta vs ref' (BASELINE.json metric) on the benched configuration, OUTSIDE the
-    timed region: the first ``n_utt`` utterances of the bench batch, the engine's current weights,
-    dither off / no SpecAugment / eval mode, through (a) the bf16 path that was timed, (b) the
-    engine's fp32 parity mode and (c) the CPU oracle (oracle/models_ref.py pinned on the
-    reference module + float64 RNN-T DP).  Returns relative errors of the mean loss."""
+def loss_delta(engine, flags, batch, rows=(0, 21, 42, 63)):
+    """'RNN-T loss delta vs ref' (BASELINE.json metric) on the benched configuration AT THE BENCHED GEOMETRY,
+    OUTSIDE the timed region: the WHOLE bench batch (B = 64: all four MFMA row tiles of the step kernels,
+    every row group of the packed joint) goes through (a) the bf16 path that was timed and (b) the engine's
+    fp32 parity mode with the engine's current weights, dither off / no SpecAugment / eval mode, and the
+    per-utterance costs of ``rows`` - one utterance per 16-row MFMA tile - are compared with (c) the CPU
+    oracle (oracle/models_ref.py pinned on the reference module + float64 RNN-T DP) run on exactly those
+    utterances (rows are independent in rnnt/models.py:55-75, so a 4-utterance oracle batch that contains the
+    longest utterance reproduces their costs).  Returns relative errors of the mean over those rows and the
+    per-row table."""
+    from edgedict_amd import ops
     from edgedict_amd.features import StackedLogFbank
     from oracle import models_ref as M
     from oracle import rnnt_loss_ref as R
     wave, wave_len, ys, ylen = batch
     dev = wave.device
+    B = wave.shape[0]
+    rows = sorted({min(B - 1, r) for r in rows} | {0})     # row 0 is the full-length utterance of synth_batch
     fb = StackedLogFbank(n_frame=flags.downsample, pad_to_divisible=True, out_dtype=torch.float32,
                          sample_rate=getattr(flags, "sample_rate", 16000), win_length=flags.win_length,
                          hop_length=flags.hop_length, n_fft=flags.n_fft, n_filt=flags.feature_size,
@@ -126,33 +139,152 @@ def loss_delta(engine, flags, batch, n_utt=4):
     model = engine.model
     was_training, cd0 = model.training, model.compute_dtype
     model.eval()
-    out = {}
+    out, costs = {}, {}
     try:
         with torch.no_grad():
-            xs, xlen = fb(wave[:n_utt], wave_len[:n_utt])
-            yl = ylen[:n_utt].clone()
+            xs, xlen = fb(wave, wave_len)
+            yl = ylen.clone()
             for name in ("bf16", "fp32"):
                 model.compute_dtype = name
-                out[name] = float(model(xs, ys[:n_utt], xlen, yl).item())
+                ops.LAST.pop("joint_costs", None)
+                out[name] = float(model(xs, ys, xlen, yl).item())
+                costs[name] = ops.LAST["joint_costs"].float().cpu().numpy().astype("float64")
             sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
-            xs_c, xlen_c, ys_c = xs.float().cpu(), xlen.cpu().to(torch.int32), ys[:n_utt].cpu()
+            ridx = torch.tensor(rows)
+            xs_c, xlen_c = xs.float().cpu()[ridx], xlen.cpu().to(torch.int32)[ridx]
+            ys_c, yl_c = ys.cpu()[ridx], yl[ridx]
             t0 = time.time()
-            logits, act = M.transducer_logits(sd, xs_c, ys_c, xlen_c, yl)
-            costs, _ = R.rnnt_loss(logits.double().numpy(), ys_c[:, :int(yl.max())].numpy(),
-                                   act.numpy(), yl.numpy(), want_grads=False)
-            ref = float(costs.mean())
+            logits, act = M.transducer_logits(sd, xs_c, ys_c, xlen_c, yl_c)
+            ref, _ = R.rnnt_loss(logits.double().numpy(), ys_c[:, :int(yl_c.max())].numpy(),
+                                 act.numpy(), yl_c.numpy(), want_grads=False)
             out["oracle_s"] = round(time.time() - t0, 2)
     finally:
         model.compute_dtype = cd0
         model.train(was_training)
-    return {"utterances": n_utt, "oracle_loss": ref, "engine_loss_bf16": out["bf16"],
-            "engine_loss_fp32": out["fp32"],
-            "loss_rel_err_bf16": abs(out["bf16"] - ref) / abs(ref),
-            "loss_rel_err_fp32": abs(out["fp32"] - ref) / abs(ref),
+    table = [{"row": int(r), "mfma_row_tile": int(r) // 16, "oracle": float(ref[i]),
+              "bf16": float(costs["bf16"][r]), "fp32": float(costs["fp32"][r]),
+              "rel_err_bf16": abs(float(costs["bf16"][r]) - float(ref[i])) / abs(float(ref[i])),
+              "rel_err_fp32": abs(float(costs["fp32"][r]) - float(ref[i])) / abs(float(ref[i]))}
+             for i, r in enumerate(rows)]
+    m_ref = float(ref.mean())
+    m_bf, m_fp = float(costs["bf16"][rows].mean()), float(costs["fp32"][rows].mean())
+    return {"utterances": len(rows), "batch": int(B), "rows": table,
+            "oracle_loss": m_ref, "engine_loss_bf16": m_bf, "engine_loss_fp32": m_fp,
+            "engine_batch_mean_bf16": out["bf16"], "engine_batch_mean_fp32": out["fp32"],
+            "loss_rel_err_bf16": abs(m_bf - m_ref) / abs(m_ref),
+            "loss_rel_err_fp32": abs(m_fp - m_ref) / abs(m_ref),
+            "max_row_rel_err_bf16": max(t["rel_err_bf16"] for t in table),
+            "max_row_rel_err_fp32": max(t["rel_err_fp32"] for t in table),
             "oracle_seconds": out["oracle_s"],
-            "note": "mean RNN-T loss of the first %d utterances of the bench batch, engine weights "
-                    "after the timed steps, vs the CPU oracle (reference-pinned model restatement + "
-                    "float64 loss); north-star bound 1e-3 relative in fp32" % n_utt}
+            "note": "the whole %d-utterance bench batch through the timed bf16 path and the fp32 parity mode "
+                    "(engine weights after the timed steps); per-utterance RNN-T costs of rows %s - one per "
+                    "16-row MFMA tile of the recurrence kernels - vs the CPU oracle (reference-pinned model "
+                    "restatement + float64 loss) on those utterances; north-star bound 1e-3 relative in fp32"
+                    % (B, rows)}
+
+
+# ---------------------------------------------------------------------------------------------------
+# secondary measurements (outside the timed region; each a few seconds): BASELINE configs 3 and 4 and the
+# decode rates, so that they appear in the DRIVER's record and not only in builder-run tools
+def stream_256(flags, device, S=256, n_chunks=40):
+    """BASELINE config 4: S concurrent streams through BatchedStreamDecoder (the rnnt/stream.py:78-120 loop,
+    batched), E6D2 model, bf16, reference-native chunk (win 1320 / hop 1200 samples = 75 ms).  Measured the
+    way the reference measures its own decoder (cli/openvino_wav_inference.py:29-46,107-110): samples
+    consumed per stream = win_length + chunks x hop_size, speed = samples / time / 16000 [audio-s/s]; its
+    README quotes 5.8 for the CPU batch-1 decoder."""
+    from edgedict_amd.flags import model_kwargs
+    from edgedict_amd.models import Transducer
+    from edgedict_amd.stream import BatchedStreamDecoder, chunk_geometry
+    torch.manual_seed(0)
+    m = Transducer(**model_kwargs(flags, vocab_size=flags.bpe_size)).to(device).eval()
+    m.compute_dtype = "bf16"
+    win, hop = chunk_geometry(flags, 2)
+    dec = BatchedStreamDecoder(m, flags, S)
+    wave = 0.1 * torch.randn(S, win + n_chunks * hop, device=device)
+    for c in range(3):
+        dec.decode(wave[:, c * hop:c * hop + win].contiguous())
+    dec.reset()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    frames = flags.win_length
+    for start in range(0, wave.shape[1] - win, hop):
+        frames += hop
+        toks = dec.decode(wave[:, start:start + win].contiguous())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"streams": S, "chunks": n_chunks, "chunk_ms": 1e3 * hop / 16000.0,
+            "encoder_frames_per_chunk": int(toks.shape[1]), "ms_per_chunk_step": 1e3 * dt / n_chunks,
+            "stream_chunks_per_s": S * n_chunks / dt, "audio_s_per_s": S * frames / dt / 16000.0,
+            "reference_readme_audio_s_per_s": 5.8, "dtype": "bf16",
+            "note": "BatchedStreamDecoder, E6D2, random weights, dither on; speed = S x (win_length + chunks x "
+                    "hop_size) / time / 16000 as cli/openvino_wav_inference.py:107-110 computes it"}
+
+
+def decode_rates(engine, flags, batch, device):
+    """Greedy decode of the bench batch (bf16 and fp32) with the engine's weights and the fraction of frames
+    whose bf16 token equals the fp32 (reference-exact, tests/test_models_gpu.py) token; W = 10 beam search on
+    a blank-dominant model (random weights pop ~V/2 hypotheses per frame; a trained model the minimum W,
+    tools/decode_bench.py)."""
+    import numpy as np
+    from edgedict_amd import decode
+    from edgedict_amd.features import StackedLogFbank
+    from edgedict_amd.flags import model_kwargs
+    from edgedict_amd.models import Transducer
+    wave, wave_len, ys, ylen = batch
+    B = wave.shape[0]
+    seconds = wave.shape[1] / 16000.0
+    fb = StackedLogFbank(n_frame=flags.downsample, pad_to_divisible=True, out_dtype=torch.float32,
+                         sample_rate=getattr(flags, "sample_rate", 16000), win_length=flags.win_length,
+                         hop_length=flags.hop_length, n_fft=flags.n_fft, n_filt=flags.feature_size,
+                         dither=0.0).to(device)
+    model = engine.model
+    was_training, cd0 = model.training, model.compute_dtype
+    model.eval()
+    res = {}
+    try:
+        with torch.no_grad():
+            xs, xlen = fb(wave, wave_len)
+            toks = {}
+            for name, reps in (("fp32", 1), ("bf16", 3)):
+                model.compute_dtype = name
+                toks[name], _ = model.greedy_decode(xs, xlen)       # warm-up + the tokens
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    model.greedy_decode(xs, xlen)
+                torch.cuda.synchronize()
+                dt = (time.perf_counter() - t0) / reps
+                res["greedy_decode_" + name] = {"utterances_per_s": B / dt, "ms_per_batch": 1e3 * dt,
+                                                "x_real_time": B * seconds / dt, "batch": B}
+            same = sum(int((a == b).sum()) for a, b in zip(toks["bf16"], toks["fp32"]))
+            total = sum(len(a) for a in toks["fp32"])
+            nonblank = sum(int((a != 0).sum()) for a in toks["fp32"])
+            res["bf16_greedy_agreement"] = {
+                "frames": total, "equal": same, "fraction": same / max(1, total),
+                "nonblank_fraction_fp32": nonblank / max(1, total),
+                "utterances_identical": sum(int(np.array_equal(a, b)) for a, b in zip(toks["bf16"], toks["fp32"])),
+                "note": "greedy tokens (blanks included) of the bench batch, bf16 throughput mode vs fp32 parity mode "
+                        "(the mode pinned bit-exactly on the reference), engine weights after the timed steps"}
+    finally:
+        model.compute_dtype = cd0
+        model.train(was_training)
+    torch.manual_seed(0)
+    m = Transducer(**model_kwargs(flags, vocab_size=flags.bpe_size)).to(device).eval()
+    m.compute_dtype = "bf16"
+    with torch.no_grad():
+        m.joint.joint[2].bias[0] += 12.0
+        m.beam_search(xs, xlen, W=10)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.beam_search(xs, xlen, W=10)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    n = decode.beam_search_batch.last_expansions
+    res["beam_search_W10"] = {"utterances_per_s": B / dt, "ms_per_batch": 1e3 * dt, "expansions": int(n),
+                              "us_per_lockstep_iteration": 1e6 * dt / max(1, n / B), "dtype": "bf16",
+                              "note": "blank-dominant random model (joint blank bias +12): every frame costs the minimum "
+                                      "of W hypothesis expansions, as a trained model does"}
+    return res
 
 
 def self_spawn(args):
@@ -162,6 +294,8 @@ def self_spawn(args):
     import socket
     import subprocess
     n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if SHARE_DEVICE and n_dev >= 1:
+        n_dev = args.gpus          # test mode: every rank drives device 0 (tests/test_bench_cli.py)
     if n_dev < args.gpus:
         raise SystemExit("bench.py: --gpus %d requested but %d HIP device(s) are visible; refusing to "
                          "report a smaller job as n_gpus=%d" % (args.gpus, n_dev, args.gpus))
@@ -192,6 +326,9 @@ def main():
                     help="route NO product to hipBLASLt (EDGEDICT_BLASLT=0, _BG=0, _SMALL=0)")
     ap.add_argument("--no-own-kernels-run", action="store_true",
                     help="skip the second, shorter run that fills value_own_kernels")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary measurements (E6D2_LARGE_Batch step, 256-stream decode, greedy / beam "
+                         "decode rates, bf16 greedy agreement)")
     ap.add_argument("--no-fp32-run", action="store_true",
                     help="skip the short fp32 parity-mode run that fills the secondary field fp32_parity_mode")
     args = ap.parse_args()
@@ -207,6 +344,8 @@ def main():
         raise SystemExit("bench.py: WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
+    if SHARE_DEVICE:
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit("bench.py: LOCAL_RANK %d but only %d HIP device(s) visible"
                          % (local_rank, torch.cuda.device_count()))
@@ -217,7 +356,7 @@ def main():
     side.stream(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(BACKEND, rank=rank, world_size=world)
 
     from edgedict_amd import ops
     from edgedict_amd.flags import make_flags
@@ -254,6 +393,24 @@ def main():
     dt = time.perf_counter() - t0
     timers = ops.timer_summary()
     ops.TIMERS = None
+    left_early = engine.reducer.last_issued_early
+    # world > 1: the SAME K steps once more with every bucket sent after the backward pass
+    # (EDGEDICT_DP_OVERLAP=0), so that one multi-GPU run answers DESIGN 7's open question - RCCL's kernels
+    # are concurrent "loud" work beside the launch-bound BPTT; `value` above is the default (overlapped) mode
+    if world > 1:
+        was = engine.reducer.overlap
+        engine.reducer.overlap = not was
+        engine.train_step(*batch)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            engine.train_step(*batch)
+        barrier()
+        dt_other = time.perf_counter() - t1
+        engine.reducer.overlap = was
+        t2 = torch.tensor([dt_other], dtype=torch.float64, device=device)
+        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        dt_other = float(t2.item())
     from edgedict_amd import encoder_stack as _es
     _es.check_wsr_error()        # no bounded in-kernel wait gave up during the timed steps (host word, after the sync)
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -372,8 +529,15 @@ def main():
             # gradient exchange: buckets of the flat fp32 gradient buffer and how many of them were handed
             # to RCCL from INSIDE the backward pass (per encoder layer, as its weight gradients became final)
             "exchange": {"buckets": len(engine.reducer.bounds),
-                         "left_during_backward": engine.reducer.last_issued_early,
-                         "bytes": 4 * engine.flat.numel} if world > 1 else None,
+                         "left_during_backward": left_early,
+                         "bytes": 4 * engine.flat.numel, "backend": BACKEND,
+                         "overlap_default": bool(engine.reducer.overlap),
+                         ("ms_per_step_overlap" if engine.reducer.overlap else "ms_per_step_after_backward"):
+                             1e3 * dt / args.steps,
+                         ("ms_per_step_after_backward" if engine.reducer.overlap else "ms_per_step_overlap"):
+                             1e3 * dt_other / args.steps,
+                         "semantics": "sum over ranks, x 1/N inside the Adam kernel (cli/lightning.py:325-331: "
+                                      "DDP mean)"} if world > 1 else None,
             "rank_devices": devices,
             "steps": args.steps,
             "warmup": args.warmup,
@@ -421,7 +585,7 @@ def main():
             # hand-written kernels, a second, shorter run in a fresh process
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), "--own-kernels-only", "--no-cpu-baseline",
-                   "--no-loss-delta", "--steps", str(min(args.steps, 12)), "--warmup", "3",
+                   "--no-loss-delta", "--no-secondary", "--steps", str(min(args.steps, 12)), "--warmup", "3",
                    "--preset", args.preset, "--batch", str(args.batch), "--seconds", str(args.seconds),
                    "--labels", str(args.labels), "--dtype", args.dtype]
             try:
@@ -438,7 +602,7 @@ def main():
             # the 1e-3 loss bound is stated for), 3 steps in a fresh process
             import subprocess
             cmd = [sys.executable, os.path.abspath(__file__), "--dtype", "fp32", "--steps", "3", "--warmup", "1",
-                   "--no-cpu-baseline", "--no-loss-delta", "--no-own-kernels-run", "--preset", args.preset,
+                   "--no-cpu-baseline", "--no-loss-delta", "--no-own-kernels-run", "--no-secondary", "--preset", args.preset,
                    "--batch", str(args.batch), "--seconds", str(args.seconds), "--labels", str(args.labels)]
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
@@ -447,6 +611,31 @@ def main():
                                            "steps": sub["steps"], "dtype": "fp32"}
             except Exception as exc:      # noqa: BLE001 - the headline number must not depend on this
                 out["fp32_parity_mode"] = {"error": repr(exc)[:200]}
+        if world == 1 and args.dtype == "bf16" and not args.no_secondary and not args.own_kernels_only:
+            import subprocess
+            # BASELINE config 3's per-GPU share: the E6D2_LARGE_Batch model (hop 320, prediction net 2x512 with
+            # dropout 0.1) on this GPU's 64 utterances, the same full training step, in a fresh process
+            cmd = [sys.executable, os.path.abspath(__file__), "--preset", "E6D2_LARGE_Batch", "--steps", "12",
+                   "--warmup", "3", "--no-cpu-baseline", "--no-loss-delta", "--no-own-kernels-run", "--no-fp32-run",
+                   "--no-secondary", "--batch", str(args.batch), "--seconds", str(args.seconds),
+                   "--labels", str(args.labels)]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                sub = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                out["E6D2_LARGE_Batch"] = {"value": sub["value"], "unit": sub["unit"], "ms_per_step": sub["ms_per_step"],
+                                           "steps": sub["steps"], "dtype": sub["dtype"],
+                                           "workload": sub["config"]["workload"],
+                                           "note": "BASELINE config 3's per-GPU share (global batch 512 = 8 x 64)"}
+            except Exception as exc:      # noqa: BLE001 - the headline number must not depend on this
+                out["E6D2_LARGE_Batch"] = {"error": repr(exc)[:200]}
+            try:
+                out["stream_256"] = stream_256(flags, device)
+            except Exception as exc:      # noqa: BLE001
+                out["stream_256"] = {"error": repr(exc)[:200]}
+            try:
+                out.update(decode_rates(engine, flags, batch, device))
+            except Exception as exc:      # noqa: BLE001
+                out["decode_rates_error"] = repr(exc)[:200]
         if not args.no_loss_delta:
             ld = loss_delta(engine, flags, batch)
             out["loss_delta_vs_ref"] = ld

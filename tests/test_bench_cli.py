@@ -43,3 +43,40 @@ def test_launcher_world_size_must_match_gpus_flag():
     assert r.returncode != 0
     assert not _json_lines(r.stdout)
     assert "WORLD_SIZE" in (r.stderr + r.stdout)
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+@pytest.mark.timeout(900)
+def test_world2_body_of_bench_runs_on_one_gpu_over_gloo():
+    """Every line of bench.py's `world > 1` body (process-group init, parameter broadcast, the bucketed
+    exchange leaving from inside the backward pass, barrier + max-over-ranks timing, the rank/device census,
+    the second timed pass with the exchange after the backward pass, the `exchange` record) executes here
+    before an 8-GPU driver runs it for the first time: two ranks, both on device 0
+    (EDGEDICT_BENCH_SHARE_DEVICE=1), gloo transport instead of RCCL (a one-GPU box cannot host a 2-rank RCCL
+    communicator), launched exactly as the driver launches N > 1 - through torch.distributed.run."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(EDGEDICT_BENCH_BACKEND="gloo", EDGEDICT_BENCH_SHARE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+           "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16", "--seconds", "5", "--labels", "20"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=840)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout[-2000:]              # rank 0 only
+    out = lines[0]
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["rank_devices"] == [0, 0]
+    assert out["config"]["global_batch"] == 32 and out["scaling"] == "weak"
+    ex = out["exchange"]
+    assert ex["backend"] == "gloo" and ex["buckets"] >= 8 and ex["bytes"] > 2e8
+    # the joint's and the encoder layers' buckets left from inside the backward pass (grads_final path)
+    assert ex["left_during_backward"] >= 7, ex
+    assert ex["ms_per_step_overlap"] > 0 and ex["ms_per_step_after_backward"] > 0
+    assert abs(out["ms_per_step"] - ex["ms_per_step_overlap"]) < 1e-6      # `value` is the default (overlapped) mode
+    assert out["value"] > 0 and out["roofline"] is not None
