@@ -332,11 +332,12 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                             float b1, float b2, float omb1, float omb2, float eps, float bc1, float bc2,
                             float weight_decay, float grad_scale_host,
                             const float* __restrict__ grad_scale,
-                            bf16_t* __restrict__ p_bf16, const unsigned* skip_words, int n_skip) {
+                            bf16_t* __restrict__ p_bf16, const unsigned* __restrict__ skip) {
     // guard (edgedict_adam_step_guarded): a bounded in-kernel wait of this step's encoder stack gave up, so
-    // its gradients are garbage - leave p, m, v untouched; the host raises at its next check of the word
-    for (int k = 0; k < n_skip; ++k)
-        if (__hip_atomic_load(skip_words + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) != 0u) return;
+    // its gradients are garbage - leave p, m, v untouched; the host raises at its next check of the word.
+    // `skip` is a DEVICE word filled by guard_fetch_kernel just before this launch (the give-up words live in
+    // pinned host memory: reading them from every workgroup here cost 0.3-1 ms per step over PCIe).
+    if (skip && *skip != 0u) return;
     const float gs = grad_scale_host * (grad_scale ? *grad_scale : 1.f);
     const float step = lr / bc1;
     const float inv_sqrt_bc2 = rsqrtf(bc2);
@@ -352,6 +353,15 @@ __global__ void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
         pi -= step * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
         p[i] = pi;
         if (p_bf16) p_bf16[i] = f32_to_bf16(pi);
+    }
+}
+
+// scratch[0] = OR of the n device-visible (host-pinned) give-up words: one lane, n PCIe reads
+__global__ void guard_fetch_kernel(const unsigned* words, int n, unsigned* scratch) {
+    if (threadIdx.x == 0) {
+        unsigned any = 0u;
+        for (int k = 0; k < n; ++k) any |= __hip_atomic_load(words + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        *scratch = any;
     }
 }
 
@@ -596,11 +606,17 @@ extern "C" int edgedict_adam_step_guarded(float* p, const float* g, float* m, fl
                                           float lr, float beta1, float beta2, float eps, int step,
                                           float weight_decay, float grad_scale_host,
                                           const float* grad_scale, void* p_bf16,
-                                          const unsigned* skip_words, int n_skip, void* stream_) {
+                                          const unsigned* skip_words, int n_skip, unsigned* guard_scratch,
+                                          void* stream_) {
     ED_CHECK_ARG(n >= 0 && step >= 1, "adam_step: bad size/step");
     if (n == 0) return ED_OK;
     ED_CHECK_ARG(p && g && m && v, "adam_step: null pointer");
-    ED_CHECK_ARG(n_skip >= 0 && n_skip <= 16 && (n_skip == 0 || skip_words), "adam_step_guarded: bad guard words");
+    ED_CHECK_ARG(n_skip >= 0 && n_skip <= 16 && (n_skip == 0 || (skip_words && guard_scratch)),
+                 "adam_step_guarded: bad guard words / scratch");
+    if (n_skip > 0) {
+        hipLaunchKernelGGL(guard_fetch_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream_, skip_words, n_skip, guard_scratch);
+        ED_CHECK_LAUNCH("guard_fetch_kernel");
+    }
     // torch.optim.Adam works out 1 - beta and 1 - beta^step in DOUBLE from the Python floats and only
     // then rounds to fp32; the betas arrive here as fp32 images of decimal literals, and 1.f - 0.999f
     // differs from (float)(1 - 0.999) by 1.3e-5 relative (it shows in exp_avg_sq).  Recover the decimal
@@ -611,7 +627,7 @@ extern "C" int edgedict_adam_step_guarded(float* p, const float* g, float* m, fl
     const float bc2 = (float)(1.0 - pow(b2d, (double)step));
     hipLaunchKernelGGL(adam_kernel, dim3(ed_grid_for(n, 256 * 4, 256 * 8)), dim3(256), 0,
                        (hipStream_t)stream_, p, g, m, v, n, lr, beta1, beta2, omb1, omb2, eps, bc1, bc2,
-                       weight_decay, grad_scale_host, grad_scale, (bf16_t*)p_bf16, skip_words, n_skip);
+                       weight_decay, grad_scale_host, grad_scale, (bf16_t*)p_bf16, n_skip > 0 ? guard_scratch : nullptr);
     ED_CHECK_LAUNCH("adam_step");
     return ED_OK;
 }
@@ -621,7 +637,7 @@ extern "C" int edgedict_adam_step(float* p, const float* g, float* m, float* v, 
                                   float weight_decay, float grad_scale_host,
                                   const float* grad_scale, void* p_bf16, void* stream_) {
     return edgedict_adam_step_guarded(p, g, m, v, n, lr, beta1, beta2, eps, step, weight_decay, grad_scale_host,
-                                      grad_scale, p_bf16, nullptr, 0, stream_);
+                                      grad_scale, p_bf16, nullptr, 0, nullptr, stream_);
 }
 
 extern "C" int edgedict_grad_clip_coef(const float* g, long long n, float max_norm,

@@ -61,6 +61,7 @@ class FusedAdam:
         self._sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._coef = torch.ones(1, dtype=torch.float32, device=dev)
         self.grad_norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self._guard_scratch = torch.zeros(1, dtype=torch.int32, device=dev)   # device copy of the give-up words
         # state_dict-compatible handle for schedulers that poke param_groups[0]['lr']
         self.param_groups = [{"lr": lr, "params": self.flat.params}]
 
@@ -83,7 +84,7 @@ class FusedAdam:
         call("adam_step_guarded", self.flat.data, self.flat.grad, self.m, self.v, _ll(self.flat.numel),
              float(self.lr), float(self.betas[0]), float(self.betas[1]), float(self.eps),
              int(self.step_count), float(self.weight_decay), float(grad_scale), coef, None,
-             ctypes.c_void_p(guard or 0), 3 if guard else 0)
+             ctypes.c_void_p(guard or 0), 3 if guard else 0, self._guard_scratch if guard else None)
         config.bump_param_epoch()
 
     def state_dict(self):

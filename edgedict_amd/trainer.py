@@ -82,7 +82,8 @@ class TrainEngine:
         # device-visible give-up words of the encoder stack's bounded in-kernel waits: the Adam kernel skips
         # its update when one is set (advisor r2: bad gradients were applied before anything raised)
         self._guard = None
-        if self.device.type == "cuda":
+        import os
+        if self.device.type == "cuda" and os.environ.get("EDGEDICT_ADAM_GUARD", "1") != "0":
             from . import _lib
             with torch.cuda.device(self.device):
                 self._guard = _lib.load().edgedict_stack_error_words(0)

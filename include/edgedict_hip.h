@@ -411,13 +411,16 @@ int edgedict_adam_step(float* p, const float* g, float* m, float* v, long long n
                        float beta1, float beta2, float eps, int step, float weight_decay,
                        float grad_scale_host, const float* grad_scale, void* p_bf16, void* stream);
 /* The same step, skipped entirely (p, m, v untouched) when any of the n_skip (<= 16) device-visible words
- * at skip_words is non-zero when the kernel starts: the trainer passes edgedict_stack_error_words(), so the
- * gradients of a step whose encoder stack gave up a bounded in-kernel wait are never applied - without a
- * host synchronisation; the host raises at its next edgedict_stack_wsr_error(). */
+ * at skip_words is non-zero: the trainer passes edgedict_stack_error_words(0), so the gradients of a step
+ * whose encoder stack gave up a bounded in-kernel wait are never applied - without a host synchronisation;
+ * the host raises at its next edgedict_stack_wsr_error().  The words live in pinned host memory: a one-lane
+ * kernel ORs them into guard_scratch[0] (caller-owned DEVICE word) right before the update, which reads
+ * only that word (reading the host words from every workgroup cost 0.3-1 ms per step). */
 int edgedict_adam_step_guarded(float* p, const float* g, float* m, float* v, long long n, float lr,
                                float beta1, float beta2, float eps, int step, float weight_decay,
                                float grad_scale_host, const float* grad_scale, void* p_bf16,
-                               const unsigned* skip_words, int n_skip, void* stream);
+                               const unsigned* skip_words, int n_skip, unsigned* guard_scratch,
+                               void* stream);
 int edgedict_grad_clip_coef(const float* g, long long n, float max_norm, float pre_scale,
                             float* sumsq_ws, float* coef, float* norm_out, void* stream);
 
