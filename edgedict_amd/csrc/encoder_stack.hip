@@ -663,6 +663,189 @@ int forward_wsr(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
     return ED_OK;
 }
 
+// Forward pass with the launch-persistent step kernel (stack_kernels.hip, stack_fwd_lpw_kernel): the
+// wavefront schedule of edgedict_stack_forward in MACRO-steps of `nsub` consecutive time steps.  Launch w
+// carries, for every runnable layer, the next `nsub` steps of that layer (never across a chunk boundary); the
+// layers' workgroups keep W_hh in registers for the launch and meet step by step through arrival counters.
+// After the launch the side stream normalises the frames each layer finished (ONE launch for all layers) and,
+// for a layer whose chunk is now complete, multiplies it into the next layer's gates and sets that chunk's
+// flag.  Runnable = the chunk the macro-step opens was enqueued at least `margin` launches ago; layers behind
+// a time reduction are paced by launch parity while a faster layer runs (Pace), and a launch holds at most
+// one workgroup per CU (max_slots).  Called with the prologue done and the internal streams forked.
+int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Streams& st, const WsLayout& wl,
+                int nsub, bool soft) {
+    const int B = d->B, H = d->H, L = d->L;
+    const long long BH = (long long)B * H;
+    char* ws = (char*)d->ws;
+    unsigned* fflag = reinterpret_cast<unsigned*>(ws + wl.wsr_sync);           // [8][512] chunk flags
+    unsigned* cnt = fflag + 2 * 8 * 512;                                       // [8] arrival counters (after the backward's flags)
+    unsigned* gerr = (st.rt && st.rt->wsr_err_dev) ? st.rt->wsr_err_dev + 2 : nullptr;
+    for (int l = 0; l < L; ++l) ED_CHECK_ARG(g[l].nchunks <= 512, "encoder_stack: too many chunks for the flag table");
+    ED_DEV(ed_stack_zero(fflag, (size_t)8 * 512 * sizeof(unsigned), st.C));
+    ED_DEV(ed_stack_zero(cnt, (size_t)16 * sizeof(unsigned), st.C));
+    ED_TRY(st.chain(st.C, st.R));
+    for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.C, st.S[l]));
+    const int WGS = (H >> 4) * ((B + 63) >> 6);
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return n;
+    }();
+    const int max_slots = max(1, min(ED_STACK_MAX_SLOTS, (g_trace ? 256 : n_cu) / WGS));
+    const char* e_m = getenv("EDGEDICT_LPW_MARGIN");
+    const int margin = (e_m && atoi(e_m) > 0) ? atoi(e_m) : 2;
+
+    std::vector<std::vector<hipEvent_t>> Eg(L);
+    std::vector<std::vector<char>> queued(L);
+    for (int l = 0; l < L; ++l) {
+        Eg[l].assign(g[l].nchunks, nullptr);
+        queued[l].assign(g[l].nchunks, 0);
+    }
+    int next_g0 = 0;
+    auto feed_layer0 = [&](int upto) -> int {
+        for (; next_g0 < g[0].nchunks && next_g0 <= upto; ++next_g0) {
+            ED_DEV(input_gemm(d, g, 0, next_g0, st.S[0]));
+            if (g_trace) g_trace->chunk_enqueued[g_trace->coff[0] + next_g0] = g_trace->launches;
+            if (soft) ED_DEV(ed_stack_set_flag(fflag + next_g0, st.S[0]));
+            else ED_TRY(st.record(Eg[0][next_g0], st.S[0]));
+            queued[0][next_g0] = 1;
+        }
+        return ED_OK;
+    };
+    ED_TRY(feed_layer0(1));
+    std::vector<int> next_t(L, 0);
+    std::vector<std::vector<int>> ready_w(L);
+    for (int l = 0; l < L; ++l) ready_w[l].assign(g[l].nchunks, l == 0 ? 0 : 0x3fffffff);
+    int launches = 0, idle = 0;
+    if (st.rt) st.rt->stamp_used[0] = 0;
+    if (st.rt && st.rt->tev[0][0]) ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][0], st.R));
+    const int T_out = (g[L - 1].T + d->layers[L - 1].reduce - 1) / d->layers[L - 1].reduce;
+    struct Ran { int l, t0, t1; };
+    for (int w = 0;; ++w) {
+        bool finished = true;
+        for (int l = 0; l < L; ++l) finished = finished && next_t[l] >= g[l].T;
+        if (finished) break;
+        EdLpwLaunch Lc;
+        Lc.nslot = 0;
+        Lc.B = B;
+        Lc.H = H;
+        Ran ran[ED_STACK_MAX_SLOTS];
+        for (int l = 0; l < L; ++l) {
+            const edgedict_stack_layer_t& y = d->layers[l];
+            const int t = next_t[l];
+            if (t >= g[l].T || Lc.nslot >= max_slots) continue;
+            const int k = t / g[l].cf;
+            const bool opens = (t % g[l].cf == 0);
+            if (opens && l > 0 && !(queued[l][k] && w >= ready_w[l][k])) continue;
+            int m_min = g[l].m;
+            for (int j = 0; j < l; ++j)
+                if (next_t[j] < g[j].T) m_min = min(m_min, g[j].m);
+            if (!Pace::allows(w, l, g[l].m, m_min)) continue;
+            if (opens) {
+                if (l == 0) ED_TRY(feed_layer0(k + 2));
+                ED_CHECK_ARG(queued[l][k], "encoder_stack: schedule violated (layer %d chunk %d)", l, k);
+                if (!soft) ED_TRY(st.wait(st.R, Eg[l][k]));
+            }
+            const int t1 = min(t + nsub, min(g[l].T, (k + 1) * g[l].cf));    // never across a chunk boundary
+            EdLpwSlot& sl = Lc.slot[Lc.nslot];
+            sl.G = bptr(y.G) + (long long)t * B * 4 * H;
+            sl.img[0] = bptr(ws + wl.frag0[l]);
+            sl.img[1] = bptr(ws + wl.frag1[l]);
+            sl.Y = bptr(y.Yx) + (long long)(t + 1) * BH;
+            sl.C_prev = y.Cx + (long long)t * BH;
+            sl.C = y.Cx + (long long)(t + 1) * BH;
+            sl.Wfrag = bptr(y.whh_f);
+            sl.counter = cnt + l;
+            sl.base = (unsigned)WGS * (unsigned)t;
+            sl.wait_flag = (soft && opens) ? fflag + l * 512 + k : nullptr;
+            sl.t0 = t;
+            sl.nsteps = t1 - t;
+            ran[Lc.nslot].l = l;
+            ran[Lc.nslot].t0 = t;
+            ran[Lc.nslot].t1 = t1;
+            ++Lc.nslot;
+            next_t[l] = t1;
+            if (g_trace)
+                for (int tt = t; tt < t1; ++tt) g_trace->step_launch[g_trace->toff[l] + tt] = g_trace->launches;
+        }
+        if (Lc.nslot == 0) {
+            ED_CHECK_ARG(++idle < 4096, "encoder_stack: forward schedule made no progress");
+            continue;
+        }
+        idle = 0;
+        ++launches;
+        Lc.stamp = st.rt ? st.rt->stamp_slot(0, st.R) : nullptr;
+        Lc.err = gerr;
+        ED_DEV(ed_stack_launch_fwd_lpw(Lc, st.R));
+        if (g_trace) {
+            g_trace->max_slots = max(g_trace->max_slots, Lc.nslot);
+            ++g_trace->launches;
+        }
+        // ---- side stream: LayerNorm of what this launch finished, then the products of completed chunks
+        hipStream_t S = st.S[0];
+        ED_TRY(st.chain(st.R, S));
+        EdChunkNorm items[ED_STACK_MAX_SLOTS];
+        for (int i = 0; i < Lc.nslot; ++i) {
+            const int l = ran[i].l;
+            const edgedict_stack_layer_t& y = d->layers[l];
+            EdChunkNorm& e = items[i];
+            e.Yx1 = bptr(y.Yx) + BH;
+            e.X = y.residual ? bptr(y.X) : nullptr;
+            e.gamma = y.ln_gamma;
+            e.beta = y.ln_beta;
+            if (l + 1 < L) {
+                e.out = bptr(d->layers[l + 1].X);
+                e.out_st = BH;
+                e.out_sb = H;
+            } else {
+                e.out = bptr(d->out);
+                e.out_st = H;
+                e.out_sb = (long long)T_out * H;
+            }
+            e.mean = y.mean;
+            e.rstd = y.rstd;
+            e.T = y.T;
+            e.t0 = ran[i].t0;
+            e.t1 = ran[i].t1;
+            e.reduce = y.reduce;
+        }
+        ED_DEV(ed_stack_multi_norm(items, Lc.nslot, B, H, d->eps, S));
+        for (int i = 0; i < Lc.nslot; ++i) {
+            const int l = ran[i].l, k = ran[i].t0 / g[l].cf;
+            if (l + 1 >= L || ran[i].t1 != min(g[l].T, (k + 1) * g[l].cf)) continue;
+            ED_DEV(input_gemm(d, g, l + 1, k, S));
+            if (g_trace) g_trace->chunk_enqueued[g_trace->coff[l + 1] + k] = g_trace->launches;
+            if (soft) ED_DEV(ed_stack_set_flag(fflag + (l + 1) * 512 + k, S));
+            else ED_TRY(st.record(Eg[l + 1][k], S));
+            queued[l + 1][k] = 1;
+            ready_w[l + 1][k] = w + margin;
+        }
+    }
+    if (st.rt && st.rt->tev[0][1]) {
+        ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][1], st.R));
+        st.rt->tlaunches[0] = launches;
+    }
+    ED_TRY(st.chain(st.R, st.C));
+    for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.S[l], st.C));
+    return ED_OK;
+}
+
+// steps per launch of the launch-persistent forward for this geometry (0 = use the launch-per-step kernels):
+// a divisor of the chunk, even when a layer halves the frame rate (its LayerNorm pairs frames)
+int lpw_steps(const edgedict_stack_desc_t* d) {
+    // read on every call (two getenv per forward pass): tests switch the path inside one process
+    const char* e_on = getenv("EDGEDICT_STACK_LPW");
+    const char* e_n = getenv("EDGEDICT_LPW_STEPS");
+    const int on = e_on ? atoi(e_on) : 0, want = e_n ? atoi(e_n) : 6;
+    if (!on || !ed_stack_lpw_supported(d->B, d->H) || (d->flags & EDGEDICT_STACK_WSR)) return 0;
+    bool reduces = false;
+    for (int l = 0; l < d->L; ++l) reduces = reduces || d->layers[l].reduce == 2;
+    int ns = max(1, min(want, d->chunk));
+    while (ns > 1 && (d->chunk % ns != 0 || (reduces && (ns & 1)))) --ns;
+    if (reduces && (ns & 1)) return 0;
+    return ns;
+}
+
 }  // namespace
 
 extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stream_) {
@@ -720,6 +903,7 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     // (layer, chunk) in the workspace's sync region, zeroed before the streams fork
     static const int soft_env = [] { const char* e = getenv("EDGEDICT_STACK_SOFT_WAIT"); return e ? atoi(e) : 1; }();
     const bool soft = soft_env && !st.serial && L <= 8;
+    if (const int ns = lpw_steps(d)) return forward_lpw(d, g, st, wl, ns, soft);
     unsigned* fflag = reinterpret_cast<unsigned*>(ws + wl.wsr_sync);           // [8][512]
     unsigned* gerr = (st.rt && st.rt->wsr_err_dev) ? st.rt->wsr_err_dev + 2 : nullptr;
     if (soft) {

@@ -371,6 +371,252 @@ __global__ __launch_bounds__(256, ED_FWD_OCC) void stack_fwd_kernel(EdFwdLaunch 
     }
 }
 
+// =====================================================================================
+// forward, launch-persistent (EdLpwLaunch): `nsteps` consecutive time steps per launch.
+//
+// Why: with one launch per time step a step costs a dependent kernel boundary (1.7-3.6 us) plus the
+// re-fetch of the workgroup's W_hh slice (128 KB) on top of the h image (128 KB): 11-12 us of kernel,
+// 14.6 us of period, of which the recurrence itself needs the h exchange, 128 MFMA per wave and the cell
+// update.  Here a workgroup owns the same (layer, 16 hidden units, 64 rows) for `nsteps` steps:
+//   * its W_hh slice is loaded ONCE per launch into 128 registers per lane (wave w: k-quarter w, all 4 gates),
+//   * its cell state c stays in LDS between steps,
+//   * the only per-step global traffic on the dependency chain is the h fragment image: written with
+//     write-through (sc1) stores, every writing wave drains, ONE lane bumps the layer's arrival counter;
+//     readers poll that counter (one lane, relaxed) and read the image with L2-served (sc1) loads - the
+//     recipe of cdna_hip_programming.md G16 / wsr_kernels.hip,
+//   * everything a LATER kernel reads (gates for the backward pass, h rows for the LayerNorm, c rows) leaves
+//     after the publish, off the chain, with plain stores.
+// The arithmetic - MFMA order per wave, order of the cross-wave sum, cell math - is that of fwd_step_role,
+// so the results are bit-identical to the launch-per-step kernel (tests/test_lpw_gpu.py).
+// Co-residency: the grid is at most one workgroup per CU (the scheduler limits the slots); a workgroup that
+// is not resident yet just delays its layer's counter; every spin is bounded (give-up code 700 + slot).
+// =====================================================================================
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
+constexpr int LPW_PER = 8;     // k-steps of 32 per wave held in registers: H <= 1024
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t lpw_rsrc(const void* p, unsigned bytes) {
+    const unsigned long long a = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
+    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)bytes, 0x00020000);
+}
+
+__global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
+    __shared__ FwdShared sh;
+    if (L.stamp && threadIdx.x == 0) atomicMin(&L.stamp[0], wall_clock64());
+    const int B = L.B, H = L.H;
+    const int UB = H >> 4, RG = (B + 63) >> 6, WGS = UB * RG;
+    const int slot = blockIdx.x / WGS, rem = blockIdx.x - slot * WGS;
+    const int ub = rem % UB, rg = rem / UB;
+    const EdLpwSlot& S = L.slot[slot];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int KS = H >> 5, per = (KS + 3) >> 2;
+    const int ks_beg = wave * per, ks_end = min(KS, ks_beg + per);
+    const int MT = (B + 15) >> 4, mt0 = rg * 4, row0 = rg * 64;
+    const long long H4 = 4ll * H, BH = (long long)B * H;
+
+    // ---- stationary weights: this wave's K quarter of the slice, all 4 gates
+    bf16x8_t w[LPW_PER][4];
+    {
+        const bf16_t* wbase = S.Wfrag + ((long long)ub * 4 * KS * 64 + lane) * 8;
+#pragma unroll
+        for (int i = 0; i < LPW_PER; ++i) {
+            const int ks = min(ks_beg + i, KS - 1);          // clamp: duplicates are masked below
+#pragma unroll
+            for (int g = 0; g < 4; ++g) w[i][g] = ldfrag(wbase + ((long long)ks * 4 + g) * 512);
+        }
+    }
+    if (S.wait_flag) soft_wait(S.wait_flag, L.err, 500u + slot);
+
+    // ---- epilogue operands of the first step
+    uint4 gin[2];
+    float4 cin = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int id = tid + 256 * i, r = id >> 3, part = id & 7, b = row0 + r;
+        gin[i] = make_uint4(0, 0, 0, 0);
+        if (b < B) gin[i] = *reinterpret_cast<const uint4*>(S.G + b * H4 + ub * 64 + part * 8);
+    }
+    {
+        const int r = tid >> 2, part = tid & 3, b = row0 + r;
+        if (b < B) cin = *reinterpret_cast<const float4*>(S.C_prev + (long long)b * H + ub * 16 + part * 4);
+    }
+    const unsigned img_bytes = (unsigned)KS * MT * 1024u;
+    const __amdgpu_buffer_rsrc_t r0 = lpw_rsrc(S.img[0], img_bytes), r1 = lpw_rsrc(S.img[1], img_bytes);
+    __shared__ unsigned bail_s;
+    if (tid == 0) bail_s = 0u;
+
+    for (int s = 0; s < S.nsteps; ++s) {
+        const int t = S.t0 + s;
+        // ---- (1) every workgroup of this layer has published h_{t-1}
+        if (s > 0 && tid == 0) {
+            const unsigned want = S.base + (unsigned)(WGS * s);
+            unsigned spins = 0;
+            while (__hip_atomic_load(S.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 21)) {                  // ~ a second: a peer never became resident
+                    if (L.err) atomicCAS(L.err, 0u, 700u + slot);
+                    bail_s = 1u;
+                    break;
+                }
+            }
+        }
+        __syncthreads();      // also: the previous step's trailing stores have read the LDS staging tiles
+        if (bail_s) break;
+        // ---- (2) h_{t-1} fragments of this wave's K quarter, L2-served (never a stale L1 line)
+        bf16x8_t a[LPW_PER][4];
+        {
+            const __amdgpu_buffer_rsrc_t rin = (t & 1) ? r1 : r0;
+#pragma unroll
+            for (int i = 0; i < LPW_PER; ++i) {
+                const int ks = min(ks_beg + i, KS - 1);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    if (ks_beg + i < ks_end && mt0 + m < MT) {
+                        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(
+                            rin, (unsigned)(((ks * MT + mt0 + m) * 64 + lane) * 16), 0, 16);
+                        a[i][m] = *reinterpret_cast<const bf16x8_t*>(&v);
+                    } else {
+                        a[i][m] = zfrag();
+                    }
+                }
+            }
+        }
+        // ---- (3) W_hh h_{t-1}, two row tiles at a time (32 accumulator registers instead of 64: with the 128
+        // weight registers the kernel has to stay under 368 so that a chunk-product workgroup of 144
+        // registers per lane fits beside it on the CU), (4) partial tiles to their owners (wave m owns row
+        // tile m) as soon as a pair is done
+        f32x4_t mine[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) mine[g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4_t acc[2][4];
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[mm][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < LPW_PER; ++i) {
+                if (ks_beg + i < ks_end) {
+#pragma unroll
+                    for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g)
+                            acc[mm][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][half * 2 + mm], w[i][g], acc[mm][g], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm) {
+                const int m = half * 2 + mm;
+                if (m != wave) {
+                    const int sl = m < wave ? m : m - 1;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        sh.hand[wave][sl][g][lane] = make_float4(acc[mm][g][0], acc[mm][g][1], acc[mm][g][2], acc[mm][g][3]);
+                } else {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) mine[g] = acc[mm][g];
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + 256 * i, r = id >> 3, part = id & 7;
+            *reinterpret_cast<uint4*>(&sh.g[r][part * 8]) = gin[i];
+        }
+        if (s == 0) *reinterpret_cast<float4*>(&sh.c[tid >> 2][(tid & 3) * 4]) = cin;   // later steps: c_t is there
+        __syncthreads();
+#pragma unroll
+        for (int src = 0; src < 4; ++src) {
+            if (src != wave) {
+                const int sl = wave < src ? wave : wave - 1;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 v = sh.hand[src][sl][g][lane];
+                    mine[g][0] += v.x; mine[g][1] += v.y; mine[g][2] += v.z; mine[g][3] += v.w;
+                }
+            }
+        }
+        // ---- (5) cell update: lane owns unit u of rows wave*16 + (lane>>4)*4 + q
+        {
+            const int u = lane & 15, rbase = wave * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rl = rbase + q;
+                const float ig = fsigmoid(bf16_to_f32(sh.g[rl][u]) + mine[0][q]);
+                const float fg = fsigmoid(bf16_to_f32(sh.g[rl][16 + u]) + mine[1][q]);
+                const float gg = ftanh(bf16_to_f32(sh.g[rl][32 + u]) + mine[2][q]);
+                const float og = fsigmoid(bf16_to_f32(sh.g[rl][48 + u]) + mine[3][q]);
+                const float c = fg * sh.c[rl][u] + ig * gg;
+                const float h = og * ftanh(c);
+                sh.g[rl][u] = f32_to_bf16(ig);
+                sh.g[rl][16 + u] = f32_to_bf16(fg);
+                sh.g[rl][32 + u] = f32_to_bf16(gg);
+                sh.g[rl][48 + u] = f32_to_bf16(og);
+                sh.c[rl][u] = c;
+                sh.h[rl][u] = f32_to_bf16(h);
+            }
+        }
+        __syncthreads();
+        // ---- (6) publish FIRST: this workgroup's slice of the next image (128 write-through 16-byte stores),
+        // every storing wave drains, one lane arrives
+        if (tid < 128) {
+            const int m = tid >> 5, kg2 = (tid >> 4) & 1, r16 = tid & 15;
+            const int mt = mt0 + m;
+            if (mt < MT) {
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (mt * 16 + r16 < B) v = *reinterpret_cast<const uint4*>(&sh.h[m * 16 + r16][kg2 * 8]);
+                const int ks = ub >> 1, kg = (ub & 1) * 2 + kg2;
+                const u32x4_t vv = {v.x, v.y, v.z, v.w};
+                __builtin_amdgcn_raw_buffer_store_b128(vv, (t & 1) ? r0 : r1,
+                                                       (unsigned)((((ks * MT + mt) * 64) + kg * 16 + r16) * 16), 0, 16);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(S.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- (7) off the chain: gates (for the backward pass), h rows (LayerNorm), c rows; next step's
+        // pre-activations into registers
+        {
+            bf16_t* G_t = S.G + (long long)s * B * H4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int task = tid + 256 * i, r = task >> 3, part = task & 7, b = row0 + r;
+                if (b < B)
+                    *reinterpret_cast<uint4*>(G_t + b * H4 + ub * 64 + part * 8) =
+                        *reinterpret_cast<const uint4*>(&sh.g[r][part * 8]);
+            }
+            if (tid < 128) {
+                const int r = tid >> 1, hf = tid & 1, b = row0 + r;
+                if (b < B)
+                    *reinterpret_cast<uint4*>(S.Y + (long long)s * BH + (long long)b * H + ub * 16 + hf * 8) =
+                        *reinterpret_cast<const uint4*>(&sh.h[r][hf * 8]);
+            }
+            {
+                const int r = tid >> 2, part = tid & 3, b = row0 + r;
+                if (b < B)
+                    *reinterpret_cast<float4*>(S.C + (long long)s * BH + (long long)b * H + ub * 16 + part * 4) =
+                        *reinterpret_cast<const float4*>(&sh.c[r][part * 4]);
+            }
+            if (s + 1 < S.nsteps) {
+                const bf16_t* G_n = G_t + (long long)B * H4;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int id = tid + 256 * i, r = id >> 3, part = id & 7, b = row0 + r;
+                    gin[i] = make_uint4(0, 0, 0, 0);
+                    if (b < B) gin[i] = *reinterpret_cast<const uint4*>(G_n + b * H4 + ub * 64 + part * 8);
+                }
+            }
+        }
+    }
+    if (L.stamp) {
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(&L.stamp[1], wall_clock64());
+    }
+}
+
+
 // LayerNorm of the frames [t0, t1) one layer has finished (weights-stationary path: the recurrence
 // kernel carries whole chunks, so the norm of a chunk is its own small launch on the side stream):
 // one workgroup per (output frame, 4 batch rows), same arithmetic as the norm role above.
@@ -386,9 +632,9 @@ struct ChunkNormArgs {
     int B, H, T, t0, reduce;
     float eps;
 };
-__global__ __launch_bounds__(256) void stack_chunk_norm_kernel(ChunkNormArgs a) {
+__device__ __forceinline__ void chunk_norm_body(const ChunkNormArgs& a, int bid) {
     const int RB = (a.B + 3) >> 2;
-    const int fo = blockIdx.x / RB, rb = blockIdx.x % RB;
+    const int fo = bid / RB, rb = bid % RB;
     const long long BH = (long long)a.B * a.H;
     EdFwdNorm p;
     int ta, tb = -1;
@@ -412,6 +658,20 @@ __global__ __launch_bounds__(256) void stack_chunk_norm_kernel(ChunkNormArgs a) 
     p.rstd1 = tb >= 0 ? a.rstd + (long long)tb * a.B : nullptr;
     p.scale = a.reduce == 1 ? 1.f : 0.5f;
     fwd_norm_role(p, rb, a.B, a.H, a.eps);
+}
+__global__ __launch_bounds__(256) void stack_chunk_norm_kernel(ChunkNormArgs a) { chunk_norm_body(a, blockIdx.x); }
+
+// the frames several layers finished in ONE launch-persistent launch, normalised by one launch (the side
+// stream then carries one norm launch per recurrence launch instead of one per layer)
+struct MultiNormArgs {
+    ChunkNormArgs a[ED_STACK_MAX_SLOTS];
+    int first[ED_STACK_MAX_SLOTS + 1];     // first workgroup of item i
+    int n;
+};
+__global__ __launch_bounds__(256) void stack_multi_norm_kernel(MultiNormArgs M) {
+    int i = 0;
+    while (i + 1 < M.n && (int)blockIdx.x >= M.first[i + 1]) ++i;
+    chunk_norm_body(M.a[i], (int)blockIdx.x - M.first[i]);
 }
 
 // =====================================================================================
@@ -831,6 +1091,45 @@ int ed_stack_chunk_norm(const bf16_t* Yx1, const bf16_t* X, const float* gamma, 
     const int frames_out = reduce == 1 ? t1 - t0 : (t1 - t0 + 1) / 2;
     hipLaunchKernelGGL(stack_chunk_norm_kernel, dim3(frames_out * ((B + 3) >> 2)), dim3(256), 0, s, a);
     ED_CHECK_LAUNCH("stack_chunk_norm_kernel");
+    return ED_OK;
+}
+
+int ed_stack_multi_norm(const EdChunkNorm* items, int n, int B, int H, float eps, hipStream_t s) {
+    if (n <= 0) return ED_OK;
+    ED_CHECK_ARG(n <= ED_STACK_MAX_SLOTS, "stack_multi_norm: too many items");
+    MultiNormArgs M;
+    int grid = 0;
+    M.n = 0;
+    for (int i = 0; i < n; ++i) {
+        const EdChunkNorm& e = items[i];
+        if (e.t1 <= e.t0) continue;
+        ChunkNormArgs& a = M.a[M.n];
+        a.Yx1 = e.Yx1; a.X = e.X; a.gamma = e.gamma; a.beta = e.beta; a.out = e.out; a.out_st = e.out_st;
+        a.out_sb = e.out_sb; a.mean = e.mean; a.rstd = e.rstd; a.B = B; a.H = H; a.T = e.T; a.t0 = e.t0;
+        a.reduce = e.reduce; a.eps = eps;
+        M.first[M.n] = grid;
+        const int frames_out = e.reduce == 1 ? e.t1 - e.t0 : (e.t1 - e.t0 + 1) / 2;
+        grid += frames_out * ((B + 3) >> 2);
+        ++M.n;
+    }
+    M.first[M.n] = grid;
+    if (grid == 0) return ED_OK;
+    hipLaunchKernelGGL(stack_multi_norm_kernel, dim3(grid), dim3(256), 0, s, M);
+    ED_CHECK_LAUNCH("stack_multi_norm_kernel");
+    return ED_OK;
+}
+
+int ed_stack_lpw_supported(int B, int H) {
+    const int UB = H >> 4, RG = (B + 63) >> 6;
+    return (H % 32 == 0 && (H >> 5) <= 4 * LPW_PER && UB * RG <= 256) ? 1 : 0;
+}
+
+int ed_stack_launch_fwd_lpw(const EdLpwLaunch& L, hipStream_t s) {
+    const int UB = L.H >> 4, RG = (L.B + 63) >> 6;
+    const int grid = L.nslot * UB * RG;
+    if (grid == 0) return ED_OK;
+    hipLaunchKernelGGL(stack_fwd_lpw_kernel, dim3(grid), dim3(256), 0, s, L);
+    ED_CHECK_LAUNCH("stack_fwd_lpw_kernel");
     return ED_OK;
 }
 

@@ -67,6 +67,45 @@ struct EdBwdLaunch {
     unsigned* err;               // as EdFwdLaunch::err
 };
 
+// ---- launch-persistent wavefront (stack_kernels.hip, stack_fwd_lpw_kernel): ONE launch carries `nsteps`
+// CONSECUTIVE time steps of every runnable layer.  A workgroup keeps its W_hh slice in registers and its
+// cell state in LDS for the whole launch; between two steps the layer's workgroups meet through an arrival
+// counter and exchange h through the fragment images with write-through stores / L2-served loads.
+struct EdLpwSlot {
+    bf16_t* G;                 // step t0: [B, 4H] interleaved (in pre-activations, out gates); step t0+s at + s*B*4H
+    bf16_t* img[2];            // h fragment images [H/32][B16/16][64][8]: step t reads img[t & 1], writes img[(t & 1) ^ 1]
+    bf16_t* Y;                 // h rows of step t0 [B, H]; step t0+s at + s*B*H
+    const float* C_prev;       // c_{t0-1} [B, H]
+    float* C;                  // c rows of step t0; step t0+s at + s*B*H
+    const bf16_t* Wfrag;       // W_hh B-fragment image (EdFwdStep::Wfrag)
+    unsigned* counter;         // arrivals of this layer's workgroups, one per finished step (zeroed per call)
+    unsigned base;             // *counter once every step < t0 is done = workgroups_per_step * (steps done before)
+    const unsigned* wait_flag; // null, or: step t0 opens a chunk whose side-stream product is done when != 0
+    int t0, nsteps;
+};
+struct EdLpwLaunch {
+    EdLpwSlot slot[ED_STACK_MAX_SLOTS];
+    int nslot;
+    int B, H;
+    unsigned long long* stamp;   // as EdFwdLaunch::stamp
+    unsigned* err;               // host-visible give-up word (may be null)
+};
+int ed_stack_launch_fwd_lpw(const EdLpwLaunch& L, hipStream_t s);
+// LayerNorm (+ residual, + pair mean under time reduction) of frames [t0, t1) of up to 8 layers in one launch
+struct EdChunkNorm {
+    const bf16_t* Yx1;         // h_t at Yx1 + t * B * H
+    const bf16_t* X;           // residual rows (time-major) or null
+    const float* gamma;
+    const float* beta;
+    bf16_t* out;               // frame tau, row b at out + tau * out_st + b * out_sb
+    long long out_st, out_sb;
+    float* mean;
+    float* rstd;
+    int T, t0, t1, reduce;
+};
+int ed_stack_multi_norm(const EdChunkNorm* items, int n, int B, int H, float eps, hipStream_t s);
+int ed_stack_lpw_supported(int B, int H);     // 1 when the launch-persistent forward kernel covers this geometry
+
 // ---- weights-stationary recurrence (wsr_kernels.hip): ONE launch carries a chunk of frames of every
 // runnable layer; a layer lives on the 32 CUs of one XCD with W_hh in registers (H = 1024, B <= 64)
 struct EdWsrSlot {

@@ -1,0 +1,82 @@
+"""GPU: the launch-persistent forward of the encoder stack (csrc/stack_kernels.hip stack_fwd_lpw_kernel +
+forward_lpw in csrc/encoder_stack.hip; EDGEDICT_STACK_LPW=1) against the launch-per-step kernels.
+
+One launch carries several CONSECUTIVE time steps of every runnable layer; workgroups keep W_hh in registers,
+meet through arrival counters and exchange h with write-through stores / L2-served loads inside the launch.
+The arithmetic is the step kernel's, so EVERYTHING must be bit-identical: outputs, final states, the saved
+gates / cell states (checked through the weight gradients the unchanged backward pass computes from them).
+A stale read of another workgroup's h, a missed counter or a wrong image parity shows up as a mismatch.
+Reference arithmetic: ResLayerNormLSTM.forward rnnt/models.py:55-75."""
+import os
+
+import pytest
+import torch
+
+from test_encoder_stack_gpu import CASES, _encoder, _run
+
+pytestmark = pytest.mark.gpu
+
+
+def _with_env(fn, **env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _same(a, b, exact_bias=False):
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    for n in a[3]:
+        if "norm" in n or "projs" in n or "bias" in n:   # column sums use fp32 atomics
+            scale = max(a[3][n].abs().max().item(), 1e-6)
+            assert (a[3][n] - b[3][n]).abs().max().item() <= 1e-4 * scale, n
+        else:
+            assert torch.equal(a[3][n], b[3][n]), n
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("steps", [2, 4])
+def test_lpw_forward_is_bit_identical_to_the_step_kernels(hip_lib, case, steps):
+    from edgedict_amd import encoder_stack
+    chunk = 4 if case[6] < 4 else case[6]        # the steps per launch divide the chunk
+    enc, xs = _encoder(case)
+    ref = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk, lag=case[7]), EDGEDICT_STACK_LPW=0)
+    got = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk, lag=case[7]),
+                    EDGEDICT_STACK_LPW=1, EDGEDICT_LPW_STEPS=steps)
+    ser = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=encoder_stack.SERIAL, chunk=chunk, lag=case[7]),
+                    EDGEDICT_STACK_LPW=1, EDGEDICT_LPW_STEPS=steps)
+    _same(ref, got)
+    _same(ref, ser)
+    encoder_stack.check_wsr_error()
+
+
+def test_lpw_forward_e6d2_full_size_bit_identical_and_carried_state(hip_lib):
+    """BASELINE config 2's encoder (B = 64, T0 = 401, 6 x 1024, 2x time reduction): 4 layer slots of 64
+    workgroups fill the chip, 6 steps per launch; then chunked evaluation with carried state."""
+    from edgedict_amd import config, encoder_stack
+    case = (64, 401, 240, 1024, 6, [1], 12, 0)
+    enc, xs = _encoder(case)
+    ref = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=12), EDGEDICT_STACK_LPW=0)
+    got = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=12), EDGEDICT_STACK_LPW=1, EDGEDICT_LPW_STEPS=6)
+    assert got[0].shape == (64, 201, 24)
+    assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]) and torch.equal(ref[2], got[2])
+    for n in ref[3]:
+        if "weight_ih" in n or "weight_hh" in n:
+            assert torch.equal(ref[3][n], got[3][n]), n
+    encoder_stack.check_wsr_error()
+
+    def chunked():
+        enc.compute_dtype = torch.bfloat16
+        with torch.no_grad():
+            full, (hf, cf) = enc(xs[:8])
+            y1, (h1, c1) = enc(xs[:8, :200])
+            y2, (h2, c2) = enc(xs[:8, 200:], (h1, c1))
+        return full, hf, cf, torch.cat([y1, y2], 1), h2, c2
+    full, hf, cf, cat, h2, c2 = _with_env(chunked, EDGEDICT_STACK_LPW=1, EDGEDICT_LPW_STEPS=6)
+    assert torch.equal(cat, full) and torch.equal(h2, hf) and torch.equal(c2, cf)
