@@ -760,6 +760,7 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
             sl.wait_flag = (soft && opens) ? fflag + l * 512 + k : nullptr;
             sl.t0 = t;
             sl.nsteps = t1 - t;
+            sl.layer = l;
             ran[Lc.nslot].l = l;
             ran[Lc.nslot].t0 = t;
             ran[Lc.nslot].t1 = t1;
@@ -776,6 +777,7 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
         ++launches;
         Lc.stamp = st.rt ? st.rt->stamp_slot(0, st.R) : nullptr;
         Lc.err = gerr;
+        Lc.trace = g_wsr_trace;      // debug buffer registered with edgedict_stack_wsr_set_trace (normally null)
         ED_DEV(ed_stack_launch_fwd_lpw(Lc, st.R));
         if (g_trace) {
             g_trace->max_slots = max(g_trace->max_slots, Lc.nslot);

@@ -446,6 +446,20 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
     __shared__ unsigned bail_s;
     if (tid == 0) bail_s = 0u;
 
+    // debug trace (tools/lpw_trace.py): the first workgroup of every slot accumulates, per phase, the 100 MHz
+    // ticks its lane 0 spent: [0] wait for the peers, [1] h loads + MFMA, [2] hand-off + cell update,
+    // [3] publish + drain, [4] arrive, [5] trailing stores; [6] steps, [7] launches
+    const bool tr = L.trace != nullptr && rem == 0 && tid == 0;
+    long long ph[6] = {0, 0, 0, 0, 0, 0};
+    long long last_ = tr ? wall_clock64() : 0;
+#define LPW_STAMP(i)                                  \
+    do {                                              \
+        if (tr) {                                     \
+            const long long now_ = wall_clock64();    \
+            ph[i] += now_ - last_;                    \
+            last_ = now_;                             \
+        }                                             \
+    } while (0)
     for (int s = 0; s < S.nsteps; ++s) {
         const int t = S.t0 + s;
         // ---- (1) every workgroup of this layer has published h_{t-1}
@@ -463,6 +477,7 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
         }
         __syncthreads();      // also: the previous step's trailing stores have read the LDS staging tiles
         if (bail_s) break;
+        LPW_STAMP(0);
         // ---- (2) h_{t-1} fragments of this wave's K quarter, L2-served (never a stale L1 line)
         bf16x8_t a[LPW_PER][4];
         {
@@ -520,6 +535,7 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
                 }
             }
         }
+        LPW_STAMP(1);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int id = tid + 256 * i, r = id >> 3, part = id & 7;
@@ -559,6 +575,7 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
             }
         }
         __syncthreads();
+        LPW_STAMP(2);
         // ---- (6) publish FIRST: this workgroup's slice of the next image (128 write-through 16-byte stores),
         // every storing wave drains, one lane arrives
         if (tid < 128) {
@@ -575,7 +592,9 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        LPW_STAMP(3);
         if (tid == 0) __hip_atomic_fetch_add(S.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        LPW_STAMP(4);
         // ---- (7) off the chain: gates (for the backward pass), h rows (LayerNorm), c rows; next step's
         // pre-activations into registers
         {
@@ -609,6 +628,14 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
                 }
             }
         }
+        LPW_STAMP(5);
+    }
+#undef LPW_STAMP
+    if (tr) {
+        long long* o = L.trace + S.layer * 8;
+        for (int i = 0; i < 6; ++i) atomicAdd((unsigned long long*)(o + i), (unsigned long long)ph[i]);
+        atomicAdd((unsigned long long*)(o + 6), (unsigned long long)S.nsteps);
+        atomicAdd((unsigned long long*)(o + 7), 1ull);
     }
     if (L.stamp) {
         __syncthreads();

@@ -82,6 +82,7 @@ struct EdLpwSlot {
     unsigned base;             // *counter once every step < t0 is done = workgroups_per_step * (steps done before)
     const unsigned* wait_flag; // null, or: step t0 opens a chunk whose side-stream product is done when != 0
     int t0, nsteps;
+    int layer;                 // for the debug trace only
 };
 struct EdLpwLaunch {
     EdLpwSlot slot[ED_STACK_MAX_SLOTS];
@@ -89,6 +90,7 @@ struct EdLpwLaunch {
     int B, H;
     unsigned long long* stamp;   // as EdFwdLaunch::stamp
     unsigned* err;               // host-visible give-up word (may be null)
+    long long* trace;            // debug (nullable): per-slot phase times of workgroup 0, see tools/lpw_trace.py
 };
 int ed_stack_launch_fwd_lpw(const EdLpwLaunch& L, hipStream_t s);
 // LayerNorm (+ residual, + pair mean under time reduction) of frames [t0, t1) of up to 8 layers in one launch
