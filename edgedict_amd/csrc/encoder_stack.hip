@@ -200,6 +200,8 @@ constexpr int LNB_GRID_TOP = 512;   // ... of the top layer's all-frames call
 
 struct WsLayout {
     std::vector<size_t> frag0, frag1, dC, lnpart;   // per layer
+    std::vector<size_t> himg;                       // per layer: one h fragment image per frame (launch-persistent forward)
+    size_t himg_stride = 0;
     size_t tmpW = 0, tmpB = 0, dX0 = 0, wsr_sync = 0, total = 0;
 };
 constexpr size_t WSR_SYNC_BYTES = 64 * 1024;   // [0] give-up code, [16..24) layer counters, [64..) 8 tickets per launch
@@ -233,6 +235,13 @@ WsLayout ws_layout(const edgedict_stack_desc_t* d) {
     w.tmpB = off; off += align256((size_t)4 * d->H * sizeof(float));
     w.dX0 = off; off += align256((size_t)d->T0 * d->B * d->I0 * sizeof(bf16_t));
     w.wsr_sync = off; off += WSR_SYNC_BYTES;
+    // one h image per frame and layer (stack_kernels.hpp EdLpwSlot::img): (T + 1) x B16 x H bf16 - 51 MB for an
+    // E6D2 layer at 15 s; 288 GB of HBM is what makes "never write an address twice" affordable
+    w.himg_stride = align256(B16 * d->H * sizeof(bf16_t));
+    for (int l = 0; l < d->L; ++l) {
+        w.himg.push_back(off);
+        off += (size_t)(d->layers[l].T + 1) * w.himg_stride;
+    }
     w.total = off;
     return w;
 }
@@ -749,8 +758,9 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
             const int t1 = min(t + nsub, min(g[l].T, (k + 1) * g[l].cf));    // never across a chunk boundary
             EdLpwSlot& sl = Lc.slot[Lc.nslot];
             sl.G = bptr(y.G) + (long long)t * B * 4 * H;
-            sl.img[0] = bptr(ws + wl.frag0[l]);
-            sl.img[1] = bptr(ws + wl.frag1[l]);
+            sl.img = bptr(ws + wl.himg[l]);
+            sl.img_stride = (long long)wl.himg_stride;
+            sl.img_bytes = (long long)(y.T + 1) * (long long)wl.himg_stride;
             sl.Y = bptr(y.Yx) + (long long)(t + 1) * BH;
             sl.C_prev = y.Cx + (long long)t * BH;
             sl.C = y.Cx + (long long)(t + 1) * BH;
@@ -881,10 +891,11 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     // ---- prologue on the caller's stream: input LayerNorm (-> X_0, time-major), initial states
     ED_DEV(ed_stack_input_norm(d->x_dtype, d->x, d->in_gamma, d->in_beta, bptr(d->layers[0].X),
                                d->in_mean, d->in_rstd, B, d->T0, d->I0, d->eps, st.C));
+    const int lpw_ns = wsr_applicable(d) ? 0 : lpw_steps(d);
     for (int l = 0; l < L; ++l) {
         const edgedict_stack_layer_t& y = d->layers[l];
         ED_DEV(ed_stack_init_state(d->h0 ? d->h0 + l * BH : nullptr, d->c0 ? d->c0 + l * BH : nullptr,
-                                   bptr(y.Yx), y.Cx, bptr(ws + wl.frag0[l]), B, H, st.C));
+                                   bptr(y.Yx), y.Cx, bptr(ws + (lpw_ns ? wl.himg[l] : wl.frag0[l])), B, H, st.C));
     }
     ED_TRY(st.chain(st.C, st.R));
     if (st.R2 != st.R) ED_TRY(st.chain(st.C, st.R2));
@@ -905,7 +916,7 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     // (layer, chunk) in the workspace's sync region, zeroed before the streams fork
     static const int soft_env = [] { const char* e = getenv("EDGEDICT_STACK_SOFT_WAIT"); return e ? atoi(e) : 1; }();
     const bool soft = soft_env && !st.serial && L <= 8;
-    if (const int ns = lpw_steps(d)) return forward_lpw(d, g, st, wl, ns, soft);
+    if (lpw_ns) return forward_lpw(d, g, st, wl, lpw_ns, soft);
     unsigned* fflag = reinterpret_cast<unsigned*>(ws + wl.wsr_sync);           // [8][512]
     unsigned* gerr = (st.rt && st.rt->wsr_err_dev) ? st.rt->wsr_err_dev + 2 : nullptr;
     if (soft) {
@@ -1165,6 +1176,20 @@ extern "C" int edgedict_stack_launch_times(int backward, float* sum_ms, int* lau
     ED_CHECK_ARG(ok > 0, "stack_launch_times: no launch stamped");
     *sum_ms = (float)(ticks * 1e-5);      // 100 MHz ticks -> ms
     *launches = ok;
+    return ED_OK;
+}
+
+extern "C" int edgedict_stack_launch_stamps(int backward, unsigned long long* out, int max_launches, int* launches) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    ED_CHECK_ARG(out && launches && max_launches > 0, "stack_launch_stamps: bad arguments");
+    Runtime* r = runtime_for_current_device();
+    const int i = backward ? 1 : 0;
+    ED_CHECK_ARG(r && r->stamps[i] && r->stamp_used[i] > 0,
+                 "stack_launch_stamps: nothing recorded (edgedict_stack_time_launches(1) first)");
+    const int n = min(max_launches, r->stamp_used[i]);
+    ED_CHECK_HIP(hipDeviceSynchronize());
+    ED_CHECK_HIP(hipMemcpy(out, r->stamps[i], (size_t)n * 16, hipMemcpyDeviceToHost));
+    *launches = n;
     return ED_OK;
 }
 

@@ -441,8 +441,7 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
         const int r = tid >> 2, part = tid & 3, b = row0 + r;
         if (b < B) cin = *reinterpret_cast<const float4*>(S.C_prev + (long long)b * H + ub * 16 + part * 4);
     }
-    const unsigned img_bytes = (unsigned)KS * MT * 1024u;
-    const __amdgpu_buffer_rsrc_t r0 = lpw_rsrc(S.img[0], img_bytes), r1 = lpw_rsrc(S.img[1], img_bytes);
+    const __amdgpu_buffer_rsrc_t rimg = lpw_rsrc(S.img, (unsigned)S.img_bytes);
     __shared__ unsigned bail_s;
     if (tid == 0) bail_s = 0u;
 
@@ -478,10 +477,12 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
         __syncthreads();      // also: the previous step's trailing stores have read the LDS staging tiles
         if (bail_s) break;
         LPW_STAMP(0);
-        // ---- (2) h_{t-1} fragments of this wave's K quarter, L2-served (never a stale L1 line)
+        // ---- (2) h_{t-1} fragments of this wave's K quarter: image t, plain loads (the address has never
+        // been touched before in this pass - nothing stale anywhere - and the first reader on an XCD brings a
+        // line into that XCD's L2 for the others)
         bf16x8_t a[LPW_PER][4];
         {
-            const __amdgpu_buffer_rsrc_t rin = (t & 1) ? r1 : r0;
+            const unsigned soff_in = (unsigned)((long long)t * S.img_stride);
 #pragma unroll
             for (int i = 0; i < LPW_PER; ++i) {
                 const int ks = min(ks_beg + i, KS - 1);
@@ -489,7 +490,7 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
                 for (int m = 0; m < 4; ++m) {
                     if (ks_beg + i < ks_end && mt0 + m < MT) {
                         const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(
-                            rin, (unsigned)(((ks * MT + mt0 + m) * 64 + lane) * 16), 0, 16);
+                            rimg, (unsigned)(((ks * MT + mt0 + m) * 64 + lane) * 16), soff_in, 0);
                         a[i][m] = *reinterpret_cast<const bf16x8_t*>(&v);
                     } else {
                         a[i][m] = zfrag();
@@ -586,8 +587,8 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
                 if (mt * 16 + r16 < B) v = *reinterpret_cast<const uint4*>(&sh.h[m * 16 + r16][kg2 * 8]);
                 const int ks = ub >> 1, kg = (ub & 1) * 2 + kg2;
                 const u32x4_t vv = {v.x, v.y, v.z, v.w};
-                __builtin_amdgcn_raw_buffer_store_b128(vv, (t & 1) ? r0 : r1,
-                                                       (unsigned)((((ks * MT + mt) * 64) + kg * 16 + r16) * 16), 0, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(vv, rimg, (unsigned)((((ks * MT + mt) * 64) + kg * 16 + r16) * 16),
+                                                       (unsigned)((long long)(t + 1) * S.img_stride), 16);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -73,7 +73,13 @@ struct EdBwdLaunch {
 // counter and exchange h through the fragment images with write-through stores / L2-served loads.
 struct EdLpwSlot {
     bf16_t* G;                 // step t0: [B, 4H] interleaved (in pre-activations, out gates); step t0+s at + s*B*4H
-    bf16_t* img[2];            // h fragment images [H/32][B16/16][64][8]: step t reads img[t & 1], writes img[(t & 1) ^ 1]
+    bf16_t* img;               // h fragment images [T+1][H/32][B16/16][64][8], ONE PER FRAME: step t reads image t
+                               // (h_{t-1}), writes image t+1.  No address is written twice inside a forward
+                               // pass, so no cache can hold a stale copy: readers use plain loads and the
+                               // 8 workgroups of a layer that share an XCD fetch an image over the fabric once
+                               // (with L2-bypassing loads of ping-pong images every workgroup did: 32 MB per step)
+    long long img_stride;      // bytes between consecutive images
+    long long img_bytes;       // bytes of the whole region (buffer descriptor)
     bf16_t* Y;                 // h rows of step t0 [B, H]; step t0+s at + s*B*H
     const float* C_prev;       // c_{t0-1} [B, H]
     float* C;                  // c rows of step t0; step t0+s at + s*B*H

@@ -340,6 +340,10 @@ int edgedict_stack_last_timing(int backward, float* ms, int* launches);
  * for timed runs. */
 int edgedict_stack_time_launches(int on);
 int edgedict_stack_launch_times(int backward, float* sum_ms, int* launches);
+/* debug / profiling: the raw stamps behind edgedict_stack_launch_times - out[2 k] = first workgroup's start,
+ * out[2 k + 1] = last workgroup's end of wavefront launch k of the last call (100 MHz ticks), in issue order;
+ * synchronises the device.  tools/lpw_timeline.py */
+int edgedict_stack_launch_stamps(int backward, unsigned long long* out, int max_launches, int* launches);
 /* Dry run of the scheduler (no device needed, nothing is launched; buffer pointers in the descriptor
  * only have to be non-NULL): the launch index that carries every layer-step and the number of
  * launches issued when each chunk's side-stream product was enqueued.
