@@ -681,6 +681,9 @@ int forward_wsr(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
 // flag.  Runnable = the chunk the macro-step opens was enqueued at least `margin` launches ago; layers behind
 // a time reduction are paced by launch parity while a faster layer runs (Pace), and a launch holds at most
 // one workgroup per CU (max_slots).  Called with the prologue done and the internal streams forked.
+// a layer's arrival counter has its own 256 bytes: the four layers of a launch are polled by 256 lanes and
+// bumped 256 times per step - in ONE line (16 bytes apart) they queued in one memory channel
+constexpr int LPW_CNT_STRIDE = 64;
 int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Streams& st, const WsLayout& wl,
                 int nsub, bool soft) {
     const int B = d->B, H = d->H, L = d->L;
@@ -691,7 +694,7 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
     unsigned* gerr = (st.rt && st.rt->wsr_err_dev) ? st.rt->wsr_err_dev + 2 : nullptr;
     for (int l = 0; l < L; ++l) ED_CHECK_ARG(g[l].nchunks <= 512, "encoder_stack: too many chunks for the flag table");
     ED_DEV(ed_stack_zero(fflag, (size_t)8 * 512 * sizeof(unsigned), st.C));
-    ED_DEV(ed_stack_zero(cnt, (size_t)16 * sizeof(unsigned), st.C));
+    ED_DEV(ed_stack_zero(cnt, (size_t)8 * LPW_CNT_STRIDE * sizeof(unsigned), st.C));
     ED_TRY(st.chain(st.C, st.R));
     for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.C, st.S[l]));
     const int WGS = (H >> 4) * ((B + 63) >> 6);
@@ -765,7 +768,7 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
             sl.C_prev = y.Cx + (long long)t * BH;
             sl.C = y.Cx + (long long)(t + 1) * BH;
             sl.Wfrag = bptr(y.whh_f);
-            sl.counter = cnt + l;
+            sl.counter = cnt + l * LPW_CNT_STRIDE;
             sl.base = (unsigned)WGS * (unsigned)t;
             sl.wait_flag = (soft && opens) ? fflag + l * 512 + k : nullptr;
             sl.t0 = t;
