@@ -401,6 +401,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t lpw_rsrc(const void* p, unsign
     return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)bytes, 0x00020000);
 }
 
+template <bool TRACE>
 __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
     __shared__ FwdShared sh;
     if (L.stamp && threadIdx.x == 0) atomicMin(&L.stamp[0], wall_clock64());
@@ -448,12 +449,12 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
     // debug trace (tools/lpw_trace.py): the first workgroup of every slot accumulates, per phase, the 100 MHz
     // ticks its lane 0 spent: [0] wait for the peers, [1] h loads + MFMA, [2] hand-off + cell update,
     // [3] publish + drain, [4] arrive, [5] trailing stores; [6] steps, [7] launches
-    const bool tr = L.trace != nullptr && rem == 0 && tid == 0;
+    const bool tr = TRACE && L.trace != nullptr && rem == 0 && tid == 0;
     long long ph[6] = {0, 0, 0, 0, 0, 0};
     long long last_ = tr ? wall_clock64() : 0;
 #define LPW_STAMP(i)                                  \
     do {                                              \
-        if (tr) {                                     \
+        if (TRACE && tr) {                            \
             const long long now_ = wall_clock64();    \
             ph[i] += now_ - last_;                    \
             last_ = now_;                             \
@@ -632,7 +633,7 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
         LPW_STAMP(5);
     }
 #undef LPW_STAMP
-    if (tr) {
+    if (TRACE && tr) {
         long long* o = L.trace + S.layer * 8;
         for (int i = 0; i < 6; ++i) atomicAdd((unsigned long long*)(o + i), (unsigned long long)ph[i]);
         atomicAdd((unsigned long long*)(o + 6), (unsigned long long)S.nsteps);
@@ -1156,7 +1157,8 @@ int ed_stack_launch_fwd_lpw(const EdLpwLaunch& L, hipStream_t s) {
     const int UB = L.H >> 4, RG = (L.B + 63) >> 6;
     const int grid = L.nslot * UB * RG;
     if (grid == 0) return ED_OK;
-    hipLaunchKernelGGL(stack_fwd_lpw_kernel, dim3(grid), dim3(256), 0, s, L);
+    if (L.trace) hipLaunchKernelGGL(stack_fwd_lpw_kernel<true>, dim3(grid), dim3(256), 0, s, L);
+    else hipLaunchKernelGGL(stack_fwd_lpw_kernel<false>, dim3(grid), dim3(256), 0, s, L);
     ED_CHECK_LAUNCH("stack_fwd_lpw_kernel");
     return ED_OK;
 }
