@@ -697,6 +697,17 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
     ED_DEV(ed_stack_zero(cnt, (size_t)8 * LPW_CNT_STRIDE * sizeof(unsigned), st.C));
     ED_TRY(st.chain(st.C, st.R));
     for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.C, st.S[l]));
+    // TWO side streams: what follows a full-rate layer (its LayerNorm, the next layer's product) runs on the
+    // chunk-GEMM stream, what follows a layer behind the time reduction on the CALLER's stream - idle until the
+    // join and already one of the four hardware queues.  One side stream was the bottleneck: per recurrence
+    // launch (55 us) it had an event wait, the norm launch (12-17 us beside a full chip), 1-2 products
+    // (20-55 us) and their flag kernels to carry.  Layer 0's products need nothing from the recurrence: all of
+    // them go onto the caller's stream up front, behind the input LayerNorm that feeds them.
+    int split = L;
+    for (int l = 0; l < L; ++l)
+        if (d->layers[l].reduce == 2) { split = l + 1; break; }
+    if (split >= L) split = (L + 1) / 2;
+    auto side = [&](int l) -> hipStream_t { return (st.serial || l < split) ? st.S[0] : st.C; };
     const int WGS = (H >> 4) * ((B + 63) >> 6);
     static const int n_cu = [] {
         int dev = 0, n = 256;
@@ -716,15 +727,15 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
     int next_g0 = 0;
     auto feed_layer0 = [&](int upto) -> int {
         for (; next_g0 < g[0].nchunks && next_g0 <= upto; ++next_g0) {
-            ED_DEV(input_gemm(d, g, 0, next_g0, st.S[0]));
+            ED_DEV(input_gemm(d, g, 0, next_g0, st.C));
             if (g_trace) g_trace->chunk_enqueued[g_trace->coff[0] + next_g0] = g_trace->launches;
-            if (soft) ED_DEV(ed_stack_set_flag(fflag + next_g0, st.S[0]));
-            else ED_TRY(st.record(Eg[0][next_g0], st.S[0]));
+            if (soft) ED_DEV(ed_stack_set_flag(fflag + next_g0, st.C));
+            else ED_TRY(st.record(Eg[0][next_g0], st.C));
             queued[0][next_g0] = 1;
         }
         return ED_OK;
     };
-    ED_TRY(feed_layer0(1));
+    ED_TRY(feed_layer0(g[0].nchunks));
     std::vector<int> next_t(L, 0);
     std::vector<std::vector<int>> ready_w(L);
     for (int l = 0; l < L; ++l) ready_w[l].assign(g[l].nchunks, l == 0 ? 0 : 0x3fffffff);
@@ -796,44 +807,63 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
             g_trace->max_slots = max(g_trace->max_slots, Lc.nslot);
             ++g_trace->launches;
         }
-        // ---- side stream: LayerNorm of what this launch finished, then the products of completed chunks
-        hipStream_t S = st.S[0];
-        ED_TRY(st.chain(st.R, S));
-        EdChunkNorm items[ED_STACK_MAX_SLOTS];
-        for (int i = 0; i < Lc.nslot; ++i) {
-            const int l = ran[i].l;
-            const edgedict_stack_layer_t& y = d->layers[l];
-            EdChunkNorm& e = items[i];
-            e.Yx1 = bptr(y.Yx) + BH;
-            e.X = y.residual ? bptr(y.X) : nullptr;
-            e.gamma = y.ln_gamma;
-            e.beta = y.ln_beta;
-            if (l + 1 < L) {
-                e.out = bptr(d->layers[l + 1].X);
-                e.out_st = BH;
-                e.out_sb = H;
-            } else {
-                e.out = bptr(d->out);
-                e.out_st = H;
-                e.out_sb = (long long)T_out * H;
+        // ---- side streams: LayerNorm of what this launch finished, then the products of completed chunks
+        for (int pass = 0; pass < 2; ++pass) {
+            hipStream_t S = pass == 0 ? st.S[0] : st.C;
+            EdChunkNorm items[ED_STACK_MAX_SLOTS];
+            int idx[ED_STACK_MAX_SLOTS], ni = 0;
+            for (int i = 0; i < Lc.nslot; ++i) {
+                const int l = ran[i].l;
+                if (side(l) != S) continue;
+                const edgedict_stack_layer_t& y = d->layers[l];
+                EdChunkNorm& e = items[ni];
+                e.Yx1 = bptr(y.Yx) + BH;
+                e.X = y.residual ? bptr(y.X) : nullptr;
+                e.gamma = y.ln_gamma;
+                e.beta = y.ln_beta;
+                if (l + 1 < L) {
+                    e.out = bptr(d->layers[l + 1].X);
+                    e.out_st = BH;
+                    e.out_sb = H;
+                } else {
+                    e.out = bptr(d->out);
+                    e.out_st = H;
+                    e.out_sb = (long long)T_out * H;
+                }
+                e.mean = y.mean;
+                e.rstd = y.rstd;
+                e.T = y.T;
+                e.t0 = ran[i].t0;
+                e.t1 = ran[i].t1;
+                e.reduce = y.reduce;
+                idx[ni++] = i;
             }
-            e.mean = y.mean;
-            e.rstd = y.rstd;
-            e.T = y.T;
-            e.t0 = ran[i].t0;
-            e.t1 = ran[i].t1;
-            e.reduce = y.reduce;
-        }
-        ED_DEV(ed_stack_multi_norm(items, Lc.nslot, B, H, d->eps, S));
-        for (int i = 0; i < Lc.nslot; ++i) {
-            const int l = ran[i].l, k = ran[i].t0 / g[l].cf;
-            if (l + 1 >= L || ran[i].t1 != min(g[l].T, (k + 1) * g[l].cf)) continue;
-            ED_DEV(input_gemm(d, g, l + 1, k, S));
-            if (g_trace) g_trace->chunk_enqueued[g_trace->coff[l + 1] + k] = g_trace->launches;
-            if (soft) ED_DEV(ed_stack_set_flag(fflag + (l + 1) * 512 + k, S));
-            else ED_TRY(st.record(Eg[l + 1][k], S));
-            queued[l + 1][k] = 1;
-            ready_w[l + 1][k] = w + margin;
+            if (ni == 0) continue;
+            if (soft) {
+                // order S behind this launch's steps through their arrival counters, not through an event
+                const unsigned* cp[ED_STACK_MAX_SLOTS];
+                unsigned tg[ED_STACK_MAX_SLOTS];
+                for (int j = 0; j < ni; ++j) {
+                    cp[j] = cnt + ran[idx[j]].l * LPW_CNT_STRIDE;
+                    tg[j] = (unsigned)WGS * (unsigned)ran[idx[j]].t1;
+                }
+                ED_DEV(ed_stack_wait_counters(cp, tg, ni, gerr, S));
+            } else {
+                ED_TRY(st.chain(st.R, S));
+            }
+            ED_DEV(ed_stack_multi_norm(items, ni, B, H, d->eps, S));
+            for (int j = 0; j < ni; ++j) {
+                const int i = idx[j];
+                const int l = ran[i].l, k = ran[i].t0 / g[l].cf;
+                if (l + 1 >= L || ran[i].t1 != min(g[l].T, (k + 1) * g[l].cf)) continue;
+                ED_DEV(input_gemm(d, g, l + 1, k, S));
+                if (g_trace) g_trace->chunk_enqueued[g_trace->coff[l + 1] + k] = g_trace->launches;
+                if (soft) ED_DEV(ed_stack_set_flag(fflag + (l + 1) * 512 + k, S));
+                else ED_TRY(st.record(Eg[l + 1][k], S));
+                queued[l + 1][k] = 1;
+                ready_w[l + 1][k] = w + margin;
+            }
+            if (st.serial) break;     // one stream: the first pass took every slot
         }
     }
     if (st.rt && st.rt->tev[0][1]) {

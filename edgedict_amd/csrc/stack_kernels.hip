@@ -344,6 +344,31 @@ __device__ __forceinline__ void soft_wait(const unsigned* flag, unsigned* err, u
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 
+// One lane waits until every counter[i] >= target[i] (the launch-persistent forward's arrival counters): placed
+// on a side stream in front of the LayerNorm of the frames a recurrence launch is still working on, it orders
+// that stream behind the steps WITHOUT an event record between the recurrence stream's launches (each record
+// cost ~3.5 us of inter-launch gap there).  What the waited-for steps published (write-through, drained before
+// the arrive) is in memory when the counter shows them; the kernels behind this one start with clean caches.
+struct WaitCountersArgs {
+    const unsigned* counter[ED_STACK_MAX_SLOTS];
+    unsigned target[ED_STACK_MAX_SLOTS];
+    int n;
+    unsigned* err;
+};
+__global__ void stack_wait_counters_kernel(WaitCountersArgs a) {
+    if (threadIdx.x != 0) return;
+    for (int i = 0; i < a.n; ++i) {
+        unsigned spins = 0;
+        while (__hip_atomic_load(a.counter[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.target[i]) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 22)) {
+                if (a.err) atomicCAS(a.err, 0u, 800u + i);
+                return;
+            }
+        }
+    }
+}
+
 __global__ void stack_set_flag_kernel(unsigned* flag) {
     if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -592,6 +617,17 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
                                                        (unsigned)((long long)(t + 1) * S.img_stride), 16);
             }
         }
+        // the h rows too (2 KB, the LayerNorm's input): write-through and BEFORE the arrive, so that a side
+        // stream can order its LayerNorm launch behind this launch's steps by polling the counter
+        // (stack_wait_counters_kernel) instead of an event recorded on the recurrence stream
+        if (tid >= 128) {
+            const int id = tid - 128, r = id >> 1, hf = id & 1, b = row0 + r;
+            if (b < B) {
+                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&sh.h[r][hf * 8]);
+                bf16_t* dst = S.Y + (long long)s * BH + (long long)b * H + ub * 16 + hf * 8;
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+            }
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         LPW_STAMP(3);
@@ -607,12 +643,6 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
                 if (b < B)
                     *reinterpret_cast<uint4*>(G_t + b * H4 + ub * 64 + part * 8) =
                         *reinterpret_cast<const uint4*>(&sh.g[r][part * 8]);
-            }
-            if (tid < 128) {
-                const int r = tid >> 1, hf = tid & 1, b = row0 + r;
-                if (b < B)
-                    *reinterpret_cast<uint4*>(S.Y + (long long)s * BH + (long long)b * H + ub * 16 + hf * 8) =
-                        *reinterpret_cast<const uint4*>(&sh.h[r][hf * 8]);
             }
             {
                 const int r = tid >> 2, part = tid & 3, b = row0 + r;
@@ -1145,6 +1175,21 @@ int ed_stack_multi_norm(const EdChunkNorm* items, int n, int B, int H, float eps
     if (grid == 0) return ED_OK;
     hipLaunchKernelGGL(stack_multi_norm_kernel, dim3(grid), dim3(256), 0, s, M);
     ED_CHECK_LAUNCH("stack_multi_norm_kernel");
+    return ED_OK;
+}
+
+int ed_stack_wait_counters(const unsigned* const* counters, const unsigned* targets, int n, unsigned* err, hipStream_t s) {
+    if (n <= 0) return ED_OK;
+    ED_CHECK_ARG(n <= ED_STACK_MAX_SLOTS, "stack_wait_counters: too many counters");
+    WaitCountersArgs a;
+    for (int i = 0; i < n; ++i) {
+        a.counter[i] = counters[i];
+        a.target[i] = targets[i];
+    }
+    a.n = n;
+    a.err = err;
+    hipLaunchKernelGGL(stack_wait_counters_kernel, dim3(1), dim3(64), 0, s, a);
+    ED_CHECK_LAUNCH("stack_wait_counters_kernel");
     return ED_OK;
 }
 

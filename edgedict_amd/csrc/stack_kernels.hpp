@@ -111,6 +111,8 @@ struct EdChunkNorm {
     float* rstd;
     int T, t0, t1, reduce;
 };
+// one lane spins on stream s until counters[i] >= targets[i] for every i (bounded: give-up code 800 + i)
+int ed_stack_wait_counters(const unsigned* const* counters, const unsigned* targets, int n, unsigned* err, hipStream_t s);
 int ed_stack_multi_norm(const EdChunkNorm* items, int n, int B, int H, float eps, hipStream_t s);
 int ed_stack_lpw_supported(int B, int H);     // 1 when the launch-persistent forward kernel covers this geometry
 
