@@ -13,7 +13,8 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libedgedict_hip.so")
+# EDGEDICT_LIB: an alternative build of the library (tuning experiments: tools/build_variant.sh)
+LIB_PATH = os.environ.get("EDGEDICT_LIB") or os.path.join(_HERE, "csrc", "libedgedict_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "edgedict_hip.h")
 
 ED_F32 = 0

@@ -881,7 +881,7 @@ int lpw_steps(const edgedict_stack_desc_t* d) {
     // read on every call (two getenv per forward pass): tests switch the path inside one process
     const char* e_on = getenv("EDGEDICT_STACK_LPW");
     const char* e_n = getenv("EDGEDICT_LPW_STEPS");
-    const int on = e_on ? atoi(e_on) : 0, want = e_n ? atoi(e_n) : 6;
+    const int on = e_on ? atoi(e_on) : 1, want = e_n ? atoi(e_n) : 12;
     if (!on || !ed_stack_lpw_supported(d->B, d->H) || (d->flags & EDGEDICT_STACK_WSR)) return 0;
     bool reduces = false;
     for (int l = 0; l < d->L; ++l) reduces = reduces || d->layers[l].reduce == 2;

@@ -1195,7 +1195,8 @@ int ed_stack_wait_counters(const unsigned* const* counters, const unsigned* targ
 
 int ed_stack_lpw_supported(int B, int H) {
     const int UB = H >> 4, RG = (B + 63) >> 6;
-    return (H % 32 == 0 && (H >> 5) <= 4 * LPW_PER && UB * RG <= 256) ? 1 : 0;
+    // at least four layer slots of one workgroup per CU must fit on the chip (256 CUs)
+    return (H % 32 == 0 && (H >> 5) <= 4 * LPW_PER && UB * RG <= 64) ? 1 : 0;
 }
 
 int ed_stack_launch_fwd_lpw(const EdLpwLaunch& L, hipStream_t s) {

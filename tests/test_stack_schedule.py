@@ -1,9 +1,15 @@
-"""CPU: the encoder stack's dynamic wavefront schedule (csrc/encoder_stack.hip) run DRY through
+"""CPU: the encoder stack's dynamic wavefront schedules (csrc/encoder_stack.hip) run DRY through
 ``edgedict_stack_schedule`` - no device, nothing launched - and checked for the invariants the
 kernels rely on: every layer-step is carried by exactly one launch, in recurrence order; a layer
 never opens a chunk before the side-stream product that feeds it was enqueued, and that product is
 enqueued only after the producing layer finished (and, forward, normalised) the chunk's frames; a
-launch never carries more layer-steps than the launch structure holds; the E6D2 launch counts."""
+launch never carries more layer-steps than the launch structure holds; the E6D2 launch counts.
+
+Two forward schedules: the launch-per-step one (EDGEDICT_STACK_LPW=0: every layer steps at most once per
+launch) and the default launch-persistent one (forward_lpw: a launch carries up to EDGEDICT_LPW_STEPS
+CONSECUTIVE steps of each of its layers, never across a chunk boundary).  The backward pass is launch-per-step."""
+import os
+
 import numpy as np
 import pytest
 from hypothesis import given, settings, strategies as st
@@ -28,9 +34,60 @@ def _geometry(T0, reductions, chunk):
     return L, Ts, cf
 
 
+def _sched(lpw, *args, **kw):
+    old = os.environ.get("EDGEDICT_STACK_LPW")
+    os.environ["EDGEDICT_STACK_LPW"] = "1" if lpw else "0"
+    try:
+        return es.schedule(*args, **kw)
+    finally:
+        if old is None:
+            os.environ.pop("EDGEDICT_STACK_LPW", None)
+        else:
+            os.environ["EDGEDICT_STACK_LPW"] = old
+
+
+def _check_lpw(T0, reductions, chunk, nsub, H=64, B=3):
+    """forward_lpw: macro-steps of <= nsub consecutive steps."""
+    L, Ts, cf = _geometry(T0, reductions, chunk)
+    old = os.environ.get("EDGEDICT_LPW_STEPS")
+    os.environ["EDGEDICT_LPW_STEPS"] = str(nsub)
+    try:
+        steps, enq, n, max_slots = _sched(True, T0, 64, H, reductions, B=B, chunk=chunk, backward=False)
+    finally:
+        if old is None:
+            os.environ.pop("EDGEDICT_LPW_STEPS", None)
+        else:
+            os.environ["EDGEDICT_LPW_STEPS"] = old
+    wgs = (H // 16) * ((B + 63) // 64)
+    assert 1 <= max_slots <= min(MAX_SLOTS, 256 // wgs)
+    slots = np.zeros(n, dtype=int)
+    longest = 0
+    for l in range(L):
+        s = steps[l].astype(int)
+        assert len(s) == Ts[l] and (s >= 0).all() and (s < n).all()
+        assert (np.diff(s) >= 0).all(), "recurrence order"
+        for w in np.unique(s):
+            ts = np.nonzero(s == w)[0]
+            assert (np.diff(ts) == 1).all(), "a launch carries CONSECUTIVE steps of a layer"
+            assert ts[0] // cf[l] == ts[-1] // cf[l], "never across a chunk boundary"
+            longest = max(longest, len(ts))
+            slots[w] += 1
+    assert slots.max() == max_slots and slots.min() >= 1
+    for l in range(1, L):
+        for k in range(len(enq[l])):
+            opening = int(steps[l][k * cf[l]])
+            e = int(enq[l][k])
+            last = int(steps[l - 1][min(Ts[l - 1], (k + 1) * cf[l - 1]) - 1])
+            assert e == last + 1, "the product is enqueued right behind the launch that finishes the chunk"
+            # margin 2: normally a whole launch lies between; when nothing else is runnable the scheduler does
+            # not wait with empty launches - the consumer's workgroups then poll the chunk's flag themselves
+            assert opening >= e, "the consumer's launch is enqueued after the product"
+    return n, longest
+
+
 def _check(T0, reductions, chunk, backward):
     L, Ts, cf = _geometry(T0, reductions, chunk)
-    steps, enq, n, max_slots = es.schedule(T0, 64, 64, reductions, B=3, chunk=chunk, backward=backward)
+    steps, enq, n, max_slots = _sched(False, T0, 64, 64, reductions, B=3, chunk=chunk, backward=backward)
     assert 1 <= max_slots <= MAX_SLOTS
     per_launch = np.zeros(n, dtype=int)
     for l in range(L):
@@ -75,3 +132,21 @@ def test_schedule_invariants_on_random_geometries(T0, reductions, chunk, backwar
     if int(np.prod(reductions)) > 4:          # at most two time reductions (period 4), as tested on the GPU
         reductions = [1 if i > 1 else r for i, r in enumerate(reductions)]
     _check(T0, reductions, chunk, backward)
+
+
+def test_e6d2_launch_persistent_forward_schedule():
+    # 64 x H=1024: 64 workgroups per layer, at most 4 layers per launch (256 CUs)
+    n, longest = _check_lpw(401, [1, 2, 1, 1, 1, 1], 12, 12, H=1024, B=64)
+    assert longest == 12 and n <= 60
+    n6, longest6 = _check_lpw(401, [1, 2, 1, 1, 1, 1], 12, 6, H=1024, B=64)
+    assert longest6 == 6 and n6 == 83
+
+
+@settings(max_examples=60, deadline=None, derandomize=True)
+@given(st.integers(1, 90), st.lists(st.sampled_from([1, 1, 2]), min_size=1, max_size=6),
+       st.sampled_from([2, 4, 6, 8]), st.sampled_from([2, 4, 6, 12]))
+def test_launch_persistent_schedule_invariants_on_random_geometries(T0, reductions, chunk, nsub):
+    if int(np.prod(reductions)) > 4:
+        reductions = [1 if i > 1 else r for i, r in enumerate(reductions)]
+    n, longest = _check_lpw(T0, reductions, chunk, nsub)
+    assert longest <= nsub
