@@ -23,6 +23,9 @@
 // the epilogue is a 16-byte vector staged through LDS.
 #include "stack_kernels.hpp"
 
+#ifndef ED_STEP_PRIO
+#define ED_STEP_PRIO 3   // s_setprio of the recurrence kernels' waves (0..3): they are latency-critical, the products
+#endif                   // that share their CUs are not (measured: backward pass 11.9 -> 11.5 ms, forward unchanged)
 #ifndef ED_STACK_DBG
 #define ED_STACK_DBG 0   // tools/stack_probe.hip builds ablation variants with this mask:
 #endif                   // 1 no operand loads/MFMA, 2 no stores, 4 cheap activations, 8 no staging loads
@@ -429,6 +432,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t lpw_rsrc(const void* p, unsign
 template <bool TRACE>
 __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
     __shared__ FwdShared sh;
+    if (ED_STEP_PRIO) __builtin_amdgcn_s_setprio(ED_STEP_PRIO);
     if (L.stamp && threadIdx.x == 0) atomicMin(&L.stamp[0], wall_clock64());
     const int B = L.B, H = L.H;
     const int UB = H >> 4, RG = (B + 63) >> 6, WGS = UB * RG;
@@ -909,6 +913,7 @@ __device__ __forceinline__ void bwd_step_role(const EdBwdStep& p, int nb, int rg
 
 __global__ __launch_bounds__(256, ED_BWD_OCC) void stack_bwd_kernel(EdBwdLaunch L) {
     __shared__ BwdShared sh;
+    if (ED_STEP_PRIO) __builtin_amdgcn_s_setprio(ED_STEP_PRIO);
     if (L.stamp && threadIdx.x == 0) atomicMin(&L.stamp[0], wall_clock64());   // see stack_fwd_kernel
     const int NB = L.H >> 5, RG = (L.B + 31) >> 5;
     const int bid = blockIdx.x;
