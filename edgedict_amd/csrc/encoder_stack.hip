@@ -202,6 +202,8 @@ struct WsLayout {
     std::vector<size_t> frag0, frag1, dC, lnpart;   // per layer
     std::vector<size_t> himg;                       // per layer: one h fragment image per frame (launch-persistent forward)
     size_t himg_stride = 0;
+    std::vector<size_t> gimg;                       // per layer: one dG fragment image per frame (launch-persistent BPTT)
+    size_t gimg_stride = 0;
     size_t tmpW = 0, tmpB = 0, dX0 = 0, wsr_sync = 0, total = 0;
 };
 constexpr size_t WSR_SYNC_BYTES = 64 * 1024;   // [0] give-up code, [16..24) layer counters, [64..) 8 tickets per launch
@@ -241,6 +243,12 @@ WsLayout ws_layout(const edgedict_stack_desc_t* d) {
     for (int l = 0; l < d->L; ++l) {
         w.himg.push_back(off);
         off += (size_t)(d->layers[l].T + 1) * w.himg_stride;
+    }
+    // ... and one dG image per frame for the launch-persistent BPTT: T x B16 x 4H bf16 (205 MB per full-rate E6D2 layer)
+    w.gimg_stride = align256(B16 * 4 * d->H * sizeof(bf16_t));
+    for (int l = 0; l < d->L; ++l) {
+        w.gimg.push_back(off);
+        off += (size_t)(d->layers[l].T + 1) * w.gimg_stride;
     }
     w.total = off;
     return w;
@@ -891,6 +899,17 @@ int lpw_steps(const edgedict_stack_desc_t* d) {
     return ns;
 }
 
+// ... and of the launch-persistent BPTT (stack_bwd_lpw_kernel); EDGEDICT_STACK_LPW_BWD=0 keeps one launch per step
+int lpw_bwd_steps(const edgedict_stack_desc_t* d) {
+    const char* e_on = getenv("EDGEDICT_STACK_LPW_BWD");
+    const char* e_n = getenv("EDGEDICT_LPW_STEPS_B");
+    const int on = e_on ? atoi(e_on) : 0, want = e_n ? atoi(e_n) : 6;
+    if (!on || !ed_stack_lpw_bwd_supported(d->B, d->H)) return 0;
+    int ns = max(1, min(want, d->chunk));
+    while (ns > 1 && d->chunk % ns != 0) --ns;
+    return ns;
+}
+
 }  // namespace
 
 extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stream_) {
@@ -1256,6 +1275,11 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
         for (int l = 0; l < L; ++l) ED_CHECK_ARG(g[l].nchunks <= 512, "encoder_stack: too many chunks for the flag table");
         ED_DEV(ed_stack_zero(bflag, (size_t)8 * 512 * sizeof(unsigned), st.C));
     }
+    // launch-persistent BPTT (stack_bwd_lpw_kernel): steps per launch (0 = one launch per step) and the layers'
+    // arrival counters, behind the forward pass's in the sync region
+    const int lpw_ns = lpw_bwd_steps(d);
+    unsigned* cntb = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + 2 * 8 * 512 + 8 * LPW_CNT_STRIDE;
+    if (lpw_ns) ED_DEV(ed_stack_zero(cntb, (size_t)8 * LPW_CNT_STRIDE * sizeof(unsigned), st.C));
     // ---- prologue: running dL/dc = 0
     for (int l = 0; l < L; ++l) ED_DEV(ed_stack_zero(ws + wl.dC[l], (size_t)BH * sizeof(float), st.C));
     ED_TRY(st.chain(st.C, st.R));
@@ -1331,14 +1355,143 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     int tail_split = 0;   // measured: 4 -> +0.2..0.7 ms per step (BPTT period 23.6 -> 24.8 us outweighs the shorter tail)
     if (const char* e = getenv("EDGEDICT_STACK_TAIL_SPLIT")) tail_split = atoi(e);
 
-    const int margin = margin_launches(d, g, true);
+    int margin = margin_launches(d, g, true);
     std::vector<int> next_t(L, 0);          // BPTT steps done; the next one is frame T - 1 - next_t
     std::vector<std::vector<int>> ready_w(L);
     for (int l = 0; l < L; ++l) ready_w[l].assign(g[l].nchunks, l == L - 1 ? 0 : 0x3fffffff);
+    // side work of a chunk that layer l's BPTT has just passed (enqueued right after the launch that carries the
+    // chunk's last step, launch index w): dX product + LayerNorm backward for the layer below, weight gradients
+    auto chunk_done = [&](int l, int k, int w) -> int {
+            const edgedict_stack_layer_t& y = d->layers[l];
+            if (l > 0) {
+                // dX_l[chunk] (+)= dG_l[chunk] W_ih, then LayerNorm backward into layer l-1
+                const edgedict_stack_layer_t& z = d->layers[l - 1];
+                const int t0 = k * g[l].cf, t1 = min(y.T, t0 + g[l].cf);
+                const long long r0 = (long long)t0 * B;
+                hipStream_t S = st.S[l];
+                ED_TRY(st.chain(st.RS(l), S));
+                ED_DEV(edgedict_gemm(ED_BF16, ED_BF16, bptr(y.G) + r0 * 4 * H, 4ll * H, 1,
+                                     y.wih_t ? y.wih_t : y.wih_p, y.wih_t ? 4ll * H : y.I,
+                                     y.wih_t ? 1 : 0, bptr(y.dX) + r0 * y.I, y.I, (t1 - t0) * B, y.I,
+                                     4 * H, nullptr, nullptr, y.dX == y.dZ ? 1 : 0, 1, S));
+                const int u0 = k * g[l - 1].cf, u1 = min(z.T, u0 + g[l - 1].cf);
+                ED_DEV(ed_stack_ln_bwd(bptr(y.dX), (long long)B * y.I, y.I, bptr(z.Yx) + BH,
+                                       z.residual ? bptr(z.X) : nullptr, z.ln_gamma, z.mean, z.rstd,
+                                       bptr(z.dZ), (float*)(ws + wl.lnpart[l - 1]) + (size_t)k * LNB_GRID * 2 * H,
+                                       LNB_GRID, B, H, u0, u1, z.reduce, S));
+                if (soft) ED_DEV(ed_stack_set_flag(bflag + (l - 1) * 512 + k, S));
+                else ED_TRY(st.record(Eb[l - 1][k], S));
+                queued[l - 1][k] = 1;
+                ready_w[l - 1][k] = w + margin;
+                if (g_trace) g_trace->chunk_enqueued[g_trace->coff[l - 1] + k] = g_trace->launches;
+            }
+            // chunks complete from the last to the first: a segment [k, k + dw_seg) is complete when
+            // its lowest chunk is (k a multiple of dw_seg, counted so that the LAST segment issued,
+            // the one ending at chunk 0, is a full one)
+            // Experiment (EDGEDICT_STACK_TAIL_SPLIT=n, off by default): split the two layers that
+            // finish LAST once more - frames [nchunks/n * cf, T) issued when the BPTT passes that
+            // chunk - so that less work is left for the 0.7 ms tail after the last launch.  Measured
+            // slower: the extra products disturb more BPTT launches than the tail shrinks.
+            const int k_split = (l <= 1 && tail_split > 1 && g[l].nchunks >= 2 * tail_split && dw_seg >= g[l].nchunks &&
+                                 !(d->flags & EDGEDICT_STACK_DW_AT_END))
+                                    ? g[l].nchunks / tail_split : 0;
+            if (k_split > 0 && k == k_split) {
+                ED_TRY(st.chain(st.RS(l), st.W));
+                ED_TRY(weight_grads(l, k * g[l].cf, y.T, true, false));
+            } else if (k_split > 0 && k == 0) {
+                ED_TRY(st.chain(st.RS(l), st.W));
+                ED_TRY(weight_grads(l, 0, k_split * g[l].cf, false, l == 0));
+            } else if (k_split == 0 && k % dw_seg == 0) {
+                if (d->flags & EDGEDICT_STACK_DW_AT_END) {
+                    if (k == 0) deferred.push_back(l);
+                } else {
+                    const int k1 = min(g[l].nchunks, k + dw_seg);
+                    const int t0 = k * g[l].cf, t1 = min(y.T, k1 * g[l].cf);
+                    ED_TRY(st.chain(st.RS(l), st.W));
+                    ED_TRY(weight_grads(l, t0, t1, k1 == g[l].nchunks, l == 0 && k == 0));
+                }
+            }
+        return ED_OK;
+    };
     int launches = 0, idle = 0;
     if (st.rt) st.rt->stamp_used[1] = 0;
     if (st.rt && st.rt->tev[1][0]) ED_CHECK_HIP(hipEventRecord(st.rt->tev[1][0], st.R));
     struct Done { int l, k, t; };
+    if (lpw_ns) {
+        // ---- macro-steps: launch w carries, for every runnable layer, its next <= lpw_ns BPTT steps (descending t,
+        // never across a chunk boundary); the schedule is the one below in units of macro-steps
+        const int WGS = (H >> 5) * ((B + 31) >> 5);
+        static const int n_cu = [] {
+            int dev = 0, n = 256;
+            if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+            return n;
+        }();
+        const int max_slots = max(1, min(ED_STACK_MAX_SLOTS, (g_trace ? 256 : n_cu) / WGS));
+        const char* e_m = getenv("EDGEDICT_LPW_MARGIN_B");
+        margin = (e_m && atoi(e_m) > 0) ? atoi(e_m) : 2;
+        for (int w = 0;; ++w) {
+            bool finished = true;
+            for (int l = 0; l < L; ++l) finished = finished && next_t[l] >= g[l].T;
+            if (finished) break;
+            EdLpwBwdLaunch Lc;
+            Lc.nslot = 0;
+            Lc.B = B;
+            Lc.H = H;
+            Done done[ED_STACK_MAX_SLOTS];
+            int ndone = 0;
+            for (int l = L - 1; l >= 0; --l) {
+                const edgedict_stack_layer_t& y = d->layers[l];
+                if (next_t[l] >= g[l].T || Lc.nslot >= max_slots) continue;
+                const int t = g[l].T - 1 - next_t[l];
+                const int k = t / g[l].cf;
+                const bool opens = (t == min(g[l].T, (k + 1) * g[l].cf) - 1);
+                if (opens && !(queued[l][k] && w >= ready_w[l][k])) continue;
+                int m_min = g[l].m;   // paced only while a faster layer below is in flight
+                for (int j = 0; j < l; ++j)
+                    if (next_t[j] > 0 && next_t[j] < g[j].T) m_min = min(m_min, g[j].m);
+                if (!Pace::allows(w, l, g[l].m, m_min)) continue;
+                if (opens && !soft) ED_TRY(st.wait(st.R, Eb[l][k]));
+                const int t_end = max(k * g[l].cf, t - lpw_ns + 1);      // last (lowest) frame of this macro-step
+                EdLpwBwdSlot& sl = Lc.slot[Lc.nslot++];
+                sl.G = bptr(y.G) + (long long)t * B * 4 * H;
+                sl.img = bptr(ws + wl.gimg[l]);
+                sl.img_stride = (long long)wl.gimg_stride;
+                sl.img_bytes = (long long)(y.T + 1) * (long long)wl.gimg_stride;
+                sl.dY = bptr(y.dZ) + (long long)t * BH;
+                sl.Cx = y.Cx;
+                sl.dC = (float*)(ws + wl.dC[l]);
+                sl.WTfrag = bptr(y.whh_b);
+                sl.counter = cntb + l * LPW_CNT_STRIDE;
+                sl.base = (unsigned)WGS * (unsigned)next_t[l];
+                sl.wait_flag = (soft && opens) ? bflag + l * 512 + k : nullptr;
+                sl.t0 = t;
+                sl.nsteps = t - t_end + 1;
+                sl.T = y.T;
+                sl.layer = l;
+                if (t_end == k * g[l].cf) {
+                    done[ndone].l = l; done[ndone].k = k; done[ndone].t = t_end;
+                    ++ndone;
+                }
+                next_t[l] += t - t_end + 1;
+                if (g_trace)
+                    for (int tt = t_end; tt <= t; ++tt) g_trace->step_launch[g_trace->toff[l] + tt] = g_trace->launches;
+            }
+            if (Lc.nslot == 0) {
+                ED_CHECK_ARG(++idle < 4096, "encoder_stack: backward schedule made no progress");
+                continue;
+            }
+            idle = 0;
+            ++launches;
+            Lc.stamp = st.rt ? st.rt->stamp_slot(1, st.R) : nullptr;
+            Lc.err = gerr;
+            ED_DEV(ed_stack_launch_bwd_lpw(Lc, st.R));
+            if (g_trace) {
+                g_trace->max_slots = max(g_trace->max_slots, Lc.nslot);
+                ++g_trace->launches;
+            }
+            for (int i = 0; i < ndone; ++i) ED_TRY(chunk_done(done[i].l, done[i].k, w));
+        }
+    } else
     for (int w = 0;; ++w) {
         bool finished = true;
         for (int l = 0; l < L; ++l) finished = finished && next_t[l] >= g[l].T;
@@ -1397,58 +1550,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
             g_trace->max_slots = max(g_trace->max_slots, Lcs[0].nstep + Lcs[1].nstep);
             ++g_trace->launches;
         }
-        for (int i = 0; i < ndone; ++i) {
-            const int l = done[i].l, k = done[i].k;
-            const edgedict_stack_layer_t& y = d->layers[l];
-            if (l > 0) {
-                // dX_l[chunk] (+)= dG_l[chunk] W_ih, then LayerNorm backward into layer l-1
-                const edgedict_stack_layer_t& z = d->layers[l - 1];
-                const int t0 = k * g[l].cf, t1 = min(y.T, t0 + g[l].cf);
-                const long long r0 = (long long)t0 * B;
-                hipStream_t S = st.S[l];
-                ED_TRY(st.chain(st.RS(l), S));
-                ED_DEV(edgedict_gemm(ED_BF16, ED_BF16, bptr(y.G) + r0 * 4 * H, 4ll * H, 1,
-                                     y.wih_t ? y.wih_t : y.wih_p, y.wih_t ? 4ll * H : y.I,
-                                     y.wih_t ? 1 : 0, bptr(y.dX) + r0 * y.I, y.I, (t1 - t0) * B, y.I,
-                                     4 * H, nullptr, nullptr, y.dX == y.dZ ? 1 : 0, 1, S));
-                const int u0 = k * g[l - 1].cf, u1 = min(z.T, u0 + g[l - 1].cf);
-                ED_DEV(ed_stack_ln_bwd(bptr(y.dX), (long long)B * y.I, y.I, bptr(z.Yx) + BH,
-                                       z.residual ? bptr(z.X) : nullptr, z.ln_gamma, z.mean, z.rstd,
-                                       bptr(z.dZ), (float*)(ws + wl.lnpart[l - 1]) + (size_t)k * LNB_GRID * 2 * H,
-                                       LNB_GRID, B, H, u0, u1, z.reduce, S));
-                if (soft) ED_DEV(ed_stack_set_flag(bflag + (l - 1) * 512 + k, S));
-                else ED_TRY(st.record(Eb[l - 1][k], S));
-                queued[l - 1][k] = 1;
-                ready_w[l - 1][k] = w + margin;
-                if (g_trace) g_trace->chunk_enqueued[g_trace->coff[l - 1] + k] = g_trace->launches;
-            }
-            // chunks complete from the last to the first: a segment [k, k + dw_seg) is complete when
-            // its lowest chunk is (k a multiple of dw_seg, counted so that the LAST segment issued,
-            // the one ending at chunk 0, is a full one)
-            // Experiment (EDGEDICT_STACK_TAIL_SPLIT=n, off by default): split the two layers that
-            // finish LAST once more - frames [nchunks/n * cf, T) issued when the BPTT passes that
-            // chunk - so that less work is left for the 0.7 ms tail after the last launch.  Measured
-            // slower: the extra products disturb more BPTT launches than the tail shrinks.
-            const int k_split = (l <= 1 && tail_split > 1 && g[l].nchunks >= 2 * tail_split && dw_seg >= g[l].nchunks &&
-                                 !(d->flags & EDGEDICT_STACK_DW_AT_END))
-                                    ? g[l].nchunks / tail_split : 0;
-            if (k_split > 0 && k == k_split) {
-                ED_TRY(st.chain(st.RS(l), st.W));
-                ED_TRY(weight_grads(l, k * g[l].cf, y.T, true, false));
-            } else if (k_split > 0 && k == 0) {
-                ED_TRY(st.chain(st.RS(l), st.W));
-                ED_TRY(weight_grads(l, 0, k_split * g[l].cf, false, l == 0));
-            } else if (k_split == 0 && k % dw_seg == 0) {
-                if (d->flags & EDGEDICT_STACK_DW_AT_END) {
-                    if (k == 0) deferred.push_back(l);
-                } else {
-                    const int k1 = min(g[l].nchunks, k + dw_seg);
-                    const int t0 = k * g[l].cf, t1 = min(y.T, k1 * g[l].cf);
-                    ED_TRY(st.chain(st.RS(l), st.W));
-                    ED_TRY(weight_grads(l, t0, t1, k1 == g[l].nchunks, l == 0 && k == 0));
-                }
-            }
-        }
+        for (int i = 0; i < ndone; ++i) ED_TRY(chunk_done(done[i].l, done[i].k, w));
     }
     const int Wtot = launches;
     if (st.rt && st.rt->tev[1][1]) {

@@ -927,6 +927,225 @@ __global__ __launch_bounds__(256, ED_BWD_OCC) void stack_bwd_kernel(EdBwdLaunch 
 }
 
 // =====================================================================================
+// backward, launch-persistent (EdLpwBwdLaunch): see stack_kernels.hpp.  The body of a step is bwd_step_role's
+// (same tiling, same MFMA order, same order of the cross-wave sum, same cell arithmetic): bit-identical results.
+// =====================================================================================
+__global__ __launch_bounds__(256, ED_BWD_OCC) void stack_bwd_lpw_kernel(EdLpwBwdLaunch L) {
+    __shared__ BwdShared sh;
+    __shared__ unsigned bail_s;
+    if (ED_STEP_PRIO) __builtin_amdgcn_s_setprio(ED_STEP_PRIO);
+    if (L.stamp && threadIdx.x == 0) atomicMin(&L.stamp[0], wall_clock64());
+    const int B = L.B, H = L.H;
+    const int NB = H >> 5, RG = (B + 31) >> 5, WGS = NB * RG;
+    const int slot = blockIdx.x / WGS, rem = blockIdx.x - slot * WGS;
+    const int nb = rem % NB, rg = rem / NB;
+    const EdLpwBwdSlot& S = L.slot[slot];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int KS = H >> 3;   // 4H / 32
+    const int per = (KS + 3) >> 2;
+    const int ks_beg = wave * per, ks_end = min(KS, ks_beg + per);
+    const int MT = (B + 15) >> 4, mt0 = rg * 2, row0 = rg * 32;
+    const long long H4 = 4ll * H, BH = (long long)B * H;
+    const __amdgpu_buffer_rsrc_t rimg = lpw_rsrc(S.img, (unsigned)S.img_bytes);
+    if (tid == 0) bail_s = 0u;
+    if (S.wait_flag) soft_wait(S.wait_flag, L.err, 600u + slot);
+
+    // ---- epilogue operands of the first frame (later frames: prefetched during the step before)
+    uint4 gin[2], dyin = make_uint4(0, 0, 0, 0);
+    float4 ctin, cpin;
+    auto fetch = [&](int t, int s) {
+        const bf16_t* G_t = S.G - (long long)s * B * H4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + 256 * i, r = id >> 4, part = id & 15, b = row0 + r;
+            gin[i] = make_uint4(0, 0, 0, 0);
+            if (b < B) gin[i] = *reinterpret_cast<const uint4*>(G_t + b * H4 + nb * 128 + part * 8);
+        }
+        const int r = tid >> 3, part = tid & 7, b = row0 + r;
+        ctin = cpin = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < B) {
+            const long long o = (long long)b * H + nb * 32 + part * 4;
+            ctin = *reinterpret_cast<const float4*>(S.Cx + (long long)(t + 1) * BH + o);
+            cpin = *reinterpret_cast<const float4*>(S.Cx + (long long)t * BH + o);
+        }
+        dyin = make_uint4(0, 0, 0, 0);
+        if (tid < 128) {
+            const int r2 = tid >> 2, part2 = tid & 3, b2 = row0 + r2;
+            if (S.dY && b2 < B)
+                dyin = *reinterpret_cast<const uint4*>(S.dY - (long long)s * BH + (long long)b2 * H + nb * 32 + part2 * 8);
+        }
+    };
+    fetch(S.t0, 0);
+    {   // the running dL/dc lives in LDS for the whole launch
+        const int r = tid >> 3, part = tid & 7, b = row0 + r;
+        float4 dcin = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (b < B) dcin = *reinterpret_cast<const float4*>(S.dC + (long long)b * H + nb * 32 + part * 4);
+        *reinterpret_cast<float4*>(&sh.dc[r][part * 4]) = dcin;
+    }
+
+    for (int s = 0; s < S.nsteps; ++s) {
+        const int t = S.t0 - s;
+        // ---- (1) every workgroup of this layer has published dG_{t+1}
+        if (s > 0 && tid == 0) {
+            const unsigned want = S.base + (unsigned)(WGS * s);
+            unsigned spins = 0;
+            while (__hip_atomic_load(S.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 21)) {
+                    if (L.err) atomicCAS(L.err, 0u, 900u + slot);
+                    bail_s = 1u;
+                    break;
+                }
+            }
+        }
+        __syncthreads();      // also: the previous step's trailing stores have read the LDS tiles
+        if (bail_s) break;
+        // the frame's operands (requested during the step before) go to their LDS tiles NOW, so that their 20
+        // registers are free during the operand stream below
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int id = tid + 256 * i, r = id >> 4, part = id & 15;
+            *reinterpret_cast<uint4*>(&sh.g[r][part * 8]) = gin[i];
+        }
+        {
+            const int r = tid >> 3, part = tid & 7;
+            *reinterpret_cast<float4*>(&sh.ct[r][part * 4]) = ctin;
+            *reinterpret_cast<float4*>(&sh.cp[r][part * 4]) = cpin;
+            if (tid < 128) *reinterpret_cast<uint4*>(&sh.dy[tid >> 2][(tid & 3) * 8]) = dyin;
+        }
+        // ---- (2) W_hh^T dG_{t+1}: this wave's K quarter, 2 x 2 tiles, operands streamed through two register buffers
+        f32x4_t acc[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[m][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (t < S.T - 1) {
+            const unsigned soff = (unsigned)((long long)(t + 1) * S.img_stride);
+            const bf16_t* wbase = S.WTfrag + ((long long)nb * 2 * KS * 64 + lane) * 8;
+            bf16x8_t a0[BCH][2], w0[BCH][2], a1[BCH][2], w1[BCH][2];
+            auto load = [&](bf16x8_t (&a)[BCH][2], bf16x8_t (&w)[BCH][2], int ks0) {
+#pragma unroll
+                for (int i = 0; i < BCH; ++i) {
+                    const int ks = min(ks0 + i, ks_end - 1);
+#pragma unroll
+                    for (int m = 0; m < 2; ++m) {
+                        if (mt0 + m < MT) {
+                            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(
+                                rimg, (unsigned)(((ks * MT + mt0 + m) * 64 + lane) * 16), soff, 0);
+                            a[i][m] = *reinterpret_cast<const bf16x8_t*>(&v);
+                        } else {
+                            a[i][m] = zfrag();
+                        }
+                    }
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) w[i][n] = ldfrag(wbase + ((long long)ks * 2 + n) * 512);
+                }
+            };
+            auto mma = [&](bf16x8_t (&a)[BCH][2], bf16x8_t (&w)[BCH][2], int ks0) {
+#pragma unroll
+                for (int i = 0; i < BCH; ++i) {
+                    if (ks0 + i < ks_end) {
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#pragma unroll
+                            for (int n = 0; n < 2; ++n)
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][m], w[i][n], acc[m][n], 0, 0, 0);
+                    }
+                }
+            };
+            if (ks_beg < ks_end) {
+                load(a0, w0, ks_beg);
+                for (int ks0 = ks_beg; ks0 < ks_end; ks0 += 2 * BCH) {
+                    if (ks0 + BCH < ks_end) load(a1, w1, ks0 + BCH);
+                    mma(a0, w0, ks0);
+                    if (ks0 + 2 * BCH < ks_end) load(a0, w0, ks0 + 2 * BCH);
+                    if (ks0 + BCH < ks_end) mma(a1, w1, ks0 + BCH);
+                }
+            }
+        }
+        // ---- (3) partial tiles to their owners (wave w owns tile (m = w >> 1, n = w & 1)), staging
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            if (tt != wave) {
+                const int sl = tt < wave ? tt : tt - 1;
+                const f32x4_t v = acc[tt >> 1][tt & 1];
+                sh.hand[wave][sl][lane] = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+        __syncthreads();
+        f32x4_t mine = wave == 0 ? acc[0][0] : wave == 1 ? acc[0][1] : wave == 2 ? acc[1][0] : acc[1][1];
+#pragma unroll
+        for (int src = 0; src < 4; ++src) {
+            if (src != wave) {
+                const int sl = wave < src ? wave : wave - 1;
+                const float4 v = sh.hand[src][sl][lane];
+                mine[0] += v.x; mine[1] += v.y; mine[2] += v.z; mine[3] += v.w;
+            }
+        }
+        {
+            const int m = wave >> 1, n = wave & 1;
+            const int u = lane & 15, ul = n * 16 + u, cb = n * 64 + u, rbase = m * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int rl = rbase + q;
+                const float ig = bf16_to_f32(sh.g[rl][cb]), fg = bf16_to_f32(sh.g[rl][cb + 16]);
+                const float gg = bf16_to_f32(sh.g[rl][cb + 32]), og = bf16_to_f32(sh.g[rl][cb + 48]);
+                const float dh = bf16_to_f32(sh.dy[rl][ul]) + mine[q];
+                const float tc = ftanh(sh.ct[rl][ul]);
+                const float dct = sh.dc[rl][ul] + dh * og * (1.f - tc * tc);
+                sh.g[rl][cb] = f32_to_bf16(dct * gg * ig * (1.f - ig));
+                sh.g[rl][cb + 16] = f32_to_bf16(dct * sh.cp[rl][ul] * fg * (1.f - fg));
+                sh.g[rl][cb + 32] = f32_to_bf16(dct * ig * (1.f - gg * gg));
+                sh.g[rl][cb + 48] = f32_to_bf16(dh * tc * og * (1.f - og));
+                sh.dc[rl][ul] = dct * fg;
+            }
+        }
+        __syncthreads();
+        // ---- (4) publish FIRST: this workgroup's part of image t (512 write-through 16-byte stores), drain, arrive
+        if (t > 0) {
+            const unsigned soff_out = (unsigned)((long long)t * S.img_stride);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int id = tid + 256 * i, mm = id >> 8, ksl = (id >> 6) & 3, kg = (id >> 4) & 3, r16 = id & 15;
+                const int mt = mt0 + mm;
+                if (mt < MT) {
+                    u32x4_t v = {0u, 0u, 0u, 0u};
+                    if (mt * 16 + r16 < B) v = *reinterpret_cast<const u32x4_t*>(&sh.g[mm * 16 + r16][ksl * 32 + kg * 8]);
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        v, rimg, (unsigned)(((((nb * 4 + ksl) * MT + mt) * 64) + kg * 16 + r16) * 16), soff_out, 16);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(S.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- (5) off the chain: dG rows (for the dX / weight-gradient products), next frame's operands
+        {
+            bf16_t* G_t = S.G - (long long)s * B * H4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int task = tid + 256 * i, r = task >> 4, part = task & 15, b = row0 + r;
+                if (b < B)
+                    *reinterpret_cast<uint4*>(G_t + b * H4 + nb * 128 + part * 8) =
+                        *reinterpret_cast<const uint4*>(&sh.g[r][part * 8]);
+            }
+            if (s + 1 < S.nsteps) fetch(t - 1, s + 1);
+        }
+    }
+    __syncthreads();
+    {
+        const int r = tid >> 3, part = tid & 7, b = row0 + r;
+        if (b < B)
+            *reinterpret_cast<float4*>(S.dC + (long long)b * H + nb * 32 + part * 4) =
+                *reinterpret_cast<const float4*>(&sh.dc[r][part * 4]);
+    }
+    if (L.stamp) {
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(&L.stamp[1], wall_clock64());
+    }
+}
+
+// =====================================================================================
 // LayerNorm backward, time-major, frames [t0, t1) of one layer.  One wave per input row (t, b):
 //   z = y (+ res), xhat = (z - mean) rstd, dy = dout[t / reduce, b] / reduce, g = dy gamma
 //   dz = rstd (g - mean_H(g) - xhat mean_H(g xhat));  dgamma += dy xhat;  dbeta += dy
@@ -1195,6 +1414,20 @@ int ed_stack_wait_counters(const unsigned* const* counters, const unsigned* targ
     a.err = err;
     hipLaunchKernelGGL(stack_wait_counters_kernel, dim3(1), dim3(64), 0, s, a);
     ED_CHECK_LAUNCH("stack_wait_counters_kernel");
+    return ED_OK;
+}
+
+int ed_stack_lpw_bwd_supported(int B, int H) {
+    const int NB = H >> 5, RG = (B + 31) >> 5;
+    return (H % 32 == 0 && NB * RG <= 64) ? 1 : 0;
+}
+
+int ed_stack_launch_bwd_lpw(const EdLpwBwdLaunch& L, hipStream_t s) {
+    const int NB = L.H >> 5, RG = (L.B + 31) >> 5;
+    const int grid = L.nslot * NB * RG;
+    if (grid == 0) return ED_OK;
+    hipLaunchKernelGGL(stack_bwd_lpw_kernel, dim3(grid), dim3(256), 0, s, L);
+    ED_CHECK_LAUNCH("stack_bwd_lpw_kernel");
     return ED_OK;
 }
 

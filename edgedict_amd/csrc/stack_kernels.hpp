@@ -116,6 +116,37 @@ int ed_stack_wait_counters(const unsigned* const* counters, const unsigned* targ
 int ed_stack_multi_norm(const EdChunkNorm* items, int n, int B, int H, float eps, hipStream_t s);
 int ed_stack_lpw_supported(int B, int H);     // 1 when the launch-persistent forward kernel covers this geometry
 
+// ---- launch-persistent BPTT (stack_kernels.hip, stack_bwd_lpw_kernel): `nsteps` consecutive BPTT steps
+// (descending t) of every runnable layer per launch.  Tiling and arithmetic of stack_bwd_kernel (W_hh^T is
+// still streamed: its 256 KB slice does not fit beside the background products' registers); what goes away
+// is the kernel boundary per step - the layer's workgroups meet through an arrival counter, dG_t travels
+// through one fragment image per frame (write-through stores, plain loads), the running dL/dc stays in LDS.
+struct EdLpwBwdSlot {
+    bf16_t* G;                 // frame t0: [B, 4H] interleaved, in gates / out dL/d(pre-activation); frame t0-s at - s*B*4H
+    bf16_t* img;               // dG fragment images [T][4H/32][B16/16][64][8], one per frame: step t reads image t+1
+                               // (absent at t = T-1), writes image t (not at t = 0)
+    long long img_stride;      // bytes between images
+    long long img_bytes;       // bytes of the region (buffer descriptor)
+    const bf16_t* dY;          // dL/dh rows of frame t0 from above [B, H]; frame t0-s at - s*B*H
+    const float* Cx;           // cell states: c_t at Cx + (t+1)*B*H (row 0 = c0)
+    float* dC;                 // [B, H] running dL/dc, in/out
+    const bf16_t* WTfrag;      // W_hh^T B-fragment image (EdBwdStep::WTfrag)
+    unsigned* counter;         // arrivals of this layer's workgroups, one per finished BPTT step (zeroed per call)
+    unsigned base;             // *counter once every step of a frame > t0 is done
+    const unsigned* wait_flag; // null, or: frame t0 opens a chunk whose dY rows are done when != 0
+    int t0, nsteps, T;
+    int layer;
+};
+struct EdLpwBwdLaunch {
+    EdLpwBwdSlot slot[ED_STACK_MAX_SLOTS];
+    int nslot;
+    int B, H;
+    unsigned long long* stamp;
+    unsigned* err;
+};
+int ed_stack_launch_bwd_lpw(const EdLpwBwdLaunch& L, hipStream_t s);
+int ed_stack_lpw_bwd_supported(int B, int H);
+
 // ---- weights-stationary recurrence (wsr_kernels.hip): ONE launch carries a chunk of frames of every
 // runnable layer; a layer lives on the 32 CUs of one XCD with W_hh in registers (H = 1024, B <= 64)
 struct EdWsrSlot {

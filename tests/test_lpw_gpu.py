@@ -80,3 +80,40 @@ def test_lpw_forward_e6d2_full_size_bit_identical_and_carried_state(hip_lib):
         return full, hf, cf, torch.cat([y1, y2], 1), h2, c2
     full, hf, cf, cat, h2, c2 = _with_env(chunked, EDGEDICT_STACK_LPW=1, EDGEDICT_LPW_STEPS=6)
     assert torch.equal(cat, full) and torch.equal(h2, hf) and torch.equal(c2, cf)
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("steps", [2, 4])
+def test_lpw_backward_is_bit_identical_to_the_step_kernels(hip_lib, case, steps):
+    """stack_bwd_lpw_kernel (EDGEDICT_STACK_LPW_BWD=1): several consecutive BPTT steps per launch, the layer's
+    workgroups meet through arrival counters, dG_t travels through one fragment image per frame.  Tiling and
+    arithmetic are the step kernel's: every gradient the products compute from the dG rows must be bit-identical."""
+    from edgedict_amd import encoder_stack
+    chunk = 4 if case[6] < 4 else case[6]
+    enc, xs = _encoder(case)
+    ref = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk, lag=case[7]),
+                    EDGEDICT_STACK_LPW=0, EDGEDICT_STACK_LPW_BWD=0)
+    got = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk, lag=case[7]),
+                    EDGEDICT_STACK_LPW=0, EDGEDICT_STACK_LPW_BWD=1, EDGEDICT_LPW_STEPS_B=steps)
+    both = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk, lag=case[7]),
+                     EDGEDICT_STACK_LPW=1, EDGEDICT_STACK_LPW_BWD=1, EDGEDICT_LPW_STEPS=steps, EDGEDICT_LPW_STEPS_B=steps)
+    ser = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=encoder_stack.SERIAL, chunk=chunk, lag=case[7]),
+                    EDGEDICT_STACK_LPW=1, EDGEDICT_STACK_LPW_BWD=1, EDGEDICT_LPW_STEPS=steps, EDGEDICT_LPW_STEPS_B=steps)
+    _same(ref, got)
+    _same(ref, both)
+    _same(ref, ser)
+    encoder_stack.check_wsr_error()
+
+
+def test_lpw_backward_e6d2_full_size_bit_identical(hip_lib):
+    from edgedict_amd import encoder_stack
+    case = (64, 401, 240, 1024, 6, [1], 12, 0)
+    enc, xs = _encoder(case)
+    ref = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=12), EDGEDICT_STACK_LPW_BWD=0)
+    got = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=12), EDGEDICT_STACK_LPW_BWD=1, EDGEDICT_LPW_STEPS_B=6)
+    assert torch.equal(ref[0], got[0])
+    for n in ref[3]:
+        assert torch.isfinite(got[3][n]).all(), n
+        if "weight_ih" in n or "weight_hh" in n:
+            assert torch.equal(ref[3][n], got[3][n]), n
+    encoder_stack.check_wsr_error()

@@ -16,7 +16,10 @@ torch.manual_seed(0)
 enc = Encoder(240, 1024, 6, 0.0, 640).cuda()
 enc.compute_dtype = torch.bfloat16
 xs = torch.randn(B, T0, 240, device="cuda")
-KEYS = {"LPW": "EDGEDICT_STACK_LPW", "STEPS": "EDGEDICT_LPW_STEPS", "MARGIN": "EDGEDICT_LPW_MARGIN"}
+for p in enc.parameters():          # gradients accumulate in place (flat-buffer training does the same)
+    p.grad = torch.zeros_like(p)
+KEYS = {"LPW": "EDGEDICT_STACK_LPW", "STEPS": "EDGEDICT_LPW_STEPS", "MARGIN": "EDGEDICT_LPW_MARGIN",
+        "LPWB": "EDGEDICT_STACK_LPW_BWD", "STEPSB": "EDGEDICT_LPW_STEPS_B", "MARGINB": "EDGEDICT_LPW_MARGIN_B"}
 for spec in sys.argv[1:] or ["LPW=0"]:
     kv = dict(x.split("=") for x in spec.split(","))
     for k, v in kv.items():
@@ -26,7 +29,6 @@ for spec in sys.argv[1:] or ["LPW=0"]:
     bwd = kv.get("BWD", "0") == "1"
     res = []
     for it in range(6):
-        enc.zero_grad(set_to_none=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         if bwd:
