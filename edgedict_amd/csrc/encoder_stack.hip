@@ -22,6 +22,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -1439,7 +1440,14 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
             Lc.H = H;
             Done done[ED_STACK_MAX_SLOTS];
             int ndone = 0;
-            for (int l = L - 1; l >= 0; --l) {
+            // the launch has room for max_slots layers: the layers with the most steps left go first (the full-rate
+            // layers at the bottom are the critical path; top-down order let the four layers behind the time
+            // reduction take every slot and the two full-rate ones run alone, on half the chip, at the end)
+            int order[ED_STACK_MAX_SLOTS];
+            for (int l = 0; l < L; ++l) order[l] = l;
+            std::stable_sort(order, order + L, [&](int a, int b) { return g[a].T - next_t[a] > g[b].T - next_t[b]; });
+            for (int oi = 0; oi < L; ++oi) {
+                const int l = order[oi];
                 const edgedict_stack_layer_t& y = d->layers[l];
                 if (next_t[l] >= g[l].T || Lc.nslot >= max_slots) continue;
                 const int t = g[l].T - 1 - next_t[l];
