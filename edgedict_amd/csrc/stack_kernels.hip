@@ -108,7 +108,9 @@ __device__ __forceinline__ void fwd_step_role(const EdFwdStep& p, int ub, int rg
             const int ks = min(ks0 + i, ks_end - 1);   // clamp: duplicates are masked in mma()
 #pragma unroll
             for (int m = 0; m < 4; ++m)
-                a[i][m] = (mt0 + m < MT) ? ldfrag(abase + ((long long)ks * MT + mt0 + m) * 512) : zfrag();
+                // (row tiles past the batch: a duplicate of the last tile instead of a branch - their rows are never
+                // stored, and straight-line loads let the compiler count its waits, see bwd_step_role)
+                a[i][m] = ldfrag(abase + ((long long)ks * MT + min(mt0 + m, MT - 1)) * 512);
 #pragma unroll
             for (int g = 0; g < 4; ++g) w[i][g] = ldfrag(wbase + ((long long)ks * 4 + g) * 512);
         }
@@ -126,12 +128,27 @@ __device__ __forceinline__ void fwd_step_role(const EdFwdStep& p, int ub, int rg
         }
     };
     if (ks_beg < ks_end && !(ED_STACK_DBG & 1)) {
+        // steady state WITHOUT conditional loads: behind an `if (...) load(...)` the compiler's wait counts are
+        // those of the path that did not load (vmcnt(13) where 29 were in flight) - the second buffer then never
+        // overlapped the first.  The conditions live in the loop bounds and in a peeled tail instead.
         load(a0, w0, ks_beg);
-        for (int ks0 = ks_beg; ks0 < ks_end; ks0 += 2 * FCH) {
-            if (ks0 + FCH < ks_end) load(a1, w1, ks0 + FCH);
+        int ks0 = ks_beg;
+        for (; ks0 + 2 * FCH < ks_end; ks0 += 2 * FCH) {
+            load(a1, w1, ks0 + FCH);
+            __builtin_amdgcn_sched_barrier(0);      // the whole buffer is requested before the other one is consumed
             mma(a0, w0, ks0);
-            if (ks0 + 2 * FCH < ks_end) load(a0, w0, ks0 + 2 * FCH);
-            if (ks0 + FCH < ks_end) mma(a1, w1, ks0 + FCH);
+            __builtin_amdgcn_sched_barrier(0);
+            load(a0, w0, ks0 + 2 * FCH);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(a1, w1, ks0 + FCH);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ks0 + FCH < ks_end) {
+            load(a1, w1, ks0 + FCH);
+            mma(a0, w0, ks0);
+            mma(a1, w1, ks0 + FCH);
+        } else {
+            mma(a0, w0, ks0);
         }
     }
 
@@ -518,13 +535,9 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
                 const int ks = min(ks_beg + i, KS - 1);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    if (ks_beg + i < ks_end && mt0 + m < MT) {
-                        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(
-                            rimg, (unsigned)(((ks * MT + mt0 + m) * 64 + lane) * 16), soff_in, 0);
-                        a[i][m] = *reinterpret_cast<const bf16x8_t*>(&v);
-                    } else {
-                        a[i][m] = zfrag();
-                    }
+                    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(
+                        rimg, (unsigned)(((ks * MT + min(mt0 + m, MT - 1)) * 64 + lane) * 16), soff_in, 0);
+                    a[i][m] = *reinterpret_cast<const bf16x8_t*>(&v);
                 }
             }
         }
@@ -805,7 +818,10 @@ __device__ __forceinline__ void bwd_step_role(const EdBwdStep& p, int nb, int rg
                 const int ks = min(ks0 + i, ks_end - 1);
 #pragma unroll
                 for (int m = 0; m < 2; ++m)
-                    a[i][m] = (mt0 + m < MT) ? ldfrag(abase + ((long long)ks * MT + mt0 + m) * 512) : zfrag();
+                    // unconditional (a duplicate tile past the batch): a conditional load is an exec-masked branch
+                    // per fragment, and across those blocks the compiler's wait counts collapsed to vmcnt(6..7) -
+                    // half a buffer in flight instead of two
+                    a[i][m] = ldfrag(abase + ((long long)ks * MT + min(mt0 + m, MT - 1)) * 512);
 #pragma unroll
                 for (int n = 0; n < 2; ++n) w[i][n] = ldfrag(wbase + ((long long)ks * 2 + n) * 512);
             }
@@ -822,13 +838,25 @@ __device__ __forceinline__ void bwd_step_role(const EdBwdStep& p, int nb, int rg
                 }
             }
         };
-        if (ks_beg < ks_end) {
+        if (ks_beg < ks_end) {       // no conditional loads in the steady state: see fwd_step_role
             load(a0, w0, ks_beg);
-            for (int ks0 = ks_beg; ks0 < ks_end; ks0 += 2 * BCH) {
-                if (ks0 + BCH < ks_end) load(a1, w1, ks0 + BCH);
+            int ks0 = ks_beg;
+            for (; ks0 + 2 * BCH < ks_end; ks0 += 2 * BCH) {
+                load(a1, w1, ks0 + BCH);
+                __builtin_amdgcn_sched_barrier(0);
                 mma(a0, w0, ks0);
-                if (ks0 + 2 * BCH < ks_end) load(a0, w0, ks0 + 2 * BCH);
-                if (ks0 + BCH < ks_end) mma(a1, w1, ks0 + BCH);
+                __builtin_amdgcn_sched_barrier(0);
+                load(a0, w0, ks0 + 2 * BCH);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(a1, w1, ks0 + BCH);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (ks0 + BCH < ks_end) {
+                load(a1, w1, ks0 + BCH);
+                mma(a0, w0, ks0);
+                mma(a1, w1, ks0 + BCH);
+            } else {
+                mma(a0, w0, ks0);
             }
         }
     }
@@ -1029,13 +1057,9 @@ __global__ __launch_bounds__(256, ED_BWD_OCC) void stack_bwd_lpw_kernel(EdLpwBwd
                     const int ks = min(ks0 + i, ks_end - 1);
 #pragma unroll
                     for (int m = 0; m < 2; ++m) {
-                        if (mt0 + m < MT) {
-                            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(
-                                rimg, (unsigned)(((ks * MT + mt0 + m) * 64 + lane) * 16), soff, 0);
-                            a[i][m] = *reinterpret_cast<const bf16x8_t*>(&v);
-                        } else {
-                            a[i][m] = zfrag();
-                        }
+                        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(
+                            rimg, (unsigned)(((ks * MT + min(mt0 + m, MT - 1)) * 64 + lane) * 16), soff, 0);
+                        a[i][m] = *reinterpret_cast<const bf16x8_t*>(&v);
                     }
 #pragma unroll
                     for (int n = 0; n < 2; ++n) w[i][n] = ldfrag(wbase + ((long long)ks * 2 + n) * 512);
@@ -1053,13 +1077,25 @@ __global__ __launch_bounds__(256, ED_BWD_OCC) void stack_bwd_lpw_kernel(EdLpwBwd
                     }
                 }
             };
-            if (ks_beg < ks_end) {
+            if (ks_beg < ks_end) {       // no conditional loads in the steady state: see fwd_step_role
                 load(a0, w0, ks_beg);
-                for (int ks0 = ks_beg; ks0 < ks_end; ks0 += 2 * BCH) {
-                    if (ks0 + BCH < ks_end) load(a1, w1, ks0 + BCH);
+                int ks0 = ks_beg;
+                for (; ks0 + 2 * BCH < ks_end; ks0 += 2 * BCH) {
+                    load(a1, w1, ks0 + BCH);
+                    __builtin_amdgcn_sched_barrier(0);
                     mma(a0, w0, ks0);
-                    if (ks0 + 2 * BCH < ks_end) load(a0, w0, ks0 + 2 * BCH);
-                    if (ks0 + BCH < ks_end) mma(a1, w1, ks0 + BCH);
+                    __builtin_amdgcn_sched_barrier(0);
+                    load(a0, w0, ks0 + 2 * BCH);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mma(a1, w1, ks0 + BCH);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (ks0 + BCH < ks_end) {
+                    load(a1, w1, ks0 + BCH);
+                    mma(a0, w0, ks0);
+                    mma(a1, w1, ks0 + BCH);
+                } else {
+                    mma(a0, w0, ks0);
                 }
             }
         }
