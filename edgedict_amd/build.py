@@ -27,9 +27,16 @@ CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
 
 def _sources():
     out = []
+    # the hipBLASLt bridge is quarantined under csrc/optional/: the default library contains the stubs of
+    # blaslt_off.cpp instead (EDGEDICT_WITH_BLASLT=1 swaps them)
+    with_vendor = os.environ.get("EDGEDICT_WITH_BLASLT", "0") == "1"
     for fn in sorted(os.listdir(CSRC)):
         if fn.endswith(".hip") or fn.endswith(".cpp"):
+            if fn == "blaslt_off.cpp" and with_vendor:
+                continue
             out.append(os.path.join(CSRC, fn))
+    if with_vendor:
+        out.append(os.path.join(CSRC, "optional", "blaslt.cpp"))
     return out
 
 
