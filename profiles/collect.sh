@@ -10,7 +10,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-loss-delta --no-own-kernels-run --no-fp32-run"
+CMD="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-loss-delta --no-own-kernels-run --no-fp32-run --no-secondary"
 rm -rf /tmp/prof_$TAG
 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG/trace -o t -- $CMD > $OUT/${TAG}_trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do

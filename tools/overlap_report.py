@@ -59,12 +59,16 @@ def child(variant):
         n = ctypes.c_int(0)
         if lib.edgedict_stack_launch_stamps(bw, buf, 4096, ctypes.byref(n)) != 0:
             continue
-        st = np.array(buf[:2 * n.value], dtype=np.float64).reshape(-1, 2) * 0.01
+        raw = np.array(buf[:2 * n.value], dtype=np.uint64).reshape(-1, 2)
+        ok = (raw[:, 1] > raw[:, 0]) & (raw[:, 0] != np.uint64(0xffffffffffffffff))   # slots of launches that stamped
+        st = raw[ok].astype(np.float64) * 0.01
+        if len(st) < 2:
+            continue
         d = st[:, 1] - st[:, 0]
         g = st[1:, 0] - st[:-1, 1]
-        print("   %-8s %3d launches: span %.2f ms, kernels %.2f ms, gaps %.2f ms; mean kernel %.1f us, mean gap %.1f us, "
-              "period %.1f us" % (name, n.value, (st[-1, 1] - st[0, 0]) * 1e-3, d.sum() * 1e-3, g.sum() * 1e-3, d.mean(), g.mean(),
-                                  (st[-1, 1] - st[0, 0]) / n.value))
+        print("   %-8s %3d stamped launches: span %.2f ms, kernels %.2f ms, gaps %.2f ms; mean kernel %.1f us, mean gap %.1f us, "
+              "period %.1f us" % (name, len(st), (st[-1, 1] - st[0, 0]) * 1e-3, d.sum() * 1e-3, g.sum() * 1e-3, d.mean(), g.mean(),
+                                  (st[-1, 1] - st[0, 0]) / len(st)))
     lib.edgedict_stack_time_launches(0)
 
 
