@@ -791,6 +791,8 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
             sl.counter = cnt + l * LPW_CNT_STRIDE;
             sl.base = (unsigned)WGS * (unsigned)t;
             sl.wait_flag = (soft && opens) ? fflag + l * 512 + k : nullptr;
+            sl.flags = nullptr;
+            sl.cf = g[l].cf;
             sl.t0 = t;
             sl.nsteps = t1 - t;
             sl.layer = l;
@@ -874,6 +876,174 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
             }
             if (st.serial) break;     // one stream: the first pass took every slot
         }
+    }
+    if (st.rt && st.rt->tev[0][1]) {
+        ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][1], st.R));
+        st.rt->tlaunches[0] = launches;
+    }
+    ED_TRY(st.chain(st.R, st.C));
+    for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.S[l], st.C));
+    return ED_OK;
+}
+
+// The launch-persistent forward with launches that run ACROSS chunk boundaries (EDGEDICT_LPW_CROSS, default on
+// when flag waits are on).  forward_lpw ties three things to the launch: the W_hh reload (10 us of fabric traffic
+// per launch), the hand-over of a finished chunk to the layer above (enqueued after the launch, consumed `margin`
+// launches later) and the alternation of the layers behind the time reduction.  With 12 steps per launch a layer
+// therefore trailed its producer by chunk + 2 launches = 48 steps, 240 steps (1.7 ms) over the five hand-overs.
+// Here the hand-over is decoupled from the launch:
+//   * a slot takes up to `nsub` steps whatever chunks they fall in; the kernel waits for a chunk's flag when a step
+//     opens it (EdLpwSlot::flags);
+//   * the side work of every chunk a slot completes is enqueued BEFORE the launch, gated on the layer's arrival
+//     counter (stack_wait_counters_kernel): LayerNorm of the chunk's frames, the next layer's product, its flag -
+//     they run the moment the chunk's last step is out, in the middle of the launch;
+//   * a consumer may open chunk k in a launch when the chunk's side work is enqueued and its last step lies at
+//     least `lead` step-times before the opening step (the product needs ~40 us); otherwise its slot ends there.
+// Chunks can then be small (the fill is chunk + lead per hand-over) while launches stay long.
+int forward_lpw_cross(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Streams& st, const WsLayout& wl,
+                      int nsub) {
+    const int B = d->B, H = d->H, L = d->L;
+    const long long BH = (long long)B * H;
+    char* ws = (char*)d->ws;
+    unsigned* fflag = reinterpret_cast<unsigned*>(ws + wl.wsr_sync);
+    unsigned* cnt = fflag + 2 * 8 * 512;
+    unsigned* gerr = (st.rt && st.rt->wsr_err_dev) ? st.rt->wsr_err_dev + 2 : nullptr;
+    for (int l = 0; l < L; ++l) ED_CHECK_ARG(g[l].nchunks <= 512, "encoder_stack: too many chunks for the flag table");
+    ED_DEV(ed_stack_zero(fflag, (size_t)8 * 512 * sizeof(unsigned), st.C));
+    ED_DEV(ed_stack_zero(cnt, (size_t)8 * LPW_CNT_STRIDE * sizeof(unsigned), st.C));
+    ED_TRY(st.chain(st.C, st.R));
+    for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.C, st.S[l]));
+    int split = L;
+    for (int l = 0; l < L; ++l)
+        if (d->layers[l].reduce == 2) { split = l + 1; break; }
+    if (split >= L) split = (L + 1) / 2;
+    auto side = [&](int l) -> hipStream_t { return l < split ? st.S[0] : st.C; };
+    const int WGS = (H >> 4) * ((B + 63) >> 6);
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return n;
+    }();
+    const int max_slots = max(1, min(ED_STACK_MAX_SLOTS, n_cu / WGS));
+    const char* e_l = getenv("EDGEDICT_LPW_LEAD");
+    const int lead = (e_l && atoi(e_l) >= 0) ? atoi(e_l) : 8;
+    const int T_out = (g[L - 1].T + d->layers[L - 1].reduce - 1) / d->layers[L - 1].reduce;
+
+    // layer 0's products need nothing from the recurrence: all of them up front on the caller's stream
+    for (int k = 0; k < g[0].nchunks; ++k) {
+        ED_DEV(input_gemm(d, g, 0, k, st.C));
+        ED_DEV(ed_stack_set_flag(fflag + k, st.C));
+    }
+    // enqueued[l][k]: the side work that produces layer l's chunk k is on its stream; done_clk[l][k]: step-time at
+    // which the producer's last step of that chunk ends (clock = steps since the first launch, all slots in step)
+    std::vector<std::vector<char>> enqueued(L);
+    std::vector<std::vector<long long>> done_clk(L);
+    for (int l = 0; l < L; ++l) {
+        enqueued[l].assign(g[l].nchunks, l == 0 ? 1 : 0);
+        done_clk[l].assign(g[l].nchunks, -(1ll << 40));
+    }
+    std::vector<int> next_t(L, 0);
+    int launches = 0, idle = 0;
+    long long clk = 0;
+    if (st.rt) st.rt->stamp_used[0] = 0;
+    if (st.rt && st.rt->tev[0][0]) ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][0], st.R));
+    for (int w = 0;; ++w) {
+        bool finished = true;
+        for (int l = 0; l < L; ++l) finished = finished && next_t[l] >= g[l].T;
+        if (finished) break;
+        EdLpwLaunch Lc;
+        Lc.nslot = 0;
+        Lc.B = B;
+        Lc.H = H;
+        int longest = 0;
+        for (int l = 0; l < L; ++l) {
+            const edgedict_stack_layer_t& y = d->layers[l];
+            const int t = next_t[l];
+            if (t >= g[l].T || Lc.nslot >= max_slots) continue;
+            int m_min = g[l].m;
+            for (int j = 0; j < l; ++j)
+                if (next_t[j] < g[j].T) m_min = min(m_min, g[j].m);
+            if (!Pace::allows(w, l, g[l].m, m_min)) continue;
+            // how far this slot may run: every chunk it opens must be enqueued and far enough behind
+            int t1 = t;
+            const int t_max = min(t + nsub, g[l].T);
+            while (t1 < t_max) {
+                if (t1 % g[l].cf == 0 && l > 0) {
+                    const int k = t1 / g[l].cf;
+                    if (!enqueued[l][k] || clk + (t1 - t) < done_clk[l][k] + lead) break;
+                }
+                t1 = min(t_max, (t1 / g[l].cf + 1) * g[l].cf);
+            }
+            if (t1 == t) continue;
+            EdLpwSlot& sl = Lc.slot[Lc.nslot++];
+            sl.G = bptr(y.G) + (long long)t * B * 4 * H;
+            sl.img = bptr(ws + wl.himg[l]);
+            sl.img_stride = (long long)wl.himg_stride;
+            sl.img_bytes = (long long)(y.T + 1) * (long long)wl.himg_stride;
+            sl.Y = bptr(y.Yx) + (long long)(t + 1) * BH;
+            sl.C_prev = y.Cx + (long long)t * BH;
+            sl.C = y.Cx + (long long)(t + 1) * BH;
+            sl.Wfrag = bptr(y.whh_f);
+            sl.counter = cnt + l * LPW_CNT_STRIDE;
+            sl.base = (unsigned)WGS * (unsigned)t;
+            sl.wait_flag = nullptr;
+            sl.flags = fflag + l * 512;
+            sl.cf = g[l].cf;
+            sl.t0 = t;
+            sl.nsteps = t1 - t;
+            sl.layer = l;
+            longest = max(longest, t1 - t);
+            next_t[l] = t1;
+            // ---- side work of the chunks this slot completes, gated on the layer's counter, enqueued NOW
+            for (int k = t / g[l].cf; k * g[l].cf < t1; ++k) {
+                const int c0 = k * g[l].cf, c1 = min(g[l].T, c0 + g[l].cf);
+                if (c1 > t1 || c1 <= t) continue;                 // completed by an earlier or a later slot
+                hipStream_t S = side(l);
+                const unsigned* cp[1] = {cnt + l * LPW_CNT_STRIDE};
+                const unsigned tg[1] = {(unsigned)WGS * (unsigned)c1};
+                ED_DEV(ed_stack_wait_counters(cp, tg, 1, gerr, S));
+                EdChunkNorm e;
+                e.Yx1 = bptr(y.Yx) + BH;
+                e.X = y.residual ? bptr(y.X) : nullptr;
+                e.gamma = y.ln_gamma;
+                e.beta = y.ln_beta;
+                if (l + 1 < L) {
+                    e.out = bptr(d->layers[l + 1].X);
+                    e.out_st = BH;
+                    e.out_sb = H;
+                } else {
+                    e.out = bptr(d->out);
+                    e.out_st = H;
+                    e.out_sb = (long long)T_out * H;
+                }
+                e.mean = y.mean;
+                e.rstd = y.rstd;
+                e.T = y.T;
+                e.t0 = c0;
+                e.t1 = c1;
+                e.reduce = y.reduce;
+                ED_DEV(ed_stack_multi_norm(&e, 1, B, H, d->eps, S));
+                if (l + 1 < L) {
+                    ED_DEV(input_gemm(d, g, l + 1, k, S));
+                    ED_DEV(ed_stack_set_flag(fflag + (l + 1) * 512 + k, S));
+                    enqueued[l + 1][k] = 1;
+                    done_clk[l + 1][k] = clk + (c1 - t);
+                }
+            }
+        }
+        if (Lc.nslot == 0) {
+            // nothing may start yet: every waiting layer needs `lead` more step-times behind its producer
+            ED_CHECK_ARG(++idle < 1 << 16, "encoder_stack: forward schedule made no progress");
+            ++clk;
+            continue;
+        }
+        idle = 0;
+        ++launches;
+        Lc.stamp = st.rt ? st.rt->stamp_slot(0, st.R) : nullptr;
+        Lc.err = gerr;
+        Lc.trace = g_wsr_trace;
+        ED_DEV(ed_stack_launch_fwd_lpw(Lc, st.R));
+        clk += longest;
     }
     if (st.rt && st.rt->tev[0][1]) {
         ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][1], st.R));
@@ -969,7 +1139,11 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     // (layer, chunk) in the workspace's sync region, zeroed before the streams fork
     static const int soft_env = [] { const char* e = getenv("EDGEDICT_STACK_SOFT_WAIT"); return e ? atoi(e) : 1; }();
     const bool soft = soft_env && !st.serial && L <= 8;
-    if (lpw_ns) return forward_lpw(d, g, st, wl, lpw_ns, soft);
+    if (lpw_ns) {
+        const char* e_x = getenv("EDGEDICT_LPW_CROSS");
+        const bool cross = (e_x ? atoi(e_x) : 0) != 0 && soft && !g_trace;
+        return cross ? forward_lpw_cross(d, g, st, wl, lpw_ns) : forward_lpw(d, g, st, wl, lpw_ns, soft);
+    }
     unsigned* fflag = reinterpret_cast<unsigned*>(ws + wl.wsr_sync);           // [8][512]
     unsigned* gerr = (st.rt && st.rt->wsr_err_dev) ? st.rt->wsr_err_dev + 2 : nullptr;
     if (soft) {

@@ -474,6 +474,7 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
         }
     }
     if (S.wait_flag) soft_wait(S.wait_flag, L.err, 500u + slot);
+    if (S.flags && S.t0 % S.cf == 0) soft_wait(S.flags + S.t0 / S.cf, L.err, 500u + slot);
 
     // ---- epilogue operands of the first step
     uint4 gin[2];
@@ -523,6 +524,19 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
         }
         __syncthreads();      // also: the previous step's trailing stores have read the LDS staging tiles
         if (bail_s) break;
+        if (S.flags && s > 0 && t % S.cf == 0) {
+            // this step opens a new chunk INSIDE the launch: its pre-activations come from a side-stream product
+            // that was enqueued (gated on the producing layer's counter) before this launch - wait for its flag,
+            // then fetch the rows that the step before could not prefetch
+            soft_wait(S.flags + t / S.cf, L.err, 500u + slot);
+            const bf16_t* G_t = S.G + (long long)s * B * H4;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int id = tid + 256 * i, r = id >> 3, part = id & 7, b = row0 + r;
+                gin[i] = make_uint4(0, 0, 0, 0);
+                if (b < B) gin[i] = *reinterpret_cast<const uint4*>(G_t + b * H4 + ub * 64 + part * 8);
+            }
+        }
         LPW_STAMP(0);
         // ---- (2) h_{t-1} fragments of this wave's K quarter: image t, plain loads (the address has never
         // been touched before in this pass - nothing stale anywhere - and the first reader on an XCD brings a
@@ -667,7 +681,7 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
                     *reinterpret_cast<float4*>(S.C + (long long)s * BH + (long long)b * H + ub * 16 + part * 4) =
                         *reinterpret_cast<const float4*>(&sh.c[r][part * 4]);
             }
-            if (s + 1 < S.nsteps) {
+            if (s + 1 < S.nsteps && !(S.flags && (t + 1) % S.cf == 0)) {     // not across a chunk opening
                 const bf16_t* G_n = G_t + (long long)B * H4;
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {

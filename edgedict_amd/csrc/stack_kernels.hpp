@@ -87,6 +87,9 @@ struct EdLpwSlot {
     unsigned* counter;         // arrivals of this layer's workgroups, one per finished step (zeroed per call)
     unsigned base;             // *counter once every step < t0 is done = workgroups_per_step * (steps done before)
     const unsigned* wait_flag; // null, or: step t0 opens a chunk whose side-stream product is done when != 0
+    const unsigned* flags;     // null, or (launches that run ACROSS chunk boundaries): the layer's chunk flags - before
+                               // every step t with t % cf == 0 the workgroup waits for flags[t / cf] != 0
+    int cf;                    // frames per chunk of this layer (with `flags`)
     int t0, nsteps;
     int layer;                 // for the debug trace only
 };

@@ -117,3 +117,18 @@ def test_lpw_backward_e6d2_full_size_bit_identical(hip_lib):
         if "weight_ih" in n or "weight_hh" in n:
             assert torch.equal(ref[3][n], got[3][n]), n
     encoder_stack.check_wsr_error()
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("steps,lead", [(4, 0), (8, 3)])
+def test_lpw_forward_across_chunk_boundaries_is_bit_identical(hip_lib, case, steps, lead):
+    """EDGEDICT_LPW_CROSS=1: a launch runs across chunk boundaries (in-kernel flag waits) and the side work of the
+    chunks it completes is enqueued before the launch, gated on the layer's arrival counter."""
+    from edgedict_amd import encoder_stack
+    chunk = 4 if case[6] < 4 else case[6]
+    enc, xs = _encoder(case)
+    ref = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk, lag=case[7]), EDGEDICT_STACK_LPW=0)
+    got = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk, lag=case[7]),
+                    EDGEDICT_STACK_LPW=1, EDGEDICT_LPW_STEPS=steps, EDGEDICT_LPW_CROSS=1, EDGEDICT_LPW_LEAD=lead)
+    _same(ref, got)
+    encoder_stack.check_wsr_error()
