@@ -346,6 +346,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
     if SHARE_DEVICE:
         local_rank = 0
+        # two processes on ONE device cannot both keep a launch-persistent forward launch (one workgroup per CU,
+        # workgroups that wait for their layer's peers) resident: the ranks' launches starve each other until a
+        # bounded wait gives up (code 70x).  The test mode therefore runs the launch-per-step forward kernels.
+        os.environ.setdefault("EDGEDICT_STACK_LPW", "0")
     if local_rank >= torch.cuda.device_count():
         raise SystemExit("bench.py: LOCAL_RANK %d but only %d HIP device(s) visible"
                          % (local_rank, torch.cuda.device_count()))

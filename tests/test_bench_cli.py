@@ -67,6 +67,11 @@ def test_world2_body_of_bench_runs_on_one_gpu_over_gloo():
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
            "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "16", "--seconds", "5", "--labels", "20"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=840)
+    if r.returncode != 0:                                  # keep the ranks' own words (pytest truncates the assert)
+        out_dir = os.path.join(ROOT, "gpurun_out")
+        if os.path.isdir(out_dir):
+            with open(os.path.join(out_dir, "bench_world2_failure.txt"), "w") as fh:
+                fh.write(r.stdout[-20000:] + "\n=== stderr ===\n" + r.stderr[-40000:])
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     lines = _json_lines(r.stdout)
     assert len(lines) == 1, r.stdout[-2000:]              # rank 0 only
