@@ -205,9 +205,10 @@ struct WsLayout {
     size_t himg_stride = 0;
     std::vector<size_t> gimg;                       // per layer: one dG fragment image per frame (launch-persistent BPTT)
     size_t gimg_stride = 0;
+    std::vector<size_t> skpart;                     // per layer: partial sums of the split-K BPTT [2][H/64][4][64][64] f32
     size_t tmpW = 0, tmpB = 0, dX0 = 0, wsr_sync = 0, total = 0;
 };
-constexpr size_t WSR_SYNC_BYTES = 64 * 1024;   // [0] give-up code, [16..24) layer counters, [64..) 8 tickets per launch
+constexpr size_t WSR_SYNC_BYTES = 128 * 1024;  // flags 32 KB | forward counters 2 KB | BPTT counters 2 KB | ... | from 64 KB: unit-block counters of the split-K BPTT (8 layers x 16 x 256 bytes)
 
 WsLayout ws_layout(const edgedict_stack_desc_t* d) {
     WsLayout w;
@@ -250,6 +251,10 @@ WsLayout ws_layout(const edgedict_stack_desc_t* d) {
     for (int l = 0; l < d->L; ++l) {
         w.gimg.push_back(off);
         off += (size_t)(d->layers[l].T + 1) * w.gimg_stride;
+    }
+    for (int l = 0; l < d->L; ++l) {
+        w.skpart.push_back(off);
+        off += align256((size_t)2 * (d->H / 64 + 1) * 4 * 64 * 64 * sizeof(float));
     }
     w.total = off;
     return w;
@@ -1070,6 +1075,19 @@ int lpw_steps(const edgedict_stack_desc_t* d) {
     return ns;
 }
 
+// split-K weights-stationary BPTT (stack_bwd_sk_kernel): steps per launch, 0 = not applicable / switched off
+int sk_bwd_steps(const edgedict_stack_desc_t* d) {
+    const char* e_on = getenv("EDGEDICT_STACK_BWD_SK");
+    const char* e_n = getenv("EDGEDICT_SK_STEPS");
+    const int on = e_on ? atoi(e_on) : 0, want = e_n ? atoi(e_n) : 6;
+    if (!on || !ed_stack_sk_supported(d->B, d->H)) return 0;
+    for (int l = 0; l < d->L; ++l)
+        if (!d->layers[l].whh_s) return 0;
+    int ns = max(1, min(want, d->chunk));
+    while (ns > 1 && d->chunk % ns != 0) --ns;
+    return ns;
+}
+
 // ... and of the launch-persistent BPTT (stack_bwd_lpw_kernel); EDGEDICT_STACK_LPW_BWD=0 keeps one launch per step
 int lpw_bwd_steps(const edgedict_stack_desc_t* d) {
     const char* e_on = getenv("EDGEDICT_STACK_LPW_BWD");
@@ -1307,6 +1325,12 @@ extern "C" int edgedict_stack_pack_wsr(const float* w_hh, int H, void* whh_r, vo
     return ed_wsr_pack_fwd(w_hh, (bf16_t*)whh_r, (hipStream_t)stream_);
 }
 
+extern "C" int edgedict_stack_pack_sk(const float* w_hh, int H, void* whh_s, void* stream_) {
+    ED_CHECK_ARG(H >= 64 && H % 64 == 0 && H <= 1024, "stack_pack_sk: needs H %% 64 == 0 and H <= 1024 (got %d)", H);
+    ED_CHECK_ARG(w_hh && whh_s, "stack_pack_sk: null pointer");
+    return ed_stack_pack_sk(w_hh, (bf16_t*)whh_s, H, (hipStream_t)stream_);
+}
+
 extern "C" int edgedict_stack_wsr_set_trace(void* device_buffer) {
     std::lock_guard<std::mutex> lock(g_mu);
     g_wsr_trace = (long long*)device_buffer;
@@ -1452,9 +1476,12 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     }
     // launch-persistent BPTT (stack_bwd_lpw_kernel): steps per launch (0 = one launch per step) and the layers'
     // arrival counters, behind the forward pass's in the sync region
-    const int lpw_ns = lpw_bwd_steps(d);
+    const int sk_ns = sk_bwd_steps(d);
+    const int lpw_ns = sk_ns ? sk_ns : lpw_bwd_steps(d);
     unsigned* cntb = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + 2 * 8 * 512 + 8 * LPW_CNT_STRIDE;
+    unsigned* gcnt = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + 16 * 1024;     // 64 KB into the sync region: [8][16][64]
     if (lpw_ns) ED_DEV(ed_stack_zero(cntb, (size_t)8 * LPW_CNT_STRIDE * sizeof(unsigned), st.C));
+    if (sk_ns) ED_DEV(ed_stack_zero(gcnt, (size_t)8 * 16 * 64 * sizeof(unsigned), st.C));
     // ---- prologue: running dL/dc = 0
     for (int l = 0; l < L; ++l) ED_DEV(ed_stack_zero(ws + wl.dC[l], (size_t)BH * sizeof(float), st.C));
     ED_TRY(st.chain(st.C, st.R));
@@ -1595,7 +1622,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     if (lpw_ns) {
         // ---- macro-steps: launch w carries, for every runnable layer, its next <= lpw_ns BPTT steps (descending t,
         // never across a chunk boundary); the schedule is the one below in units of macro-steps
-        const int WGS = (H >> 5) * ((B + 31) >> 5);
+        const int WGS = sk_ns ? (H >> 6) * 4 : (H >> 5) * ((B + 31) >> 5);
         static const int n_cu = [] {
             int dev = 0, n = 256;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
@@ -1612,6 +1639,10 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
             Lc.nslot = 0;
             Lc.B = B;
             Lc.H = H;
+            EdSkLaunch Ls;
+            Ls.nslot = 0;
+            Ls.B = B;
+            Ls.H = H;
             Done done[ED_STACK_MAX_SLOTS];
             int ndone = 0;
             // the launch has room for max_slots layers: the layers with the most steps left go first (the full-rate
@@ -1634,6 +1665,27 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                 if (!Pace::allows(w, l, g[l].m, m_min)) continue;
                 if (opens && !soft) ED_TRY(st.wait(st.R, Eb[l][k]));
                 const int t_end = max(k * g[l].cf, t - lpw_ns + 1);      // last (lowest) frame of this macro-step
+                if (sk_ns) {
+                    EdSkSlot& ss = Ls.slot[Ls.nslot++];
+                    ss.G = bptr(y.G) + (long long)t * B * 4 * H;
+                    ss.img = bptr(ws + wl.gimg[l]);
+                    ss.img_stride = (long long)wl.gimg_stride;
+                    ss.img_bytes = (long long)(y.T + 1) * (long long)wl.gimg_stride;
+                    ss.dY = bptr(y.dZ) + (long long)t * BH;
+                    ss.Cx = y.Cx;
+                    ss.dC = (float*)(ws + wl.dC[l]);
+                    ss.Wsk = bptr(y.whh_s);
+                    ss.part = (float*)(ws + wl.skpart[l]);
+                    ss.counter = cntb + l * LPW_CNT_STRIDE;
+                    ss.base = (unsigned)WGS * (unsigned)next_t[l];
+                    ss.gcounter = gcnt + l * 16 * 64;
+                    ss.gbase = 4u * (unsigned)next_t[l];
+                    ss.wait_flag = (soft && opens) ? bflag + l * 512 + k : nullptr;
+                    ss.t0 = t;
+                    ss.nsteps = t - t_end + 1;
+                    ss.T = y.T;
+                    ss.layer = l;
+                }
                 EdLpwBwdSlot& sl = Lc.slot[Lc.nslot++];
                 sl.G = bptr(y.G) + (long long)t * B * 4 * H;
                 sl.img = bptr(ws + wl.gimg[l]);
@@ -1664,9 +1716,10 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
             }
             idle = 0;
             ++launches;
-            Lc.stamp = st.rt ? st.rt->stamp_slot(1, st.R) : nullptr;
-            Lc.err = gerr;
-            ED_DEV(ed_stack_launch_bwd_lpw(Lc, st.R));
+            Lc.stamp = Ls.stamp = st.rt ? st.rt->stamp_slot(1, st.R) : nullptr;
+            Lc.err = Ls.err = gerr;
+            if (sk_ns) ED_DEV(ed_stack_launch_bwd_sk(Ls, st.R));
+            else ED_DEV(ed_stack_launch_bwd_lpw(Lc, st.R));
             if (g_trace) {
                 g_trace->max_slots = max(g_trace->max_slots, Lc.nslot);
                 ++g_trace->launches;

@@ -1196,6 +1196,323 @@ __global__ __launch_bounds__(256, ED_BWD_OCC) void stack_bwd_lpw_kernel(EdLpwBwd
 }
 
 // =====================================================================================
+// backward, split-K + weights-stationary (EdSkLaunch, stack_kernels.hpp).  Workgroup (unit block ub of 64 units,
+// K quarter kq of the 4H interleaved gate columns), all 64 rows:
+//   partial[row][unit] = sum_{k in quarter} dG_{t+1}[row][k] W_hh[row(k)][unit]      (128 MFMA 16x16x32 per wave,
+//       W as the first operand: a lane then holds 4 CONSECUTIVE units of one row - 16-byte partial stores,
+//       8-byte gate accesses in the cell update, no LDS transposition)
+//   the 4 workgroups of a unit block publish their partials (write-through), meet on the block's counter, and
+//   workgroup kq finishes rows [16 kq, 16 kq + 16): dh = sum of the 4 partials in fixed order, cell backward in
+//   registers (dL/dc never leaves them inside a launch), dG_t into image t (write-through) and into G (plain).
+// Blocks of one launch slot are numbered ub * 4 + kq: blockIdx % 8 = 4 (ub & 1) + kq, so an XCD only ever reads
+// ONE quarter of a layer's dG image (128 KB, shared by its 8 workgroups through L2).
+// Registers: 128 (W) + 64 (two buffers of 4 k-steps x 2 row tiles) + 32 (accumulators of one row-tile pair) + ...
+// <= 256, LDS 50 KB: a gemm_tn256 workgroup (2 waves per SIMD x 128 registers, 96 KB) still fits beside it.
+// =====================================================================================
+#ifndef ED_SK_GK
+#define ED_SK_GK 2
+#endif
+#ifndef ED_SK_NBUF
+#define ED_SK_NBUF 3
+#endif
+#ifndef ED_SK_TP
+#define ED_SK_TP 1
+#endif
+constexpr int SK_TP = ED_SK_TP;       // row tiles per pass over the weights (accumulators: 16 registers per tile)
+constexpr int SK_NBUF = ED_SK_NBUF;   // register buffers of SK_GK k-steps x 2 row tiles in flight (NBUF - 1 ahead)
+constexpr int SK_PER = 8;     // k-steps of 32 per wave: H <= 1024
+constexpr int SK_GK = ED_SK_GK;      // k-steps per register buffer
+typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
+
+struct __attribute__((aligned(16))) SkShared {
+    float4 hand[4][SK_TP][4][64];    // [source wave][row tile of the pass][unit tile][lane]   16 KB per row tile
+    uint2 st_g[4][256];              // thread-private staging of the next frame's operands (no cross-thread use)
+    float4 st_ct[256];
+    float4 st_cp[256];
+    uint2 st_dy[256];
+};
+
+__global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
+    __shared__ SkShared sh;
+    __shared__ unsigned bail_s;
+    if (ED_STEP_PRIO) __builtin_amdgcn_s_setprio(ED_STEP_PRIO);
+    if (L.stamp && threadIdx.x == 0) atomicMin(&L.stamp[0], wall_clock64());
+    const int B = L.B, H = L.H;
+    const int UBK = H >> 6, WGS = UBK * 4;
+    const int slot = blockIdx.x / WGS, rem = blockIdx.x - slot * WGS;
+    const int ub = rem >> 2, kq = rem & 3;
+    const EdSkSlot& S = L.slot[slot];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int KSq = H >> 5, per = (KSq + 3) >> 2;
+    const int ks_beg = wave * per, ks_end = min(KSq, ks_beg + per);
+    const int MT = (B + 15) >> 4;
+    const long long H4 = 4ll * H, BH = (long long)B * H;
+    const __amdgpu_buffer_rsrc_t rimg = lpw_rsrc(S.img, (unsigned)S.img_bytes);
+    const __amdgpu_buffer_rsrc_t rpart = lpw_rsrc(S.part, (unsigned)(2u * UBK * 4u * 64u * 64u * 4u));
+    if (tid == 0) bail_s = 0u;
+
+    // ---- stationary weights: this wave's k-steps of the (ub, kq) slice, 4 unit tiles
+    bf16x8_t w[SK_PER][4];
+    {
+        const bf16_t* wbase = S.Wsk + ((((long long)(ub * 4 + kq) * KSq) * 4) * 64 + lane) * 8;
+#pragma unroll
+        for (int i = 0; i < SK_PER; ++i) {
+            const int ksl = min(ks_beg + i, KSq - 1);
+#pragma unroll
+            for (int n = 0; n < 4; ++n) w[i][n] = ldfrag(wbase + ((long long)ksl * 4 + n) * 512);
+        }
+    }
+    if (S.wait_flag) soft_wait(S.wait_flag, L.err, 600u + slot);
+
+    // ---- this lane's cells: row 16 kq + (lane & 15), units ub*64 + quad*4 .. +3
+    const int crow = kq * 16 + (lane & 15), quad = wave * 4 + (lane >> 4);
+    const bool live = crow < B;
+    const int unit0 = ub * 64 + quad * 4;
+    const int gcol0 = (unit0 >> 4) * 64 + (unit0 & 15);      // + gate * 16
+    float4 dc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (live) dc = *reinterpret_cast<const float4*>(S.dC + (long long)crow * H + unit0);
+    uint2 gq[4], dyq;
+    float4 ctq, cpq;
+    auto fetch = [&](int t, int s) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gq[g] = make_uint2(0u, 0u);
+        ctq = cpq = make_float4(0.f, 0.f, 0.f, 0.f);
+        dyq = make_uint2(0u, 0u);
+        if (live) {
+            const bf16_t* G_t = S.G - (long long)s * B * H4 + (long long)crow * H4 + gcol0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) gq[g] = *reinterpret_cast<const uint2*>(G_t + g * 16);
+            const long long o = (long long)crow * H + unit0;
+            ctq = *reinterpret_cast<const float4*>(S.Cx + (long long)(t + 1) * BH + o);
+            cpq = *reinterpret_cast<const float4*>(S.Cx + (long long)t * BH + o);
+            if (S.dY) dyq = *reinterpret_cast<const uint2*>(S.dY - (long long)s * BH + o);
+        }
+    };
+    fetch(S.t0, 0);
+
+    for (int s = 0; s < S.nsteps; ++s) {
+        const int t = S.t0 - s;
+        // ---- (1) every workgroup of this layer has published dG_{t+1}
+        if (s > 0 && tid == 0) {
+            const unsigned want = S.base + (unsigned)(WGS * s);
+            unsigned spins = 0;
+            while (__hip_atomic_load(S.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 21)) {
+                    if (L.err) atomicCAS(L.err, 0u, 900u + slot);
+                    bail_s = 1u;
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (bail_s) break;
+        // the frame's operands (requested during the step before) to their thread-private LDS slots: their 18
+        // registers are free during the product below
+#pragma unroll
+        for (int g = 0; g < 4; ++g) sh.st_g[g][tid] = gq[g];
+        sh.st_ct[tid] = ctq;
+        sh.st_cp[tid] = cpq;
+        sh.st_dy[tid] = dyq;
+
+        // ---- (2) partial product of this K quarter; row tiles in two pairs, operand stream in buffers of 4 k-steps
+        // partial tile of rows 16 wave + (lane & 15): 4 x 16 bytes per lane, write-through
+        const unsigned pbase = (unsigned)((((((t & 1) * UBK + ub) * 4 + kq) * 64 + wave * 16 + (lane & 15)) * 64 + (lane >> 4) * 4) * 4);
+        if (t < S.T - 1) {
+            const unsigned soff = (unsigned)((long long)(t + 1) * S.img_stride);
+            const int ksg0 = kq * KSq;
+            bf16x8_t abuf[SK_NBUF][SK_GK][SK_TP];
+            // per-lane offset: lane * 16 (+ row tile * 1024); everything that depends on the frame and the k-step is
+            // wave-uniform and goes into the scalar offset - no address register per fragment
+            const unsigned vlane = (unsigned)lane * 16u;
+            auto load = [&](bf16x8_t (&a)[SK_GK][SK_TP], int half, int kg) {
+#pragma unroll
+                for (int j = 0; j < SK_GK; ++j) {
+                    const int ks = min(ks_beg + kg * SK_GK + j, max(ks_end - 1, 0));
+                    const unsigned so = soff + (unsigned)((ksg0 + ks) * MT) * 1024u;
+#pragma unroll
+                    for (int mm = 0; mm < SK_TP; ++mm) {
+                        const int m = min(half * SK_TP + mm, MT - 1);
+                        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rimg, vlane + (unsigned)m * 1024u, so, 0);
+                        a[j][mm] = *reinterpret_cast<const bf16x8_t*>(&v);
+                    }
+                }
+            };
+            f32x4_t acc[SK_TP][4];
+            auto zero = [&]() {
+#pragma unroll
+                for (int mm = 0; mm < SK_TP; ++mm)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) acc[mm][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            };
+            auto mma = [&](bf16x8_t (&a)[SK_GK][SK_TP], int kg) {
+#pragma unroll
+                for (int j = 0; j < SK_GK; ++j) {
+                    if (ks_beg + kg * SK_GK + j < ks_end) {
+#pragma unroll
+                        for (int mm = 0; mm < SK_TP; ++mm)
+#pragma unroll
+                            for (int n = 0; n < 4; ++n)
+                                acc[mm][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[kg * SK_GK + j][n], a[j][mm], acc[mm][n], 0, 0, 0);
+                    }
+                }
+            };
+            // wave (2 half + mm) owns row tile 2 half + mm: everybody's partial of that tile goes through LDS, the
+            // owner adds the four K parts in the order of the source waves (the same for every tile)
+            auto handoff = [&](int half) {
+#pragma unroll
+                for (int mm = 0; mm < SK_TP; ++mm)
+#pragma unroll
+                    for (int n = 0; n < 4; ++n)
+                        sh.hand[wave][mm][n][lane] = make_float4(acc[mm][n][0], acc[mm][n][1], acc[mm][n][2], acc[mm][n][3]);
+                __syncthreads();
+                if (wave / SK_TP == half) {
+                    const int mm = wave % SK_TP;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                        for (int src = 0; src < 4; ++src) {
+                            const float4 v = sh.hand[src][mm][n][lane];
+                            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                        }
+                        const u32x4_t o = {__float_as_uint(sum.x), __float_as_uint(sum.y), __float_as_uint(sum.z), __float_as_uint(sum.w)};
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rpart, pbase + (unsigned)(n * 16 * 4), 0, 16);
+                        __builtin_amdgcn_sched_barrier(0);      // one unit tile at a time: 16 registers, not 64
+                    }
+                }
+                __syncthreads();
+            };
+            // software pipeline over the 2 x NG groups (row-tile pair, k-group): SK_NBUF - 1 groups requested ahead
+            constexpr int NG = SK_PER / SK_GK, NQ = (4 / SK_TP) * NG;
+#pragma unroll
+            for (int q = 0; q < SK_NBUF - 1 && q < NQ; ++q) load(abuf[q % SK_NBUF], q / NG, q % NG);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                if (q + SK_NBUF - 1 < NQ) load(abuf[(q + SK_NBUF - 1) % SK_NBUF], (q + SK_NBUF - 1) / NG, (q + SK_NBUF - 1) % NG);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q % NG == 0) zero();
+                mma(abuf[q % SK_NBUF], q % NG);
+                __builtin_amdgcn_sched_barrier(0);
+                if (q % NG == NG - 1) handoff(q / NG);
+            }
+        } else {
+            // the last frame has no dG_{t+1}: the partial is zero (the exchange below still runs: one rule for every step)
+            const u32x4_t z = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int n = 0; n < 4; ++n) __builtin_amdgcn_raw_buffer_store_b128(z, rpart, pbase + (unsigned)(n * 16 * 4), 0, 16);
+        }
+        // ---- (3) the partials were published by the owner waves right after their hand-off; every storing wave
+        // drains; one lane arrives on the unit block's counter
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            unsigned* gc = S.gcounter + ub * 64;      // one 256-byte line per unit block
+            __hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned want = S.gbase + 4u * (unsigned)(s + 1);
+            unsigned spins = 0;
+            while (__hip_atomic_load(gc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 21)) {
+                    if (L.err) atomicCAS(L.err, 0u, 950u + slot);
+                    bail_s = 1u;
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        if (bail_s) break;
+        // ---- (4) dL/dh_t of this lane's cells: the four K parts in fixed order (L2-served loads: the buffers are reused)
+        float dh[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(
+                rpart, (unsigned)((((((t & 1) * UBK + ub) * 4 + q) * 64 + crow) * 64 + quad * 4) * 4), 0, 16);
+            dh[0] += __uint_as_float(v[0]); dh[1] += __uint_as_float(v[1]);
+            dh[2] += __uint_as_float(v[2]); dh[3] += __uint_as_float(v[3]);
+        }
+        // ---- (5) cell backward in registers
+        uint2 outg[4];
+        {
+            uint2 g4[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) g4[g] = sh.st_g[g][tid];
+            const float4 ct4 = sh.st_ct[tid], cp4 = sh.st_cp[tid];
+            const uint2 dy4 = sh.st_dy[tid];
+            const float ctv[4] = {ct4.x, ct4.y, ct4.z, ct4.w}, cpv[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
+            float dcv[4] = {dc.x, dc.y, dc.z, dc.w};
+            float o[4][4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                auto pick = [&](const uint2& u) {
+                    const unsigned wd = (j < 2) ? u.x : u.y;
+                    return __uint_as_float((j & 1) ? (wd & 0xffff0000u) : (wd << 16));
+                };
+                const float ig = pick(g4[0]), fg = pick(g4[1]), gg = pick(g4[2]), og = pick(g4[3]);
+                const float dht = pick(dy4) + dh[j];
+                const float tc = ftanh(ctv[j]);
+                const float dct = dcv[j] + dht * og * (1.f - tc * tc);
+                o[0][j] = dct * gg * ig * (1.f - ig);
+                o[1][j] = dct * cpv[j] * fg * (1.f - fg);
+                o[2][j] = dct * ig * (1.f - gg * gg);
+                o[3][j] = dht * tc * og * (1.f - og);
+                dcv[j] = dct * fg;
+            }
+            dc = make_float4(dcv[0], dcv[1], dcv[2], dcv[3]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                outg[g].x = f32x2_to_bf16x2(o[g][0], o[g][1]);
+                outg[g].y = f32x2_to_bf16x2(o[g][2], o[g][3]);
+            }
+        }
+        // ---- (6) publish dG_t: this lane's 4 units x 4 gates into image t (8-byte write-through stores), drain, arrive
+        if (t > 0 && live) {
+            const unsigned soff_out = (unsigned)((long long)t * S.img_stride);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int kc = gcol0 + g * 16;                   // interleaved gate column of the first unit
+                const int ks = kc >> 5, kg = (kc >> 3) & 3, e0 = kc & 7;
+                const u32x2_t v = {outg[g].x, outg[g].y};
+                __builtin_amdgcn_raw_buffer_store_b64(
+                    v, rimg, (unsigned)((((ks * MT + (crow >> 4)) * 64 + kg * 16 + (crow & 15)) * 16) + e0 * 2), soff_out, 16);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(S.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- (7) off the chain: dG rows (for the dX / weight-gradient products), next frame's operands
+        if (live) {
+            bf16_t* G_t = S.G - (long long)s * B * H4 + (long long)crow * H4 + gcol0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<uint2*>(G_t + g * 16) = outg[g];
+        }
+        if (s + 1 < S.nsteps) fetch(t - 1, s + 1);
+    }
+    if (live) *reinterpret_cast<float4*>(S.dC + (long long)crow * H + unit0) = dc;
+    if (L.stamp) {
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax(&L.stamp[1], wall_clock64());
+    }
+}
+
+// split-K fragment image of W_hh: frag[ub H/64][kq 4][ksl H/32][n 4][lane 64][8], W as the FIRST MFMA operand:
+// row index lane & 15 -> unit ub*64 + n*16 + (lane & 15); k = interleaved gate column kq*H + ksl*32 + (lane >> 4)*8 + e
+__global__ void pack_whh_sk_kernel(const float* __restrict__ W, bf16_t* __restrict__ out, int H) {
+    const long long n = 4ll * H * H;
+    const int KSq = H >> 5;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), nn = (int)((i >> 9) & 3);
+        const long long blk = i >> 11;
+        const int ksl = (int)(blk % KSq), kq = (int)((blk / KSq) & 3), ub = (int)(blk / KSq / 4);
+        const int unit = ub * 64 + nn * 16 + (lane & 15);
+        const int kcol = kq * H + ksl * 32 + (lane >> 4) * 8 + e;
+        const int ubk = kcol >> 6, g = (kcol >> 4) & 3, u = kcol & 15;
+        out[i] = f32_to_bf16(W[((long long)g * H + ubk * 16 + u) * H + unit]);
+    }
+}
+
+// =====================================================================================
 // LayerNorm backward, time-major, frames [t0, t1) of one layer.  One wave per input row (t, b):
 //   z = y (+ res), xhat = (z - mean) rstd, dy = dout[t / reduce, b] / reduce, g = dy gamma
 //   dz = rstd (g - mean_H(g) - xhat mean_H(g xhat));  dgamma += dy xhat;  dbeta += dy
@@ -1464,6 +1781,22 @@ int ed_stack_wait_counters(const unsigned* const* counters, const unsigned* targ
     a.err = err;
     hipLaunchKernelGGL(stack_wait_counters_kernel, dim3(1), dim3(64), 0, s, a);
     ED_CHECK_LAUNCH("stack_wait_counters_kernel");
+    return ED_OK;
+}
+
+int ed_stack_sk_supported(int B, int H) { return (B >= 1 && B <= 64 && H % 64 == 0 && H >= 64 && H <= 1024) ? 1 : 0; }
+
+int ed_stack_pack_sk(const float* w_hh, bf16_t* out, int H, hipStream_t s) {
+    hipLaunchKernelGGL(pack_whh_sk_kernel, dim3(ed_grid_for(4ll * H * H, 256, 4096)), dim3(256), 0, s, w_hh, out, H);
+    ED_CHECK_LAUNCH("pack_whh_sk_kernel");
+    return ED_OK;
+}
+
+int ed_stack_launch_bwd_sk(const EdSkLaunch& L, hipStream_t s) {
+    const int grid = L.nslot * (L.H >> 6) * 4;
+    if (grid == 0) return ED_OK;
+    hipLaunchKernelGGL(stack_bwd_sk_kernel, dim3(grid), dim3(256), 0, s, L);
+    ED_CHECK_LAUNCH("stack_bwd_sk_kernel");
     return ED_OK;
 }
 

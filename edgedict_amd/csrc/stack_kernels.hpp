@@ -150,6 +150,39 @@ struct EdLpwBwdLaunch {
 int ed_stack_launch_bwd_lpw(const EdLpwBwdLaunch& L, hipStream_t s);
 int ed_stack_lpw_bwd_supported(int B, int H);
 
+// ---- split-K, weights-stationary BPTT (stack_kernels.hip, stack_bwd_sk_kernel; needs B <= 64, H % 64 == 0,
+// H <= 1024).  The launch-per-step BPTT moves 512 KB into every CU per step (W_hh^T slice 256 KB + dG image
+// 256 KB) and a CU pulls 40-60 GB/s: 13-17 us.  Here a workgroup owns (64 units, one QUARTER of the 4H gate
+// columns) for all 64 rows: its W_hh^T slice is 128 KB and stays in 128 registers per lane for the whole launch,
+// the only dependent fetch of a step is its quarter of the dG image (128 KB).  The four workgroups of a unit
+// block exchange their partial sums (16 KB fp32 each, write-through) and each finishes 16 of the 64 rows.
+struct EdSkSlot {
+    bf16_t* G;                 // frame t0 [B, 4H] interleaved (in gates, out dL/d(pre-activation)); frame t0-s at - s*B*4H
+    bf16_t* img;               // dG fragment images, one per frame (EdLpwBwdSlot::img)
+    long long img_stride, img_bytes;
+    const bf16_t* dY;          // dL/dh rows of frame t0 from above [B, H]; frame t0-s at - s*B*H
+    const float* Cx;           // c_t at Cx + (t+1)*B*H
+    float* dC;                 // [B, H] running dL/dc, in/out
+    const bf16_t* Wsk;         // split-K fragment image of W_hh (edgedict_stack_pack_sk)
+    float* part;               // [2][H/64][4][64][64] f32 partial sums, ping-pong by step parity
+    unsigned* counter;         // all workgroups of the layer: one arrival per finished step
+    unsigned base;
+    unsigned* gcounter;        // [H/64] words LPW_CNT_STRIDE apart: the 4 workgroups of a unit block, one arrival per step
+    unsigned gbase;            // 4 * (steps done before)
+    const unsigned* wait_flag;
+    int t0, nsteps, T, layer;
+};
+struct EdSkLaunch {
+    EdSkSlot slot[ED_STACK_MAX_SLOTS];
+    int nslot;
+    int B, H;
+    unsigned long long* stamp;
+    unsigned* err;
+};
+int ed_stack_launch_bwd_sk(const EdSkLaunch& L, hipStream_t s);
+int ed_stack_sk_supported(int B, int H);
+int ed_stack_pack_sk(const float* w_hh, bf16_t* out, int H, hipStream_t s);
+
 // ---- weights-stationary recurrence (wsr_kernels.hip): ONE launch carries a chunk of frames of every
 // runnable layer; a layer lives on the 32 CUs of one XCD with W_hh in registers (H = 1024, B <= 64)
 struct EdWsrSlot {

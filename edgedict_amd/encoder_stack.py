@@ -28,7 +28,7 @@ class StackLayer(ctypes.Structure):
                 ("whh_r", _vp), ("ln_gamma", _fp), ("ln_beta", _fp),
                 ("X", _vp), ("G", _vp), ("Yx", _vp), ("Cx", _fp), ("mean", _fp), ("rstd", _fp),
                 ("dZ", _vp), ("dX", _vp), ("dW_ih", _fp), ("dW_hh", _fp), ("db", _fp), ("db_hh", _fp),
-                ("dgamma", _fp), ("dbeta", _fp)]
+                ("dgamma", _fp), ("dbeta", _fp), ("whh_s", _vp)]
 
 
 class StackDesc(ctypes.Structure):
@@ -62,6 +62,9 @@ FLAGS = int(os.environ.get("EDGEDICT_STACK_FLAGS", "0"))
 # XCDs round-robin at dispatch), so the chunk products serialise with it instead of overlapping
 if os.environ.get("EDGEDICT_STACK_WSR", "0") == "1":
     FLAGS |= WSR
+# pack the split-K image of W_hh (8 MB per layer) for the weights-stationary BPTT kernel whenever the geometry
+# allows it; the kernel itself is chosen per call by the library (EDGEDICT_STACK_BWD_SK, read there)
+BWD_SK = os.environ.get("EDGEDICT_STACK_BWD_SK_PACK", "1") != "0"
 
 
 def _p(t):
@@ -80,7 +83,7 @@ def supported(cd, H, I0, L, reductions):
 
 class _PackedLayer:
     """bf16 weight images of one LSTM layer, rebuilt when the fp32 masters change."""
-    __slots__ = ("key", "ref", "wih_p", "wih_t", "bias_p", "whh_f", "whh_b", "whh_r")
+    __slots__ = ("key", "ref", "wih_p", "wih_t", "bias_p", "whh_f", "whh_b", "whh_r", "whh_s")
 
     def __init__(self, owner):
         self.key = None
@@ -97,7 +100,7 @@ def packed_weights(w_ih, w_hh, b_ih, b_hh):
             del _PACKED[k]                       # images of parameters that no longer exist
         ent = _PACKED[id(w_hh)] = _PackedLayer(w_hh)
     key = (w_ih.data_ptr(), w_hh.data_ptr(), w_ih._version, w_hh._version, b_ih._version,
-           b_hh._version, config.param_epoch(), bool(FLAGS & WSR))
+           b_hh._version, config.param_epoch(), bool(FLAGS & WSR), BWD_SK)
     if ent.key != key:
         H4, I = w_ih.shape
         H = H4 // 4
@@ -108,6 +111,8 @@ def packed_weights(w_ih, w_hh, b_ih, b_hh):
         ent.whh_f = torch.empty(H4 * H, dtype=BF16, device=dev)
         ent.whh_b = torch.empty(H4 * H, dtype=BF16, device=dev)
         ent.whh_r = torch.empty(H4 * H, dtype=BF16, device=dev) if (H == 1024 and FLAGS & WSR) else None
+        # split-K image of the weights-stationary BPTT kernel (csrc/stack_kernels.hip stack_bwd_sk_kernel)
+        ent.whh_s = torch.empty(H4 * H, dtype=BF16, device=dev) if (BWD_SK and H % 64 == 0 and 64 <= H <= 1024) else None
         srcs = [t.detach().contiguous() for t in (w_ih, w_hh, b_ih, b_hh)]
         for t in srcs:
             if t.dtype != F32:
@@ -116,6 +121,8 @@ def packed_weights(w_ih, w_hh, b_ih, b_hh):
         check(lib.edgedict_stack_pack_weights(ptr(srcs[0]), ptr(srcs[1]), ptr(srcs[2]), ptr(srcs[3]),
                                               H, I, ptr(ent.wih_p), ptr(ent.wih_t), ptr(ent.bias_p), ptr(ent.whh_f),
                                               ptr(ent.whh_b), stream_ptr()), "stack_pack_weights")
+        if ent.whh_s is not None:
+            check(lib.edgedict_stack_pack_sk(ptr(srcs[1]), H, ptr(ent.whh_s), stream_ptr()), "stack_pack_sk")
         if ent.whh_r is not None:      # register image of the weights-stationary forward kernel
             check(lib.edgedict_stack_pack_wsr(ptr(srcs[1]), H, ptr(ent.whh_r), stream_ptr()), "stack_pack_wsr")
         ent.key = key
@@ -193,9 +200,10 @@ class _Plan:
             y.T, y.I, y.reduce, y.residual = T, I, reductions[l], int(l != 0)
             y.wih_p, y.wih_t, y.bias_p, y.whh_f, y.whh_b, y.whh_r = map(
                 _p, (pk.wih_p, pk.wih_t, pk.bias_p, pk.whh_f, pk.whh_b, pk.whh_r))
+            y.whh_s = _p(pk.whh_s)
             g, b = ln_w.detach(), ln_b.detach()
             y.ln_gamma, y.ln_beta = _p(g), _p(b)
-            self.keep += [pk.wih_p, pk.wih_t, pk.bias_p, pk.whh_f, pk.whh_b, pk.whh_r, g, b]
+            self.keep += [pk.wih_p, pk.wih_t, pk.bias_p, pk.whh_f, pk.whh_b, pk.whh_r, pk.whh_s, g, b]
             for k, v in bufs.items():
                 setattr(y, k, _p(v))
             T = (T + reductions[l] - 1) // reductions[l]

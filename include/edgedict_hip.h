@@ -251,6 +251,9 @@ typedef struct edgedict_stack_layer {
     float* db_hh;          /* nullable second destination of the same values (b_hh.grad when accumulating) */
     float* dgamma;         /* f32 [H] ACCUMULATED (+=): zero before the call */
     float* dbeta;
+    const void* whh_s;     /* bf16 split-K fragment image of W_hh (edgedict_stack_pack_sk), nullable: with it (and B <= 64,
+                              H % 64 == 0, H <= 1024, EDGEDICT_STACK_BWD_SK != 0) the BPTT runs on the split-K
+                              weights-stationary kernel, several steps per launch; without it one launch per step */
 } edgedict_stack_layer_t;
 
 #define EDGEDICT_STACK_SERIAL 1     /* run everything on the caller's stream (debug / bit-exact check) */
@@ -315,6 +318,10 @@ int edgedict_stack_pack_weights(const float* w_ih, const float* w_hh, const floa
 /* W_hh [4H, H] f32 (H = 1024) -> bf16 register image for EDGEDICT_STACK_WSR (8 MB): workgroup j of a
  * layer's XCD loads rows [j*256 KB, (j+1)*256 KB) of it once per launch and keeps them in registers. */
 int edgedict_stack_pack_wsr(const float* w_hh, int H, void* whh_r, void* stream);
+/* W_hh [4H, H] f32 (H % 64 == 0, H <= 1024) -> bf16 split-K image for the weights-stationary BPTT kernel
+ * (edgedict_stack_layer_t.whh_s, 4H*H elements): workgroup (unit block of 64, quarter of the 4H interleaved gate
+ * columns) keeps its 128 KB in registers for a whole launch */
+int edgedict_stack_pack_sk(const float* w_hh, int H, void* whh_s, void* stream);
 /* give-up code of the last weights-stationary launch on the current device that ran into a bounded
  * spin (0 = none since the last call of this function; reading clears it) - see csrc/wsr_kernels.hip */
 int edgedict_stack_wsr_error(void);
