@@ -1643,6 +1643,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
             Ls.nslot = 0;
             Ls.B = B;
             Ls.H = H;
+            Ls.trace = g_wsr_trace;
             Done done[ED_STACK_MAX_SLOTS];
             int ndone = 0;
             // the launch has room for max_slots layers: the layers with the most steps left go first (the full-rate

@@ -1198,42 +1198,28 @@ __global__ __launch_bounds__(256, ED_BWD_OCC) void stack_bwd_lpw_kernel(EdLpwBwd
 // =====================================================================================
 // backward, split-K + weights-stationary (EdSkLaunch, stack_kernels.hpp).  Workgroup (unit block ub of 64 units,
 // K quarter kq of the 4H interleaved gate columns), all 64 rows:
-//   partial[row][unit] = sum_{k in quarter} dG_{t+1}[row][k] W_hh[row(k)][unit]      (128 MFMA 16x16x32 per wave,
-//       W as the first operand: a lane then holds 4 CONSECUTIVE units of one row - 16-byte partial stores,
-//       8-byte gate accesses in the cell update, no LDS transposition)
+//   partial[row][unit] = sum_{k in quarter} dG_{t+1}[row][k] W_hh[row(k)][unit]
+//       wave n owns unit tile n (16 units) for ALL rows and the WHOLE quarter: its 32 W fragments stay in 128
+//       registers for the launch; the dG fragments (128 KB per step, the only dependent fetch) go through a ring of
+//       three 16 KB LDS slots by LDS-DMA (wave w brings row tile w of every k-step) with counted waits and raw
+//       barriers, every wave reads all of them: no cross-wave sum, no register buffers for the stream;
+//       W is the FIRST MFMA operand, so a lane holds 4 CONSECUTIVE units of one row - 16-byte partial stores,
+//       8-byte gate accesses in the cell update;
 //   the 4 workgroups of a unit block publish their partials (write-through), meet on the block's counter, and
 //   workgroup kq finishes rows [16 kq, 16 kq + 16): dh = sum of the 4 partials in fixed order, cell backward in
 //   registers (dL/dc never leaves them inside a launch), dG_t into image t (write-through) and into G (plain).
 // Blocks of one launch slot are numbered ub * 4 + kq: blockIdx % 8 = 4 (ub & 1) + kq, so an XCD only ever reads
 // ONE quarter of a layer's dG image (128 KB, shared by its 8 workgroups through L2).
-// Registers: 128 (W) + 64 (two buffers of 4 k-steps x 2 row tiles) + 32 (accumulators of one row-tile pair) + ...
-// <= 256, LDS 50 KB: a gemm_tn256 workgroup (2 waves per SIMD x 128 registers, 96 KB) still fits beside it.
+// Registers <= 256 and LDS 48 KB: a gemm_tn256 workgroup (2 waves per SIMD x 128 registers, 96 KB) fits beside it.
 // =====================================================================================
-#ifndef ED_SK_GK
-#define ED_SK_GK 2
-#endif
-#ifndef ED_SK_NBUF
-#define ED_SK_NBUF 3
-#endif
-#ifndef ED_SK_TP
-#define ED_SK_TP 1
-#endif
-constexpr int SK_TP = ED_SK_TP;       // row tiles per pass over the weights (accumulators: 16 registers per tile)
-constexpr int SK_NBUF = ED_SK_NBUF;   // register buffers of SK_GK k-steps x 2 row tiles in flight (NBUF - 1 ahead)
-constexpr int SK_PER = 8;     // k-steps of 32 per wave: H <= 1024
-constexpr int SK_GK = ED_SK_GK;      // k-steps per register buffer
+constexpr int SK_GK = 4;                    // k-steps per ring slot
+constexpr int SK_SLOT = SK_GK * 4 * 1024;   // 16 KB: 4 k-steps x 4 row tiles x 1 KB
+constexpr int SK_RING = 3;
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 
-struct __attribute__((aligned(16))) SkShared {
-    float4 hand[4][SK_TP][4][64];    // [source wave][row tile of the pass][unit tile][lane]   16 KB per row tile
-    uint2 st_g[4][256];              // thread-private staging of the next frame's operands (no cross-thread use)
-    float4 st_ct[256];
-    float4 st_cp[256];
-    uint2 st_dy[256];
-};
-
+template <bool TRACE>
 __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
-    __shared__ SkShared sh;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];      // SK_RING * SK_SLOT bytes (dynamic)
     __shared__ unsigned bail_s;
     if (ED_STEP_PRIO) __builtin_amdgcn_s_setprio(ED_STEP_PRIO);
     if (L.stamp && threadIdx.x == 0) atomicMin(&L.stamp[0], wall_clock64());
@@ -1243,23 +1229,27 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
     const int ub = rem >> 2, kq = rem & 3;
     const EdSkSlot& S = L.slot[slot];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int KSq = H >> 5, per = (KSq + 3) >> 2;
-    const int ks_beg = wave * per, ks_end = min(KSq, ks_beg + per);
+    const int KSq = H >> 5;                         // k-steps of this workgroup's quarter (<= 32)
+    const int NGRP = (KSq + SK_GK - 1) / SK_GK;     // ring slots per step (<= 8)
+    // the 8 workgroups of an XCD that read the same K quarter (same kq, same parity of ub) start their walk over the
+    // quarter's k-groups at 8 different places: the first window of each brings a different eighth of the image
+    // into the XCD's L2, the later windows of all of them hit it (fresh write-through data is an L2 miss for the
+    // first reader; in lock-step every workgroup paid that miss on every window)
+    const int rot = (ub >> 1) % NGRP;
     const int MT = (B + 15) >> 4;
     const long long H4 = 4ll * H, BH = (long long)B * H;
     const __amdgpu_buffer_rsrc_t rimg = lpw_rsrc(S.img, (unsigned)S.img_bytes);
     const __amdgpu_buffer_rsrc_t rpart = lpw_rsrc(S.part, (unsigned)(2u * UBK * 4u * 64u * 64u * 4u));
     if (tid == 0) bail_s = 0u;
 
-    // ---- stationary weights: this wave's k-steps of the (ub, kq) slice, 4 unit tiles
-    bf16x8_t w[SK_PER][4];
+    // ---- stationary weights: unit tile `wave` of the (ub, kq) slice, every k-step of the quarter
+    bf16x8_t w[32];
     {
-        const bf16_t* wbase = S.Wsk + ((((long long)(ub * 4 + kq) * KSq) * 4) * 64 + lane) * 8;
+        const bf16_t* wbase = S.Wsk + (((((long long)(ub * 4 + kq) * KSq) * 4) + wave) * 64 + lane) * 8;
 #pragma unroll
-        for (int i = 0; i < SK_PER; ++i) {
-            const int ksl = min(ks_beg + i, KSq - 1);
-#pragma unroll
-            for (int n = 0; n < 4; ++n) w[i][n] = ldfrag(wbase + ((long long)ksl * 4 + n) * 512);
+        for (int i = 0; i < 32; ++i) {
+            const int ks = (min(i, NGRP * SK_GK - 1) + rot * SK_GK) % (NGRP * SK_GK);      // register i <-> k-step, rotated
+            w[i] = ldfrag(wbase + (long long)min(ks, KSq - 1) * 4 * 512);
         }
     }
     if (S.wait_flag) soft_wait(S.wait_flag, L.err, 600u + slot);
@@ -1271,13 +1261,31 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
     const int gcol0 = (unit0 >> 4) * 64 + (unit0 & 15);      // + gate * 16
     float4 dc = make_float4(0.f, 0.f, 0.f, 0.f);
     if (live) dc = *reinterpret_cast<const float4*>(S.dC + (long long)crow * H + unit0);
-    uint2 gq[4], dyq;
-    float4 ctq, cpq;
-    auto fetch = [&](int t, int s) {
+    // partial tile position of this lane in the MFMA result: rows 16 m + (lane & 15), units wave*16 + (lane >> 4)*4 ..
+    const unsigned pmine = (unsigned)(((lane & 15) * 64 + wave * 16 + (lane >> 4) * 4) * 4);
+
+    // debug trace (tools/sk_trace.py): workgroup 0 of every slot accumulates the 100 MHz ticks its lane 0 spent in
+    // [0] wait for the layer, [1] dG ring + MFMA, [2] partial stores + unit-block wait, [3] partial reads + cell,
+    // [4] publish + drain + arrive, [5] trailing stores; [6] steps, [7] launches
+    const bool tr = TRACE && L.trace != nullptr && rem == 0 && tid == 0;
+    long long ph[6] = {0, 0, 0, 0, 0, 0};
+    long long last_ = tr ? wall_clock64() : 0;
+#define SK_STAMP(i)                                   \
+    do {                                              \
+        if (TRACE && tr) {                            \
+            const long long now_ = wall_clock64();    \
+            ph[i] += now_ - last_;                    \
+            last_ = now_;                             \
+        }                                             \
+    } while (0)
+    for (int s = 0; s < S.nsteps; ++s) {
+        const int t = S.t0 - s;
+        // ---- this frame's cell operands (HBM: the forward pass wrote them long ago): requested now, used after the
+        // product - nothing here depends on the peers
+        uint2 gq[4], dyq = make_uint2(0u, 0u);
+        float4 ctq = make_float4(0.f, 0.f, 0.f, 0.f), cpq = ctq;
 #pragma unroll
         for (int g = 0; g < 4; ++g) gq[g] = make_uint2(0u, 0u);
-        ctq = cpq = make_float4(0.f, 0.f, 0.f, 0.f);
-        dyq = make_uint2(0u, 0u);
         if (live) {
             const bf16_t* G_t = S.G - (long long)s * B * H4 + (long long)crow * H4 + gcol0;
 #pragma unroll
@@ -1287,11 +1295,6 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
             cpq = *reinterpret_cast<const float4*>(S.Cx + (long long)t * BH + o);
             if (S.dY) dyq = *reinterpret_cast<const uint2*>(S.dY - (long long)s * BH + o);
         }
-    };
-    fetch(S.t0, 0);
-
-    for (int s = 0; s < S.nsteps; ++s) {
-        const int t = S.t0 - s;
         // ---- (1) every workgroup of this layer has published dG_{t+1}
         if (s > 0 && tid == 0) {
             const unsigned want = S.base + (unsigned)(WGS * s);
@@ -1307,103 +1310,77 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
         }
         __syncthreads();
         if (bail_s) break;
-        // the frame's operands (requested during the step before) to their thread-private LDS slots: their 18
-        // registers are free during the product below
-#pragma unroll
-        for (int g = 0; g < 4; ++g) sh.st_g[g][tid] = gq[g];
-        sh.st_ct[tid] = ctq;
-        sh.st_cp[tid] = cpq;
-        sh.st_dy[tid] = dyq;
-
-        // ---- (2) partial product of this K quarter; row tiles in two pairs, operand stream in buffers of 4 k-steps
-        // partial tile of rows 16 wave + (lane & 15): 4 x 16 bytes per lane, write-through
-        const unsigned pbase = (unsigned)((((((t & 1) * UBK + ub) * 4 + kq) * 64 + wave * 16 + (lane & 15)) * 64 + (lane >> 4) * 4) * 4);
+        SK_STAMP(0);
+        const int par = t & 1;
+        const unsigned pbase = (unsigned)((((par * UBK + ub) * 4 + kq) * 64 * 64) * 4);
         if (t < S.T - 1) {
-            const unsigned soff = (unsigned)((long long)(t + 1) * S.img_stride);
-            const int ksg0 = kq * KSq;
-            bf16x8_t abuf[SK_NBUF][SK_GK][SK_TP];
-            // per-lane offset: lane * 16 (+ row tile * 1024); everything that depends on the frame and the k-step is
-            // wave-uniform and goes into the scalar offset - no address register per fragment
-            const unsigned vlane = (unsigned)lane * 16u;
-            auto load = [&](bf16x8_t (&a)[SK_GK][SK_TP], int half, int kg) {
+            // ---- (2) partial product of this K quarter.  Ring slot = 4 k-steps x 4 row tiles; wave w brings row tile
+            // w (clamped to the batch) of each k-step: one 1 KB LDS-DMA per (wave, k-step)
+            const unsigned char* img = reinterpret_cast<const unsigned char*>(S.img) + (long long)(t + 1) * S.img_stride;
+            const int mrow = min(wave, MT - 1);
+            const unsigned char* abase = img + ((long long)(kq * KSq * MT + mrow) * 64 + lane) * 16;
+            auto issue = [&](int g) {
+                unsigned char* dst = ring + (g % SK_RING) * SK_SLOT + wave * 1024;
 #pragma unroll
                 for (int j = 0; j < SK_GK; ++j) {
-                    const int ks = min(ks_beg + kg * SK_GK + j, max(ks_end - 1, 0));
-                    const unsigned so = soff + (unsigned)((ksg0 + ks) * MT) * 1024u;
-#pragma unroll
-                    for (int mm = 0; mm < SK_TP; ++mm) {
-                        const int m = min(half * SK_TP + mm, MT - 1);
-                        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rimg, vlane + (unsigned)m * 1024u, so, 0);
-                        a[j][mm] = *reinterpret_cast<const bf16x8_t*>(&v);
-                    }
+                    int gr = g + rot;
+                    if (gr >= NGRP) gr -= NGRP;
+                    const int ks = min(gr * SK_GK + j, KSq - 1);
+                    // hand-written: the compiler makes every LDS read wait for ALL outstanding LDS-DMA it knows of
+                    // (vmcnt(0) right after the next slot's issue); the counted waits below are the real rule
+                    const unsigned m0v = __builtin_amdgcn_readfirstlane(
+                        (unsigned)(size_t)(__attribute__((address_space(3))) void*)(dst + j * 4096));
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
+                                 ::"v"(abase + (long long)ks * MT * 1024), "s"(m0v) : "memory", "m0");
                 }
             };
-            f32x4_t acc[SK_TP][4];
-            auto zero = [&]() {
+            f32x4_t acc[4];
 #pragma unroll
-                for (int mm = 0; mm < SK_TP; ++mm)
+            for (int m = 0; m < 4; ++m) acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the counted waits below count this step's DMAs only
+            issue(0);
+            if (NGRP > 1) issue(1);
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) acc[mm][n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            };
-            auto mma = [&](bf16x8_t (&a)[SK_GK][SK_TP], int kg) {
+            for (int g = 0; g < 8; ++g) {
+                if (g < NGRP) {
+                    if (g + 1 < NGRP) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    asm volatile("s_barrier" ::: "memory");
+                    if (g + 2 < NGRP) issue(g + 2);
+                    const unsigned char* src = ring + (g % SK_RING) * SK_SLOT + lane * 16;
+                    bf16x8_t af[2][4];
 #pragma unroll
-                for (int j = 0; j < SK_GK; ++j) {
-                    if (ks_beg + kg * SK_GK + j < ks_end) {
+                    for (int m = 0; m < 4; ++m) af[0][m] = *reinterpret_cast<const bf16x8_t*>(src + m * 1024);
 #pragma unroll
-                        for (int mm = 0; mm < SK_TP; ++mm)
+                    for (int j = 0; j < SK_GK; ++j) {
+                        if (j + 1 < SK_GK) {
 #pragma unroll
-                            for (int n = 0; n < 4; ++n)
-                                acc[mm][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[kg * SK_GK + j][n], a[j][mm], acc[mm][n], 0, 0, 0);
-                    }
-                }
-            };
-            // wave (2 half + mm) owns row tile 2 half + mm: everybody's partial of that tile goes through LDS, the
-            // owner adds the four K parts in the order of the source waves (the same for every tile)
-            auto handoff = [&](int half) {
-#pragma unroll
-                for (int mm = 0; mm < SK_TP; ++mm)
-#pragma unroll
-                    for (int n = 0; n < 4; ++n)
-                        sh.hand[wave][mm][n][lane] = make_float4(acc[mm][n][0], acc[mm][n][1], acc[mm][n][2], acc[mm][n][3]);
-                __syncthreads();
-                if (wave / SK_TP == half) {
-                    const int mm = wave % SK_TP;
-#pragma unroll
-                    for (int n = 0; n < 4; ++n) {
-                        float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-                        for (int src = 0; src < 4; ++src) {
-                            const float4 v = sh.hand[src][mm][n][lane];
-                            sum.x += v.x; sum.y += v.y; sum.z += v.z; sum.w += v.w;
+                            for (int m = 0; m < 4; ++m)
+                                af[(j + 1) & 1][m] = *reinterpret_cast<const bf16x8_t*>(src + (j + 1) * 4096 + m * 1024);
                         }
-                        const u32x4_t o = {__float_as_uint(sum.x), __float_as_uint(sum.y), __float_as_uint(sum.z), __float_as_uint(sum.w)};
-                        __builtin_amdgcn_raw_buffer_store_b128(o, rpart, pbase + (unsigned)(n * 16 * 4), 0, 16);
-                        __builtin_amdgcn_sched_barrier(0);      // one unit tile at a time: 16 registers, not 64
+                        if (KSq % SK_GK == 0 || ((g + rot) % NGRP) * SK_GK + j < KSq) {
+#pragma unroll
+                            for (int m = 0; m < 4; ++m)
+                                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g * SK_GK + j], af[j & 1][m], acc[m], 0, 0, 0);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
-                __syncthreads();
-            };
-            // software pipeline over the 2 x NG groups (row-tile pair, k-group): SK_NBUF - 1 groups requested ahead
-            constexpr int NG = SK_PER / SK_GK, NQ = (4 / SK_TP) * NG;
+            }
+            // ---- (3) publish the partial: rows 16 m + (lane & 15), 4 consecutive units per lane, write-through
 #pragma unroll
-            for (int q = 0; q < SK_NBUF - 1 && q < NQ; ++q) load(abuf[q % SK_NBUF], q / NG, q % NG);
-#pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                if (q + SK_NBUF - 1 < NQ) load(abuf[(q + SK_NBUF - 1) % SK_NBUF], (q + SK_NBUF - 1) / NG, (q + SK_NBUF - 1) % NG);
-                __builtin_amdgcn_sched_barrier(0);
-                if (q % NG == 0) zero();
-                mma(abuf[q % SK_NBUF], q % NG);
-                __builtin_amdgcn_sched_barrier(0);
-                if (q % NG == NG - 1) handoff(q / NG);
+            for (int m = 0; m < 4; ++m) {
+                const u32x4_t o = {__float_as_uint(acc[m][0]), __float_as_uint(acc[m][1]), __float_as_uint(acc[m][2]), __float_as_uint(acc[m][3])};
+                __builtin_amdgcn_raw_buffer_store_b128(o, rpart, pbase + pmine + (unsigned)(m * 16 * 64 * 4), 0, 16);
             }
         } else {
             // the last frame has no dG_{t+1}: the partial is zero (the exchange below still runs: one rule for every step)
             const u32x4_t z = {0u, 0u, 0u, 0u};
 #pragma unroll
-            for (int n = 0; n < 4; ++n) __builtin_amdgcn_raw_buffer_store_b128(z, rpart, pbase + (unsigned)(n * 16 * 4), 0, 16);
+            for (int m = 0; m < 4; ++m) __builtin_amdgcn_raw_buffer_store_b128(z, rpart, pbase + pmine + (unsigned)(m * 16 * 64 * 4), 0, 16);
         }
-        // ---- (3) the partials were published by the owner waves right after their hand-off; every storing wave
-        // drains; one lane arrives on the unit block's counter
+        SK_STAMP(1);
+        // every storing wave drains; one lane arrives on the unit block's counter and waits for the other three
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) {
@@ -1422,24 +1399,20 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
         }
         __syncthreads();
         if (bail_s) break;
+        SK_STAMP(2);
         // ---- (4) dL/dh_t of this lane's cells: the four K parts in fixed order (L2-served loads: the buffers are reused)
         float dh[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(
-                rpart, (unsigned)((((((t & 1) * UBK + ub) * 4 + q) * 64 + crow) * 64 + quad * 4) * 4), 0, 16);
+                rpart, (unsigned)((((((par * UBK + ub) * 4 + q) * 64 + crow) * 64) + quad * 4) * 4), 0, 16);
             dh[0] += __uint_as_float(v[0]); dh[1] += __uint_as_float(v[1]);
             dh[2] += __uint_as_float(v[2]); dh[3] += __uint_as_float(v[3]);
         }
         // ---- (5) cell backward in registers
         uint2 outg[4];
         {
-            uint2 g4[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) g4[g] = sh.st_g[g][tid];
-            const float4 ct4 = sh.st_ct[tid], cp4 = sh.st_cp[tid];
-            const uint2 dy4 = sh.st_dy[tid];
-            const float ctv[4] = {ct4.x, ct4.y, ct4.z, ct4.w}, cpv[4] = {cp4.x, cp4.y, cp4.z, cp4.w};
+            const float ctv[4] = {ctq.x, ctq.y, ctq.z, ctq.w}, cpv[4] = {cpq.x, cpq.y, cpq.z, cpq.w};
             float dcv[4] = {dc.x, dc.y, dc.z, dc.w};
             float o[4][4];
 #pragma unroll
@@ -1448,8 +1421,8 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
                     const unsigned wd = (j < 2) ? u.x : u.y;
                     return __uint_as_float((j & 1) ? (wd & 0xffff0000u) : (wd << 16));
                 };
-                const float ig = pick(g4[0]), fg = pick(g4[1]), gg = pick(g4[2]), og = pick(g4[3]);
-                const float dht = pick(dy4) + dh[j];
+                const float ig = pick(gq[0]), fg = pick(gq[1]), gg = pick(gq[2]), og = pick(gq[3]);
+                const float dht = pick(dyq) + dh[j];
                 const float tc = ftanh(ctv[j]);
                 const float dct = dcv[j] + dht * og * (1.f - tc * tc);
                 o[0][j] = dct * gg * ig * (1.f - ig);
@@ -1465,28 +1438,54 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
                 outg[g].y = f32x2_to_bf16x2(o[g][2], o[g][3]);
             }
         }
-        // ---- (6) publish dG_t: this lane's 4 units x 4 gates into image t (8-byte write-through stores), drain, arrive
-        if (t > 0 && live) {
-            const unsigned soff_out = (unsigned)((long long)t * S.img_stride);
+        SK_STAMP(3);
+        // ---- (6) publish dG_t into image t.  Lanes l and l ^ 16 hold units u..u+3 and u+4..u+7 of one row: they swap
+        // two gates each, so every lane stores two whole 16-byte chunks (8 consecutive gate columns) write-through
+        {
+            const bool hi = (lane >> 4) & 1;
+            // (bit masks, not ?: - the compiler turns a select between two array elements into an indexed scratch load)
+            const unsigned himask = 0u - (unsigned)hi;
+            const unsigned g0x = (outg[0].x & himask) | (outg[2].x & ~himask), g0y = (outg[0].y & himask) | (outg[2].y & ~himask);
+            const unsigned g1x = (outg[1].x & himask) | (outg[3].x & ~himask), g1y = (outg[1].y & himask) | (outg[3].y & ~himask);
+            uint2 got0, got1;
+            got0.x = __shfl_xor(g0x, 16); got0.y = __shfl_xor(g0y, 16);
+            got1.x = __shfl_xor(g1x, 16); got1.y = __shfl_xor(g1y, 16);
+            if (t > 0 && live) {
+                const unsigned soff_out = (unsigned)((long long)t * S.img_stride);
+                const int gate0 = hi ? 2 : 0;
+                const int kc0 = (gcol0 & ~7) + gate0 * 16;        // first of the pair's 8 columns, gate `gate0`
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int kc = gcol0 + g * 16;                   // interleaved gate column of the first unit
-                const int ks = kc >> 5, kg = (kc >> 3) & 3, e0 = kc & 7;
-                const u32x2_t v = {outg[g].x, outg[g].y};
-                __builtin_amdgcn_raw_buffer_store_b64(
-                    v, rimg, (unsigned)((((ks * MT + (crow >> 4)) * 64 + kg * 16 + (crow & 15)) * 16) + e0 * 2), soff_out, 16);
+                for (int i = 0; i < 2; ++i) {
+                    const int kc = kc0 + i * 16;
+                    const int ks = kc >> 5, kg = (kc >> 3) & 3;
+                    const uint2 oth = i ? got1 : got0;
+                    uint2 own;
+                    own.x = (outg[2 + i].x & himask) | (outg[i].x & ~himask);
+                    own.y = (outg[2 + i].y & himask) | (outg[i].y & ~himask);
+                    const u32x4_t v = hi ? (u32x4_t){oth.x, oth.y, own.x, own.y} : (u32x4_t){own.x, own.y, oth.x, oth.y};
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        v, rimg, (unsigned)(((ks * MT + (crow >> 4)) * 64 + kg * 16 + (crow & 15)) * 16), soff_out, 16);
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(S.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // ---- (7) off the chain: dG rows (for the dX / weight-gradient products), next frame's operands
+        SK_STAMP(4);
+        // ---- (7) off the chain: dG rows (for the dX / weight-gradient products)
         if (live) {
             bf16_t* G_t = S.G - (long long)s * B * H4 + (long long)crow * H4 + gcol0;
 #pragma unroll
             for (int g = 0; g < 4; ++g) *reinterpret_cast<uint2*>(G_t + g * 16) = outg[g];
         }
-        if (s + 1 < S.nsteps) fetch(t - 1, s + 1);
+        SK_STAMP(5);
+    }
+#undef SK_STAMP
+    if (TRACE && tr) {
+        long long* o = L.trace + S.layer * 8;
+        for (int i = 0; i < 6; ++i) atomicAdd((unsigned long long*)(o + i), (unsigned long long)ph[i]);
+        atomicAdd((unsigned long long*)(o + 6), (unsigned long long)S.nsteps);
+        atomicAdd((unsigned long long*)(o + 7), 1ull);
     }
     if (live) *reinterpret_cast<float4*>(S.dC + (long long)crow * H + unit0) = dc;
     if (L.stamp) {
@@ -1795,7 +1794,8 @@ int ed_stack_pack_sk(const float* w_hh, bf16_t* out, int H, hipStream_t s) {
 int ed_stack_launch_bwd_sk(const EdSkLaunch& L, hipStream_t s) {
     const int grid = L.nslot * (L.H >> 6) * 4;
     if (grid == 0) return ED_OK;
-    hipLaunchKernelGGL(stack_bwd_sk_kernel, dim3(grid), dim3(256), 0, s, L);
+    if (L.trace) hipLaunchKernelGGL(stack_bwd_sk_kernel<true>, dim3(grid), dim3(256), SK_RING * SK_SLOT, s, L);
+    else hipLaunchKernelGGL(stack_bwd_sk_kernel<false>, dim3(grid), dim3(256), SK_RING * SK_SLOT, s, L);
     ED_CHECK_LAUNCH("stack_bwd_sk_kernel");
     return ED_OK;
 }

@@ -178,6 +178,7 @@ struct EdSkLaunch {
     int B, H;
     unsigned long long* stamp;
     unsigned* err;
+    long long* trace;          // debug (nullable): per-slot phase times of workgroup 0, see tools/sk_trace.py
 };
 int ed_stack_launch_bwd_sk(const EdSkLaunch& L, hipStream_t s);
 int ed_stack_sk_supported(int B, int H);
