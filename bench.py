@@ -350,6 +350,7 @@ def main():
         # workgroups that wait for their layer's peers) resident: the ranks' launches starve each other until a
         # bounded wait gives up (code 70x).  The test mode therefore runs the launch-per-step forward kernels.
         os.environ.setdefault("EDGEDICT_STACK_LPW", "0")
+        os.environ.setdefault("EDGEDICT_STACK_BWD_SK", "0")      # (the split-K BPTT kernel waits for peers the same way)
     if local_rank >= torch.cuda.device_count():
         raise SystemExit("bench.py: LOCAL_RANK %d but only %d HIP device(s) visible"
                          % (local_rank, torch.cuda.device_count()))

@@ -208,7 +208,7 @@ struct WsLayout {
     std::vector<size_t> skpart;                     // per layer: partial sums of the split-K BPTT [2][H/64][4][64][64] f32
     size_t tmpW = 0, tmpB = 0, dX0 = 0, wsr_sync = 0, total = 0;
 };
-constexpr size_t WSR_SYNC_BYTES = 128 * 1024;  // flags 32 KB | forward counters 2 KB | BPTT counters 2 KB | ... | from 64 KB: unit-block counters of the split-K BPTT (8 layers x 16 x 256 bytes)
+constexpr size_t WSR_SYNC_BYTES = 128 * 1024;  // flags 32 KB | forward counters 2 KB | BPTT counters 2 KB | ... | from 64 KB: unit-block and quarter counters of the split-K BPTT (8 layers x 32 x 256 bytes)
 
 WsLayout ws_layout(const edgedict_stack_desc_t* d) {
     WsLayout w;
@@ -1079,7 +1079,7 @@ int lpw_steps(const edgedict_stack_desc_t* d) {
 int sk_bwd_steps(const edgedict_stack_desc_t* d) {
     const char* e_on = getenv("EDGEDICT_STACK_BWD_SK");
     const char* e_n = getenv("EDGEDICT_SK_STEPS");
-    const int on = e_on ? atoi(e_on) : 0, want = e_n ? atoi(e_n) : 6;
+    const int on = e_on ? atoi(e_on) : 1, want = e_n ? atoi(e_n) : 12;
     if (!on || !ed_stack_sk_supported(d->B, d->H)) return 0;
     for (int l = 0; l < d->L; ++l)
         if (!d->layers[l].whh_s) return 0;
@@ -1479,9 +1479,9 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     const int sk_ns = sk_bwd_steps(d);
     const int lpw_ns = sk_ns ? sk_ns : lpw_bwd_steps(d);
     unsigned* cntb = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + 2 * 8 * 512 + 8 * LPW_CNT_STRIDE;
-    unsigned* gcnt = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + 16 * 1024;     // 64 KB into the sync region: [8][16][64]
+    unsigned* gcnt = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + 16 * 1024;     // 64 KB into the sync region: [8][32][64] (16 unit blocks + 4 quarters per layer)
     if (lpw_ns) ED_DEV(ed_stack_zero(cntb, (size_t)8 * LPW_CNT_STRIDE * sizeof(unsigned), st.C));
-    if (sk_ns) ED_DEV(ed_stack_zero(gcnt, (size_t)8 * 16 * 64 * sizeof(unsigned), st.C));
+    if (sk_ns) ED_DEV(ed_stack_zero(gcnt, (size_t)8 * 32 * 64 * sizeof(unsigned), st.C));
     // ---- prologue: running dL/dc = 0
     for (int l = 0; l < L; ++l) ED_DEV(ed_stack_zero(ws + wl.dC[l], (size_t)BH * sizeof(float), st.C));
     ED_TRY(st.chain(st.C, st.R));
@@ -1679,7 +1679,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                     ss.part = (float*)(ws + wl.skpart[l]);
                     ss.counter = cntb + l * LPW_CNT_STRIDE;
                     ss.base = (unsigned)WGS * (unsigned)next_t[l];
-                    ss.gcounter = gcnt + l * 16 * 64;
+                    ss.gcounter = gcnt + l * 32 * 64;
                     ss.gbase = 4u * (unsigned)next_t[l];
                     ss.wait_flag = (soft && opens) ? bflag + l * 512 + k : nullptr;
                     ss.t0 = t;

@@ -1212,15 +1212,43 @@ __global__ __launch_bounds__(256, ED_BWD_OCC) void stack_bwd_lpw_kernel(EdLpwBwd
 // ONE quarter of a layer's dG image (128 KB, shared by its 8 workgroups through L2).
 // Registers <= 256 and LDS 48 KB: a gemm_tn256 workgroup (2 waves per SIMD x 128 registers, 96 KB) fits beside it.
 // =====================================================================================
-constexpr int SK_GK = 4;                    // k-steps per ring slot
+#ifndef ED_SK_GK
+#define ED_SK_GK 4
+#endif
+#ifndef ED_SK_RING
+#define ED_SK_RING 3
+#endif
+#ifndef ED_SK_ABLATE
+#define ED_SK_ABLATE 0      // timing experiments only (results wrong): 1 no dG stream, 2 no LDS reads / MFMA
+#endif
+constexpr int SK_GK = ED_SK_GK;             // k-steps per ring slot
 constexpr int SK_SLOT = SK_GK * 4 * 1024;   // 16 KB: 4 k-steps x 4 row tiles x 1 KB
-constexpr int SK_RING = 3;
+constexpr int SK_RING = ED_SK_RING;         // slots: RING - 1 of them in flight while one is consumed
+constexpr int SK_MAXG = 32 / SK_GK;         // ring slots per step at H = 1024
+// s_waitcnt vmcnt(n * SK_GK): all but the n youngest slots of this wave's DMA have landed
+template <int N>
+__device__ __forceinline__ void sk_wait_slots() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N * SK_GK) : "memory");
+}
+__device__ __forceinline__ void sk_wait_younger(int n) {
+    if (n <= 0) sk_wait_slots<0>();
+    else if (n == 1) sk_wait_slots<1>();
+    else if (n == 2) sk_wait_slots<2>();
+    else if (n == 3) sk_wait_slots<3>();
+    else if (n == 4) sk_wait_slots<4>();
+    else if (n == 5) sk_wait_slots<5>();
+    else sk_wait_slots<6>();
+}
+static_assert(SK_RING >= 2 && SK_RING <= 8 && (SK_RING - 2) * SK_GK < 64, "ring depth");
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 
 template <bool TRACE>
 __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];      // SK_RING * SK_SLOT bytes (dynamic)
-    __shared__ unsigned bail_s;
+    // the give-up flag of the two spin waits lives in the LAST ring slot: the ring is idle around both waits, and that
+    // slot is first refilled behind the first in-loop barrier, which no wave reaches before it has read the flag
+    // (not a static word: with 4 x 16 KB of ring the kernel owns exactly the 64 KB gemm_tn256 leaves free)
+    volatile unsigned* bail_p = reinterpret_cast<volatile unsigned*>(ring + (SK_RING - 1) * SK_SLOT);
     if (ED_STEP_PRIO) __builtin_amdgcn_s_setprio(ED_STEP_PRIO);
     if (L.stamp && threadIdx.x == 0) atomicMin(&L.stamp[0], wall_clock64());
     const int B = L.B, H = L.H;
@@ -1230,7 +1258,7 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
     const EdSkSlot& S = L.slot[slot];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int KSq = H >> 5;                         // k-steps of this workgroup's quarter (<= 32)
-    const int NGRP = (KSq + SK_GK - 1) / SK_GK;     // ring slots per step (<= 8)
+    const int NGRP = (KSq + SK_GK - 1) / SK_GK;     // ring slots per step (<= SK_MAXG)
     // the 8 workgroups of an XCD that read the same K quarter (same kq, same parity of ub) start their walk over the
     // quarter's k-groups at 8 different places: the first window of each brings a different eighth of the image
     // into the XCD's L2, the later windows of all of them hit it (fresh write-through data is an L2 miss for the
@@ -1240,7 +1268,13 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
     const long long H4 = 4ll * H, BH = (long long)B * H;
     const __amdgpu_buffer_rsrc_t rimg = lpw_rsrc(S.img, (unsigned)S.img_bytes);
     const __amdgpu_buffer_rsrc_t rpart = lpw_rsrc(S.part, (unsigned)(2u * UBK * 4u * 64u * 64u * 4u));
-    if (tid == 0) bail_s = 0u;
+    // who this workgroup waits for: quarter kq of the gate columns is the 4 gates of units [kq H/4, (kq+1) H/4), i.e.
+    // of unit blocks [kq UBK/4, (kq+1) UBK/4) - 16 of the layer's 64 workgroups at H = 1024.  One arrival counter per
+    // quarter (a 256-byte line each, behind the unit-block counters) when the blocks do not straddle quarters;
+    // otherwise the layer's single counter
+    const bool quarters = (UBK & 3) == 0;
+    unsigned* cnt_arrive = quarters ? S.gcounter + (16 + ub / (UBK >> 2)) * 64 : S.counter;
+    const unsigned* cnt_poll = quarters ? S.gcounter + (16 + kq) * 64 : S.counter;
 
     // ---- stationary weights: unit tile `wave` of the (ub, kq) slice, every k-step of the quarter
     bf16x8_t w[32];
@@ -1296,20 +1330,22 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
             if (S.dY) dyq = *reinterpret_cast<const uint2*>(S.dY - (long long)s * BH + o);
         }
         // ---- (1) every workgroup of this layer has published dG_{t+1}
-        if (s > 0 && tid == 0) {
-            const unsigned want = S.base + (unsigned)(WGS * s);
+        if (tid == 0) {
+            unsigned bail = 0u;
+            const unsigned want = quarters ? (S.base >> 2) + (unsigned)((WGS >> 2) * s) : S.base + (unsigned)(WGS * s);
             unsigned spins = 0;
-            while (__hip_atomic_load(S.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            while (s > 0 && __hip_atomic_load(cnt_poll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1u << 21)) {
                     if (L.err) atomicCAS(L.err, 0u, 900u + slot);
-                    bail_s = 1u;
+                    bail = 1u;
                     break;
                 }
             }
+            *bail_p = bail;
         }
         __syncthreads();
-        if (bail_s) break;
+        if (*bail_p) break;
         SK_STAMP(0);
         const int par = t & 1;
         const unsigned pbase = (unsigned)((((par * UBK + ub) * 4 + kq) * 64 * 64) * 4);
@@ -1318,7 +1354,7 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
             // w (clamped to the batch) of each k-step: one 1 KB LDS-DMA per (wave, k-step)
             const unsigned char* img = reinterpret_cast<const unsigned char*>(S.img) + (long long)(t + 1) * S.img_stride;
             const int mrow = min(wave, MT - 1);
-            const unsigned char* abase = img + ((long long)(kq * KSq * MT + mrow) * 64 + lane) * 16;
+            const unsigned avoff = (unsigned)(((kq * KSq * MT + mrow) * 64 + lane) * 16);     // + scalar base: one VGPR
             auto issue = [&](int g) {
                 unsigned char* dst = ring + (g % SK_RING) * SK_SLOT + wave * 1024;
 #pragma unroll
@@ -1330,23 +1366,24 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
                     // (vmcnt(0) right after the next slot's issue); the counted waits below are the real rule
                     const unsigned m0v = __builtin_amdgcn_readfirstlane(
                         (unsigned)(size_t)(__attribute__((address_space(3))) void*)(dst + j * 4096));
-                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"
-                                 ::"v"(abase + (long long)ks * MT * 1024), "s"(m0v) : "memory", "m0");
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
+                                 ::"v"(avoff), "s"(m0v), "s"(img + (long long)ks * MT * 1024) : "memory", "m0");
                 }
             };
             f32x4_t acc[4];
 #pragma unroll
             for (int m = 0; m < 4; ++m) acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the counted waits below count this step's DMAs only
-            issue(0);
-            if (NGRP > 1) issue(1);
+            // (older loads of this wave - the cell operands - only make the counted waits below conservative)
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
+            for (int g = 0; g < SK_RING - 1; ++g)
+                if (ED_SK_ABLATE != 1 && g < NGRP) issue(g);
+#pragma unroll
+            for (int g = 0; g < SK_MAXG; ++g) {
                 if (g < NGRP) {
-                    if (g + 1 < NGRP) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    sk_wait_younger(min(SK_RING - 2, NGRP - 1 - g));
                     asm volatile("s_barrier" ::: "memory");
-                    if (g + 2 < NGRP) issue(g + 2);
+                    if (ED_SK_ABLATE != 1 && g + SK_RING - 1 < NGRP) issue(g + SK_RING - 1);
+                    if (ED_SK_ABLATE == 2) continue;
                     const unsigned char* src = ring + (g % SK_RING) * SK_SLOT + lane * 16;
                     bf16x8_t af[2][4];
 #pragma unroll
@@ -1387,18 +1424,19 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
             unsigned* gc = S.gcounter + ub * 64;      // one 256-byte line per unit block
             __hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const unsigned want = S.gbase + 4u * (unsigned)(s + 1);
-            unsigned spins = 0;
+            unsigned spins = 0, bail = 0u;
             while (__hip_atomic_load(gc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1u << 21)) {
                     if (L.err) atomicCAS(L.err, 0u, 950u + slot);
-                    bail_s = 1u;
+                    bail = 1u;
                     break;
                 }
             }
+            *bail_p = bail;
         }
         __syncthreads();
-        if (bail_s) break;
+        if (*bail_p) break;
         SK_STAMP(2);
         // ---- (4) dL/dh_t of this lane's cells: the four K parts in fixed order (L2-served loads: the buffers are reused)
         float dh[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1470,7 +1508,7 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(S.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_fetch_add(cnt_arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         SK_STAMP(4);
         // ---- (7) off the chain: dG rows (for the dX / weight-gradient products)
         if (live) {

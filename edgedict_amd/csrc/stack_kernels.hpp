@@ -167,7 +167,8 @@ struct EdSkSlot {
     float* part;               // [2][H/64][4][64][64] f32 partial sums, ping-pong by step parity
     unsigned* counter;         // all workgroups of the layer: one arrival per finished step
     unsigned base;
-    unsigned* gcounter;        // [H/64] words LPW_CNT_STRIDE apart: the 4 workgroups of a unit block, one arrival per step
+    unsigned* gcounter;        // words LPW_CNT_STRIDE apart: [0, H/64) the 4 workgroups of a unit block, [16, 20) the workgroups
+                               // that write one quarter of the gate columns (H % 256 == 0); one arrival per step each
     unsigned gbase;            // 4 * (steps done before)
     const unsigned* wait_flag;
     int t0, nsteps, T, layer;

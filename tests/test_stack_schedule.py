@@ -35,15 +35,20 @@ def _geometry(T0, reductions, chunk):
 
 
 def _sched(lpw, *args, **kw):
-    old = os.environ.get("EDGEDICT_STACK_LPW")
-    os.environ["EDGEDICT_STACK_LPW"] = "1" if lpw else "0"
+    """lpw: the launch-persistent forward kernel AND the split-K BPTT kernel (both carry several steps of a
+    layer per launch); False: the launch-per-step kernels of both passes."""
+    keys = ("EDGEDICT_STACK_LPW", "EDGEDICT_STACK_BWD_SK")
+    old = {k: os.environ.get(k) for k in keys}
+    for k in keys:
+        os.environ[k] = "1" if lpw else "0"
     try:
         return es.schedule(*args, **kw)
     finally:
-        if old is None:
-            os.environ.pop("EDGEDICT_STACK_LPW", None)
-        else:
-            os.environ["EDGEDICT_STACK_LPW"] = old
+        for k in keys:
+            if old[k] is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = old[k]
 
 
 def _check_lpw(T0, reductions, chunk, nsub, H=64, B=3):
@@ -82,6 +87,42 @@ def _check_lpw(T0, reductions, chunk, nsub, H=64, B=3):
             # margin 2: normally a whole launch lies between; when nothing else is runnable the scheduler does
             # not wait with empty launches - the consumer's workgroups then poll the chunk's flag themselves
             assert opening >= e, "the consumer's launch is enqueued after the product"
+    return n, longest
+
+
+def _check_sk(T0, reductions, chunk, nsub, H=64, B=3):
+    """the split-K BPTT's macro-steps: <= nsub consecutive steps of a layer per launch, descending t."""
+    L, Ts, cf = _geometry(T0, reductions, chunk)
+    old = os.environ.get("EDGEDICT_SK_STEPS")
+    os.environ["EDGEDICT_SK_STEPS"] = str(nsub)
+    try:
+        steps, enq, n, max_slots = _sched(True, T0, 64, H, reductions, B=B, chunk=chunk, backward=True)
+    finally:
+        if old is None:
+            os.environ.pop("EDGEDICT_SK_STEPS", None)
+        else:
+            os.environ["EDGEDICT_SK_STEPS"] = old
+    wgs = (H // 64) * 4
+    assert 1 <= max_slots <= min(MAX_SLOTS, 256 // wgs)
+    slots = np.zeros(n, dtype=int)
+    longest = 0
+    for l in range(L):
+        s = steps[l].astype(int)
+        assert len(s) == Ts[l] and (s >= 0).all() and (s < n).all()
+        assert (np.diff(s[::-1]) >= 0).all(), "recurrence order (last frame first)"
+        for w in np.unique(s):
+            ts = np.nonzero(s == w)[0]
+            assert (np.diff(ts) == 1).all(), "a launch carries CONSECUTIVE steps of a layer"
+            assert ts[0] // cf[l] == ts[-1] // cf[l], "never across a chunk boundary"
+            longest = max(longest, len(ts))
+            slots[w] += 1
+    assert slots.max() == max_slots
+    for l in range(L - 1):
+        for k in range(len(enq[l])):
+            hi = min(Ts[l], (k + 1) * cf[l]) - 1
+            opening, e = int(steps[l][hi]), int(enq[l][k])
+            last = int(steps[l + 1][k * cf[l + 1]])          # the producer's lowest frame of the chunk runs last
+            assert e >= last + 1 and opening >= e, (l, k, e, last, opening)
     return n, longest
 
 
@@ -149,4 +190,22 @@ def test_launch_persistent_schedule_invariants_on_random_geometries(T0, reductio
     if int(np.prod(reductions)) > 4:
         reductions = [1 if i > 1 else r for i, r in enumerate(reductions)]
     n, longest = _check_lpw(T0, reductions, chunk, nsub)
+    assert longest <= nsub
+
+
+def test_e6d2_split_k_bptt_schedule():
+    # 64 x H=1024: 64 workgroups per layer (16 unit blocks x 4 K quarters), at most 4 layers per launch
+    n, longest = _check_sk(401, [1, 2, 1, 1, 1, 1], 12, 12, H=1024, B=64)
+    assert longest == 12 and n <= 50
+    n6, longest6 = _check_sk(401, [1, 2, 1, 1, 1, 1], 12, 6, H=1024, B=64)
+    assert longest6 == 6 and n6 <= 90
+
+
+@settings(max_examples=60, deadline=None, derandomize=True)
+@given(st.integers(1, 90), st.lists(st.sampled_from([1, 1, 2]), min_size=1, max_size=6),
+       st.sampled_from([2, 4, 6, 8]), st.sampled_from([2, 4, 6, 12]))
+def test_split_k_bptt_schedule_invariants_on_random_geometries(T0, reductions, chunk, nsub):
+    if int(np.prod(reductions)) > 4:
+        reductions = [1 if i > 1 else r for i, r in enumerate(reductions)]
+    n, longest = _check_sk(T0, reductions, chunk, nsub)
     assert longest <= nsub
