@@ -487,14 +487,25 @@ def main():
                 mfma_util = ent.get("mfma_util")
         except (OSError, ValueError, KeyError):
             pass
-        # ---- dominant kernel: stack_bwd_kernel (the BPTT wavefront launches, ~23 % of all kernel time)
-        # HBM-fetch bound: every launch re-streams W_hh^T of each layer-step it carries (L2 is
-        # invalidated at kernel boundaries).  Algorithmic bytes of ONE layer-step, each operand once:
+        # ---- dominant kernel: the BPTT recurrence launches (~35 % of the step).  Which kernel ran is asked of the
+        # library (edgedict_stack_last_mode): the split-K weights-stationary kernel by default (W_hh^T stays in
+        # registers for the `steps` time steps of a layer one launch carries), stack_bwd_kernel (one time step per
+        # launch, W_hh^T re-streamed every step) with EDGEDICT_STACK_BWD_SK=0.
+        # Algorithmic bytes of ONE layer-step, each operand once: the dG_{t+1} image, the
+        # gates, c_t, c_{t-1}, dY read; dG_t (row form + image) written; W_hh^T once per launch of `steps` steps.
+        # The running dL/dc and the split-K partial sums are NOT algorithmic (registers / an artefact of the split).
         import ctypes
         from edgedict_amd import _lib
         H, L, Bq = flags.enc_hidden_size, flags.enc_layers, args.batch
-        rd = 4 * H * H * 2 + Bq * 4 * H * 2 * 2 + 3 * Bq * H * 4 + Bq * H * 2   # W^T, dG image, gates, c_t, c_{t-1}, dC, dY
-        wr = Bq * 4 * H * 2 * 2 + Bq * H * 4                                     # dG (plain + image), dC
+        kind, steps_pl = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.load().edgedict_stack_last_mode(1, ctypes.byref(kind), ctypes.byref(steps_pl))
+        w_bytes = 4 * H * H * 2
+        w_per_step = w_bytes / max(1, steps_pl.value) if kind.value in (1, 2) else w_bytes
+        rd = w_per_step + Bq * 4 * H * 2 * 2 + 2 * Bq * H * 4 + Bq * H * 2      # W^T, dG image, gates, c_t, c_{t-1}, dY
+        wr = Bq * 4 * H * 2 * 2                                                # dG (row form + image)
+        if kind.value == 0:
+            rd += Bq * H * 4                                                   # the per-step kernel reads and writes dL/dc
+            wr += Bq * H * 4
         layer_steps = xs_frames * 2 + Tp * (L - 2)          # layers 0,1 at T0, the rest behind the 2x reduction
         ms_b, n_b = span_ms, span_n
         stack = None
@@ -504,26 +515,36 @@ def main():
             # the kernel's average duration: in-kernel begin/end stamps of every launch (two extra steps after
             # the timed region); the period also contains the gaps between dependent launches
             kernel_us = kern["bwd"][0] if "bwd" in kern else period_us
+            kname = {0: "stack_bwd_kernel", 1: "stack_bwd_lpw_kernel", 2: "stack_bwd_sk_kernel"}.get(kind.value, "stack_bwd_kernel")
             tr = None
             try:
-                ent = pmc.get("stack_bwd_kernel")
+                ent = next((v for k, v in pmc.items() if k.startswith(kname)), None)
                 tr = ent["hbm_bytes"] if ent else None
             except NameError:
                 pass
+            # serial-chain view (the recurrence is latency-bound): a layer's steps are dependent, the
+            # launch lasts as long as its longest slot; floor = 5 us per step (one device-wide hand-off + fetch)
+            chain_steps = max(1, steps_pl.value)
             stack = {
-                "kernel": "stack_bwd_kernel (BPTT wavefront launch: one time step of every runnable "
-                          "layer; %d launches carry %d layer-steps)" % (n_b.value, layer_steps),
+                "kernel": "%s (BPTT: %s; %d launches carry %d layer-steps)" % (
+                    kname, "split-K, W_hh^T stationary in registers, %d time steps of every runnable layer per launch"
+                    % steps_pl.value if kind.value == 2 else
+                    ("launch-persistent, %d time steps per launch" % steps_pl.value if kind.value == 1 else
+                     "one time step of every runnable layer per launch"), n_b.value, layer_steps),
                 "bound": "hbm", "achieved": per_launch / (kernel_us * 1e-6) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": per_launch / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": tr,
                 "algorithmic_bytes": per_launch, "kernel_us": kernel_us, "launch_period_us": period_us,
                 "launches_timed": kern["bwd"][1] if "bwd" in kern else n_b.value,
                 "fwd_kernel_us": kern["fwd"][0] if "fwd" in kern else None,
+                "us_per_dependent_step": kernel_us / chain_steps, "step_latency_floor_us": 5.0,
                 "note": "kernel_us = mean over the launches of (last workgroup's end - first workgroup's start), "
                         "stamped in-kernel on the 100 MHz clock during two steps after the timed region "
                         "(edgedict_stack_time_launches; compare the rocprofv3 average in profiles/); "
                         "launch_period_us = span of the timed launch sequence / launches (adds the gaps "
-                        "between dependent launches and waits for the chunk-GEMM stream)",
+                        "between dependent launches and waits for the chunk-GEMM stream); the recurrence is a chain "
+                        "of dependent steps, not a stream: us_per_dependent_step against step_latency_floor_us "
+                        "(SURVEY 8d) is the figure that moves, the HBM fraction is reported as the contract asks",
             }
         out = {
             "metric": "utterances/sec (E6D2, 15 s audio)",

@@ -109,6 +109,7 @@ struct Runtime {
     // timing of the recurrence stream's launch sequence of the last forward / backward call
     hipEvent_t tev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
     int tlaunches[2] = {0, 0};
+    int tkind[2] = {0, 0}, tsteps[2] = {0, 0};   // recurrence kernel of the last pass (edgedict_stack_last_mode)
     // opt-in (edgedict_stack_time_launches): every wavefront launch of a call stamps its first workgroup's
     // start and its last workgroup's end (100 MHz clock) into its own slot of a device buffer - the kernels'
     // own durations, without the gaps between launches that the span above includes
@@ -356,8 +357,26 @@ struct Streams {
     bool serial;
     Runtime* rt;
     // order `waiter` after everything enqueued so far on `src`
+    // share(src): ONE record on `src` that every chain(src, ...) reuses until unshare() - the side work of all the
+    // chunks a BPTT launch completes hangs on the same point of the recurrence stream, and each record on that
+    // stream costs the next launch ~3.5 us
+    hipEvent_t shared_ev = nullptr;
+    hipStream_t shared_src = nullptr;
+    int share(hipStream_t src) {
+        if (serial) return ED_OK;
+        shared_ev = rt->get();
+        ED_CHECK_ARG(shared_ev != nullptr, "encoder_stack: event creation failed");
+        ED_CHECK_HIP(hipEventRecord(shared_ev, src));
+        shared_src = src;
+        return ED_OK;
+    }
+    void unshare() { shared_ev = nullptr; shared_src = nullptr; }
     int chain(hipStream_t src, hipStream_t waiter) {
         if (serial || src == waiter) return ED_OK;
+        if (shared_ev && src == shared_src) {
+            ED_CHECK_HIP(hipStreamWaitEvent(waiter, shared_ev, 0));
+            return ED_OK;
+        }
         hipEvent_t e = rt->get();
         ED_CHECK_ARG(e != nullptr, "encoder_stack: event creation failed");
         ED_CHECK_HIP(hipEventRecord(e, src));
@@ -1133,6 +1152,10 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     ED_DEV(ed_stack_input_norm(d->x_dtype, d->x, d->in_gamma, d->in_beta, bptr(d->layers[0].X),
                                d->in_mean, d->in_rstd, B, d->T0, d->I0, d->eps, st.C));
     const int lpw_ns = wsr_applicable(d) ? 0 : lpw_steps(d);
+    if (st.rt) {
+        st.rt->tkind[0] = wsr_applicable(d) ? 3 : (lpw_ns ? 1 : 0);
+        st.rt->tsteps[0] = lpw_ns;
+    }
     for (int l = 0; l < L; ++l) {
         const edgedict_stack_layer_t& y = d->layers[l];
         ED_DEV(ed_stack_init_state(d->h0 ? d->h0 + l * BH : nullptr, d->c0 ? d->c0 + l * BH : nullptr,
@@ -1398,6 +1421,16 @@ extern "C" int edgedict_stack_last_timing(int backward, float* ms, int* launches
     return ED_OK;
 }
 
+extern "C" int edgedict_stack_last_mode(int backward, int* kind, int* steps_per_launch) {
+    std::lock_guard<std::mutex> lock(g_mu);
+    ED_CHECK_ARG(kind && steps_per_launch, "stack_last_mode: null pointer");
+    Runtime* r = runtime_for_current_device();
+    ED_CHECK_ARG(r, "stack_last_mode: no device runtime");
+    *kind = r->tkind[backward ? 1 : 0];
+    *steps_per_launch = r->tsteps[backward ? 1 : 0];
+    return ED_OK;
+}
+
 extern "C" int edgedict_stack_time_launches(int on) {
     std::lock_guard<std::mutex> lock(g_mu);
     Runtime* r = runtime_for_current_device();
@@ -1478,6 +1511,10 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     // arrival counters, behind the forward pass's in the sync region
     const int sk_ns = sk_bwd_steps(d);
     const int lpw_ns = sk_ns ? sk_ns : lpw_bwd_steps(d);
+    if (st.rt) {
+        st.rt->tkind[1] = sk_ns ? 2 : (lpw_ns ? 1 : 0);
+        st.rt->tsteps[1] = lpw_ns;
+    }
     unsigned* cntb = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + 2 * 8 * 512 + 8 * LPW_CNT_STRIDE;
     unsigned* gcnt = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + 16 * 1024;     // 64 KB into the sync region: [8][32][64] (16 unit blocks + 4 quarters per layer)
     if (lpw_ns) ED_DEV(ed_stack_zero(cntb, (size_t)8 * LPW_CNT_STRIDE * sizeof(unsigned), st.C));
@@ -1563,6 +1600,22 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     for (int l = 0; l < L; ++l) ready_w[l].assign(g[l].nchunks, l == L - 1 ? 0 : 0x3fffffff);
     // side work of a chunk that layer l's BPTT has just passed (enqueued right after the launch that carries the
     // chunk's last step, launch index w): dX product + LayerNorm backward for the layer below, weight gradients
+    // order `waiter` after layer l's recurrence so far.  Split-K BPTT with flag waits: the side stream polls the
+    // layer's done counter (one arrival per workgroup per launch, behind its last write-through dG row) - nothing is
+    // recorded on the recurrence stream, where every record costs the next launch ~3.5 us; otherwise an event
+    std::vector<unsigned> done_target(L, 0u);
+    // (measured at E6D2: 21.87 ms per step with the counter, 21.70 with ONE shared event per launch - the write-through
+    // dG rows lengthen the launches by more than the shorter gaps save; opt-in)
+    static const int side_counter_env = [] { const char* e = getenv("EDGEDICT_SK_SIDE_COUNTER"); return e ? atoi(e) : 0; }();
+    const bool side_counter = sk_ns && soft && side_counter_env;
+    auto after_recurrence = [&](int l, hipStream_t waiter) -> int {
+        if (side_counter && !g_trace) {
+            const unsigned* cp[1] = {gcnt + l * 32 * 64 + 20 * 64};
+            const unsigned tg[1] = {done_target[l]};
+            return ed_stack_wait_counters(cp, tg, 1, gerr, waiter);
+        }
+        return st.chain(st.RS(l), waiter);
+    };
     auto chunk_done = [&](int l, int k, int w) -> int {
             const edgedict_stack_layer_t& y = d->layers[l];
             if (l > 0) {
@@ -1571,7 +1624,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                 const int t0 = k * g[l].cf, t1 = min(y.T, t0 + g[l].cf);
                 const long long r0 = (long long)t0 * B;
                 hipStream_t S = st.S[l];
-                ED_TRY(st.chain(st.RS(l), S));
+                ED_TRY(after_recurrence(l, S));
                 ED_DEV(edgedict_gemm(ED_BF16, ED_BF16, bptr(y.G) + r0 * 4 * H, 4ll * H, 1,
                                      y.wih_t ? y.wih_t : y.wih_p, y.wih_t ? 4ll * H : y.I,
                                      y.wih_t ? 1 : 0, bptr(y.dX) + r0 * y.I, y.I, (t1 - t0) * B, y.I,
@@ -1598,10 +1651,10 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                                  !(d->flags & EDGEDICT_STACK_DW_AT_END))
                                     ? g[l].nchunks / tail_split : 0;
             if (k_split > 0 && k == k_split) {
-                ED_TRY(st.chain(st.RS(l), st.W));
+                ED_TRY(after_recurrence(l, st.W));
                 ED_TRY(weight_grads(l, k * g[l].cf, y.T, true, false));
             } else if (k_split > 0 && k == 0) {
-                ED_TRY(st.chain(st.RS(l), st.W));
+                ED_TRY(after_recurrence(l, st.W));
                 ED_TRY(weight_grads(l, 0, k_split * g[l].cf, false, l == 0));
             } else if (k_split == 0 && k % dw_seg == 0) {
                 if (d->flags & EDGEDICT_STACK_DW_AT_END) {
@@ -1609,7 +1662,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                 } else {
                     const int k1 = min(g[l].nchunks, k + dw_seg);
                     const int t0 = k * g[l].cf, t1 = min(y.T, k1 * g[l].cf);
-                    ED_TRY(st.chain(st.RS(l), st.W));
+                    ED_TRY(after_recurrence(l, st.W));
                     ED_TRY(weight_grads(l, t0, t1, k1 == g[l].nchunks, l == 0 && k == 0));
                 }
             }
@@ -1644,6 +1697,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
             Ls.B = B;
             Ls.H = H;
             Ls.trace = g_wsr_trace;
+            Ls.done_counter = side_counter ? 1 : 0;
             Done done[ED_STACK_MAX_SLOTS];
             int ndone = 0;
             // the launch has room for max_slots layers: the layers with the most steps left go first (the full-rate
@@ -1725,7 +1779,11 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                 g_trace->max_slots = max(g_trace->max_slots, Lc.nslot);
                 ++g_trace->launches;
             }
+            if (sk_ns)
+                for (int i = 0; i < Ls.nslot; ++i) done_target[Ls.slot[i].layer] += (unsigned)WGS;
+            if (ndone > 1 && !side_counter) ED_TRY(st.share(st.R));
             for (int i = 0; i < ndone; ++i) ED_TRY(chunk_done(done[i].l, done[i].k, w));
+            st.unshare();
         }
     } else
     for (int w = 0;; ++w) {

@@ -1478,31 +1478,33 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
         }
         SK_STAMP(3);
         // ---- (6) publish dG_t into image t.  Lanes l and l ^ 16 hold units u..u+3 and u+4..u+7 of one row: they swap
-        // two gates each, so every lane stores two whole 16-byte chunks (8 consecutive gate columns) write-through
+        // two gates each, so every lane holds two whole 16-byte chunks (8 consecutive gate columns), stored write-through
+        u32x4_t v16[2];
+        const bool hi = (lane >> 4) & 1;
+        const int kc0 = (gcol0 & ~7) + (hi ? 32 : 0);        // first of the pair's 8 columns, gate 2 (hi) or 0
         {
-            const bool hi = (lane >> 4) & 1;
             // (bit masks, not ?: - the compiler turns a select between two array elements into an indexed scratch load)
             const unsigned himask = 0u - (unsigned)hi;
             const unsigned g0x = (outg[0].x & himask) | (outg[2].x & ~himask), g0y = (outg[0].y & himask) | (outg[2].y & ~himask);
             const unsigned g1x = (outg[1].x & himask) | (outg[3].x & ~himask), g1y = (outg[1].y & himask) | (outg[3].y & ~himask);
-            uint2 got0, got1;
-            got0.x = __shfl_xor(g0x, 16); got0.y = __shfl_xor(g0y, 16);
-            got1.x = __shfl_xor(g1x, 16); got1.y = __shfl_xor(g1y, 16);
+            uint2 got[2];
+            got[0].x = __shfl_xor(g0x, 16); got[0].y = __shfl_xor(g0y, 16);
+            got[1].x = __shfl_xor(g1x, 16); got[1].y = __shfl_xor(g1y, 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                uint2 own;
+                own.x = (outg[2 + i].x & himask) | (outg[i].x & ~himask);
+                own.y = (outg[2 + i].y & himask) | (outg[i].y & ~himask);
+                v16[i] = hi ? (u32x4_t){got[i].x, got[i].y, own.x, own.y} : (u32x4_t){own.x, own.y, got[i].x, got[i].y};
+            }
             if (t > 0 && live) {
                 const unsigned soff_out = (unsigned)((long long)t * S.img_stride);
-                const int gate0 = hi ? 2 : 0;
-                const int kc0 = (gcol0 & ~7) + gate0 * 16;        // first of the pair's 8 columns, gate `gate0`
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
                     const int kc = kc0 + i * 16;
                     const int ks = kc >> 5, kg = (kc >> 3) & 3;
-                    const uint2 oth = i ? got1 : got0;
-                    uint2 own;
-                    own.x = (outg[2 + i].x & himask) | (outg[i].x & ~himask);
-                    own.y = (outg[2 + i].y & himask) | (outg[i].y & ~himask);
-                    const u32x4_t v = hi ? (u32x4_t){oth.x, oth.y, own.x, own.y} : (u32x4_t){own.x, own.y, oth.x, oth.y};
                     __builtin_amdgcn_raw_buffer_store_b128(
-                        v, rimg, (unsigned)(((ks * MT + (crow >> 4)) * 64 + kg * 16 + (crow & 15)) * 16), soff_out, 16);
+                        v16[i], rimg, (unsigned)(((ks * MT + (crow >> 4)) * 64 + kg * 16 + (crow & 15)) * 16), soff_out, 16);
                 }
             }
         }
@@ -1510,11 +1512,20 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(cnt_arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         SK_STAMP(4);
-        // ---- (7) off the chain: dG rows (for the dX / weight-gradient products)
+        // ---- (7) off the chain: the dG rows the dX / weight-gradient products read, the same two chunks.  Written
+        // through as well: the consumers are kernels of OTHER streams released by the done counter below, not by
+        // this launch's end - their data must be in memory when the last store is acknowledged
         if (live) {
-            bf16_t* G_t = S.G - (long long)s * B * H4 + (long long)crow * H4 + gcol0;
+            bf16_t* G_t = S.G - (long long)s * B * H4 + (long long)crow * H4 + kc0;
+            if (!L.done_counter) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) *reinterpret_cast<uint2*>(G_t + g * 16) = outg[g];
+                for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4_t*>(G_t + i * 16) = v16[i];
+            } else
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                // (s_nop: a store of more than 8 bytes needs wait states before its data registers are overwritten, and
+                // the hazard recognizer does not look inside an asm)
+                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(G_t + i * 16), "v"(v16[i]) : "memory");
         }
         SK_STAMP(5);
     }
@@ -1526,6 +1537,11 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
         atomicAdd((unsigned long long*)(o + 7), 1ull);
     }
     if (live) *reinterpret_cast<float4*>(S.dC + (long long)crow * H + unit0) = dc;
+    // every dG row of this launch is in memory: one arrival per workgroup on the layer's done counter (the side
+    // streams' products wait on it - stack_wait_counters_kernel - instead of on an event of the recurrence stream)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (L.done_counter && tid == 0) __hip_atomic_fetch_add(S.gcounter + 20 * 64, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (L.stamp) {
         __syncthreads();
         if (threadIdx.x == 0) atomicMax(&L.stamp[1], wall_clock64());

@@ -168,7 +168,8 @@ struct EdSkSlot {
     unsigned* counter;         // all workgroups of the layer: one arrival per finished step
     unsigned base;
     unsigned* gcounter;        // words LPW_CNT_STRIDE apart: [0, H/64) the 4 workgroups of a unit block, [16, 20) the workgroups
-                               // that write one quarter of the gate columns (H % 256 == 0); one arrival per step each
+                               // that write one quarter of the gate columns (H % 256 == 0), one arrival per step each;
+                               // [20] one arrival per workgroup per LAUNCH, after its last dG row is in memory
     unsigned gbase;            // 4 * (steps done before)
     const unsigned* wait_flag;
     int t0, nsteps, T, layer;
@@ -180,6 +181,8 @@ struct EdSkLaunch {
     unsigned long long* stamp;
     unsigned* err;
     long long* trace;          // debug (nullable): per-slot phase times of workgroup 0, see tools/sk_trace.py
+    int done_counter;          // 1: dG rows written through + one arrival per workgroup on gcounter[20] at the end (side
+                               // streams poll it); 0: plain dG rows, consumers ordered by an event behind the launch
 };
 int ed_stack_launch_bwd_sk(const EdSkLaunch& L, hipStream_t s);
 int ed_stack_sk_supported(int B, int H);

@@ -338,6 +338,12 @@ int edgedict_stack_forward(const edgedict_stack_desc_t* desc, void* stream);
  * launch of the most recent forward (backward = 0) or backward (1) call on this device, and the
  * number of launches in it; blocks until that call's launches have executed. */
 int edgedict_stack_last_timing(int backward, float* ms, int* launches);
+/* which recurrence kernel the most recent forward (backward = 0) / backward (1) call on this device ran:
+ * kind 0 = one launch per time step (stack_fwd_kernel / stack_bwd_kernel), 1 = launch-persistent
+ * (stack_fwd_lpw_kernel / stack_bwd_lpw_kernel), 2 = split-K weights-stationary BPTT (stack_bwd_sk_kernel),
+ * 3 = the opt-in weights-stationary forward (EDGEDICT_STACK_WSR); steps_per_launch = consecutive time steps of a
+ * layer one launch carries (0 for kind 0). */
+int edgedict_stack_last_mode(int backward, int* kind, int* steps_per_launch);
 /* measurement aid, opt-in: with on != 0 every wavefront launch of the following forward / backward calls on
  * this device stamps its first workgroup's start and its last workgroup's end (constant 100 MHz clock) into
  * an internal device buffer (64 KB per direction, allocated on first use).  edgedict_stack_launch_times then
