@@ -295,13 +295,13 @@ __global__ __launch_bounds__(256) void rnnt_grad(
     int U1, int V, int blank, const float* __restrict__ denom, const double* __restrict__ alphas,
     const double* __restrict__ betas, const double* __restrict__ ll, float scale_host,
     const float* __restrict__ scale_dev, int scale_stride, int vec_ok,
-    const long long* __restrict__ pk_off) {
+    const long long* __restrict__ pk_off, int b0) {
     constexpr int VEC = ElemIO<T>::VEC;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     // grid (x, B), 32-bit index arithmetic (see rnnt_lse_gather).  Dense layout: every cell of the
     // [Tm, U1] slab of utterance b is written (zeros outside its box); packed: only the box exists.
-    const int b = blockIdx.y;
+    const int b = b0 + blockIdx.y;      // utterances [b0, b0 + gridDim.y) of the batch
     const int Tb = min(act_lens[b], Tm), Ub = min(label_lens[b], U1 - 1);
     const float scale = scale_host * (scale_dev ? scale_dev[(long long)b * scale_stride] : 1.f);
     const int Wb = pk_off ? Ub + 1 : U1, ncells = pk_off ? Tb * Wb : Tm * U1;
@@ -482,8 +482,11 @@ static int loss_backward(const void* acts, int acts_dtype, void* grads, const in
                          const int32_t* act_lens, const int32_t* label_lens, int B, int T, int U1,
                          int V, int blank, const void* workspace, float grad_scale_host,
                          const float* grad_scale_dev, int grad_scale_stride,
-                         const long long* pk_off, void* stream_) {
+                         const long long* pk_off, void* stream_, int b0 = 0, int nb = -1) {
     if (int rc = check_common(B, T, U1, V, blank, acts_dtype)) return rc;
+    if (nb < 0) nb = B - b0;
+    ED_CHECK_ARG(b0 >= 0 && nb >= 0 && b0 + nb <= B, "rnnt_loss_backward: utterance range [%d, %d) outside the batch of %d", b0, b0 + nb, B);
+    if (nb == 0) return ED_OK;
     ED_CHECK_ARG(acts && grads && (labels || U1 == 1) && act_lens && label_lens && workspace,
                  "rnnt_loss_backward: null pointer argument");
     hipStream_t stream = (hipStream_t)stream_;
@@ -496,17 +499,17 @@ static int loss_backward(const void* acts, int acts_dtype, void* grads, const in
     const size_t esz = acts_dtype == ED_F32 ? 4 : 2;
     const int vec_ok = ((V * esz) % 16 == 0) && (((uintptr_t)acts & 15) == 0) &&
                        (((uintptr_t)grads & 15) == 0);
-    const dim3 grid(ed_grid_for((long long)T * U1, 4, max(1, 256 * 16 / B)), B);
+    const dim3 grid(ed_grid_for((long long)T * U1, 4, max(1, 256 * 16 / B)), nb);
     if (acts_dtype == ED_F32)
         hipLaunchKernelGGL(rnnt_grad<float>, grid, dim3(256), 0, stream, (const float*)acts,
                            (float*)grads, labels, act_lens, label_lens, B, T, U1, V, blank, denom,
                            alphas, betas, ll, grad_scale_host, grad_scale_dev, grad_scale_stride,
-                           vec_ok, pk_off);
+                           vec_ok, pk_off, b0);
     else
         hipLaunchKernelGGL(rnnt_grad<bf16_t>, grid, dim3(256), 0, stream,
                            (const bf16_t*)acts, (bf16_t*)grads, labels, act_lens, label_lens, B, T,
                            U1, V, blank, denom, alphas, betas, ll, grad_scale_host, grad_scale_dev,
-                           grad_scale_stride, vec_ok, pk_off);
+                           grad_scale_stride, vec_ok, pk_off, b0);
     ED_CHECK_LAUNCH("rnnt_grad");
     return ED_OK;
 }
@@ -532,4 +535,17 @@ extern "C" int edgedict_rnnt_loss_backward_packed(const void* acts, int acts_dty
     return loss_backward(acts, acts_dtype, grads, labels, act_lens, label_lens, B, T, U1, V, blank,
                          workspace, grad_scale_host, grad_scale_dev, grad_scale_stride, row_offsets,
                          stream_);
+}
+
+extern "C" int edgedict_rnnt_loss_backward_packed_range(const void* acts, int acts_dtype, void* grads,
+                                                        const int32_t* labels, const int32_t* act_lens,
+                                                        const int32_t* label_lens,
+                                                        const long long* row_offsets, int B, int T, int U1,
+                                                        int V, int blank, const void* workspace,
+                                                        float grad_scale_host, const float* grad_scale_dev,
+                                                        int grad_scale_stride, int b0, int nb, void* stream_) {
+    ED_CHECK_ARG(row_offsets, "rnnt_loss_backward_packed_range: null row_offsets");
+    return loss_backward(acts, acts_dtype, grads, labels, act_lens, label_lens, B, T, U1, V, blank,
+                         workspace, grad_scale_host, grad_scale_dev, grad_scale_stride, row_offsets,
+                         stream_, b0, nb);
 }

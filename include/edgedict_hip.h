@@ -104,6 +104,15 @@ int edgedict_rnnt_loss_backward_packed(const void* acts, int acts_dtype, void* g
                                        int B, int T, int U1, int V, int blank, const void* workspace,
                                        float grad_scale_host, const float* grad_scale_dev,
                                        int grad_scale_stride, void* stream);
+/* the same for utterances [b0, b0 + nb) of the batch only (all array arguments are still the whole batch's):
+ * lets the host pipeline the gradient of one group of utterances (HBM-bound) against the joint's dhid product
+ * of the previous group (matrix-pipe-bound) on a second stream. */
+int edgedict_rnnt_loss_backward_packed_range(const void* acts, int acts_dtype, void* grads,
+                                             const int32_t* labels, const int32_t* act_lens,
+                                             const int32_t* label_lens, const long long* row_offsets,
+                                             int B, int T, int U1, int V, int blank, const void* workspace,
+                                             float grad_scale_host, const float* grad_scale_dev,
+                                             int grad_scale_stride, int b0, int nb, void* stream);
 /* debug / test accessors into a filled workspace (device pointers):
  * which: 0 = log-softmax denominators f32[B,T,U1], 1 = alphas f64[B,T,U1], 2 = betas f64,
  * 3 = log-likelihoods f64[B,2] (alpha-side, beta-side), 4 = lp_blank f32[B,T,U1], 5 = lp_label */

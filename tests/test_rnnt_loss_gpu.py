@@ -215,3 +215,42 @@ def test_hip_loss_equals_the_sum_over_all_alignments(hip_lib):
         loss, g = _run_hip(acts, np.ascontiguousarray(labels), al, ll, reduction="none")
         np.testing.assert_allclose(loss, c_bf, rtol=2e-6, atol=2e-6)
         np.testing.assert_allclose(g, g_bf, rtol=0, atol=5e-6)
+
+
+@pytest.mark.gpu
+def test_backward_in_utterance_ranges_equals_one_pass(hip_lib):
+    """edgedict_rnnt_loss_backward_packed_range over [0,2), [2,2), [2,5) writes exactly the gradient of the one-pass
+    entry point (same kernel, utterance index offset by b0): bit-identical, rows of other utterances untouched."""
+    from edgedict_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(11)
+    B, T, U1, V = 5, 23, 7, 256
+    act = torch.tensor([23, 20, 9, 23, 4], dtype=torch.int32)
+    lab = torch.tensor([6, 2, 6, 0, 5], dtype=torch.int32)
+    rows = act.long() * (lab.long() + 1)
+    off = torch.zeros(B, dtype=torch.int64)
+    off[1:] = torch.cumsum(rows, 0)[:-1]
+    M = int(rows.sum())
+    for dt, code in ((torch.float32, 0), (torch.bfloat16, 1)):
+        logits = torch.randn(M, V, generator=g).to(dt).cuda()
+        labels = torch.randint(1, V, (B, U1 - 1), generator=g, dtype=torch.int32).cuda()
+        act_d, lab_d, off_d = act.cuda(), lab.cuda(), off.cuda()
+        ws = torch.zeros(lib.edgedict_rnnt_workspace_bytes(B, T, U1), dtype=torch.uint8, device="cuda")
+        costs, red = torch.empty(B, device="cuda"), torch.empty(1, device="cuda")
+        _lib.call("rnnt_loss_forward_packed", logits, code, labels, act_d, lab_d, off_d, B, T, U1, V, 0, costs, red,
+                  1.0 / B, ws)
+        one = torch.zeros_like(logits)
+        _lib.call("rnnt_loss_backward_packed", logits, code, one, labels, act_d, lab_d, off_d, B, T, U1, V, 0, ws,
+                  1.0 / B, None, 0)
+        parts = torch.full_like(logits, 7.0)
+        for b0, nb in ((0, 2), (2, 0), (2, 3)):
+            _lib.call("rnnt_loss_backward_packed_range", logits, code, parts, labels, act_d, lab_d, off_d, B, T, U1, V,
+                      0, ws, 1.0 / B, None, 0, b0, nb)
+            if (b0, nb) == (0, 2):
+                torch.cuda.synchronize()
+                assert (parts[int(off[2]):] == 7.0).all()        # utterances 2.. not touched yet
+        torch.cuda.synchronize()
+        assert torch.equal(one, parts)
+    with pytest.raises(RuntimeError):
+        _lib.call("rnnt_loss_backward_packed_range", logits, code, parts, labels, act_d, lab_d, off_d, B, T, U1, V, 0, ws,
+                  1.0 / B, None, 0, 3, 3)
