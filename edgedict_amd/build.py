@@ -86,5 +86,54 @@ def build_all(force=False, verbose=True):
     return LIB_PATH
 
 
+ASAN_DIR = os.path.join(CSRC, "asan")
+ASAN_LIB = os.path.join(ASAN_DIR, "libedgedict_hip_asan.so")
+
+
+def asan_runtime():
+    """Path of the AddressSanitizer runtime of the ROCm clang (to LD_PRELOAD into a python that loads the library)."""
+    r = subprocess.run(["/opt/rocm/lib/llvm/bin/clang", "-print-file-name=libclang_rt.asan-x86_64.so"],
+                       capture_output=True, text=True)
+    p = r.stdout.strip()
+    return p if r.returncode == 0 and os.path.isabs(p) and os.path.exists(p) else None
+
+
+def build_asan(verbose=True):
+    """HOST-side AddressSanitizer build of the same sources -> csrc/asan/libedgedict_hip_asan.so (the gfx950 code
+    objects are compiled as usual: device-side ASAN needs an xnack+ target).  For the ctypes boundary: load it with
+    EDGEDICT_LIB=<path>, LD_PRELOAD=<asan_runtime()>, ASAN_OPTIONS=detect_leaks=0 (tests/test_asan_boundary.py runs
+    the host-only entry points - dry-run scheduler, size queries, argument checks - that way)."""
+    os.makedirs(ASAN_DIR, exist_ok=True)
+    srcs = _sources()
+    hdr_mtime = _deps_mtime()
+    flags = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address", "-shared-libsan", "-Wno-option-ignored"]
+    base = [f for f in CXXFLAGS if f != "-O3"]
+
+    def one(src):
+        obj = os.path.join(ASAN_DIR, os.path.splitext(os.path.basename(src))[0] + ".o")
+        if os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_mtime):
+            return obj
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-x", "hip"] + base + flags + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc (asan) failed for %s:\n%s\n%s" % (src, " ".join(cmd), r.stderr))
+        return obj
+
+    with ThreadPoolExecutor(max(1, min(len(srcs), (os.cpu_count() or 2)))) as ex:
+        objs = list(ex.map(one, srcs))
+    if not os.path.exists(ASAN_LIB) or any(os.path.getmtime(o) > os.path.getmtime(ASAN_LIB) for o in objs):
+        cmd = [HIPCC, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fsanitize=address", "-shared-libsan",
+               "-Wno-option-ignored", "-o", ASAN_LIB] + objs + ["-ldl"]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link (asan) failed:\n%s\n%s" % (" ".join(cmd), r.stderr))
+    if verbose:
+        print("[edgedict_amd.build] %s (%d objects)" % (ASAN_LIB, len(objs)))
+    return ASAN_LIB
+
+
 if __name__ == "__main__":
-    build_all(force="--force" in sys.argv)
+    if "--asan" in sys.argv:
+        build_asan()
+    else:
+        build_all(force="--force" in sys.argv)
