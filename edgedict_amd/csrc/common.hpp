@@ -79,6 +79,10 @@ template <> struct ElemIO<float> {
     __device__ static __forceinline__ void store_vec(float* p, const float (&o)[4]) {
         *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
     }
+    // the 16 raw bytes now, the floats later (lets a kernel put independent work between request and use)
+    __device__ static __forceinline__ void cvt_vec(const uint4& v, float (&o)[4]) {
+        o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
+    }
 };
 template <> struct ElemIO<bf16_t> {
     static constexpr int VEC = 8;
@@ -86,6 +90,14 @@ template <> struct ElemIO<bf16_t> {
     __device__ static __forceinline__ void store(bf16_t* p, float v) { *p = f32_to_bf16(v); }
     __device__ static __forceinline__ void load_vec(const bf16_t* p, float (&o)[8]) {
         const uint4 v = *reinterpret_cast<const uint4*>(p);
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[2 * i] = __uint_as_float(w[i] << 16);
+            o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+    __device__ static __forceinline__ void cvt_vec(const uint4& v, float (&o)[8]) {
         const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int i = 0; i < 4; ++i) {

@@ -7,6 +7,7 @@
 //   Joint.forward     rnnt/models.py:169-179  Linear(cat[enc;dec]) -> Tanh  (the first Linear is
 //                     split as W1e*enc + W1d*dec + b1; here: tanh(E1[b,t]+D1[b,u]))
 //   optimiser         cli/train.py:135-146,268 torch.optim.Adam (no weight decay)
+#include <cstdlib>
 #include "common.hpp"
 
 namespace {
@@ -574,7 +575,10 @@ static int joint_hidden_bwd_impl(int dtype, const void* dhid, const void* hid, f
     }
     ED_CHECK_ARG(J % 8 == 0, "joint_hidden_bwd: joint size %d must be a multiple of 8", J);
     const int jblocks = (J + 63) / 64;
-    int tslabs = (2048 + B * jblocks - 1) / (B * jblocks);  // aim at >= ~2k workgroups
+    static const int wg_target = [] { const char* e = getenv("EDGEDICT_JHB_WGS"); return e && atoi(e) > 0 ? atoi(e) : 1280; }();
+    // t slabs per (utterance, 64-column block): every slab ends with U1 x 64 atomics into dD1, so more workgroups are
+    // not better - E6D2 bench batch: 640 / 1280 / 2048 / 4096 / 8192 workgroups = 0.52 / 0.45 / 0.49 / 0.63 / 1.0 ms
+    int tslabs = (wg_target + B * jblocks - 1) / (B * jblocks);
     if (tslabs > (T + 7) / 8) tslabs = (T + 7) / 8;         // at least two frames per wave
     if (tslabs < 1) tslabs = 1;
     const int tpb = (T + tslabs - 1) / tslabs;

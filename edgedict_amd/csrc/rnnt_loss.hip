@@ -288,8 +288,11 @@ __global__ __launch_bounds__(256) void rnnt_costs(const double* __restrict__ ll,
 }
 
 // ------------------------------------------------------------------ kernel 3
+#ifndef ED_GRAD_OCC
+#define ED_GRAD_OCC 1
+#endif
 template <typename T>
-__global__ __launch_bounds__(256) void rnnt_grad(
+__global__ __launch_bounds__(256, ED_GRAD_OCC) void rnnt_grad(
     const T* __restrict__ acts, T* __restrict__ grads, const int32_t* __restrict__ labels,
     const int32_t* __restrict__ act_lens, const int32_t* __restrict__ label_lens, int B, int Tm,
     int U1, int V, int blank, const float* __restrict__ denom, const double* __restrict__ alphas,
@@ -312,6 +315,17 @@ __global__ __launch_bounds__(256) void rnnt_grad(
         const long long arow = pk_off ? pk_off[b] + r : row;
         const T* z = acts + arow * (long long)V;
         T* g = grads + arow * (long long)V;
+        // the first (for V <= 64 * VEC * 4: the only) batch of logits is requested BEFORE the cell's alpha / beta /
+        // denominator are: the row does not depend on them, and behind them it would start a second round trip
+        constexpr int NB = 4;
+        uint4 raw[NB];
+        if (vec_ok && inside) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int v = (lane + 64 * j) * VEC;
+                if (v < V) raw[j] = *reinterpret_cast<const uint4*>(z + v);
+            }
+        }
         float c_all = 0.f, c_blank = -INFINITY, c_label = -INFINITY;
         int y = -1;
         if (inside) {
@@ -329,11 +343,17 @@ __global__ __launch_bounds__(256) void rnnt_grad(
             }
         }
         if (vec_ok) {
-            for (int v = lane * VEC; v < V; v += 64 * VEC) {
+            for (int v = lane * VEC, j = 0; v < V; v += 64 * VEC, ++j) {
                 float o[VEC];
                 if (inside) {
                     float x[VEC];
-                    ElemIO<T>::load_vec(z + v, x);
+                    if (j < NB) {
+                        // (static indices only: a run-time raw[j] would put the array in scratch)
+                        const uint4 rv = j == 0 ? raw[0] : (j == 1 ? raw[1] : (j == 2 ? raw[2] : raw[3]));
+                        ElemIO<T>::cvt_vec(rv, x);
+                    } else {
+                        ElemIO<T>::load_vec(z + v, x);
+                    }
 #pragma unroll
                     for (int i = 0; i < VEC; ++i) {
                         float gv = __expf(x[i] + c_all);

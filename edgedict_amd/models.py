@@ -465,8 +465,9 @@ class _JointLossFn(torch.autograd.Function):
         E1 = ops.gemm(enc2, w1c[:, :P])
         D1 = ops.gemm(dec2, w1c[:, P:], bias=b1.detach())
         hid = torch.empty(M, J, dtype=cd, device=dev)
-        _lib.call("joint_hidden_fwd_packed", _lib.dtype_code(cd), E1, D1, hid, al_d, ll_d, off_d,
-                  B, T, U1, J)
+        with ops.timed("joint_hidden_fwd"):
+            _lib.call("joint_hidden_fwd_packed", _lib.dtype_code(cd), E1, D1, hid, al_d, ll_d, off_d,
+                      B, T, U1, J)
         ops.LAST["joint_rows"] = M
         lib = _lib.load()
         ws = torch.empty(lib.edgedict_rnnt_workspace_bytes(B, T, U1), dtype=torch.uint8, device=dev)
@@ -481,8 +482,9 @@ class _JointLossFn(torch.autograd.Function):
             with ops.timed("joint_logits_gemm"):
                 _lib.call("gemm_nt_lse", hid, ops._ll(J), w2c, ops._ll(J), logits, ops._ll(V), M, V, J,
                           b2.detach(), parts)
-            _lib.call("rnnt_loss_forward_packed_parts", logits, labels, al_d, ll_d, off_d, B, T, U1, V,
-                      int(blank), costs, reduced, 1.0 / B, ws, parts, slots)
+            with ops.timed("rnnt_loss_fwd"):
+                _lib.call("rnnt_loss_forward_packed_parts", logits, labels, al_d, ll_d, off_d, B, T, U1, V,
+                          int(blank), costs, reduced, 1.0 / B, ws, parts, slots)
         else:
             with ops.timed("joint_logits_gemm"):
                 logits = ops.gemm(hid, w2c, bias=b2.detach())
@@ -543,13 +545,15 @@ class _JointLossFn(torch.autograd.Function):
                 main.wait_stream(aux)
             del logits
         else:
-            _lib.call("rnnt_loss_backward_packed", logits, _lib.dtype_code(cd), dl, labels, al_d, ll_d,
-                      off_d, B, T, U1, V, blank, ws, 1.0 / B, gscale, 0)
+            with ops.timed("rnnt_grad"):
+                _lib.call("rnnt_loss_backward_packed", logits, _lib.dtype_code(cd), dl, labels, al_d, ll_d,
+                          off_d, B, T, U1, V, blank, ws, 1.0 / B, gscale, 0)
             del logits
             with ops.timed("joint_dhid_gemm"):
                 dhid = ops.gemm(dl, w2t)
-            _lib.call("joint_hidden_bwd_packed", _lib.dtype_code(cd), dhid, hid, dE1, dD1, al_d, ll_d,
-                      off_d, B, T, U1, J)
+            with ops.timed("joint_hidden_bwd"):
+                _lib.call("joint_hidden_bwd_packed", _lib.dtype_code(cd), dhid, hid, dE1, dD1, al_d, ll_d,
+                          off_d, B, T, U1, J)
         if not defer:
             dw2 = ops.gemm(dl.t(), hid.t(), out_dtype=F32, split_k=ops.pick_split_k(V, J, M))
             db2 = ops.colsum(dl)
