@@ -538,6 +538,10 @@ def main():
                 "launches_timed": kern["bwd"][1] if "bwd" in kern else n_b.value,
                 "fwd_kernel_us": kern["fwd"][0] if "fwd" in kern else None,
                 "us_per_dependent_step": kernel_us / chain_steps, "step_latency_floor_us": 5.0,
+                # continuity with rounds 1-2, whose kernel re-streamed W_hh^T on every step (11.2 MB per layer-step):
+                # the same work priced at THOSE bytes
+                "frac_at_restreamed_weight_bytes": (w_bytes + rd - w_per_step + wr + (0 if kind.value == 0 else 2 * Bq * H * 4))
+                                                   * layer_steps / n_b.value / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                 "note": "kernel_us = mean over the launches of (last workgroup's end - first workgroup's start), "
                         "stamped in-kernel on the 100 MHz clock during two steps after the timed region "
                         "(edgedict_stack_time_launches; compare the rocprofv3 average in profiles/); "
