@@ -33,7 +33,9 @@ def _with_env(fn, **env):
 def _same(a, b, exact_bias=False):
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
     for n in a[3]:
-        if "norm" in n or "projs" in n or "bias" in n:   # column sums use fp32 atomics
+        # column sums use fp32 atomics; the output projection's weight gradient is a split-K product with atomic
+        # accumulation when the batch is large enough (B = 64 x H = 512 here) - neither goes through the recurrence
+        if "norm" in n or "proj" in n or "bias" in n:
             scale = max(a[3][n].abs().max().item(), 1e-6)
             assert (a[3][n] - b[3][n]).abs().max().item() <= 1e-4 * scale, n
         else:
@@ -145,7 +147,13 @@ def _close(a, b, tol):
     return worst
 
 
-SK_CASES = [c for c in CASES if c[3] % 64 == 0 and c[0] <= 64] + [(7, 21, 32, 128, 3, [1], 4, 0), (33, 30, 16, 64, 2, [0], 6, 0)]
+SK_CASES = [c for c in CASES if c[3] % 64 == 0 and c[0] <= 64] + [
+    (7, 21, 32, 128, 3, [1], 4, 0), (33, 30, 16, 64, 2, [0], 6, 0),
+    (9, 13, 32, 256, 2, [0], 4, 0),       # H % 256 == 0: per-quarter arrival counters, 4 unit blocks
+    (64, 10, 16, 512, 2, [], 4, 0),       # 8 unit blocks, full batch
+    (5, 11, 16, 192, 2, [1], 4, 0),       # 6 k-steps per quarter: a partial ring slot, rotated walk over 2 groups
+    (40, 9, 16, 320, 1, [], 4, 0),        # 10 k-steps per quarter, 3 row tiles
+]
 
 
 @pytest.mark.parametrize("case", SK_CASES)
