@@ -1219,8 +1219,9 @@ __global__ __launch_bounds__(256, ED_BWD_OCC) void stack_bwd_lpw_kernel(EdLpwBwd
 #define ED_SK_RING 3
 #endif
 #ifndef ED_SK_ABLATE
-#define ED_SK_ABLATE 0      // timing experiments only (results wrong): 1 no dG stream, 2 no LDS reads / MFMA
+#define ED_SK_ABLATE 0      // timing experiments only (results wrong): 1 no dG stream, 2 no LDS reads / MFMA, 3 half of them, 4 all MFMAs but a quarter of the LDS reads
 #endif
+constexpr int SK_MA = ED_SK_ABLATE == 3 ? 2 : 4;     // row tiles read and multiplied per k-step
 constexpr int SK_GK = ED_SK_GK;             // k-steps per ring slot
 constexpr int SK_SLOT = SK_GK * 4 * 1024;   // 16 KB: 4 k-steps x 4 row tiles x 1 KB
 constexpr int SK_RING = ED_SK_RING;         // slots: RING - 1 of them in flight while one is consumed
@@ -1387,18 +1388,18 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
                     const unsigned char* src = ring + (g % SK_RING) * SK_SLOT + lane * 16;
                     bf16x8_t af[2][4];
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) af[0][m] = *reinterpret_cast<const bf16x8_t*>(src + m * 1024);
+                    for (int m = 0; m < SK_MA; ++m) af[0][m] = *reinterpret_cast<const bf16x8_t*>(src + m * 1024);
 #pragma unroll
                     for (int j = 0; j < SK_GK; ++j) {
-                        if (j + 1 < SK_GK) {
+                        if (j + 1 < SK_GK && ED_SK_ABLATE != 4) {
 #pragma unroll
-                            for (int m = 0; m < 4; ++m)
+                            for (int m = 0; m < SK_MA; ++m)
                                 af[(j + 1) & 1][m] = *reinterpret_cast<const bf16x8_t*>(src + (j + 1) * 4096 + m * 1024);
                         }
                         if (KSq % SK_GK == 0 || ((g + rot) % NGRP) * SK_GK + j < KSq) {
 #pragma unroll
-                            for (int m = 0; m < 4; ++m)
-                                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g * SK_GK + j], af[j & 1][m], acc[m], 0, 0, 0);
+                            for (int m = 0; m < SK_MA; ++m)
+                                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g * SK_GK + j], af[ED_SK_ABLATE == 4 ? 0 : (j & 1)][m], acc[m], 0, 0, 0);
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
