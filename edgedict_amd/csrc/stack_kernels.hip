@@ -448,7 +448,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t lpw_rsrc(const void* p, unsign
 
 template <bool TRACE>
 __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
-    __shared__ FwdShared sh;
+    __shared__ float4 hand[4][3][4][64];      // cross-wave K sum: [source wave][slot of the owner][gate][lane], 48 KB
     if (ED_STEP_PRIO) __builtin_amdgcn_s_setprio(ED_STEP_PRIO);
     if (L.stamp && threadIdx.x == 0) atomicMin(&L.stamp[0], wall_clock64());
     const int B = L.B, H = L.H;
@@ -476,19 +476,24 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
     if (S.wait_flag) soft_wait(S.wait_flag, L.err, 500u + slot);
     if (S.flags && S.t0 % S.cf == 0) soft_wait(S.flags + S.t0 / S.cf, L.err, 500u + slot);
 
-    // ---- epilogue operands of the first step
-    uint4 gin[2];
-    float4 cin = make_float4(0.f, 0.f, 0.f, 0.f);
+    // ---- this lane's cells.  W is the FIRST MFMA operand below, so a lane ends up with 4 CONSECUTIVE units of one row
+    // for each of the 4 gates: row 16 wave + (lane & 15) of the workgroup's 64 (wave w owns row tile w after the
+    // cross-wave sum), units 4 q .. 4 q + 3 of its 16 (q = lane >> 4).  The cell update then needs no LDS at all:
+    // pre-activations arrive as four 8-byte loads, the cell state stays in 4 registers for the whole launch, gates /
+    // c / h leave as 8- and 16-byte stores (round 2's lane owned ONE unit of 4 rows: 44 two-byte LDS accesses per step)
+    const int q = lane >> 4, r16 = lane & 15;
+    const int brow = row0 + wave * 16 + r16;
+    const bool live = brow < B;
+    const long long goff = (long long)brow * H4 + ub * 64 + q * 4;       // + gate * 16
+    const long long coff = (long long)brow * H + ub * 16 + q * 4;
+    uint2 gpre[4];
+    float4 cst = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int id = tid + 256 * i, r = id >> 3, part = id & 7, b = row0 + r;
-        gin[i] = make_uint4(0, 0, 0, 0);
-        if (b < B) gin[i] = *reinterpret_cast<const uint4*>(S.G + b * H4 + ub * 64 + part * 8);
+    for (int g = 0; g < 4; ++g) {
+        gpre[g] = make_uint2(0u, 0u);
+        if (live) gpre[g] = *reinterpret_cast<const uint2*>(S.G + goff + g * 16);
     }
-    {
-        const int r = tid >> 2, part = tid & 3, b = row0 + r;
-        if (b < B) cin = *reinterpret_cast<const float4*>(S.C_prev + (long long)b * H + ub * 16 + part * 4);
-    }
+    if (live) cst = *reinterpret_cast<const float4*>(S.C_prev + coff);
     const __amdgpu_buffer_rsrc_t rimg = lpw_rsrc(S.img, (unsigned)S.img_bytes);
     __shared__ unsigned bail_s;
     if (tid == 0) bail_s = 0u;
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
                 }
             }
         }
-        __syncthreads();      // also: the previous step's trailing stores have read the LDS staging tiles
+        __syncthreads();
         if (bail_s) break;
         if (S.flags && s > 0 && t % S.cf == 0) {
             // this step opens a new chunk INSIDE the launch: its pre-activations come from a side-stream product
@@ -531,11 +536,8 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
             soft_wait(S.flags + t / S.cf, L.err, 500u + slot);
             const bf16_t* G_t = S.G + (long long)s * B * H4;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int id = tid + 256 * i, r = id >> 3, part = id & 7, b = row0 + r;
-                gin[i] = make_uint4(0, 0, 0, 0);
-                if (b < B) gin[i] = *reinterpret_cast<const uint4*>(G_t + b * H4 + ub * 64 + part * 8);
-            }
+            for (int g = 0; g < 4; ++g)
+                if (live) gpre[g] = *reinterpret_cast<const uint2*>(G_t + goff + g * 16);
         }
         LPW_STAMP(0);
         // ---- (2) h_{t-1} fragments of this wave's K quarter: image t, plain loads (the address has never
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
                     for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
-                            acc[mm][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i][half * 2 + mm], w[i][g], acc[mm][g], 0, 0, 0);
+                            acc[mm][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i][g], a[i][half * 2 + mm], acc[mm][g], 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -586,7 +588,7 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
                     const int sl = m < wave ? m : m - 1;
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
-                        sh.hand[wave][sl][g][lane] = make_float4(acc[mm][g][0], acc[mm][g][1], acc[mm][g][2], acc[mm][g][3]);
+                        hand[wave][sl][g][lane] = make_float4(acc[mm][g][0], acc[mm][g][1], acc[mm][g][2], acc[mm][g][3]);
                 } else {
 #pragma unroll
                     for (int g = 0; g < 4; ++g) mine[g] = acc[mm][g];
@@ -594,12 +596,6 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
             }
         }
         LPW_STAMP(1);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int id = tid + 256 * i, r = id >> 3, part = id & 7;
-            *reinterpret_cast<uint4*>(&sh.g[r][part * 8]) = gin[i];
-        }
-        if (s == 0) *reinterpret_cast<float4*>(&sh.c[tid >> 2][(tid & 3) * 4]) = cin;   // later steps: c_t is there
         __syncthreads();
 #pragma unroll
         for (int src = 0; src < 4; ++src) {
@@ -607,56 +603,57 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
                 const int sl = wave < src ? wave : wave - 1;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const float4 v = sh.hand[src][sl][g][lane];
+                    const float4 v = hand[src][sl][g][lane];
                     mine[g][0] += v.x; mine[g][1] += v.y; mine[g][2] += v.z; mine[g][3] += v.w;
                 }
             }
         }
-        // ---- (5) cell update: lane owns unit u of rows wave*16 + (lane>>4)*4 + q
+        // ---- (5) cell update in registers: 4 units of one row, all four gates
+        uint2 gout[4], hq;
+        float4 cnew;
         {
-            const int u = lane & 15, rbase = wave * 16 + (lane >> 4) * 4;
+            float hv[4], cv[4], o[4][4];
+            const float cp[4] = {cst.x, cst.y, cst.z, cst.w};
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int rl = rbase + q;
-                const float ig = fsigmoid(bf16_to_f32(sh.g[rl][u]) + mine[0][q]);
-                const float fg = fsigmoid(bf16_to_f32(sh.g[rl][16 + u]) + mine[1][q]);
-                const float gg = ftanh(bf16_to_f32(sh.g[rl][32 + u]) + mine[2][q]);
-                const float og = fsigmoid(bf16_to_f32(sh.g[rl][48 + u]) + mine[3][q]);
-                const float c = fg * sh.c[rl][u] + ig * gg;
-                const float h = og * ftanh(c);
-                sh.g[rl][u] = f32_to_bf16(ig);
-                sh.g[rl][16 + u] = f32_to_bf16(fg);
-                sh.g[rl][32 + u] = f32_to_bf16(gg);
-                sh.g[rl][48 + u] = f32_to_bf16(og);
-                sh.c[rl][u] = c;
-                sh.h[rl][u] = f32_to_bf16(h);
+            for (int i = 0; i < 4; ++i) {
+                auto pre = [&](const uint2& u) {
+                    const unsigned wd = (i < 2) ? u.x : u.y;
+                    return __uint_as_float((i & 1) ? (wd & 0xffff0000u) : (wd << 16));
+                };
+                const float ig = fsigmoid(pre(gpre[0]) + mine[0][i]);
+                const float fg = fsigmoid(pre(gpre[1]) + mine[1][i]);
+                const float gg = ftanh(pre(gpre[2]) + mine[2][i]);
+                const float og = fsigmoid(pre(gpre[3]) + mine[3][i]);
+                const float c = fg * cp[i] + ig * gg;
+                hv[i] = og * ftanh(c);
+                cv[i] = c;
+                o[0][i] = ig; o[1][i] = fg; o[2][i] = gg; o[3][i] = og;
             }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                gout[g].x = f32x2_to_bf16x2(o[g][0], o[g][1]);
+                gout[g].y = f32x2_to_bf16x2(o[g][2], o[g][3]);
+            }
+            hq.x = f32x2_to_bf16x2(hv[0], hv[1]);
+            hq.y = f32x2_to_bf16x2(hv[2], hv[3]);
+            cnew = make_float4(cv[0], cv[1], cv[2], cv[3]);
         }
-        __syncthreads();
         LPW_STAMP(2);
-        // ---- (6) publish FIRST: this workgroup's slice of the next image (128 write-through 16-byte stores),
-        // every storing wave drains, one lane arrives
-        if (tid < 128) {
-            const int m = tid >> 5, kg2 = (tid >> 4) & 1, r16 = tid & 15;
-            const int mt = mt0 + m;
-            if (mt < MT) {
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (mt * 16 + r16 < B) v = *reinterpret_cast<const uint4*>(&sh.h[m * 16 + r16][kg2 * 8]);
-                const int ks = ub >> 1, kg = (ub & 1) * 2 + kg2;
-                const u32x4_t vv = {v.x, v.y, v.z, v.w};
+        // ---- (6) publish FIRST: lanes l and l ^ 16 hold units 4q..4q+3 and 4q+4..4q+7 of one row - the even one stores
+        // the 16-byte chunk of the next image and of the h row (the LayerNorm's input), write-through and BEFORE the
+        // arrive (a side stream orders its LayerNorm launch behind this launch's steps by polling the counter)
+        {
+            const unsigned px = __shfl_xor(hq.x, 16), py = __shfl_xor(hq.y, 16);
+            const int mt = mt0 + wave;
+            if ((q & 1) == 0 && mt < MT) {
+                const u32x4_t vv = live ? (u32x4_t){hq.x, hq.y, px, py} : (u32x4_t){0u, 0u, 0u, 0u};
+                const int ks = ub >> 1, kg = (ub & 1) * 2 + (q >> 1);
                 __builtin_amdgcn_raw_buffer_store_b128(vv, rimg, (unsigned)((((ks * MT + mt) * 64) + kg * 16 + r16) * 16),
                                                        (unsigned)((long long)(t + 1) * S.img_stride), 16);
-            }
-        }
-        // the h rows too (2 KB, the LayerNorm's input): write-through and BEFORE the arrive, so that a side
-        // stream can order its LayerNorm launch behind this launch's steps by polling the counter
-        // (stack_wait_counters_kernel) instead of an event recorded on the recurrence stream
-        if (tid >= 128) {
-            const int id = tid - 128, r = id >> 1, hf = id & 1, b = row0 + r;
-            if (b < B) {
-                const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&sh.h[r][hf * 8]);
-                bf16_t* dst = S.Y + (long long)s * BH + (long long)b * H + ub * 16 + hf * 8;
-                asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+                if (live) {
+                    bf16_t* dst = S.Y + (long long)s * BH + (long long)brow * H + ub * 16 + (q >> 1) * 8;
+                    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(vv) : "memory");
+                }
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -664,31 +661,17 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
         LPW_STAMP(3);
         if (tid == 0) __hip_atomic_fetch_add(S.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         LPW_STAMP(4);
-        // ---- (7) off the chain: gates (for the backward pass), h rows (LayerNorm), c rows; next step's
-        // pre-activations into registers
-        {
+        // ---- (7) off the chain: gates (for the backward pass), c rows; next step's pre-activations into registers
+        cst = cnew;
+        if (live) {
             bf16_t* G_t = S.G + (long long)s * B * H4;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int task = tid + 256 * i, r = task >> 3, part = task & 7, b = row0 + r;
-                if (b < B)
-                    *reinterpret_cast<uint4*>(G_t + b * H4 + ub * 64 + part * 8) =
-                        *reinterpret_cast<const uint4*>(&sh.g[r][part * 8]);
-            }
-            {
-                const int r = tid >> 2, part = tid & 3, b = row0 + r;
-                if (b < B)
-                    *reinterpret_cast<float4*>(S.C + (long long)s * BH + (long long)b * H + ub * 16 + part * 4) =
-                        *reinterpret_cast<const float4*>(&sh.c[r][part * 4]);
-            }
+            for (int g = 0; g < 4; ++g) *reinterpret_cast<uint2*>(G_t + goff + g * 16) = gout[g];
+            *reinterpret_cast<float4*>(S.C + (long long)s * BH + coff) = cnew;
             if (s + 1 < S.nsteps && !(S.flags && (t + 1) % S.cf == 0)) {     // not across a chunk opening
                 const bf16_t* G_n = G_t + (long long)B * H4;
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int id = tid + 256 * i, r = id >> 3, part = id & 7, b = row0 + r;
-                    gin[i] = make_uint4(0, 0, 0, 0);
-                    if (b < B) gin[i] = *reinterpret_cast<const uint4*>(G_n + b * H4 + ub * 64 + part * 8);
-                }
+                for (int g = 0; g < 4; ++g) gpre[g] = *reinterpret_cast<const uint2*>(G_n + goff + g * 16);
             }
         }
         LPW_STAMP(5);
