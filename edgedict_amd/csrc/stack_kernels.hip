@@ -527,7 +527,9 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
                 }
             }
         }
-        __syncthreads();
+        // (a raw barrier: __syncthreads() would also wait for this wave's trailing stores and the prefetched
+        // pre-activations - an HBM round trip that belongs behind the gather, not in front of it)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (bail_s) break;
         if (S.flags && s > 0 && t % S.cf == 0) {
             // this step opens a new chunk INSIDE the launch: its pre-activations come from a side-stream product
@@ -1296,15 +1298,16 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
             last_ = now_;                             \
         }                                             \
     } while (0)
-    for (int s = 0; s < S.nsteps; ++s) {
-        const int t = S.t0 - s;
-        // ---- this frame's cell operands (HBM: the forward pass wrote them long ago): requested now, used after the
-        // product - nothing here depends on the peers
-        uint2 gq[4], dyq = make_uint2(0u, 0u);
-        float4 ctq = make_float4(0.f, 0.f, 0.f, 0.f), cpq = ctq;
+    // ---- a frame's cell operands (HBM: the forward pass wrote them long ago).  Requested at the END of the step before
+    // (and here for the first one): the wait for the peers is their flight time, and nothing of this wave is outstanding
+    // in front of the poll or of the first ring slot except loads that are about to land
+    uint2 gq[4], dyq = make_uint2(0u, 0u);
+    float4 ctq = make_float4(0.f, 0.f, 0.f, 0.f), cpq = ctq;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) gq[g] = make_uint2(0u, 0u);
+    for (int g = 0; g < 4; ++g) gq[g] = make_uint2(0u, 0u);
+    auto request_operands = [&](int s) {
         if (live) {
+            const int t = S.t0 - s;
             const bf16_t* G_t = S.G - (long long)s * B * H4 + (long long)crow * H4 + gcol0;
 #pragma unroll
             for (int g = 0; g < 4; ++g) gq[g] = *reinterpret_cast<const uint2*>(G_t + g * 16);
@@ -1313,6 +1316,10 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
             cpq = *reinterpret_cast<const float4*>(S.Cx + (long long)t * BH + o);
             if (S.dY) dyq = *reinterpret_cast<const uint2*>(S.dY - (long long)s * BH + o);
         }
+    };
+    request_operands(0);
+    for (int s = 0; s < S.nsteps; ++s) {
+        const int t = S.t0 - s;
         // ---- (1) every workgroup of this layer has published dG_{t+1}
         if (tid == 0) {
             unsigned bail = 0u;
@@ -1328,7 +1335,8 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
             }
             *bail_p = bail;
         }
-        __syncthreads();
+        // (a raw barrier: __syncthreads() would make every wave wait for its own operand loads here)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (*bail_p) break;
         SK_STAMP(0);
         const int par = t & 1;
@@ -1511,6 +1519,7 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
                 // the hazard recognizer does not look inside an asm)
                 asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(G_t + i * 16), "v"(v16[i]) : "memory");
         }
+        if (s + 1 < S.nsteps) request_operands(s + 1);
         SK_STAMP(5);
     }
 #undef SK_STAMP
