@@ -1084,7 +1084,7 @@ int lpw_steps(const edgedict_stack_desc_t* d) {
     // read on every call (two getenv per forward pass): tests switch the path inside one process
     const char* e_on = getenv("EDGEDICT_STACK_LPW");
     const char* e_n = getenv("EDGEDICT_LPW_STEPS");
-    const int on = e_on ? atoi(e_on) : 1, want = e_n ? atoi(e_n) : 12;
+    const int on = e_on ? atoi(e_on) : 1, want = e_n ? atoi(e_n) : min(d->chunk, 16);      // default: a chunk per launch
     if (!on || !ed_stack_lpw_supported(d->B, d->H) || (d->flags & EDGEDICT_STACK_WSR)) return 0;
     bool reduces = false;
     for (int l = 0; l < d->L; ++l) reduces = reduces || d->layers[l].reduce == 2;
@@ -1098,7 +1098,7 @@ int lpw_steps(const edgedict_stack_desc_t* d) {
 int sk_bwd_steps(const edgedict_stack_desc_t* d) {
     const char* e_on = getenv("EDGEDICT_STACK_BWD_SK");
     const char* e_n = getenv("EDGEDICT_SK_STEPS");
-    const int on = e_on ? atoi(e_on) : 1, want = e_n ? atoi(e_n) : 12;
+    const int on = e_on ? atoi(e_on) : 1, want = e_n ? atoi(e_n) : min(d->chunk, 16);      // default: a chunk per launch
     if (!on || !ed_stack_sk_supported(d->B, d->H)) return 0;
     for (int l = 0; l < d->L; ++l)
         if (!d->layers[l].whh_s) return 0;

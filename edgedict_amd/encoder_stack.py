@@ -52,7 +52,9 @@ ACCUM_GRADS = 8
 WSR = 32          # weights-stationary recurrence kernels (csrc/wsr_kernels.hip) when H = 1024, B <= 64
 
 # schedule knobs (env overrides are for tuning runs; the defaults are what bench.py measures)
-CHUNK = int(os.environ.get("EDGEDICT_STACK_CHUNK", "12"))
+# output-rate frames per chunk (= steps per launch of the launch-persistent kernels).  E6D2 training step, round 3:
+# 8 / 10 / 12 / 16 / 20 / 24 / 32 frames = 22.8 / 22.2 / 21.2 / 21.0 / 21.3 / 21.4 / 22.1 ms
+CHUNK = int(os.environ.get("EDGEDICT_STACK_CHUNK", "16"))
 LAG = int(os.environ.get("EDGEDICT_STACK_LAG", "0"))
 SPLIT_K = int(os.environ.get("EDGEDICT_STACK_SPLITK", "0"))
 FLAGS = int(os.environ.get("EDGEDICT_STACK_FLAGS", "0"))
