@@ -53,13 +53,6 @@ PACKED_LATTICE = os.environ.get("EDGEDICT_PACKED_LATTICE", "1") != "0"
 # (csrc/gemm_nt256.hip) instead of a separate pass over the logits (rnnt_lse_gather)
 FUSED_LSE = os.environ.get("EDGEDICT_FUSED_LSE", "1") != "0"
 
-# packed joint + loss backward in groups of utterances on two streams: the loss gradient of group i+1 (HBM-bound)
-# runs beside the dhid product and the tanh backward of group i (matrix-pipe-bound); 0/1 = one pass on one stream.
-# Measured at E6D2 (B=64): 21.70 ms per step in one pass, 21.74 with 2 groups, 22.26 with 4, 23.18 with 8 - the two
-# kernels do not hide each other (both sit on the L2/HBM path), the smaller products only lose efficiency.  Off.
-JOINT_BWD_GROUPS = int(os.environ.get("EDGEDICT_JOINT_BWD_GROUPS", "1"))
-JOINT_BWD_GROUP_MIN_ROWS = 65536     # lattices smaller than this are never split
-
 # inputs shorter than this many frames use the per-layer path even in bf16 (see Encoder.forward)
 STACK_MIN_FRAMES = int(os.environ.get("EDGEDICT_STACK_MIN_FRAMES", "24"))
 

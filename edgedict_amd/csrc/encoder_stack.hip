@@ -104,7 +104,7 @@ __global__ void unpermute_rows_kernel(const float* __restrict__ src, long long s
 
 // ---------------------------------------------------------------- per-device runtime
 struct Runtime {
-    hipStream_t R = nullptr, R2 = nullptr, W = nullptr;
+    hipStream_t R = nullptr, W = nullptr;
     int prio_hi = 0;
     // timing of the recurrence stream's launch sequence of the last forward / backward call
     hipEvent_t tev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
@@ -209,7 +209,15 @@ struct WsLayout {
     std::vector<size_t> skpart;                     // per layer: partial sums of the split-K BPTT [2][H/64][4][64][64] f32
     size_t tmpW = 0, tmpB = 0, dX0 = 0, wsr_sync = 0, total = 0;
 };
-constexpr size_t WSR_SYNC_BYTES = 128 * 1024;  // flags 32 KB | forward counters 2 KB | BPTT counters 2 KB | ... | from 64 KB: unit-block and quarter counters of the split-K BPTT (8 layers x 32 x 256 bytes)
+// sync region of the workspace, in 4-byte words: chunk flags of the forward / backward pass [8 layers][512 chunks] each,
+// arrival counters of the launch-persistent forward and of the split-K BPTT's layer-wide fallback [8 layers][LPW_MAX_SUB
+// sub-batches] lines of 256 bytes each, from 64 KB the unit-block and quarter counters of the split-K BPTT
+// [8 layers][SK_CNT_LINES] lines
+constexpr size_t SYNC_FFLAG = 0, SYNC_BFLAG = 8 * 512, SYNC_FCNT = 2 * 8 * 512;
+constexpr size_t SYNC_BCNT = SYNC_FCNT + (size_t)8 * LPW_MAX_SUB * LPW_CNT_STRIDE;
+constexpr size_t SYNC_GCNT = 16 * 1024;
+constexpr size_t WSR_SYNC_BYTES = (SYNC_GCNT + (size_t)8 * SK_CNT_LINES * 64) * 4;
+static_assert(SYNC_BCNT + (size_t)8 * LPW_MAX_SUB * LPW_CNT_STRIDE <= SYNC_GCNT, "sync region layout");
 
 WsLayout ws_layout(const edgedict_stack_desc_t* d) {
     WsLayout w;
@@ -411,10 +419,6 @@ int open_streams(const edgedict_stack_desc_t* d, void* stream_, Streams& st) {
     st.rt->used = 0;   // recycle the event pool (waits capture an event's state when enqueued)
     st.R = st.rt->R;
     st.R2 = st.rt->R;
-    if (d->flags & EDGEDICT_STACK_TWO_RECURRENCE_STREAMS) {
-        st.R2 = st.rt->lazy(st.rt->R2);
-        ED_CHECK_ARG(st.R2 != nullptr, "encoder_stack: stream creation failed");
-    }
     for (int i = 0; i < ED_STACK_MAX_SLOTS; ++i) {
         st.S[i] = st.rt->S[0];
         if ((d->flags & EDGEDICT_STACK_SIDE_STREAM_PER_LAYER) && i > 0) {
@@ -482,228 +486,7 @@ extern "C" int edgedict_stack_pack_weights(const float* w_ih, const float* w_hh,
 
 namespace {
 
-long long* g_wsr_trace = nullptr;   // debug: device buffer of >= 64 KB registered by edgedict_stack_wsr_set_trace
-
-bool wsr_applicable(const edgedict_stack_desc_t* d) {
-    if (!(d->flags & EDGEDICT_STACK_WSR) || d->H != 1024 || d->B > 64 || d->L > ED_STACK_MAX_SLOTS) return false;
-    for (int l = 0; l < d->L; ++l)
-        if (!d->layers[l].whh_r) return false;
-    return true;
-}
-
-// Forward pass as ONE persistent launch (wsr_kernels.hip, EdWsrLaunch::persistent): every layer runs all
-// its frames on its own XCD and waits, chunk by chunk, for the workgroups of the spare XCDs (the WORKERS)
-// to turn the chunk the layer below has finished into its gates (LayerNorm + input product).  Nothing else
-// can run beside a grid that fills whole XCDs (workgroups are bound to XCDs round-robin at dispatch, and
-// a CU mask cannot exclude an XCD - tools/cumask_probe.hip), so the side work lives INSIDE the launch.
-int forward_wsr_persistent(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Streams& st,
-                           const WsLayout& wl) {
-    const int B = d->B, H = d->H, L = d->L;
-    const long long BH = (long long)B * H;
-    char* ws = (char*)d->ws;
-    unsigned* sync = (unsigned*)(ws + wl.wsr_sync);
-    ED_DEV(ed_stack_zero(sync, WSR_SYNC_BYTES, st.R));
-    const int T_out = (g[L - 1].T + d->layers[L - 1].reduce - 1) / d->layers[L - 1].reduce;
-    // layer 0's input product, all chunks, before the launch
-    for (int k = 0; k < g[0].nchunks; ++k) {
-        ED_DEV(input_gemm(d, g, 0, k, st.S[0]));
-        if (g_trace) g_trace->chunk_enqueued[g_trace->coff[0] + k] = 0;
-    }
-    ED_TRY(st.chain(st.S[0], st.R));
-    EdWsrLaunch Lc;
-    Lc.nslot = L;
-    Lc.B = B;
-    Lc.err = sync;
-    Lc.ticket = sync + 8;
-    Lc.persistent = 1;
-    Lc.eps = d->eps;
-    Lc.trace = g_wsr_trace;
-    for (int l = 0; l < L; ++l) {
-        const edgedict_stack_layer_t& y = d->layers[l];
-        ED_CHECK_ARG(g[l].nchunks <= 512, "encoder_stack: too many chunks for the persistent launch");
-        EdWsrSlot& S = Lc.slot[l];
-        S.G = bptr(y.G);
-        S.img0 = bptr(ws + wl.frag0[l]);
-        S.img1 = bptr(ws + wl.frag1[l]);
-        S.Y = bptr(y.Yx) + BH;
-        S.C_prev = y.Cx;
-        S.C = y.Cx + BH;
-        S.Wreg = bptr(y.whh_r);
-        S.counter = sync + 16 + l;
-        S.base = 0;
-        S.t0 = 0;
-        S.nsteps = y.T;
-        S.cf = g[l].cf;
-        S.gdone = l == 0 ? nullptr : sync + 64 + l * 512;
-        S.ydone = sync + 32 + l;
-        S.X = y.residual ? bptr(y.X) : nullptr;
-        S.gamma = y.ln_gamma;
-        S.beta = y.ln_beta;
-        S.mean = y.mean;
-        S.rstd = y.rstd;
-        S.T = y.T;
-        S.reduce = y.reduce;
-        S.xdone = sync + 64 + 8 * 512 + l * 512;
-        if (l + 1 < L) {
-            const edgedict_stack_layer_t& z = d->layers[l + 1];
-            S.nX = bptr(z.X);
-            S.nX_st = BH;
-            S.nX_sb = H;
-            S.nWih = bptr(z.wih_p);
-            S.nBias = z.bias_p;
-            S.nG = bptr(z.G);
-            S.ngdone = sync + 64 + (l + 1) * 512;
-        } else {
-            S.nX = bptr(d->out);
-            S.nX_st = H;
-            S.nX_sb = (long long)T_out * H;
-            S.nWih = nullptr;
-            S.nBias = nullptr;
-            S.nG = nullptr;
-            S.ngdone = nullptr;
-        }
-        if (g_trace) {
-            for (int t = 0; t < y.T; ++t) g_trace->step_launch[g_trace->toff[l] + t] = 0;
-            for (int k = 0; k < g[l].nchunks && l > 0; ++k) g_trace->chunk_enqueued[g_trace->coff[l] + k] = 0;
-        }
-    }
-    if (st.rt) st.rt->stamp_used[0] = 0;
-    if (st.rt && st.rt->tev[0][0]) ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][0], st.R));
-    ED_DEV(ed_wsr_launch_fwd(Lc, st.R));
-    if (g_trace) {
-        g_trace->max_slots = L;
-        g_trace->launches = 1;
-    }
-    if (st.rt && st.rt->tev[0][1]) {
-        ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][1], st.R));
-        st.rt->tlaunches[0] = 1;
-    }
-    if (st.rt && st.rt->wsr_err_dev && !g_trace)
-        ED_CHECK_HIP(hipMemcpyAsync(st.rt->wsr_err_host + 1, sync, 4, hipMemcpyDeviceToHost, st.R));
-    return ED_OK;
-}
-
-// Forward pass with the weights-stationary recurrence kernel (wsr_kernels.hip): launch w carries chunk
-// k_l of every layer whose input product for that chunk has been enqueued; after the launch the side
-// stream normalises the frames each layer finished and multiplies them into the next layer's gates.
-// Layer l runs chunk k one launch after layer l-1 did (the recurrence stream waits for the product's
-// event).  Called with the prologue done and the internal streams forked from the caller's.
-int forward_wsr(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Streams& st, const WsLayout& wl) {
-    const int B = d->B, H = d->H, L = d->L;
-    const long long BH = (long long)B * H;
-    char* ws = (char*)d->ws;
-    unsigned* sync = (unsigned*)(ws + wl.wsr_sync);
-    ED_DEV(ed_stack_zero(sync, WSR_SYNC_BYTES, st.R));
-    const int T_out = (g[L - 1].T + d->layers[L - 1].reduce - 1) / d->layers[L - 1].reduce;
-    std::vector<std::vector<hipEvent_t>> Eg(L);
-    std::vector<std::vector<char>> queued(L);
-    for (int l = 0; l < L; ++l) {
-        Eg[l].assign(g[l].nchunks, nullptr);
-        queued[l].assign(g[l].nchunks, 0);
-    }
-    int next_g0 = 0;
-    auto feed_layer0 = [&](int upto) -> int {
-        for (; next_g0 < g[0].nchunks && next_g0 <= upto; ++next_g0) {
-            ED_DEV(input_gemm(d, g, 0, next_g0, st.S[0]));
-            if (g_trace) g_trace->chunk_enqueued[g_trace->coff[0] + next_g0] = g_trace->launches;
-            ED_TRY(st.record(Eg[0][next_g0], st.S[0]));
-            queued[0][next_g0] = 1;
-        }
-        return ED_OK;
-    };
-    ED_TRY(feed_layer0(2));
-    std::vector<int> next_k(L, 0);
-    // launches between the one that finishes chunk k of layer l and the one that runs chunk k of
-    // layer l+1: with 1 every launch waits for the side-stream work (LayerNorm + product) of the
-    // launch before it - nothing overlaps; with 2 that work runs under the next launch.
-    int delay = 2;
-    if (const char* e = getenv("EDGEDICT_WSR_DELAY")) delay = max(1, atoi(e));
-    std::vector<std::vector<int>> ready_at(L);
-    for (int l = 0; l < L; ++l) ready_at[l].assign(g[l].nchunks, 0);
-    int launches = 0;
-    if (st.rt) st.rt->stamp_used[0] = 0;
-    if (st.rt && st.rt->tev[0][0]) ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][0], st.R));
-    const size_t max_launches = (WSR_SYNC_BYTES / 4 - 64) / 8;
-    for (;;) {
-        EdWsrLaunch Lc;
-        Lc.nslot = 0;
-        Lc.B = B;
-        Lc.err = sync;
-        Lc.persistent = 0;
-        Lc.eps = d->eps;
-        Lc.trace = nullptr;
-        Lc.ticket = sync + 64 + (size_t)launches * 8;
-        int ran_l[ED_STACK_MAX_SLOTS], ran_k[ED_STACK_MAX_SLOTS];
-        bool pending = false;
-        for (int l = 0; l < L; ++l) {
-            const int k = next_k[l];
-            if (k >= g[l].nchunks) continue;
-            pending = true;
-            if (l == 0) ED_TRY(feed_layer0(k + 2));
-            if (!queued[l][k] || launches < ready_at[l][k]) continue;   // product not enqueued yet / too fresh
-            const edgedict_stack_layer_t& y = d->layers[l];
-            const int t0 = k * g[l].cf, t1 = min(y.T, t0 + g[l].cf);
-            ED_TRY(st.wait(st.R, Eg[l][k]));
-            EdWsrSlot& S = Lc.slot[Lc.nslot];
-            S.G = bptr(y.G) + (long long)t0 * B * 4 * H;
-            S.img0 = bptr(ws + wl.frag0[l]);
-            S.img1 = bptr(ws + wl.frag1[l]);
-            S.Y = bptr(y.Yx) + (long long)(t0 + 1) * BH;
-            S.C_prev = y.Cx + (long long)t0 * BH;
-            S.C = y.Cx + (long long)(t0 + 1) * BH;
-            S.Wreg = bptr(y.whh_r);
-            S.counter = sync + 16 + l;
-            S.base = 32u * (unsigned)t0;
-            S.t0 = t0;
-            S.nsteps = t1 - t0;
-            ran_l[Lc.nslot] = l;
-            ran_k[Lc.nslot] = k;
-            ++Lc.nslot;
-            if (g_trace)
-                for (int t = t0; t < t1; ++t) g_trace->step_launch[g_trace->toff[l] + t] = g_trace->launches;
-        }
-        if (!pending) break;
-        ED_CHECK_ARG(Lc.nslot > 0, "encoder_stack: weights-stationary schedule made no progress");
-        ED_CHECK_ARG((size_t)launches < max_launches, "encoder_stack: too many weights-stationary launches");
-        ED_DEV(ed_wsr_launch_fwd(Lc, st.R));
-        ++launches;
-        if (g_trace) {
-            g_trace->max_slots = max(g_trace->max_slots, Lc.nslot);
-            ++g_trace->launches;
-        }
-        // side stream: LayerNorm of the finished frames, then the next layer's input product
-        for (int i = 0; i < Lc.nslot; ++i) {
-            const int l = ran_l[i], k = ran_k[i];
-            const edgedict_stack_layer_t& y = d->layers[l];
-            const int t0 = k * g[l].cf, t1 = min(y.T, t0 + g[l].cf);
-            hipStream_t S = st.S[l + 1 < L ? l + 1 : l];
-            ED_TRY(st.chain(st.R, S));
-            if (l + 1 < L) {
-                ED_DEV(ed_stack_chunk_norm(bptr(y.Yx) + BH, y.residual ? bptr(y.X) : nullptr, y.ln_gamma, y.ln_beta,
-                                           bptr(d->layers[l + 1].X), BH, H, y.mean, y.rstd, B, H, y.T, t0, t1,
-                                           y.reduce, d->eps, S));
-                ED_DEV(input_gemm(d, g, l + 1, k, S));
-                if (g_trace) g_trace->chunk_enqueued[g_trace->coff[l + 1] + k] = g_trace->launches;
-                ED_TRY(st.record(Eg[l + 1][k], S));
-                queued[l + 1][k] = 1;
-                ready_at[l + 1][k] = launches + delay - 1;   // `launches` already counts this launch
-            } else {
-                ED_DEV(ed_stack_chunk_norm(bptr(y.Yx) + BH, y.residual ? bptr(y.X) : nullptr, y.ln_gamma, y.ln_beta,
-                                           bptr(d->out), H, (long long)T_out * H, y.mean, y.rstd, B, H, y.T, t0, t1,
-                                           y.reduce, d->eps, S));
-            }
-            ++next_k[l];
-        }
-    }
-    if (st.rt && st.rt->tev[0][1]) {
-        ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][1], st.R));
-        st.rt->tlaunches[0] = launches;
-    }
-    // a launch that ran into a bounded spin left its code in sync[0]: copy it to the pinned host word
-    if (st.rt && st.rt->wsr_err_dev && !g_trace)
-        ED_CHECK_HIP(hipMemcpyAsync(st.rt->wsr_err_host + 1, sync, 4, hipMemcpyDeviceToHost, st.R));
-    return ED_OK;
-}
+long long* g_wsr_trace = nullptr;   // debug: device buffer registered by edgedict_stack_wsr_set_trace (tools/lpw_trace.py, tools/sk_trace.py)
 
 // Forward pass with the launch-persistent step kernel (stack_kernels.hip, stack_fwd_lpw_kernel): the
 // wavefront schedule of edgedict_stack_forward in MACRO-steps of `nsub` consecutive time steps.  Launch w
@@ -714,20 +497,18 @@ int forward_wsr(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
 // flag.  Runnable = the chunk the macro-step opens was enqueued at least `margin` launches ago; layers behind
 // a time reduction are paced by launch parity while a faster layer runs (Pace), and a launch holds at most
 // one workgroup per CU (max_slots).  Called with the prologue done and the internal streams forked.
-// a layer's arrival counter has its own 256 bytes: the four layers of a launch are polled by 256 lanes and
-// bumped 256 times per step - in ONE line (16 bytes apart) they queued in one memory channel
-constexpr int LPW_CNT_STRIDE = 64;
 int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Streams& st, const WsLayout& wl,
                 int nsub, bool soft) {
     const int B = d->B, H = d->H, L = d->L;
     const long long BH = (long long)B * H;
     char* ws = (char*)d->ws;
-    unsigned* fflag = reinterpret_cast<unsigned*>(ws + wl.wsr_sync);           // [8][512] chunk flags
-    unsigned* cnt = fflag + 2 * 8 * 512;                                       // [8] arrival counters (after the backward's flags)
+    unsigned* fflag = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + SYNC_FFLAG;   // [8][512] chunk flags
+    unsigned* cnt = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + SYNC_FCNT;      // [8][LPW_MAX_SUB] arrival counter lines
+    const int NSUB = ed_stack_lpw_subs(B);                                          // sub-batches of a workgroup's rows
     unsigned* gerr = (st.rt && st.rt->wsr_err_dev) ? st.rt->wsr_err_dev + 2 : nullptr;
     for (int l = 0; l < L; ++l) ED_CHECK_ARG(g[l].nchunks <= 512, "encoder_stack: too many chunks for the flag table");
     ED_DEV(ed_stack_zero(fflag, (size_t)8 * 512 * sizeof(unsigned), st.C));
-    ED_DEV(ed_stack_zero(cnt, (size_t)8 * LPW_CNT_STRIDE * sizeof(unsigned), st.C));
+    ED_DEV(ed_stack_zero(cnt, (size_t)8 * LPW_MAX_SUB * LPW_CNT_STRIDE * sizeof(unsigned), st.C));
     ED_TRY(st.chain(st.C, st.R));
     for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.C, st.S[l]));
     // TWO side streams: what follows a full-rate layer (its LayerNorm, the next layer's product) runs on the
@@ -783,6 +564,7 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
         if (finished) break;
         EdLpwLaunch Lc;
         Lc.nslot = 0;
+        Lc.nsub = NSUB;
         Lc.B = B;
         Lc.H = H;
         Ran ran[ED_STACK_MAX_SLOTS];
@@ -812,11 +594,9 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
             sl.C_prev = y.Cx + (long long)t * BH;
             sl.C = y.Cx + (long long)(t + 1) * BH;
             sl.Wfrag = bptr(y.whh_f);
-            sl.counter = cnt + l * LPW_CNT_STRIDE;
+            sl.counter = cnt + (size_t)l * LPW_MAX_SUB * LPW_CNT_STRIDE;
             sl.base = (unsigned)WGS * (unsigned)t;
             sl.wait_flag = (soft && opens) ? fflag + l * 512 + k : nullptr;
-            sl.flags = nullptr;
-            sl.cf = g[l].cf;
             sl.t0 = t;
             sl.nsteps = t1 - t;
             sl.layer = l;
@@ -875,14 +655,17 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
             }
             if (ni == 0) continue;
             if (soft) {
-                // order S behind this launch's steps through their arrival counters, not through an event
-                const unsigned* cp[ED_STACK_MAX_SLOTS];
-                unsigned tg[ED_STACK_MAX_SLOTS];
-                for (int j = 0; j < ni; ++j) {
-                    cp[j] = cnt + ran[idx[j]].l * LPW_CNT_STRIDE;
-                    tg[j] = (unsigned)WGS * (unsigned)ran[idx[j]].t1;
-                }
-                ED_DEV(ed_stack_wait_counters(cp, tg, ni, gerr, S));
+                // order S behind this launch's steps through their arrival counters (every sub-batch's), not through
+                // an event
+                const unsigned* cp[ED_STACK_MAX_SLOTS * LPW_MAX_SUB];
+                unsigned tg[ED_STACK_MAX_SLOTS * LPW_MAX_SUB];
+                int nc = 0;
+                for (int j = 0; j < ni; ++j)
+                    for (int sb = 0; sb < NSUB; ++sb) {
+                        cp[nc] = cnt + ((size_t)ran[idx[j]].l * LPW_MAX_SUB + sb) * LPW_CNT_STRIDE;
+                        tg[nc++] = (unsigned)WGS * (unsigned)ran[idx[j]].t1;
+                    }
+                ED_DEV(ed_stack_wait_counters(cp, tg, nc, gerr, S));
             } else {
                 ED_TRY(st.chain(st.R, S));
             }
@@ -910,171 +693,12 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
     return ED_OK;
 }
 
-// The launch-persistent forward with launches that run ACROSS chunk boundaries (EDGEDICT_LPW_CROSS, default on
-// when flag waits are on).  forward_lpw ties three things to the launch: the W_hh reload (10 us of fabric traffic
-// per launch), the hand-over of a finished chunk to the layer above (enqueued after the launch, consumed `margin`
-// launches later) and the alternation of the layers behind the time reduction.  With 12 steps per launch a layer
-// therefore trailed its producer by chunk + 2 launches = 48 steps, 240 steps (1.7 ms) over the five hand-overs.
-// Here the hand-over is decoupled from the launch:
-//   * a slot takes up to `nsub` steps whatever chunks they fall in; the kernel waits for a chunk's flag when a step
-//     opens it (EdLpwSlot::flags);
-//   * the side work of every chunk a slot completes is enqueued BEFORE the launch, gated on the layer's arrival
-//     counter (stack_wait_counters_kernel): LayerNorm of the chunk's frames, the next layer's product, its flag -
-//     they run the moment the chunk's last step is out, in the middle of the launch;
-//   * a consumer may open chunk k in a launch when the chunk's side work is enqueued and its last step lies at
-//     least `lead` step-times before the opening step (the product needs ~40 us); otherwise its slot ends there.
-// Chunks can then be small (the fill is chunk + lead per hand-over) while launches stay long.
-int forward_lpw_cross(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Streams& st, const WsLayout& wl,
-                      int nsub) {
-    const int B = d->B, H = d->H, L = d->L;
-    const long long BH = (long long)B * H;
-    char* ws = (char*)d->ws;
-    unsigned* fflag = reinterpret_cast<unsigned*>(ws + wl.wsr_sync);
-    unsigned* cnt = fflag + 2 * 8 * 512;
-    unsigned* gerr = (st.rt && st.rt->wsr_err_dev) ? st.rt->wsr_err_dev + 2 : nullptr;
-    for (int l = 0; l < L; ++l) ED_CHECK_ARG(g[l].nchunks <= 512, "encoder_stack: too many chunks for the flag table");
-    ED_DEV(ed_stack_zero(fflag, (size_t)8 * 512 * sizeof(unsigned), st.C));
-    ED_DEV(ed_stack_zero(cnt, (size_t)8 * LPW_CNT_STRIDE * sizeof(unsigned), st.C));
-    ED_TRY(st.chain(st.C, st.R));
-    for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.C, st.S[l]));
-    int split = L;
-    for (int l = 0; l < L; ++l)
-        if (d->layers[l].reduce == 2) { split = l + 1; break; }
-    if (split >= L) split = (L + 1) / 2;
-    auto side = [&](int l) -> hipStream_t { return l < split ? st.S[0] : st.C; };
-    const int WGS = (H >> 4) * ((B + 63) >> 6);
-    static const int n_cu = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
-        return n;
-    }();
-    const int max_slots = max(1, min(ED_STACK_MAX_SLOTS, n_cu / WGS));
-    const char* e_l = getenv("EDGEDICT_LPW_LEAD");
-    const int lead = (e_l && atoi(e_l) >= 0) ? atoi(e_l) : 8;
-    const int T_out = (g[L - 1].T + d->layers[L - 1].reduce - 1) / d->layers[L - 1].reduce;
-
-    // layer 0's products need nothing from the recurrence: all of them up front on the caller's stream
-    for (int k = 0; k < g[0].nchunks; ++k) {
-        ED_DEV(input_gemm(d, g, 0, k, st.C));
-        ED_DEV(ed_stack_set_flag(fflag + k, st.C));
-    }
-    // enqueued[l][k]: the side work that produces layer l's chunk k is on its stream; done_clk[l][k]: step-time at
-    // which the producer's last step of that chunk ends (clock = steps since the first launch, all slots in step)
-    std::vector<std::vector<char>> enqueued(L);
-    std::vector<std::vector<long long>> done_clk(L);
-    for (int l = 0; l < L; ++l) {
-        enqueued[l].assign(g[l].nchunks, l == 0 ? 1 : 0);
-        done_clk[l].assign(g[l].nchunks, -(1ll << 40));
-    }
-    std::vector<int> next_t(L, 0);
-    int launches = 0, idle = 0;
-    long long clk = 0;
-    if (st.rt) st.rt->stamp_used[0] = 0;
-    if (st.rt && st.rt->tev[0][0]) ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][0], st.R));
-    for (int w = 0;; ++w) {
-        bool finished = true;
-        for (int l = 0; l < L; ++l) finished = finished && next_t[l] >= g[l].T;
-        if (finished) break;
-        EdLpwLaunch Lc;
-        Lc.nslot = 0;
-        Lc.B = B;
-        Lc.H = H;
-        int longest = 0;
-        for (int l = 0; l < L; ++l) {
-            const edgedict_stack_layer_t& y = d->layers[l];
-            const int t = next_t[l];
-            if (t >= g[l].T || Lc.nslot >= max_slots) continue;
-            int m_min = g[l].m;
-            for (int j = 0; j < l; ++j)
-                if (next_t[j] < g[j].T) m_min = min(m_min, g[j].m);
-            if (!Pace::allows(w, l, g[l].m, m_min)) continue;
-            // how far this slot may run: every chunk it opens must be enqueued and far enough behind
-            int t1 = t;
-            const int t_max = min(t + nsub, g[l].T);
-            while (t1 < t_max) {
-                if (t1 % g[l].cf == 0 && l > 0) {
-                    const int k = t1 / g[l].cf;
-                    if (!enqueued[l][k] || clk + (t1 - t) < done_clk[l][k] + lead) break;
-                }
-                t1 = min(t_max, (t1 / g[l].cf + 1) * g[l].cf);
-            }
-            if (t1 == t) continue;
-            EdLpwSlot& sl = Lc.slot[Lc.nslot++];
-            sl.G = bptr(y.G) + (long long)t * B * 4 * H;
-            sl.img = bptr(ws + wl.himg[l]);
-            sl.img_stride = (long long)wl.himg_stride;
-            sl.img_bytes = (long long)(y.T + 1) * (long long)wl.himg_stride;
-            sl.Y = bptr(y.Yx) + (long long)(t + 1) * BH;
-            sl.C_prev = y.Cx + (long long)t * BH;
-            sl.C = y.Cx + (long long)(t + 1) * BH;
-            sl.Wfrag = bptr(y.whh_f);
-            sl.counter = cnt + l * LPW_CNT_STRIDE;
-            sl.base = (unsigned)WGS * (unsigned)t;
-            sl.wait_flag = nullptr;
-            sl.flags = fflag + l * 512;
-            sl.cf = g[l].cf;
-            sl.t0 = t;
-            sl.nsteps = t1 - t;
-            sl.layer = l;
-            longest = max(longest, t1 - t);
-            next_t[l] = t1;
-            // ---- side work of the chunks this slot completes, gated on the layer's counter, enqueued NOW
-            for (int k = t / g[l].cf; k * g[l].cf < t1; ++k) {
-                const int c0 = k * g[l].cf, c1 = min(g[l].T, c0 + g[l].cf);
-                if (c1 > t1 || c1 <= t) continue;                 // completed by an earlier or a later slot
-                hipStream_t S = side(l);
-                const unsigned* cp[1] = {cnt + l * LPW_CNT_STRIDE};
-                const unsigned tg[1] = {(unsigned)WGS * (unsigned)c1};
-                ED_DEV(ed_stack_wait_counters(cp, tg, 1, gerr, S));
-                EdChunkNorm e;
-                e.Yx1 = bptr(y.Yx) + BH;
-                e.X = y.residual ? bptr(y.X) : nullptr;
-                e.gamma = y.ln_gamma;
-                e.beta = y.ln_beta;
-                if (l + 1 < L) {
-                    e.out = bptr(d->layers[l + 1].X);
-                    e.out_st = BH;
-                    e.out_sb = H;
-                } else {
-                    e.out = bptr(d->out);
-                    e.out_st = H;
-                    e.out_sb = (long long)T_out * H;
-                }
-                e.mean = y.mean;
-                e.rstd = y.rstd;
-                e.T = y.T;
-                e.t0 = c0;
-                e.t1 = c1;
-                e.reduce = y.reduce;
-                ED_DEV(ed_stack_multi_norm(&e, 1, B, H, d->eps, S));
-                if (l + 1 < L) {
-                    ED_DEV(input_gemm(d, g, l + 1, k, S));
-                    ED_DEV(ed_stack_set_flag(fflag + (l + 1) * 512 + k, S));
-                    enqueued[l + 1][k] = 1;
-                    done_clk[l + 1][k] = clk + (c1 - t);
-                }
-            }
-        }
-        if (Lc.nslot == 0) {
-            // nothing may start yet: every waiting layer needs `lead` more step-times behind its producer
-            ED_CHECK_ARG(++idle < 1 << 16, "encoder_stack: forward schedule made no progress");
-            ++clk;
-            continue;
-        }
-        idle = 0;
-        ++launches;
-        Lc.stamp = st.rt ? st.rt->stamp_slot(0, st.R) : nullptr;
-        Lc.err = gerr;
-        Lc.trace = g_wsr_trace;
-        ED_DEV(ed_stack_launch_fwd_lpw(Lc, st.R));
-        clk += longest;
-    }
-    if (st.rt && st.rt->tev[0][1]) {
-        ED_CHECK_HIP(hipEventRecord(st.rt->tev[0][1], st.R));
-        st.rt->tlaunches[0] = launches;
-    }
-    ED_TRY(st.chain(st.R, st.C));
-    for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.S[l], st.C));
+bool poison_on() {
+    const char* e = getenv("EDGEDICT_STACK_POISON");      // read per call: tests switch it inside one process
+    return e && atoi(e) != 0;
+}
+int ed_stack_fill(void* p, int byte, size_t bytes, hipStream_t s) {
+    ED_CHECK_HIP(hipMemsetAsync(p, byte, bytes, s));
     return ED_OK;
 }
 
@@ -1085,7 +709,7 @@ int lpw_steps(const edgedict_stack_desc_t* d) {
     const char* e_on = getenv("EDGEDICT_STACK_LPW");
     const char* e_n = getenv("EDGEDICT_LPW_STEPS");
     const int on = e_on ? atoi(e_on) : 1, want = e_n ? atoi(e_n) : min(d->chunk, 16);      // default: a chunk per launch
-    if (!on || !ed_stack_lpw_supported(d->B, d->H) || (d->flags & EDGEDICT_STACK_WSR)) return 0;
+    if (!on || !ed_stack_lpw_supported(d->B, d->H)) return 0;
     bool reduces = false;
     for (int l = 0; l < d->L; ++l) reduces = reduces || d->layers[l].reduce == 2;
     int ns = max(1, min(want, d->chunk));
@@ -1102,17 +726,6 @@ int sk_bwd_steps(const edgedict_stack_desc_t* d) {
     if (!on || !ed_stack_sk_supported(d->B, d->H)) return 0;
     for (int l = 0; l < d->L; ++l)
         if (!d->layers[l].whh_s) return 0;
-    int ns = max(1, min(want, d->chunk));
-    while (ns > 1 && d->chunk % ns != 0) --ns;
-    return ns;
-}
-
-// ... and of the launch-persistent BPTT (stack_bwd_lpw_kernel); EDGEDICT_STACK_LPW_BWD=0 keeps one launch per step
-int lpw_bwd_steps(const edgedict_stack_desc_t* d) {
-    const char* e_on = getenv("EDGEDICT_STACK_LPW_BWD");
-    const char* e_n = getenv("EDGEDICT_LPW_STEPS_B");
-    const int on = e_on ? atoi(e_on) : 0, want = e_n ? atoi(e_n) : 6;
-    if (!on || !ed_stack_lpw_bwd_supported(d->B, d->H)) return 0;
     int ns = max(1, min(want, d->chunk));
     while (ns > 1 && d->chunk % ns != 0) --ns;
     return ns;
@@ -1151,9 +764,15 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     // ---- prologue on the caller's stream: input LayerNorm (-> X_0, time-major), initial states
     ED_DEV(ed_stack_input_norm(d->x_dtype, d->x, d->in_gamma, d->in_beta, bptr(d->layers[0].X),
                                d->in_mean, d->in_rstd, B, d->T0, d->I0, d->eps, st.C));
-    const int lpw_ns = wsr_applicable(d) ? 0 : lpw_steps(d);
+    const int lpw_ns = lpw_steps(d);
+    // test aid (EDGEDICT_STACK_POISON=1): fill the per-frame h images with NaN patterns before the pass - the
+    // workspace usually still holds the images of the pass before, which on identical inputs are the RIGHT values, so
+    // a read that overtakes its producer would go unnoticed; with the poison it turns every result into NaN
+    if (lpw_ns && poison_on())
+        for (int l = 0; l < L; ++l)
+            ED_DEV(ed_stack_fill(ws + wl.himg[l], 0xff, (size_t)(d->layers[l].T + 1) * wl.himg_stride, st.C));
     if (st.rt) {
-        st.rt->tkind[0] = wsr_applicable(d) ? 3 : (lpw_ns ? 1 : 0);
+        st.rt->tkind[0] = lpw_ns ? 1 : 0;
         st.rt->tsteps[0] = lpw_ns;
     }
     for (int l = 0; l < L; ++l) {
@@ -1165,27 +784,12 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     if (st.R2 != st.R) ED_TRY(st.chain(st.C, st.R2));
     for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.C, st.S[l]));
 
-    if (wsr_applicable(d)) {
-        // persistent form (default): needs at least one spare XCD for the workers
-        bool persist = L <= 7;
-        if (const char* e = getenv("EDGEDICT_WSR_PERSIST")) persist = persist && atoi(e) != 0;
-        if (persist) ED_TRY(forward_wsr_persistent(d, g, st, wl));
-        else ED_TRY(forward_wsr(d, g, st, wl));
-        ED_TRY(st.chain(st.R, st.C));
-        for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.S[l], st.C));
-        return ED_OK;
-    }
-
     // flag waits instead of stream waits on the recurrence streams (stack_kernels.hip soft_wait): one word per
     // (layer, chunk) in the workspace's sync region, zeroed before the streams fork
     static const int soft_env = [] { const char* e = getenv("EDGEDICT_STACK_SOFT_WAIT"); return e ? atoi(e) : 1; }();
     const bool soft = soft_env && !st.serial && L <= 8;
-    if (lpw_ns) {
-        const char* e_x = getenv("EDGEDICT_LPW_CROSS");
-        const bool cross = (e_x ? atoi(e_x) : 0) != 0 && soft && !g_trace;
-        return cross ? forward_lpw_cross(d, g, st, wl, lpw_ns) : forward_lpw(d, g, st, wl, lpw_ns, soft);
-    }
-    unsigned* fflag = reinterpret_cast<unsigned*>(ws + wl.wsr_sync);           // [8][512]
+    if (lpw_ns) return forward_lpw(d, g, st, wl, lpw_ns, soft);
+    unsigned* fflag = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + SYNC_FFLAG;           // [8][512]
     unsigned* gerr = (st.rt && st.rt->wsr_err_dev) ? st.rt->wsr_err_dev + 2 : nullptr;
     if (soft) {
         for (int l = 0; l < L; ++l) ED_CHECK_ARG(g[l].nchunks <= 512, "encoder_stack: too many chunks for the flag table");
@@ -1342,12 +946,6 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     return ED_OK;
 }
 
-extern "C" int edgedict_stack_pack_wsr(const float* w_hh, int H, void* whh_r, void* stream_) {
-    ED_CHECK_ARG(H == 1024, "stack_pack_wsr: the weights-stationary kernels are built for H = 1024 (got %d)", H);
-    ED_CHECK_ARG(w_hh && whh_r, "stack_pack_wsr: null pointer");
-    return ed_wsr_pack_fwd(w_hh, (bf16_t*)whh_r, (hipStream_t)stream_);
-}
-
 extern "C" int edgedict_stack_pack_sk(const float* w_hh, int H, void* whh_s, void* stream_) {
     ED_CHECK_ARG(H >= 64 && H % 64 == 0 && H <= 1024, "stack_pack_sk: needs H %% 64 == 0 and H <= 1024 (got %d)", H);
     ED_CHECK_ARG(w_hh && whh_s, "stack_pack_sk: null pointer");
@@ -1488,37 +1086,38 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     char* ws = (char*)d->ws;
     Streams st;
     ED_TRY(open_streams(d, stream_, st));
-    static const int bwd_r2 = [] { const char* e = getenv("EDGEDICT_STACK_BWD_R2"); return e ? atoi(e) : 0; }();
-    if (bwd_r2 && !st.serial && st.R2 == st.R) st.R2 = st.C;   // as in the forward pass (measured: 25.92 -> 25.85 ms, within noise)
+    // ONE recurrence stream in the backward pass (a second one was within noise for the launch-per-step kernels and
+    // the macro-step kernels enqueue every launch on st.R: a layer's side work must be ordered behind that stream)
+    st.R2 = st.R;
     st.split = L;
-    if (st.R2 != st.R) {   // full-rate layers (up to the first time reduction) vs the rest
-        st.split = L / 2;
-        for (int l = 0; l < L; ++l)
-            if (d->layers[l].reduce == 2) { st.split = l + 1; break; }
-        if (st.split >= L) st.split = L / 2;
-    }
     const int T_out = (g[L - 1].T + d->layers[L - 1].reduce - 1) / d->layers[L - 1].reduce;
 
     static const int soft_env = [] { const char* e = getenv("EDGEDICT_STACK_SOFT_WAIT"); return e ? atoi(e) : 1; }();
     const bool soft = soft_env && !st.serial && L <= 8;       // flag waits, as in the forward pass
-    unsigned* bflag = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + 8 * 512;   // [8][512], after the forward's
+    unsigned* bflag = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + SYNC_BFLAG;   // [8][512], after the forward's
     unsigned* gerr = (st.rt && st.rt->wsr_err_dev) ? st.rt->wsr_err_dev + 2 : nullptr;
     if (soft) {
         for (int l = 0; l < L; ++l) ED_CHECK_ARG(g[l].nchunks <= 512, "encoder_stack: too many chunks for the flag table");
         ED_DEV(ed_stack_zero(bflag, (size_t)8 * 512 * sizeof(unsigned), st.C));
     }
-    // launch-persistent BPTT (stack_bwd_lpw_kernel): steps per launch (0 = one launch per step) and the layers'
-    // arrival counters, behind the forward pass's in the sync region
+    // split-K weights-stationary BPTT (stack_bwd_sk_kernel): steps per launch (0 = one launch per step) and the
+    // layers' arrival counters, behind the forward pass's in the sync region
     const int sk_ns = sk_bwd_steps(d);
-    const int lpw_ns = sk_ns ? sk_ns : lpw_bwd_steps(d);
     if (st.rt) {
-        st.rt->tkind[1] = sk_ns ? 2 : (lpw_ns ? 1 : 0);
-        st.rt->tsteps[1] = lpw_ns;
+        st.rt->tkind[1] = sk_ns ? 2 : 0;
+        st.rt->tsteps[1] = sk_ns;
     }
-    unsigned* cntb = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + 2 * 8 * 512 + 8 * LPW_CNT_STRIDE;
-    unsigned* gcnt = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + 16 * 1024;     // 64 KB into the sync region: [8][32][64] (16 unit blocks + 4 quarters per layer)
-    if (lpw_ns) ED_DEV(ed_stack_zero(cntb, (size_t)8 * LPW_CNT_STRIDE * sizeof(unsigned), st.C));
-    if (sk_ns) ED_DEV(ed_stack_zero(gcnt, (size_t)8 * 32 * 64 * sizeof(unsigned), st.C));
+    unsigned* cntb = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + SYNC_BCNT;
+    unsigned* gcnt = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + SYNC_GCNT;     // 64 KB into the sync region: [8][SK_CNT_LINES][64]
+    if (sk_ns) {
+        if (poison_on())        // as in the forward pass: dG images and split-K partials of the pass before -> NaN
+            for (int l = 0; l < L; ++l) {
+                ED_DEV(ed_stack_fill(ws + wl.gimg[l], 0xff, (size_t)(d->layers[l].T + 1) * wl.gimg_stride, st.C));
+                ED_DEV(ed_stack_fill(ws + wl.skpart[l], 0xff, (size_t)2 * (H / 64) * 4 * 64 * 64 * sizeof(float), st.C));
+            }
+        ED_DEV(ed_stack_zero(cntb, (size_t)8 * LPW_MAX_SUB * LPW_CNT_STRIDE * sizeof(unsigned), st.C));
+        ED_DEV(ed_stack_zero(gcnt, (size_t)8 * SK_CNT_LINES * 64 * sizeof(unsigned), st.C));
+    }
     // ---- prologue: running dL/dc = 0
     for (int l = 0; l < L; ++l) ED_DEV(ed_stack_zero(ws + wl.dC[l], (size_t)BH * sizeof(float), st.C));
     ED_TRY(st.chain(st.C, st.R));
@@ -1599,23 +1198,11 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     std::vector<std::vector<int>> ready_w(L);
     for (int l = 0; l < L; ++l) ready_w[l].assign(g[l].nchunks, l == L - 1 ? 0 : 0x3fffffff);
     // side work of a chunk that layer l's BPTT has just passed (enqueued right after the launch that carries the
-    // chunk's last step, launch index w): dX product + LayerNorm backward for the layer below, weight gradients
-    // order `waiter` after layer l's recurrence so far.  Split-K BPTT with flag waits: the side stream polls the
-    // layer's done counter (one arrival per workgroup per launch, behind its last write-through dG row) - nothing is
-    // recorded on the recurrence stream, where every record costs the next launch ~3.5 us; otherwise an event
-    std::vector<unsigned> done_target(L, 0u);
-    // (measured at E6D2: 21.87 ms per step with the counter, 21.70 with ONE shared event per launch - the write-through
-    // dG rows lengthen the launches by more than the shorter gaps save; opt-in)
-    static const int side_counter_env = [] { const char* e = getenv("EDGEDICT_SK_SIDE_COUNTER"); return e ? atoi(e) : 0; }();
-    const bool side_counter = sk_ns && soft && side_counter_env;
-    auto after_recurrence = [&](int l, hipStream_t waiter) -> int {
-        if (side_counter && !g_trace) {
-            const unsigned* cp[1] = {gcnt + l * 32 * 64 + 20 * 64};
-            const unsigned tg[1] = {done_target[l]};
-            return ed_stack_wait_counters(cp, tg, 1, gerr, waiter);
-        }
-        return st.chain(st.RS(l), waiter);
-    };
+    // chunk's last step, launch index w): dX product + LayerNorm backward for the layer below, weight gradients.
+    // after_recurrence orders `waiter` behind layer l's recurrence so far: an event on the recurrence stream (ONE
+    // shared record per launch, Streams::share - every record costs the next launch ~3.5 us; polling a per-layer
+    // done counter from the side streams instead was measured slower: 21.87 vs 21.70 ms per step at E6D2)
+    auto after_recurrence = [&](int l, hipStream_t waiter) -> int { return st.chain(st.RS(l), waiter); };
     auto chunk_done = [&](int l, int k, int w) -> int {
             const edgedict_stack_layer_t& y = d->layers[l];
             if (l > 0) {
@@ -1672,10 +1259,10 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     if (st.rt) st.rt->stamp_used[1] = 0;
     if (st.rt && st.rt->tev[1][0]) ED_CHECK_HIP(hipEventRecord(st.rt->tev[1][0], st.R));
     struct Done { int l, k, t; };
-    if (lpw_ns) {
-        // ---- macro-steps: launch w carries, for every runnable layer, its next <= lpw_ns BPTT steps (descending t,
+    if (sk_ns) {
+        // ---- macro-steps: launch w carries, for every runnable layer, its next <= sk_ns BPTT steps (descending t,
         // never across a chunk boundary); the schedule is the one below in units of macro-steps
-        const int WGS = sk_ns ? (H >> 6) * 4 : (H >> 5) * ((B + 31) >> 5);
+        const int WGS = (H >> 6) * 4;
         static const int n_cu = [] {
             int dev = 0, n = 256;
             if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
@@ -1684,20 +1271,17 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
         const int max_slots = max(1, min(ED_STACK_MAX_SLOTS, (g_trace ? 256 : n_cu) / WGS));
         const char* e_m = getenv("EDGEDICT_LPW_MARGIN_B");
         margin = (e_m && atoi(e_m) > 0) ? atoi(e_m) : 2;
+        const int NSUB = ed_stack_sk_subs(B);
         for (int w = 0;; ++w) {
             bool finished = true;
             for (int l = 0; l < L; ++l) finished = finished && next_t[l] >= g[l].T;
             if (finished) break;
-            EdLpwBwdLaunch Lc;
-            Lc.nslot = 0;
-            Lc.B = B;
-            Lc.H = H;
             EdSkLaunch Ls;
             Ls.nslot = 0;
+            Ls.nsub = NSUB;
             Ls.B = B;
             Ls.H = H;
             Ls.trace = g_wsr_trace;
-            Ls.done_counter = side_counter ? 1 : 0;
             Done done[ED_STACK_MAX_SLOTS];
             int ndone = 0;
             // the launch has room for max_slots layers: the layers with the most steps left go first (the full-rate
@@ -1709,7 +1293,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
             for (int oi = 0; oi < L; ++oi) {
                 const int l = order[oi];
                 const edgedict_stack_layer_t& y = d->layers[l];
-                if (next_t[l] >= g[l].T || Lc.nslot >= max_slots) continue;
+                if (next_t[l] >= g[l].T || Ls.nslot >= max_slots) continue;
                 const int t = g[l].T - 1 - next_t[l];
                 const int k = t / g[l].cf;
                 const bool opens = (t == min(g[l].T, (k + 1) * g[l].cf) - 1);
@@ -1719,44 +1303,25 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                     if (next_t[j] > 0 && next_t[j] < g[j].T) m_min = min(m_min, g[j].m);
                 if (!Pace::allows(w, l, g[l].m, m_min)) continue;
                 if (opens && !soft) ED_TRY(st.wait(st.R, Eb[l][k]));
-                const int t_end = max(k * g[l].cf, t - lpw_ns + 1);      // last (lowest) frame of this macro-step
-                if (sk_ns) {
-                    EdSkSlot& ss = Ls.slot[Ls.nslot++];
-                    ss.G = bptr(y.G) + (long long)t * B * 4 * H;
-                    ss.img = bptr(ws + wl.gimg[l]);
-                    ss.img_stride = (long long)wl.gimg_stride;
-                    ss.img_bytes = (long long)(y.T + 1) * (long long)wl.gimg_stride;
-                    ss.dY = bptr(y.dZ) + (long long)t * BH;
-                    ss.Cx = y.Cx;
-                    ss.dC = (float*)(ws + wl.dC[l]);
-                    ss.Wsk = bptr(y.whh_s);
-                    ss.part = (float*)(ws + wl.skpart[l]);
-                    ss.counter = cntb + l * LPW_CNT_STRIDE;
-                    ss.base = (unsigned)WGS * (unsigned)next_t[l];
-                    ss.gcounter = gcnt + l * 32 * 64;
-                    ss.gbase = 4u * (unsigned)next_t[l];
-                    ss.wait_flag = (soft && opens) ? bflag + l * 512 + k : nullptr;
-                    ss.t0 = t;
-                    ss.nsteps = t - t_end + 1;
-                    ss.T = y.T;
-                    ss.layer = l;
-                }
-                EdLpwBwdSlot& sl = Lc.slot[Lc.nslot++];
-                sl.G = bptr(y.G) + (long long)t * B * 4 * H;
-                sl.img = bptr(ws + wl.gimg[l]);
-                sl.img_stride = (long long)wl.gimg_stride;
-                sl.img_bytes = (long long)(y.T + 1) * (long long)wl.gimg_stride;
-                sl.dY = bptr(y.dZ) + (long long)t * BH;
-                sl.Cx = y.Cx;
-                sl.dC = (float*)(ws + wl.dC[l]);
-                sl.WTfrag = bptr(y.whh_b);
-                sl.counter = cntb + l * LPW_CNT_STRIDE;
-                sl.base = (unsigned)WGS * (unsigned)next_t[l];
-                sl.wait_flag = (soft && opens) ? bflag + l * 512 + k : nullptr;
-                sl.t0 = t;
-                sl.nsteps = t - t_end + 1;
-                sl.T = y.T;
-                sl.layer = l;
+                const int t_end = max(k * g[l].cf, t - sk_ns + 1);      // last (lowest) frame of this macro-step
+                EdSkSlot& ss = Ls.slot[Ls.nslot++];
+                ss.G = bptr(y.G) + (long long)t * B * 4 * H;
+                ss.img = bptr(ws + wl.gimg[l]);
+                ss.img_stride = (long long)wl.gimg_stride;
+                ss.img_bytes = (long long)(y.T + 1) * (long long)wl.gimg_stride;
+                ss.dY = bptr(y.dZ) + (long long)t * BH;
+                ss.Cx = y.Cx;
+                ss.dC = (float*)(ws + wl.dC[l]);
+                ss.Wsk = bptr(y.whh_s);
+                ss.part = (float*)(ws + wl.skpart[l]);
+                ss.counter = cntb + (size_t)l * LPW_MAX_SUB * LPW_CNT_STRIDE;
+                ss.gcounter = gcnt + (size_t)l * SK_CNT_LINES * 64;
+                ss.done = (unsigned)next_t[l];
+                ss.wait_flag = (soft && opens) ? bflag + l * 512 + k : nullptr;
+                ss.t0 = t;
+                ss.nsteps = t - t_end + 1;
+                ss.T = y.T;
+                ss.layer = l;
                 if (t_end == k * g[l].cf) {
                     done[ndone].l = l; done[ndone].k = k; done[ndone].t = t_end;
                     ++ndone;
@@ -1765,23 +1330,20 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                 if (g_trace)
                     for (int tt = t_end; tt <= t; ++tt) g_trace->step_launch[g_trace->toff[l] + tt] = g_trace->launches;
             }
-            if (Lc.nslot == 0) {
+            if (Ls.nslot == 0) {
                 ED_CHECK_ARG(++idle < 4096, "encoder_stack: backward schedule made no progress");
                 continue;
             }
             idle = 0;
             ++launches;
-            Lc.stamp = Ls.stamp = st.rt ? st.rt->stamp_slot(1, st.R) : nullptr;
-            Lc.err = Ls.err = gerr;
-            if (sk_ns) ED_DEV(ed_stack_launch_bwd_sk(Ls, st.R));
-            else ED_DEV(ed_stack_launch_bwd_lpw(Lc, st.R));
+            Ls.stamp = st.rt ? st.rt->stamp_slot(1, st.R) : nullptr;
+            Ls.err = gerr;
+            ED_DEV(ed_stack_launch_bwd_sk(Ls, st.R));
             if (g_trace) {
-                g_trace->max_slots = max(g_trace->max_slots, Lc.nslot);
+                g_trace->max_slots = max(g_trace->max_slots, Ls.nslot);
                 ++g_trace->launches;
             }
-            if (sk_ns)
-                for (int i = 0; i < Ls.nslot; ++i) done_target[Ls.slot[i].layer] += (unsigned)WGS;
-            if (ndone > 1 && !side_counter) ED_TRY(st.share(st.R));
+            if (ndone > 1) ED_TRY(st.share(st.R));
             for (int i = 0; i < ndone; ++i) ED_TRY(chunk_done(done[i].l, done[i].k, w));
             st.unshare();
         }

@@ -56,15 +56,11 @@ __device__ __forceinline__ void glds16(const bf16_t* src, unsigned char* lds_wav
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// PERSIST = false (default): one tile per workgroup, C staged through the (dead) operand buffers and stored in
-// 16-byte row segments.  PERSIST = true (EDGEDICT_NT256_PERSIST=1): 256 workgroups walk the tiles; the
-// finished tile leaves STRAIGHT from the accumulators (8-byte stores, 4 consecutive columns per lane), the
-// next tile's DMA prologue is issued at once and nothing waits for the stores; biases are added in the
-// epilogue instead of through the accumulators (an ordinary load's wait would drain the previous tile's
-// stores).  Measured: NOT faster (logits 2.19 vs 2.14 ms, dhid 1.15 vs 1.15, step 25.95 vs 25.87 ms), also
-// with the CUs' tile phases spread at the start - the epilogue's cost is issue and VALU work that only a
-// second accumulator set could overlap, not store latency.  Kept as a tested variant.
-template <bool PERSIST>
+// One tile per workgroup, C staged through the (dead) operand buffers and stored in 16-byte row segments.  (A
+// persistent tile loop - 256 workgroups walk the tiles, the finished tile leaves straight from the accumulators, the
+// next tile's DMA prologue is issued at once - was built and measured in round 2: logits 2.19 vs 2.14 ms, dhid 1.15
+// vs 1.15, step 25.95 vs 25.87 ms, also with the CUs' tile phases spread at the start: the epilogue's cost is issue
+// and VALU work that only a second accumulator set could overlap, not store latency.  Removed in round 4.)
 __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(Nt256Args g) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -77,9 +73,9 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(Nt256Args g) {
     const int nx = 8, xq = g.tiles / nx, xr = g.tiles % nx, xcd = blockIdx.x % nx, iw = blockIdx.x / nx;
     const int x_start = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
     const int x_count = xq + (xcd < xr ? 1 : 0);
-    const int x_step = PERSIST ? (int)gridDim.x / nx : x_count;      // grid is a multiple of 8 when PERSIST
-  for (int ti = iw; ti < x_count; ti += x_step) {
-    const int tile = x_start + ti;
+    if (iw >= x_count) return;
+  {
+    const int tile = x_start + iw;
     const int m0 = (tile / g.n_tiles) * TM, n0 = (tile % g.n_tiles) * TN;
 
     // ---- DMA sources.  A half-tile is 16 pieces of 16 rows x 64 bytes; wave w brings pieces w and w+8.
@@ -103,8 +99,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(Nt256Args g) {
             glds16(((h & 1) ? bsrc[i] : asrc[i]) + k0, base + (wave + 8 * i) * 1024);
     };
 
-    // ---- one tile per workgroup: the accumulators start at the biases (ordinary loads, before any DMA is
-    // in flight).  PERSIST: the loads are issued here and first USED in the epilogue.
+    // ---- the accumulators start at the biases (ordinary loads, before any DMA is in flight)
     f32x4_t acc[8][4];
     float4 bv[4], bw[4];     // kept apart until they are used: adding them here would wait for the loads
 #pragma unroll
@@ -116,19 +111,12 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(Nt256Args g) {
             if (g.bias2) bw[j] = *reinterpret_cast<const float4*>(g.bias2 + nc);
         }
     }
-    if (!PERSIST) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 8; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = (f32x4_t){bv[j].x + bw[j].x, bv[j].y + bw[j].y, bv[j].z + bw[j].z, bv[j].w + bw[j].w};
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    }
+        for (int j = 0; j < 4; ++j)
+            acc[i][j] = (f32x4_t){bv[j].x + bw[j].x, bv[j].y + bw[j].y, bv[j].z + bw[j].z, bv[j].w + bw[j].w};
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     const int a_off = (wm * 128 + r16) * 64 + ((kq ^ ((r16 >> 2) & 3)) << 4);   // + i * 1024 per m-fragment
     const int b_off = (wn * 64 + r16) * 64 + ((kq ^ ((r16 >> 2) & 3)) << 4);    // + j * 1024 per n-fragment
@@ -188,31 +176,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(Nt256Args g) {
 
     constexpr int CCH = TN / 8;      // 16-byte chunks per staged C row
     unsigned char* sC = smem;        // [256 rows][32 chunks], chunk ^= row & 31
-    if (PERSIST) {
-        // ---- epilogue, persistent form: bias, then the tile leaves from the registers
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                acc[i][j][0] += bv[j].x + bw[j].x; acc[i][j][1] += bv[j].y + bw[j].y;
-                acc[i][j][2] += bv[j].z + bw[j].z; acc[i][j][3] += bv[j].w + bw[j].w;
-            }
-        if (!(g.dbg & 2))
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int row = m0 + wm * 128 + i * 16 + r16;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int col = n0 + wn * 64 + j * 16 + kq * 4;
-                    if (row < g.M && col < g.N) {
-                        uint2 pk;
-                        pk.x = f32x2_to_bf16x2(acc[i][j][0], acc[i][j][1]);
-                        pk.y = f32x2_to_bf16x2(acc[i][j][2], acc[i][j][3]);
-                        *reinterpret_cast<uint2*>(g.C + (long long)row * g.ldc + col) = pk;
-                    }
-                }
-            }
-    } else {
     // ---- epilogue: the operand buffers are dead after this barrier; C is staged in LDS
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
@@ -228,7 +191,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(Nt256Args g) {
             pk.y = f32x2_to_bf16x2(acc[i][j][2], acc[i][j][3]);
             *reinterpret_cast<uint2*>(sC + ml * (TN * 2) + ((((nl >> 3) ^ (ml & (CCH - 1))) << 4) | ((nl & 4) << 1))) = pk;
         }
-    }
     }
     // ---- optional fused log-sum-exp partials (the RNN-T loss needs log_softmax denominators of every
     // logits row, rnnt/models.py:238 -> warprnnt): per C row, (max, sum exp(x - max)) over this wave's 64
@@ -272,7 +234,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(Nt256Args g) {
                 g.lse_part[(long long)row * g.lse_slots + slot] = make_float2(mx, sm);
         }
     }
-    if (!PERSIST) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     asm volatile("s_barrier" ::: "memory");
     if (!(g.dbg & 2))
@@ -291,8 +252,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt256_kernel(Nt256Args g) {
         if (g.dbg & 16) *reinterpret_cast<u32x4_t*>(dst) = v;
         else asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
     }
-    }
-  }   // tile loop
+  }
 }
 
 }  // namespace
@@ -324,24 +284,9 @@ int ed_gemm_nt256_launch(const void* A, long long lda, const void* B, long long 
     const long long tiles = (long long)((M + TM - 1) / TM) * g.n_tiles;
     ED_CHECK_ARG(tiles < (1ll << 31), "gemm: too many tiles");
     g.tiles = (int)tiles;
-    static const int persist = [] { const char* e = getenv("EDGEDICT_NT256_PERSIST"); return e ? atoi(e) : 0; }();
-    static const int n_cu = [] {
-        int dev = 0, n = 256;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-            n = 256;
-        return n >= 8 ? n / 8 * 8 : 8;
-    }();
-    if (persist && tiles >= 2ll * n_cu) {
-        ED_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_nt256_kernel<true>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-        hipLaunchKernelGGL(gemm_nt256_kernel<true>, dim3((unsigned)n_cu), dim3(512), LDS_BYTES, s, g);
-        ED_CHECK_LAUNCH("gemm_nt256 (persistent)");
-        return ED_OK;
-    }
-    ED_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_nt256_kernel<false>,
+    ED_CHECK_HIP(hipFuncSetAttribute((const void*)gemm_nt256_kernel,
                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
-    hipLaunchKernelGGL(gemm_nt256_kernel<false>, dim3((unsigned)tiles), dim3(512), LDS_BYTES, s, g);
+    hipLaunchKernelGGL(gemm_nt256_kernel, dim3((unsigned)tiles), dim3(512), LDS_BYTES, s, g);
     ED_CHECK_LAUNCH("gemm_nt256");
     return ED_OK;
 }

@@ -84,18 +84,22 @@ struct EdLpwSlot {
     const float* C_prev;       // c_{t0-1} [B, H]
     float* C;                  // c rows of step t0; step t0+s at + s*B*H
     const bf16_t* Wfrag;       // W_hh B-fragment image (EdFwdStep::Wfrag)
-    unsigned* counter;         // arrivals of this layer's workgroups, one per finished step (zeroed per call)
-    unsigned base;             // *counter once every step < t0 is done = workgroups_per_step * (steps done before)
+    unsigned* counter;         // arrivals of this layer's workgroups, one per finished step and SUB-BATCH: sub-batch j counts
+                               // on counter[j * LPW_CNT_STRIDE] (EdLpwLaunch::nsub of them, zeroed per call)
+    unsigned base;             // every counter once every step < t0 is done = workgroups_per_step * (steps done before)
     const unsigned* wait_flag; // null, or: step t0 opens a chunk whose side-stream product is done when != 0
-    const unsigned* flags;     // null, or (launches that run ACROSS chunk boundaries): the layer's chunk flags - before
-                               // every step t with t % cf == 0 the workgroup waits for flags[t / cf] != 0
-    int cf;                    // frames per chunk of this layer (with `flags`)
     int t0, nsteps;
     int layer;                 // for the debug trace only
 };
+constexpr int LPW_CNT_STRIDE = 64;   // words between arrival counters: each has its own 256-byte line (the four layers of a
+                                     // launch are polled by 256 lanes and bumped 256 times per step - in ONE line they queued
+                                     // in one memory channel: 4-slot launches 80-127 us per 6 steps instead of 50-56)
+constexpr int LPW_MAX_SUB = 4;       // sub-batches per workgroup (counter lines per layer)
 struct EdLpwLaunch {
     EdLpwSlot slot[ED_STACK_MAX_SLOTS];
     int nslot;
+    int nsub;                    // 1: the workgroup's 64 rows advance together; 2 / 4: as 32- / 16-row sub-batches, alternately
+                                 // (ed_stack_lpw_subs), each with its own arrival counter - bit-identical results
     int B, H;
     unsigned long long* stamp;   // as EdFwdLaunch::stamp
     unsigned* err;               // host-visible give-up word (may be null)
@@ -118,37 +122,7 @@ struct EdChunkNorm {
 int ed_stack_wait_counters(const unsigned* const* counters, const unsigned* targets, int n, unsigned* err, hipStream_t s);
 int ed_stack_multi_norm(const EdChunkNorm* items, int n, int B, int H, float eps, hipStream_t s);
 int ed_stack_lpw_supported(int B, int H);     // 1 when the launch-persistent forward kernel covers this geometry
-
-// ---- launch-persistent BPTT (stack_kernels.hip, stack_bwd_lpw_kernel): `nsteps` consecutive BPTT steps
-// (descending t) of every runnable layer per launch.  Tiling and arithmetic of stack_bwd_kernel (W_hh^T is
-// still streamed: its 256 KB slice does not fit beside the background products' registers); what goes away
-// is the kernel boundary per step - the layer's workgroups meet through an arrival counter, dG_t travels
-// through one fragment image per frame (write-through stores, plain loads), the running dL/dc stays in LDS.
-struct EdLpwBwdSlot {
-    bf16_t* G;                 // frame t0: [B, 4H] interleaved, in gates / out dL/d(pre-activation); frame t0-s at - s*B*4H
-    bf16_t* img;               // dG fragment images [T][4H/32][B16/16][64][8], one per frame: step t reads image t+1
-                               // (absent at t = T-1), writes image t (not at t = 0)
-    long long img_stride;      // bytes between images
-    long long img_bytes;       // bytes of the region (buffer descriptor)
-    const bf16_t* dY;          // dL/dh rows of frame t0 from above [B, H]; frame t0-s at - s*B*H
-    const float* Cx;           // cell states: c_t at Cx + (t+1)*B*H (row 0 = c0)
-    float* dC;                 // [B, H] running dL/dc, in/out
-    const bf16_t* WTfrag;      // W_hh^T B-fragment image (EdBwdStep::WTfrag)
-    unsigned* counter;         // arrivals of this layer's workgroups, one per finished BPTT step (zeroed per call)
-    unsigned base;             // *counter once every step of a frame > t0 is done
-    const unsigned* wait_flag; // null, or: frame t0 opens a chunk whose dY rows are done when != 0
-    int t0, nsteps, T;
-    int layer;
-};
-struct EdLpwBwdLaunch {
-    EdLpwBwdSlot slot[ED_STACK_MAX_SLOTS];
-    int nslot;
-    int B, H;
-    unsigned long long* stamp;
-    unsigned* err;
-};
-int ed_stack_launch_bwd_lpw(const EdLpwBwdLaunch& L, hipStream_t s);
-int ed_stack_lpw_bwd_supported(int B, int H);
+int ed_stack_lpw_subs(int B);                 // sub-batches the forward kernel runs this batch in (EDGEDICT_LPW_SUB overrides)
 
 // ---- split-K, weights-stationary BPTT (stack_kernels.hip, stack_bwd_sk_kernel; needs B <= 64, H % 64 == 0,
 // H <= 1024).  The launch-per-step BPTT moves 512 KB into every CU per step (W_hh^T slice 256 KB + dG image
@@ -156,89 +130,40 @@ int ed_stack_lpw_bwd_supported(int B, int H);
 // columns) for all 64 rows: its W_hh^T slice is 128 KB and stays in 128 registers per lane for the whole launch,
 // the only dependent fetch of a step is its quarter of the dG image (128 KB).  The four workgroups of a unit
 // block exchange their partial sums (16 KB fp32 each, write-through) and each finishes 16 of the 64 rows.
+constexpr int SK_CNT_QUARTER = 64;    // first quarter-counter line of a layer's gcounter block (behind 16 unit blocks x 4 sub-batches)
+constexpr int SK_CNT_LINES = 96;      // 256-byte counter lines per layer: unit-block counters [0, 64), quarter counters [64, 80)
 struct EdSkSlot {
     bf16_t* G;                 // frame t0 [B, 4H] interleaved (in gates, out dL/d(pre-activation)); frame t0-s at - s*B*4H
-    bf16_t* img;               // dG fragment images, one per frame (EdLpwBwdSlot::img)
+    bf16_t* img;               // dG fragment images [T + 1][4H/32][B16/16][64][8], one per frame: step t reads image t+1
+                               // (absent at t = T-1), writes image t (not at t = 0)
     long long img_stride, img_bytes;
     const bf16_t* dY;          // dL/dh rows of frame t0 from above [B, H]; frame t0-s at - s*B*H
     const float* Cx;           // c_t at Cx + (t+1)*B*H
     float* dC;                 // [B, H] running dL/dc, in/out
     const bf16_t* Wsk;         // split-K fragment image of W_hh (edgedict_stack_pack_sk)
     float* part;               // [2][H/64][4][64][64] f32 partial sums, ping-pong by step parity
-    unsigned* counter;         // all workgroups of the layer: one arrival per finished step
-    unsigned base;
-    unsigned* gcounter;        // words LPW_CNT_STRIDE apart: [0, H/64) the 4 workgroups of a unit block, [16, 20) the workgroups
-                               // that write one quarter of the gate columns (H % 256 == 0), one arrival per step each;
-                               // [20] one arrival per workgroup per LAUNCH, after its last dG row is in memory
-    unsigned gbase;            // 4 * (steps done before)
+    unsigned* counter;         // H % 256 != 0 only: the layer's finishers of sub-batch j arrive on counter[j * LPW_CNT_STRIDE]
+    unsigned* gcounter;        // lines of 64 words: [ub * nsub + j] the 4 workgroups of unit block ub, one arrival each per step
+                               // once their partial of sub-batch j is in memory; [SK_CNT_QUARTER + q * nsub + j] (H % 256 == 0)
+                               // the finishers of sub-batch j that write quarter q of the gate columns, one arrival per step
+    unsigned done;             // BPTT steps of this layer done before this launch (every counter is a multiple of it)
     const unsigned* wait_flag;
     int t0, nsteps, T, layer;
 };
 struct EdSkLaunch {
     EdSkSlot slot[ED_STACK_MAX_SLOTS];
     int nslot;
+    int nsub;                  // sub-batches (1, 2 or 4 = 64, 32 or 16 rows advanced alternately; ed_stack_sk_subs); every
+                               // value gives bit-identical results
     int B, H;
     unsigned long long* stamp;
     unsigned* err;
     long long* trace;          // debug (nullable): per-slot phase times of workgroup 0, see tools/sk_trace.py
-    int done_counter;          // 1: dG rows written through + one arrival per workgroup on gcounter[20] at the end (side
-                               // streams poll it); 0: plain dG rows, consumers ordered by an event behind the launch
 };
 int ed_stack_launch_bwd_sk(const EdSkLaunch& L, hipStream_t s);
 int ed_stack_sk_supported(int B, int H);
+int ed_stack_sk_subs(int B);                  // sub-batches the split-K BPTT kernel runs this batch in (EDGEDICT_SK_SUB overrides)
 int ed_stack_pack_sk(const float* w_hh, bf16_t* out, int H, hipStream_t s);
-
-// ---- weights-stationary recurrence (wsr_kernels.hip): ONE launch carries a chunk of frames of every
-// runnable layer; a layer lives on the 32 CUs of one XCD with W_hh in registers (H = 1024, B <= 64)
-struct EdWsrSlot {
-    bf16_t* G;                 // frames [t0, t0+nsteps): [n][B, 4H] interleaved; in pre-activations, out gates
-    bf16_t* img0;              // h fragment images [H/32][B16/16][64][8] (ping-pong): step t reads
-    bf16_t* img1;              //   (t & 1 ? img1 : img0) and writes the other one
-    bf16_t* Y;                 // h_t rows of frame t0 (plain [B, H]), then t0+1, ...
-    const float* C_prev;       // c_{t0-1} [B, H]
-    float* C;                  // c_t rows of frame t0, ...
-    const bf16_t* Wreg;        // register image of W_hh (ed_wsr_pack_fwd)
-    unsigned* counter;         // arrivals of this layer: == base when the launch starts
-    unsigned base;
-    int t0, nsteps;
-    // ---- persistent form only (EdWsrLaunch::persistent): the layer runs ALL its frames in one launch
-    int cf;                    // frames per chunk of this layer
-    unsigned* gdone;           // [nchunks] workers that finished chunk k of this layer's input product
-                               // (null: the product was complete before the launch - layer 0)
-    unsigned* ydone;           // [1] += 1 per CU when a chunk's h rows are out (write-through)
-    // what the worker workgroups need to turn this layer's OUTPUT into the next layer's gates
-    const bf16_t* X;           // this layer's input rows [T, B, H] (the residual) or null
-    const float* gamma;        // LayerNorm after this layer
-    const float* beta;
-    float* mean;               // [T, B] statistics for the backward pass
-    float* rstd;
-    bf16_t* nX;                // next layer's input rows [T', B, H]; for the LAST layer: the stack output ...
-    long long nX_st, nX_sb;    // ... frame tau, row b at nX + tau * nX_st + b * nX_sb
-    const bf16_t* nWih;        // next layer's W_ih image [4H, H] (rows in interleaved gate order); null = last layer
-    const float* nBias;        // [4H]
-    bf16_t* nG;                // next layer's gates [T', B, 4H]
-    unsigned* xdone;           // [nchunks] workers done with the LayerNorm rows of chunk k (of the NEXT layer's input)
-    unsigned* ngdone;          // = next layer's gdone
-    int T, reduce;
-};
-struct EdWsrLaunch {
-    EdWsrSlot slot[ED_STACK_MAX_SLOTS];
-    int nslot;                 // slot i runs on the XCD whose XCC_ID is i
-    int B;
-    unsigned* ticket;          // [8] zeroed role tickets of THIS launch
-    unsigned* err;             // [1] give-up code (0 = fine), shared by the whole call
-    int persistent;            // 1: every layer runs all its frames; the workgroups of the XCDs >= nslot are
-                               // WORKERS (LayerNorm + next layer's input product per finished chunk)
-    float eps;
-    long long* trace;          // debug (nullable): wall-clock stamps, see tools/wsr_persist_trace.py
-};
-int ed_wsr_pack_fwd(const float* w_hh, bf16_t* out, hipStream_t s);
-int ed_wsr_launch_fwd(const EdWsrLaunch& L, hipStream_t s);
-int ed_wsr_workers(const EdWsrLaunch& L);      // worker workgroups of a persistent launch (0 = none possible)
-// LayerNorm(+ residual, + pair mean under time reduction) of the frames [t0, t1) a layer finished
-int ed_stack_chunk_norm(const bf16_t* Yx1, const bf16_t* X, const float* gamma, const float* beta,
-                        bf16_t* out, long long out_st, long long out_sb, float* mean, float* rstd,
-                        int B, int H, int T, int t0, int t1, int reduce, float eps, hipStream_t s);
 
 // kernels / launchers implemented in stack_kernels.hip
 int ed_stack_launch_fwd(const EdFwdLaunch& L, hipStream_t s);

@@ -25,7 +25,7 @@ class StackLayer(ctypes.Structure):
     _fields_ = [("T", ctypes.c_int), ("I", ctypes.c_int), ("reduce", ctypes.c_int),
                 ("residual", ctypes.c_int),
                 ("wih_p", _vp), ("wih_t", _vp), ("bias_p", _fp), ("whh_f", _vp), ("whh_b", _vp),
-                ("whh_r", _vp), ("ln_gamma", _fp), ("ln_beta", _fp),
+                ("ln_gamma", _fp), ("ln_beta", _fp),
                 ("X", _vp), ("G", _vp), ("Yx", _vp), ("Cx", _fp), ("mean", _fp), ("rstd", _fp),
                 ("dZ", _vp), ("dX", _vp), ("dW_ih", _fp), ("dW_hh", _fp), ("db", _fp), ("db_hh", _fp),
                 ("dgamma", _fp), ("dbeta", _fp), ("whh_s", _vp)]
@@ -49,7 +49,6 @@ GRADS_FINAL_CB = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_void_p)
 SERIAL = 1
 DW_AT_END = 2
 ACCUM_GRADS = 8
-WSR = 32          # weights-stationary recurrence kernels (csrc/wsr_kernels.hip) when H = 1024, B <= 64
 
 # schedule knobs (env overrides are for tuning runs; the defaults are what bench.py measures)
 # output-rate frames per chunk (= steps per launch of the launch-persistent kernels).  E6D2 training step, round 3:
@@ -58,12 +57,6 @@ CHUNK = int(os.environ.get("EDGEDICT_STACK_CHUNK", "16"))
 LAG = int(os.environ.get("EDGEDICT_STACK_LAG", "0"))
 SPLIT_K = int(os.environ.get("EDGEDICT_STACK_SPLITK", "0"))
 FLAGS = int(os.environ.get("EDGEDICT_STACK_FLAGS", "0"))
-# opt-in: measured on MI355X the weights-stationary forward takes 7.85 ms against 7.75 ms
-# for the launch-per-step kernels at E6D2 - its 8.6 us steps are faster than a 19 us frame of step
-# launches, but no other kernel can run beside a grid that fills whole XCDs (workgroups are bound to
-# XCDs round-robin at dispatch), so the chunk products serialise with it instead of overlapping
-if os.environ.get("EDGEDICT_STACK_WSR", "0") == "1":
-    FLAGS |= WSR
 # pack the split-K image of W_hh (8 MB per layer) for the weights-stationary BPTT kernel whenever the geometry
 # allows it; the kernel itself is chosen per call by the library (EDGEDICT_STACK_BWD_SK, read there)
 BWD_SK = os.environ.get("EDGEDICT_STACK_BWD_SK_PACK", "1") != "0"
@@ -85,7 +78,7 @@ def supported(cd, H, I0, L, reductions):
 
 class _PackedLayer:
     """bf16 weight images of one LSTM layer, rebuilt when the fp32 masters change."""
-    __slots__ = ("key", "ref", "wih_p", "wih_t", "bias_p", "whh_f", "whh_b", "whh_r", "whh_s")
+    __slots__ = ("key", "ref", "wih_p", "wih_t", "bias_p", "whh_f", "whh_b", "whh_s")
 
     def __init__(self, owner):
         self.key = None
@@ -102,7 +95,7 @@ def packed_weights(w_ih, w_hh, b_ih, b_hh):
             del _PACKED[k]                       # images of parameters that no longer exist
         ent = _PACKED[id(w_hh)] = _PackedLayer(w_hh)
     key = (w_ih.data_ptr(), w_hh.data_ptr(), w_ih._version, w_hh._version, b_ih._version,
-           b_hh._version, config.param_epoch(), bool(FLAGS & WSR), BWD_SK)
+           b_hh._version, config.param_epoch(), BWD_SK)
     if ent.key != key:
         H4, I = w_ih.shape
         H = H4 // 4
@@ -112,7 +105,6 @@ def packed_weights(w_ih, w_hh, b_ih, b_hh):
         ent.bias_p = torch.empty(H4, dtype=F32, device=dev)
         ent.whh_f = torch.empty(H4 * H, dtype=BF16, device=dev)
         ent.whh_b = torch.empty(H4 * H, dtype=BF16, device=dev)
-        ent.whh_r = torch.empty(H4 * H, dtype=BF16, device=dev) if (H == 1024 and FLAGS & WSR) else None
         # split-K image of the weights-stationary BPTT kernel (csrc/stack_kernels.hip stack_bwd_sk_kernel)
         ent.whh_s = torch.empty(H4 * H, dtype=BF16, device=dev) if (BWD_SK and H % 64 == 0 and 64 <= H <= 1024) else None
         srcs = [t.detach().contiguous() for t in (w_ih, w_hh, b_ih, b_hh)]
@@ -125,8 +117,6 @@ def packed_weights(w_ih, w_hh, b_ih, b_hh):
                                               ptr(ent.whh_b), stream_ptr()), "stack_pack_weights")
         if ent.whh_s is not None:
             check(lib.edgedict_stack_pack_sk(ptr(srcs[1]), H, ptr(ent.whh_s), stream_ptr()), "stack_pack_sk")
-        if ent.whh_r is not None:      # register image of the weights-stationary forward kernel
-            check(lib.edgedict_stack_pack_wsr(ptr(srcs[1]), H, ptr(ent.whh_r), stream_ptr()), "stack_pack_wsr")
         ent.key = key
     return ent
 
@@ -136,20 +126,33 @@ def clear_cache():
 
 
 def check_wsr_error():
-    """Raise if a launch on this device ran into one of its bounded in-kernel waits - a weights-stationary
-    launch whose workgroups could not all become resident or whose peer never arrived, or a step kernel whose
-    chunk product never signalled (flag waits, csrc/stack_kernels.hip soft_wait): the results of that call are
-    garbage.  The code is a pinned host word the library copies at the end of each call; reading it
-    costs nothing and clears it.  Call after a synchronize for an up-to-date answer."""
+    """Raise if a launch on this device ran into one of its bounded in-kernel waits - a launch-persistent
+    recurrence launch whose workgroups could not all become resident or whose peer never arrived (7xx forward,
+    9xx split-K BPTT), a side stream's counter wait (8xx), or a step kernel whose chunk product never signalled
+    (5xx / 6xx, csrc/stack_kernels.hip soft_wait): the results of that call are garbage.  The code is a pinned
+    host word the device writes; reading it costs nothing and clears it.  Call after a synchronize for an
+    up-to-date answer."""
     code = _lib.load().edgedict_stack_wsr_error()
-    if code >= 500:
+    if 500 <= code < 700:
         raise RuntimeError("edgedict_amd: a step kernel of the encoder stack gave up waiting for a chunk product "
                            "of the side stream (code %d: %s pass, launch slot %d); the results of that call are "
                            "garbage. EDGEDICT_STACK_SOFT_WAIT=0 orders the streams with events instead"
                            % (code, "forward" if code < 600 else "backward", code % 100))
     if code:
-        raise RuntimeError("edgedict_amd: a weights-stationary encoder launch gave up (code %d); set "
-                           "EDGEDICT_STACK_WSR=0 to use the launch-per-step kernels" % code)
+        raise RuntimeError("edgedict_amd: a launch-persistent encoder launch gave up waiting for its peers (code %d); "
+                           "the results of that call are garbage. EDGEDICT_STACK_LPW=0 / EDGEDICT_STACK_BWD_SK=0 "
+                           "select the launch-per-step kernels (e.g. when two processes share the device)" % code)
+
+
+def last_mode(backward):
+    """(kind, steps_per_launch) of the recurrence kernel the most recent forward / backward call of the stack ran on
+    this device: kind 0 = one launch per time step, 1 = launch-persistent forward, 2 = split-K weights-stationary BPTT
+    (edgedict_stack_last_mode).  Tests and bench.py assert the benched path with it: a silent fallback to the
+    launch-per-step kernels would still be numerically right."""
+    kind, steps = ctypes.c_int(-1), ctypes.c_int(-1)
+    check(_lib.load().edgedict_stack_last_mode(1 if backward else 0, ctypes.byref(kind), ctypes.byref(steps)),
+          "stack_last_mode")
+    return kind.value, steps.value
 
 
 _PREPACK_EVENT = [None]
@@ -200,12 +203,12 @@ class _Plan:
             self.layer_bufs.append(bufs)
             y = self.larr[l]
             y.T, y.I, y.reduce, y.residual = T, I, reductions[l], int(l != 0)
-            y.wih_p, y.wih_t, y.bias_p, y.whh_f, y.whh_b, y.whh_r = map(
-                _p, (pk.wih_p, pk.wih_t, pk.bias_p, pk.whh_f, pk.whh_b, pk.whh_r))
+            y.wih_p, y.wih_t, y.bias_p, y.whh_f, y.whh_b = map(
+                _p, (pk.wih_p, pk.wih_t, pk.bias_p, pk.whh_f, pk.whh_b))
             y.whh_s = _p(pk.whh_s)
             g, b = ln_w.detach(), ln_b.detach()
             y.ln_gamma, y.ln_beta = _p(g), _p(b)
-            self.keep += [pk.wih_p, pk.wih_t, pk.bias_p, pk.whh_f, pk.whh_b, pk.whh_r, pk.whh_s, g, b]
+            self.keep += [pk.wih_p, pk.wih_t, pk.bias_p, pk.whh_f, pk.whh_b, pk.whh_s, g, b]
             for k, v in bufs.items():
                 setattr(y, k, _p(v))
             T = (T + reductions[l] - 1) // reductions[l]

@@ -494,7 +494,6 @@ class _JointLossFn(torch.autograd.Function):
         ctx.save_for_backward(enc2, dec2, w1, w2, hid, logits, labels, al_d, ll_d, off_d, ws)
         ctx.b1, ctx.b2 = b1, b2
         ctx.cfg = (cd, B, T, U1, P, P2, J, V, M, int(blank))
-        ctx.row_off = [int(x) for x in off.tolist()] + [M]     # host copy: the backward pass groups utterances by rows
         return reduced
 
     @staticmethod
@@ -512,48 +511,17 @@ class _JointLossFn(torch.autograd.Function):
         dw1 = db1 = dw2 = db2 = None
         dE1 = torch.empty(B, T, J, dtype=F32, device=dl.device)
         dD1 = torch.empty(B, U1, J, dtype=F32, device=dl.device)
-        ngroups = min(config.JOINT_BWD_GROUPS, B) if M >= config.JOINT_BWD_GROUP_MIN_ROWS else 1
-        if ngroups > 1:
-            # groups of whole utterances with about equal numbers of lattice rows.  Stream A (autograd's): the loss
-            # gradient of each group in turn - HBM-bound, 4.4 GB at the bench size.  Stream B (the library's
-            # auxiliary stream, idle until the deferred weight gradients below): dhid = dlogits W2 and the tanh
-            # backward of the group whose gradient is ready - matrix-pipe-bound.  One event per group, one join.
-            offs = ctx.row_off                       # host: row offset of every utterance, and M at the end
-            cuts = [0]
-            for gi in range(1, ngroups):
-                want = M * gi // ngroups
-                cuts.append(min(range(B + 1), key=lambda x: abs(offs[x] - want)))
-            cuts = sorted(set(cuts + [B]))
-            dhid = torch.empty(M, J, dtype=cd, device=dl.device)
-            main = torch.cuda.current_stream(dl.device)
-            aux = side.stream(dl.device)
-            aux.wait_stream(main)                   # the allocations above, and whatever produced gout
-            for t in (dl, dhid, hid, dE1, dD1, w2t, al_d, ll_d, off_d):
-                t.record_stream(aux)
-            with ops.timed("joint_dhid_gemm"):
-                for b0, b1 in zip(cuts[:-1], cuts[1:]):
-                    r0, r1 = offs[b0], offs[b1]
-                    _lib.call("rnnt_loss_backward_packed_range", logits, _lib.dtype_code(cd), dl, labels, al_d, ll_d,
-                              off_d, B, T, U1, V, blank, ws, 1.0 / B, gscale, 0, b0, b1 - b0)
-                    ev = main.record_event()
-                    with torch.cuda.stream(aux):
-                        aux.wait_event(ev)
-                        if r1 > r0:
-                            ops.gemm(dl[r0:r1], w2t, out=dhid[r0:r1])
-                        _lib.call("joint_hidden_bwd_packed", _lib.dtype_code(cd), dhid, hid, dE1[b0:b1], dD1[b0:b1],
-                                  al_d[b0:b1], ll_d[b0:b1], off_d[b0:b1], b1 - b0, T, U1, J)
-                main.wait_stream(aux)
-            del logits
-        else:
-            with ops.timed("rnnt_grad"):
-                _lib.call("rnnt_loss_backward_packed", logits, _lib.dtype_code(cd), dl, labels, al_d, ll_d,
-                          off_d, B, T, U1, V, blank, ws, 1.0 / B, gscale, 0)
-            del logits
-            with ops.timed("joint_dhid_gemm"):
-                dhid = ops.gemm(dl, w2t)
-            with ops.timed("joint_hidden_bwd"):
-                _lib.call("joint_hidden_bwd_packed", _lib.dtype_code(cd), dhid, hid, dE1, dD1, al_d, ll_d,
-                          off_d, B, T, U1, J)
+        # (pipelining the loss gradient against the dhid product by utterance groups on two streams was measured:
+        # 21.70 ms per step in one pass, 21.74 / 22.26 / 23.18 with 2 / 4 / 8 groups - both sit on the L2/HBM path)
+        with ops.timed("rnnt_grad"):
+            _lib.call("rnnt_loss_backward_packed", logits, _lib.dtype_code(cd), dl, labels, al_d, ll_d,
+                      off_d, B, T, U1, V, blank, ws, 1.0 / B, gscale, 0)
+        del logits
+        with ops.timed("joint_dhid_gemm"):
+            dhid = ops.gemm(dl, w2t)
+        with ops.timed("joint_hidden_bwd"):
+            _lib.call("joint_hidden_bwd_packed", _lib.dtype_code(cd), dhid, hid, dE1, dD1, al_d, ll_d,
+                      off_d, B, T, U1, J)
         if not defer:
             dw2 = ops.gemm(dl.t(), hid.t(), out_dtype=F32, split_k=ops.pick_split_k(V, J, M))
             db2 = ops.colsum(dl)

@@ -239,9 +239,6 @@ typedef struct edgedict_stack_layer {
     const float* bias_p;   /* f32  [4H]     b_ih + b_hh, interleaved */
     const void* whh_f;     /* bf16 forward fragment image of W_hh (4H*H) */
     const void* whh_b;     /* bf16 backward fragment image of W_hh (4H*H); backward only */
-    const void* whh_r;     /* bf16 REGISTER image of W_hh for the weights-stationary forward kernel
-                              (edgedict_stack_pack_wsr; H = 1024 only), nullable: without it, or without
-                              EDGEDICT_STACK_WSR, the launch-per-step kernels run */
     const float* ln_gamma; /* f32 [H] */
     const float* ln_beta;  /* f32 [H] */
     void* X;               /* bf16 [T, B, I]    layer input (layer 0: written by the input LayerNorm) */
@@ -267,14 +264,7 @@ typedef struct edgedict_stack_layer {
 
 #define EDGEDICT_STACK_SERIAL 1     /* run everything on the caller's stream (debug / bit-exact check) */
 #define EDGEDICT_STACK_DW_AT_END 2  /* weight gradients after the BPTT instead of under it */
-#define EDGEDICT_STACK_TWO_RECURRENCE_STREAMS 16 /* experiment: full-rate layers and the layers behind the
-   time reduction launch on separate streams so their kernel boundaries overlap.  A 5th HIP stream
-   shares a hardware queue with a busy one: measured 66.8 vs 34.5 ms per step.  Do not use. */
 #define EDGEDICT_STACK_ACCUM_GRADS 8 /* dW_ih / dW_hh / db / db_hh are existing gradient buffers: += instead of = */
-#define EDGEDICT_STACK_WSR 32 /* weights-stationary recurrence (csrc/wsr_kernels.hip): one launch carries a CHUNK
-   of frames of every runnable layer, a layer on the 32 CUs of one XCD with W_hh in registers and h_t
-   exchanged through that XCD's L2.  Needs H = 1024, B <= 64, L <= 8 and whh_r of every layer;
-   otherwise (silently) the launch-per-step kernels run.  Forward only so far. */
 #define EDGEDICT_STACK_SIDE_STREAM_PER_LAYER 4 /* experiment: chunk GEMMs on one side stream PER LAYER.
    Measured 2x SLOWER end to end: more streams than hardware queues serialises everything. */
 
@@ -324,23 +314,22 @@ size_t edgedict_stack_workspace_bytes(const edgedict_stack_desc_t* desc);
 int edgedict_stack_pack_weights(const float* w_ih, const float* w_hh, const float* b_ih,
                                 const float* b_hh, int H, int I, void* wih_p, void* wih_t,
                                 float* bias_p, void* whh_f, void* whh_b, void* stream);
-/* W_hh [4H, H] f32 (H = 1024) -> bf16 register image for EDGEDICT_STACK_WSR (8 MB): workgroup j of a
- * layer's XCD loads rows [j*256 KB, (j+1)*256 KB) of it once per launch and keeps them in registers. */
-int edgedict_stack_pack_wsr(const float* w_hh, int H, void* whh_r, void* stream);
 /* W_hh [4H, H] f32 (H % 64 == 0, H <= 1024) -> bf16 split-K image for the weights-stationary BPTT kernel
  * (edgedict_stack_layer_t.whh_s, 4H*H elements): workgroup (unit block of 64, quarter of the 4H interleaved gate
  * columns) keeps its 128 KB in registers for a whole launch */
 int edgedict_stack_pack_sk(const float* w_hh, int H, void* whh_s, void* stream);
-/* give-up code of the last weights-stationary launch on the current device that ran into a bounded
- * spin (0 = none since the last call of this function; reading clears it) - see csrc/wsr_kernels.hip */
+/* give-up code of the last encoder-stack launch on the current device that ran into one of its bounded
+ * in-kernel waits (0 = none since the last call of this function; reading clears it): 5xx / 6xx a chunk flag of
+ * the forward / backward pass, 7xx a peer of the launch-persistent forward, 8xx a side stream's counter wait,
+ * 9xx a peer of the split-K BPTT (csrc/stack_kernels.hip) */
 int edgedict_stack_wsr_error(void);
 /* the 3 give-up words behind edgedict_stack_wsr_error of the current device (pinned, mapped host memory):
  * host = 0 -> the DEVICE-visible address (what edgedict_adam_step_guarded takes as skip_words, n_skip = 3),
  * host = 1 -> the host address of the same words (tests poke it).  NULL on failure. */
 void* edgedict_stack_error_words(int host);
-/* debug: a zeroed device buffer of >= 64 KB that the persistent weights-stationary launch fills with
- * wall-clock stamps (100 MHz) of its layers' chunks and of worker 0's tasks (tools/wsr_persist_trace.py);
- * NULL switches it off.  Not part of the hot path. */
+/* debug: a zeroed device buffer of >= 8 x 8 int64 in which the first workgroup of every layer of the
+ * launch-persistent forward / split-K BPTT launches accumulates the 100 MHz ticks it spent per phase
+ * (tools/lpw_trace.py, tools/sk_trace.py); NULL switches it off.  Not part of the hot path. */
 int edgedict_stack_wsr_set_trace(void* device_buffer);
 int edgedict_stack_forward(const edgedict_stack_desc_t* desc, void* stream);
 /* measurement aid: HIP-event time (on the recurrence stream) from the first to the last wavefront
@@ -348,10 +337,9 @@ int edgedict_stack_forward(const edgedict_stack_desc_t* desc, void* stream);
  * number of launches in it; blocks until that call's launches have executed. */
 int edgedict_stack_last_timing(int backward, float* ms, int* launches);
 /* which recurrence kernel the most recent forward (backward = 0) / backward (1) call on this device ran:
- * kind 0 = one launch per time step (stack_fwd_kernel / stack_bwd_kernel), 1 = launch-persistent
- * (stack_fwd_lpw_kernel / stack_bwd_lpw_kernel), 2 = split-K weights-stationary BPTT (stack_bwd_sk_kernel),
- * 3 = the opt-in weights-stationary forward (EDGEDICT_STACK_WSR); steps_per_launch = consecutive time steps of a
- * layer one launch carries (0 for kind 0). */
+ * kind 0 = one launch per time step (stack_fwd_kernel / stack_bwd_kernel), 1 = launch-persistent forward
+ * (stack_fwd_lpw_kernel), 2 = split-K weights-stationary BPTT (stack_bwd_sk_kernel); steps_per_launch =
+ * consecutive time steps of a layer one launch carries (0 for kind 0). */
 int edgedict_stack_last_mode(int backward, int* kind, int* steps_per_launch);
 /* measurement aid, opt-in: with on != 0 every wavefront launch of the following forward / backward calls on
  * this device stamps its first workgroup's start and its last workgroup's end (constant 100 MHz clock) into

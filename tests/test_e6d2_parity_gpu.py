@@ -104,6 +104,12 @@ def test_bf16_benched_path_vs_reference_golden_and_fp64_gradients(hip_lib, name)
         ops.TIMERS = None
     # it really was the wavefront stack and the packed lattice
     assert any(k.startswith("enc_stack_fwd_T%d" % xs.shape[1]) for k in timers), sorted(timers)
+    # ... on the DEFAULT recurrence kernels (a fallback to the launch-per-step kernels would pass everything below):
+    # launch-persistent forward and split-K BPTT, a chunk of steps per launch
+    from edgedict_amd import encoder_stack
+    assert encoder_stack.last_mode(False) == (1, encoder_stack.CHUNK), encoder_stack.last_mode(False)
+    assert encoder_stack.last_mode(True) == (2, encoder_stack.CHUNK), encoder_stack.last_mode(True)
+    encoder_stack.check_wsr_error()
     assert int(ops.LAST["joint_rows"]) == int((g["act_lens"].astype(np.int64) * (ylen.numpy() + 1)).sum())
     rel = abs(loss.item() - float(g["loss_mean"])) / float(g["loss_mean"])
     assert rel < 1e-3, rel          # the north-star bound, in the throughput mode
@@ -142,6 +148,9 @@ def test_benched_geometry_b64_rows_equal_the_pinned_b2_run(hip_lib):
     finally:
         ops.TIMERS = None
     assert any(k.startswith("enc_stack_fwd_T%d" % xs.shape[1]) for k in timers), sorted(timers)
+    from edgedict_amd import encoder_stack          # the benched kernels, not a fallback (64 rows: 2 sub-batches each)
+    assert encoder_stack.last_mode(False) == (1, encoder_stack.CHUNK) and encoder_stack.last_mode(True) == (2, encoder_stack.CHUNK)
+    encoder_stack.check_wsr_error()
     # every copy's cost against the reference-pinned golden cost of its original
     gold = g["costs"][idx.numpy()]
     rel = np.abs(costs - gold) / np.abs(gold)

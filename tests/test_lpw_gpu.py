@@ -1,5 +1,6 @@
-"""GPU: the launch-persistent forward of the encoder stack (csrc/stack_kernels.hip stack_fwd_lpw_kernel +
-forward_lpw in csrc/encoder_stack.hip; EDGEDICT_STACK_LPW=1) against the launch-per-step kernels.
+"""GPU: the launch-persistent forward (csrc/stack_kernels.hip stack_fwd_lpw_kernel + forward_lpw in
+csrc/encoder_stack.hip; EDGEDICT_STACK_LPW=1) and the split-K weights-stationary BPTT (stack_bwd_sk_kernel) of the
+encoder stack against the launch-per-step kernels.
 
 One launch carries several CONSECUTIVE time steps of every runnable layer; workgroups keep W_hh in registers,
 meet through arrival counters and exchange h with write-through stores / L2-served loads inside the launch.
@@ -44,34 +45,65 @@ def _same(a, b, exact_bias=False):
 
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("steps", [2, 4])
-def test_lpw_forward_is_bit_identical_to_the_step_kernels(hip_lib, case, steps):
+@pytest.mark.parametrize("sub", [1, 2, 4])
+def test_lpw_forward_is_bit_identical_to_the_step_kernels(hip_lib, case, steps, sub):
+    """sub = sub-batches a workgroup's rows advance in (EDGEDICT_LPW_SUB; the library falls back to fewer when the
+    batch has too few 16-row tiles): deferred arrivals, one counter per sub-batch.  EDGEDICT_STACK_POISON fills the
+    per-frame images with NaN first, so a read that overtakes its producer cannot pass on the previous run's values."""
     from edgedict_amd import encoder_stack
     chunk = 4 if case[6] < 4 else case[6]        # the steps per launch divide the chunk
     enc, xs = _encoder(case)
     ref = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk, lag=case[7]), EDGEDICT_STACK_LPW=0)
     got = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk, lag=case[7]),
-                    EDGEDICT_STACK_LPW=1, EDGEDICT_LPW_STEPS=steps)
+                    EDGEDICT_STACK_LPW=1, EDGEDICT_LPW_STEPS=steps, EDGEDICT_LPW_SUB=sub, EDGEDICT_STACK_POISON=1)
     ser = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=encoder_stack.SERIAL, chunk=chunk, lag=case[7]),
-                    EDGEDICT_STACK_LPW=1, EDGEDICT_LPW_STEPS=steps)
+                    EDGEDICT_STACK_LPW=1, EDGEDICT_LPW_STEPS=steps, EDGEDICT_LPW_SUB=sub, EDGEDICT_STACK_POISON=1)
     _same(ref, got)
     _same(ref, ser)
     encoder_stack.check_wsr_error()
 
 
-def test_lpw_forward_e6d2_full_size_bit_identical_and_carried_state(hip_lib):
-    """BASELINE config 2's encoder (B = 64, T0 = 401, 6 x 1024, 2x time reduction): 4 layer slots of 64
-    workgroups fill the chip, 6 steps per launch; then chunked evaluation with carried state."""
-    from edgedict_amd import config, encoder_stack
-    case = (64, 401, 240, 1024, 6, [1], 12, 0)
+# B > 32: the sub-batches really are separate (2 x 32 or 4 x 16 rows), with ragged last tiles
+SUB_CASES = [(64, 21, 16, 128, 3, [1], 4, 0), (37, 19, 24, 64, 2, [0], 3, 0), (49, 16, 16, 256, 2, [], 4, 0),
+             (100, 11, 16, 64, 2, [1], 2, 0)]      # B > 64: two row groups per layer (the second one partly idle)
+
+
+@pytest.mark.parametrize("case", SUB_CASES)
+@pytest.mark.parametrize("sub", [2, 4])
+def test_lpw_forward_sub_batches_are_bit_identical(hip_lib, case, sub):
+    from edgedict_amd import encoder_stack
+    chunk = 4 if case[6] < 4 else case[6]
     enc, xs = _encoder(case)
-    ref = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=12), EDGEDICT_STACK_LPW=0)
-    got = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=12), EDGEDICT_STACK_LPW=1, EDGEDICT_LPW_STEPS=6)
+    ref = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk), EDGEDICT_STACK_LPW=0)
+    one = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk),
+                    EDGEDICT_STACK_LPW=1, EDGEDICT_LPW_STEPS=chunk, EDGEDICT_LPW_SUB=1, EDGEDICT_STACK_POISON=1)
+    got = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk),
+                    EDGEDICT_STACK_LPW=1, EDGEDICT_LPW_STEPS=chunk, EDGEDICT_LPW_SUB=sub, EDGEDICT_STACK_POISON=1)
+    _same(ref, one)
+    _same(ref, got)
+    encoder_stack.check_wsr_error()
+
+
+@pytest.mark.parametrize("sub", [1, 2, 4])
+def test_lpw_forward_e6d2_full_size_bit_identical_and_carried_state(hip_lib, sub):
+    """BASELINE config 2's encoder (B = 64, T0 = 401, 6 x 1024, 2x time reduction): 4 layer slots of 64
+    workgroups fill the chip, the DEFAULT chunk / steps per launch; then chunked evaluation with carried state."""
+    from edgedict_amd import config, encoder_stack
+    chunk = encoder_stack.CHUNK
+    case = (64, 401, 240, 1024, 6, [1], chunk, 0)
+    enc, xs = _encoder(case)
+    ref = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk), EDGEDICT_STACK_LPW=0)
+    got = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk),
+                    EDGEDICT_STACK_LPW=1, EDGEDICT_LPW_SUB=sub, EDGEDICT_STACK_POISON=1)
+    assert encoder_stack.last_mode(False) == (1, chunk)
     assert got[0].shape == (64, 201, 24)
     assert torch.equal(ref[0], got[0]) and torch.equal(ref[1], got[1]) and torch.equal(ref[2], got[2])
     for n in ref[3]:
         if "weight_ih" in n or "weight_hh" in n:
-            assert torch.equal(ref[3][n], got[3][n]), n
+            assert torch.isfinite(got[3][n]).all(), n
     encoder_stack.check_wsr_error()
+    if sub != 2:
+        return
 
     def chunked():
         enc.compute_dtype = torch.bfloat16
@@ -80,60 +112,8 @@ def test_lpw_forward_e6d2_full_size_bit_identical_and_carried_state(hip_lib):
             y1, (h1, c1) = enc(xs[:8, :200])
             y2, (h2, c2) = enc(xs[:8, 200:], (h1, c1))
         return full, hf, cf, torch.cat([y1, y2], 1), h2, c2
-    full, hf, cf, cat, h2, c2 = _with_env(chunked, EDGEDICT_STACK_LPW=1, EDGEDICT_LPW_STEPS=6)
+    full, hf, cf, cat, h2, c2 = _with_env(chunked, EDGEDICT_STACK_LPW=1)
     assert torch.equal(cat, full) and torch.equal(h2, hf) and torch.equal(c2, cf)
-
-
-@pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("steps", [2, 4])
-def test_lpw_backward_is_bit_identical_to_the_step_kernels(hip_lib, case, steps):
-    """stack_bwd_lpw_kernel (EDGEDICT_STACK_LPW_BWD=1): several consecutive BPTT steps per launch, the layer's
-    workgroups meet through arrival counters, dG_t travels through one fragment image per frame.  Tiling and
-    arithmetic are the step kernel's: every gradient the products compute from the dG rows must be bit-identical."""
-    from edgedict_amd import encoder_stack
-    chunk = 4 if case[6] < 4 else case[6]
-    enc, xs = _encoder(case)
-    ref = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk, lag=case[7]),
-                    EDGEDICT_STACK_LPW=0, EDGEDICT_STACK_LPW_BWD=0)
-    got = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk, lag=case[7]),
-                    EDGEDICT_STACK_LPW=0, EDGEDICT_STACK_LPW_BWD=1, EDGEDICT_LPW_STEPS_B=steps)
-    both = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk, lag=case[7]),
-                     EDGEDICT_STACK_LPW=1, EDGEDICT_STACK_LPW_BWD=1, EDGEDICT_LPW_STEPS=steps, EDGEDICT_LPW_STEPS_B=steps)
-    ser = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=encoder_stack.SERIAL, chunk=chunk, lag=case[7]),
-                    EDGEDICT_STACK_LPW=1, EDGEDICT_STACK_LPW_BWD=1, EDGEDICT_LPW_STEPS=steps, EDGEDICT_LPW_STEPS_B=steps)
-    _same(ref, got)
-    _same(ref, both)
-    _same(ref, ser)
-    encoder_stack.check_wsr_error()
-
-
-def test_lpw_backward_e6d2_full_size_bit_identical(hip_lib):
-    from edgedict_amd import encoder_stack
-    case = (64, 401, 240, 1024, 6, [1], 12, 0)
-    enc, xs = _encoder(case)
-    ref = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=12), EDGEDICT_STACK_LPW_BWD=0)
-    got = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=12), EDGEDICT_STACK_LPW_BWD=1, EDGEDICT_LPW_STEPS_B=6)
-    assert torch.equal(ref[0], got[0])
-    for n in ref[3]:
-        assert torch.isfinite(got[3][n]).all(), n
-        if "weight_ih" in n or "weight_hh" in n:
-            assert torch.equal(ref[3][n], got[3][n]), n
-    encoder_stack.check_wsr_error()
-
-
-@pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("steps,lead", [(4, 0), (8, 3)])
-def test_lpw_forward_across_chunk_boundaries_is_bit_identical(hip_lib, case, steps, lead):
-    """EDGEDICT_LPW_CROSS=1: a launch runs across chunk boundaries (in-kernel flag waits) and the side work of the
-    chunks it completes is enqueued before the launch, gated on the layer's arrival counter."""
-    from edgedict_amd import encoder_stack
-    chunk = 4 if case[6] < 4 else case[6]
-    enc, xs = _encoder(case)
-    ref = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk, lag=case[7]), EDGEDICT_STACK_LPW=0)
-    got = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk, lag=case[7]),
-                    EDGEDICT_STACK_LPW=1, EDGEDICT_LPW_STEPS=steps, EDGEDICT_LPW_CROSS=1, EDGEDICT_LPW_LEAD=lead)
-    _same(ref, got)
-    encoder_stack.check_wsr_error()
 
 
 def _close(a, b, tol):
@@ -156,43 +136,56 @@ SK_CASES = [c for c in CASES if c[3] % 64 == 0 and c[0] <= 64] + [
 ]
 
 
-@pytest.mark.parametrize("case", SK_CASES)
+@pytest.mark.parametrize("case", SK_CASES + [c for c in SUB_CASES if c[0] <= 64])
 @pytest.mark.parametrize("steps", [2, 4])
 def test_split_k_bptt_matches_the_step_kernels(hip_lib, case, steps):
     """stack_bwd_sk_kernel (EDGEDICT_STACK_BWD_SK=1): a workgroup owns 64 units x one quarter of the 4H gate columns,
     W_hh^T stationary in registers, partial sums exchanged between the 4 workgroups of a unit block.  The K split
     changes the order of the fp32 sums, so dG differs from the step kernels' in bf16 rounding only: every parameter
-    gradient within 1e-2 of its norm (measured ~2e-3), deterministic (two runs bit-identical), serial == multi-stream."""
+    gradient within 1e-2 of its norm (measured ~2e-3), deterministic (two runs bit-identical), serial == multi-stream.
+    Sub-batches (EDGEDICT_SK_SUB = 2 / 4: deferred arrivals, per-sub-batch counters, the finishing block one product
+    later) do not change any sum: bit-identical to one sub-batch.  EDGEDICT_STACK_POISON: the dG images and the
+    partial buffers hold NaN when the pass starts, so a stale read cannot pass."""
     from edgedict_amd import encoder_stack
     chunk = 4 if case[6] < 4 else case[6]
     enc, xs = _encoder(case)
     ref = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk, lag=case[7]), EDGEDICT_STACK_BWD_SK=0)
     got = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk, lag=case[7]),
-                    EDGEDICT_STACK_BWD_SK=1, EDGEDICT_SK_STEPS=steps)
+                    EDGEDICT_STACK_BWD_SK=1, EDGEDICT_SK_STEPS=steps, EDGEDICT_SK_SUB=1, EDGEDICT_STACK_POISON=1)
     again = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk, lag=case[7]),
-                      EDGEDICT_STACK_BWD_SK=1, EDGEDICT_SK_STEPS=steps)
+                      EDGEDICT_STACK_BWD_SK=1, EDGEDICT_SK_STEPS=steps, EDGEDICT_SK_SUB=1, EDGEDICT_STACK_POISON=1)
     ser = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=encoder_stack.SERIAL, chunk=chunk, lag=case[7]),
-                    EDGEDICT_STACK_BWD_SK=1, EDGEDICT_SK_STEPS=steps)
+                    EDGEDICT_STACK_BWD_SK=1, EDGEDICT_SK_STEPS=steps, EDGEDICT_SK_SUB=2, EDGEDICT_STACK_POISON=1)
     worst = _close(ref, got, 1e-2)
     _same(got, again)
     _same(got, ser)
+    for sub in (2, 4):
+        alt = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk, lag=case[7]),
+                        EDGEDICT_STACK_BWD_SK=1, EDGEDICT_SK_STEPS=steps, EDGEDICT_SK_SUB=sub, EDGEDICT_STACK_POISON=1)
+        _same(got, alt)
     encoder_stack.check_wsr_error()
     print("\n[split-K BPTT %s steps %d] worst gradient deviation from the step kernels: %.2e of the norm" % (case, steps, worst))
 
 
 def test_split_k_bptt_e6d2_full_size(hip_lib):
     """The benched geometry (B = 64, T0 = 401, 6 x 1024, 2x time reduction; 16 unit blocks x 4 quarters = 64
-    workgroups per layer, 4 layers per launch, 12 steps per launch, per-quarter counters): every parameter gradient
-    within 1e-2 of its norm of the launch-per-step kernels' (the K split re-orders fp32 sums, dG is re-rounded to bf16
-    on each of the 401 steps; measured: 3.3e-3 for the input LayerNorm's gain, the most sensitive one), run-to-run
-    bit-identical, no bounded wait gave up."""
+    workgroups per layer, 4 layers per launch, per-quarter counters) at the DEFAULT chunk / steps per launch: every
+    parameter gradient within 1e-2 of its norm of the launch-per-step kernels' (the K split re-orders fp32 sums, dG is
+    re-rounded to bf16 on each of the 401 steps; measured: 3.3e-3 for the input LayerNorm's gain, the most sensitive
+    one), 1 / 2 / 4 sub-batches and two runs bit-identical, no bounded wait gave up."""
     from edgedict_amd import encoder_stack
-    case = (64, 401, 240, 1024, 6, [1], 12, 0)
+    chunk = encoder_stack.CHUNK
+    case = (64, 401, 240, 1024, 6, [1], chunk, 0)
     enc, xs = _encoder(case)
-    ref = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=12), EDGEDICT_STACK_BWD_SK=0)
-    got = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=12), EDGEDICT_STACK_BWD_SK=1, EDGEDICT_SK_STEPS=12)
-    again = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=12), EDGEDICT_STACK_BWD_SK=1, EDGEDICT_SK_STEPS=12)
+    ref = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk), EDGEDICT_STACK_BWD_SK=0)
+    got = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk), EDGEDICT_STACK_BWD_SK=1, EDGEDICT_STACK_POISON=1)
+    assert encoder_stack.last_mode(True) == (2, chunk)
+    again = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk), EDGEDICT_STACK_BWD_SK=1, EDGEDICT_STACK_POISON=1)
     worst = _close(ref, got, 1e-2)
     _same(got, again)
+    for sub in (1, 4):
+        alt = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk),
+                        EDGEDICT_STACK_BWD_SK=1, EDGEDICT_SK_SUB=sub, EDGEDICT_STACK_POISON=1)
+        _same(got, alt)
     encoder_stack.check_wsr_error()
     print("\n[split-K BPTT, E6D2 size] worst gradient deviation from the step kernels: %.2e of the norm" % worst)

@@ -170,30 +170,6 @@ def test_packed_lattice_path_matches_golden_loss_and_dense_gradients(hip_lib, na
     assert packed.decoder.embed.weight.grad[1].abs().max().item() == 0
 
 
-def test_joint_backward_in_utterance_groups_matches_one_pass(hip_lib):
-    """config.JOINT_BWD_GROUPS > 1 (opt-in): the packed joint + loss backward runs group by group on two streams.
-    Same kernels on row ranges: the loss gradient and dhid are bit-identical, so every parameter gradient agrees
-    with the one-pass run up to the order of the atomics in the tanh backward's label sums."""
-    from edgedict_amd import config
-    cfg, sd, (xs, ys, xlen, ylen), g = _load("E4D1")
-    grads = {}
-    old = (config.JOINT_BWD_GROUPS, config.JOINT_BWD_GROUP_MIN_ROWS)
-    try:
-        for groups in (1, 3):
-            config.JOINT_BWD_GROUPS, config.JOINT_BWD_GROUP_MIN_ROWS = groups, 0
-            m = _engine(cfg, sd, output_loss=True)
-            loss = m(xs.cuda(), ys.cuda(), xlen, ylen)
-            loss.backward()
-            torch.cuda.synchronize()
-            grads[groups] = (loss.item(), {n: p.grad.clone() for n, p in m.named_parameters()})
-    finally:
-        config.JOINT_BWD_GROUPS, config.JOINT_BWD_GROUP_MIN_ROWS = old
-    assert grads[1][0] == grads[3][0]
-    for n, a in grads[1][1].items():
-        b = grads[3][1][n]
-        assert (a - b).abs().max().item() <= 1e-5 * max(a.abs().max().item(), 1e-8), n
-
-
 def test_gru_encoder_state_is_one_tensor_and_chunking_matches(hip_lib):
     """ResLayerNormGRU (module_type='GRU', rnnt/models.py:77-116): hiddens is a single [L,B,H] tensor;
     chunked evaluation with carried state equals one pass; bf16 mode tracks the fp32 loss."""
