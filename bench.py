@@ -399,9 +399,10 @@ def main():
     timers = ops.timer_summary()
     ops.TIMERS = None
     left_early = engine.reducer.last_issued_early
-    # world > 1: the SAME K steps once more with every bucket sent after the backward pass
-    # (EDGEDICT_DP_OVERLAP=0), so that one multi-GPU run answers DESIGN 7's open question - RCCL's kernels
-    # are concurrent "loud" work beside the launch-bound BPTT; `value` is the faster of the two modes (mode_reported)
+    # world > 1: AFTER the timed region the same K steps run once more in the OTHER exchange mode (every bucket sent
+    # after the backward pass, EDGEDICT_DP_OVERLAP=0), so that one multi-GPU run answers DESIGN 7's open question -
+    # RCCL's kernels are concurrent "loud" work beside the launch-bound BPTT.  `value` is ALWAYS the default mode
+    # (what TrainEngine ships), the other one is a secondary field of `exchange`
     if world > 1:
         was = engine.reducer.overlap
         engine.reducer.overlap = not was
@@ -515,7 +516,7 @@ def main():
             # the kernel's average duration: in-kernel begin/end stamps of every launch (two extra steps after
             # the timed region); the period also contains the gaps between dependent launches
             kernel_us = kern["bwd"][0] if "bwd" in kern else period_us
-            kname = {0: "stack_bwd_kernel", 1: "stack_bwd_lpw_kernel", 2: "stack_bwd_sk_kernel"}.get(kind.value, "stack_bwd_kernel")
+            kname = {0: "stack_bwd_kernel", 2: "stack_bwd_sk_kernel"}.get(kind.value, "stack_bwd_kernel")
             tr = None
             try:
                 ent = next((v for k, v in pmc.items() if k.startswith(kname)), None)
@@ -529,8 +530,7 @@ def main():
                 "kernel": "%s (BPTT: %s; %d launches carry %d layer-steps)" % (
                     kname, "split-K, W_hh^T stationary in registers, %d time steps of every runnable layer per launch"
                     % steps_pl.value if kind.value == 2 else
-                    ("launch-persistent, %d time steps per launch" % steps_pl.value if kind.value == 1 else
-                     "one time step of every runnable layer per launch"), n_b.value, layer_steps),
+                    "one time step of every runnable layer per launch", n_b.value, layer_steps),
                 "bound": "hbm", "achieved": per_launch / (kernel_us * 1e-6) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": per_launch / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": tr,
@@ -550,15 +550,12 @@ def main():
                         "of dependent steps, not a stream: us_per_dependent_step against step_latency_floor_us "
                         "(SURVEY 8d) is the figure that moves, the HBM fraction is reported as the contract asks",
             }
-        # world > 1: both exchange modes were timed over exactly K steps each; `value` is the FASTER one and
-        # `exchange.mode_reported` says which (the other one is in the same record) - on one GPU there is one mode
+        # world > 1: `value` = the timed region = the DEFAULT exchange mode; the other mode (K more steps afterwards)
+        # only appears inside `exchange`
         dt_first = dt
         mode_reported = None
         if world > 1:
-            first_mode = "overlap" if engine.reducer.overlap else "after_backward"
-            other_mode = "after_backward" if engine.reducer.overlap else "overlap"
-            mode_reported = first_mode if dt_first <= dt_other else other_mode
-            dt = min(dt_first, dt_other)
+            mode_reported = "overlap" if engine.reducer.overlap else "after_backward"
         out = {
             "metric": "utterances/sec (E6D2, 15 s audio)",
             "value": args.batch * world * args.steps / dt,

@@ -104,6 +104,9 @@ __global__ void unpermute_rows_kernel(const float* __restrict__ src, long long s
 
 // ---------------------------------------------------------------- per-device runtime
 struct Runtime {
+    // ONE call at a time per device (the event pool, the timing record and the stamp buffers belong to a call);
+    // calls on different devices - one host thread per GPU, nn.DataParallel style - do not serialise
+    std::mutex mu;
     hipStream_t R = nullptr, W = nullptr;
     int prio_hi = 0;
     // timing of the recurrence stream's launch sequence of the last forward / backward call
@@ -150,12 +153,13 @@ struct Runtime {
         return pool[used++];
     }
 };
-std::mutex g_mu;
+std::mutex g_rt_mu;           // the registry below only, never held across a call
 std::vector<Runtime*> g_rt;   // indexed by device ordinal
 
 Runtime* runtime_for_current_device() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> registry(g_rt_mu);
     if ((int)g_rt.size() <= dev) g_rt.resize(dev + 1, nullptr);
     if (!g_rt[dev]) {
         Runtime* r = new Runtime();
@@ -364,6 +368,7 @@ struct Streams {
     hipStream_t S[ED_STACK_MAX_SLOTS];
     bool serial;
     Runtime* rt;
+    std::unique_lock<std::mutex> lock;     // rt->mu for the duration of the call (open_streams)
     // order `waiter` after everything enqueued so far on `src`
     // share(src): ONE record on `src` that every chain(src, ...) reuses until unshare() - the side work of all the
     // chunks a BPTT launch completes hangs on the same point of the recurrence stream, and each record on that
@@ -416,6 +421,7 @@ int open_streams(const edgedict_stack_desc_t* d, void* stream_, Streams& st) {
     }
     st.rt = runtime_for_current_device();
     ED_CHECK_ARG(st.rt != nullptr, "encoder_stack: could not create the internal streams");
+    st.lock = std::unique_lock<std::mutex>(st.rt->mu);
     st.rt->used = 0;   // recycle the event pool (waits capture an event's state when enqueued)
     st.R = st.rt->R;
     st.R2 = st.rt->R;
@@ -446,7 +452,6 @@ int input_gemm(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, int l
 }  // namespace
 
 extern "C" void* edgedict_aux_stream(int which) {
-    std::lock_guard<std::mutex> lock(g_mu);
     Runtime* r = runtime_for_current_device();
     if (!r) {
         ed_set_error("aux_stream: could not create the internal streams");
@@ -487,6 +492,22 @@ extern "C" int edgedict_stack_pack_weights(const float* w_ih, const float* w_hh,
 namespace {
 
 long long* g_wsr_trace = nullptr;   // debug: device buffer registered by edgedict_stack_wsr_set_trace (tools/lpw_trace.py, tools/sk_trace.py)
+
+bool lpw_data_poll() {
+    // default: no counter on the dependency chain - the images are filled before the pass and the readers validate what
+    // they gather; 0: the readers poll the arrival counters (round 3's protocol: 7.9 instead of 7.1 us per step)
+    const char* e = getenv("EDGEDICT_LPW_POLL");
+    return e ? atoi(e) != 0 : true;
+}
+bool poison_on() {
+    const char* e = getenv("EDGEDICT_STACK_POISON");      // read per call: tests switch it inside one process
+    return e && atoi(e) != 0;
+}
+int ed_stack_fill(void* p, int byte, size_t bytes, hipStream_t s) {
+    ED_CHECK_HIP(hipMemsetAsync(p, byte, bytes, s));
+    return ED_OK;
+}
+
 
 // Forward pass with the launch-persistent step kernel (stack_kernels.hip, stack_fwd_lpw_kernel): the
 // wavefront schedule of edgedict_stack_forward in MACRO-steps of `nsub` consecutive time steps.  Launch w
@@ -564,6 +585,7 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
         if (finished) break;
         EdLpwLaunch Lc;
         Lc.nslot = 0;
+        Lc.data_poll = lpw_data_poll() ? 1 : 0;
         Lc.nsub = NSUB;
         Lc.B = B;
         Lc.H = H;
@@ -693,15 +715,6 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
     return ED_OK;
 }
 
-bool poison_on() {
-    const char* e = getenv("EDGEDICT_STACK_POISON");      // read per call: tests switch it inside one process
-    return e && atoi(e) != 0;
-}
-int ed_stack_fill(void* p, int byte, size_t bytes, hipStream_t s) {
-    ED_CHECK_HIP(hipMemsetAsync(p, byte, bytes, s));
-    return ED_OK;
-}
-
 // steps per launch of the launch-persistent forward for this geometry (0 = use the launch-per-step kernels):
 // a divisor of the chunk, even when a layer halves the frame rate (its LayerNorm pairs frames)
 int lpw_steps(const edgedict_stack_desc_t* d) {
@@ -734,7 +747,6 @@ int sk_bwd_steps(const edgedict_stack_desc_t* d) {
 }  // namespace
 
 extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stream_) {
-    std::lock_guard<std::mutex> lock(g_mu);
     std::vector<Geom> g;
     ED_TRY(validate(d, g, false));
     const int B = d->B, H = d->H, L = d->L;
@@ -768,7 +780,9 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     // test aid (EDGEDICT_STACK_POISON=1): fill the per-frame h images with NaN patterns before the pass - the
     // workspace usually still holds the images of the pass before, which on identical inputs are the RIGHT values, so
     // a read that overtakes its producer would go unnoticed; with the poison it turns every result into NaN
-    if (lpw_ns && poison_on())
+    // ... and it is how the data-polling forward kernel works at all (stack_fwd_lpw_kernel<DP>): readers recognise a
+    // chunk that has not been written yet by this pattern (205 MB for E6D2 at 15 s: ~50 us of memset)
+    if (lpw_ns && (poison_on() || lpw_data_poll()))
         for (int l = 0; l < L; ++l)
             ED_DEV(ed_stack_fill(ws + wl.himg[l], 0xff, (size_t)(d->layers[l].T + 1) * wl.himg_stride, st.C));
     if (st.rt) {
@@ -953,16 +967,22 @@ extern "C" int edgedict_stack_pack_sk(const float* w_hh, int H, void* whh_s, voi
 }
 
 extern "C" int edgedict_stack_wsr_set_trace(void* device_buffer) {
-    std::lock_guard<std::mutex> lock(g_mu);
     g_wsr_trace = (long long*)device_buffer;
     return ED_OK;
 }
 
 extern "C" int edgedict_stack_wsr_error(void) {
-    std::lock_guard<std::mutex> lock(g_mu);
     Runtime* r = runtime_for_current_device();
+    std::unique_lock<std::mutex> lock;
+    if (r) lock = std::unique_lock<std::mutex>(r->mu);
     if (!r || !r->wsr_err_host) return 0;
     volatile unsigned* p = r->wsr_err_host;
+    if (!(p[0] | p[1] | p[2])) return 0;         // the normal case: nothing is written, nothing races
+    // A give-up code.  The words are also what the guarded Adam step of the SAME training step reads on the device
+    // (edgedict_adam_step_guarded) - and the host runs ahead of the device: clearing them now could hide the failure
+    // from a guard kernel that is enqueued but has not run yet, and the garbage gradients would be applied.  So the
+    // device drains first (an error path: the caller is about to raise), then the words are cleared
+    (void)hipDeviceSynchronize();
     const unsigned code = p[2] ? p[2] : (p[1] ? p[1] : p[0]);   // [2]: flag waits of the step kernels
     p[0] = 0;
     p[1] = 0;
@@ -971,8 +991,9 @@ extern "C" int edgedict_stack_wsr_error(void) {
 }
 
 extern "C" void* edgedict_stack_error_words(int host) {
-    std::lock_guard<std::mutex> lock(g_mu);
     Runtime* r = runtime_for_current_device();
+    std::unique_lock<std::mutex> lock;
+    if (r) lock = std::unique_lock<std::mutex>(r->mu);
     if (!r || !r->wsr_err_host || !r->wsr_err_dev) {
         ed_set_error("stack_error_words: no device runtime");
         return nullptr;
@@ -1008,9 +1029,10 @@ extern "C" int edgedict_stack_schedule(const edgedict_stack_desc_t* d, int backw
 }
 
 extern "C" int edgedict_stack_last_timing(int backward, float* ms, int* launches) {
-    std::lock_guard<std::mutex> lock(g_mu);
     ED_CHECK_ARG(ms && launches, "stack_last_timing: null pointer");
     Runtime* r = runtime_for_current_device();
+    std::unique_lock<std::mutex> lock;
+    if (r) lock = std::unique_lock<std::mutex>(r->mu);
     const int i = backward ? 1 : 0;
     ED_CHECK_ARG(r && r->tev[i][0] && r->tev[i][1] && r->tlaunches[i] > 0, "stack_last_timing: nothing recorded");
     ED_CHECK_HIP(hipEventSynchronize(r->tev[i][1]));
@@ -1020,9 +1042,10 @@ extern "C" int edgedict_stack_last_timing(int backward, float* ms, int* launches
 }
 
 extern "C" int edgedict_stack_last_mode(int backward, int* kind, int* steps_per_launch) {
-    std::lock_guard<std::mutex> lock(g_mu);
     ED_CHECK_ARG(kind && steps_per_launch, "stack_last_mode: null pointer");
     Runtime* r = runtime_for_current_device();
+    std::unique_lock<std::mutex> lock;
+    if (r) lock = std::unique_lock<std::mutex>(r->mu);
     ED_CHECK_ARG(r, "stack_last_mode: no device runtime");
     *kind = r->tkind[backward ? 1 : 0];
     *steps_per_launch = r->tsteps[backward ? 1 : 0];
@@ -1030,17 +1053,19 @@ extern "C" int edgedict_stack_last_mode(int backward, int* kind, int* steps_per_
 }
 
 extern "C" int edgedict_stack_time_launches(int on) {
-    std::lock_guard<std::mutex> lock(g_mu);
     Runtime* r = runtime_for_current_device();
+    std::unique_lock<std::mutex> lock;
+    if (r) lock = std::unique_lock<std::mutex>(r->mu);
     ED_CHECK_ARG(r, "stack_time_launches: no device runtime");
     r->time_each = on != 0;
     return ED_OK;
 }
 
 extern "C" int edgedict_stack_launch_times(int backward, float* sum_ms, int* launches) {
-    std::lock_guard<std::mutex> lock(g_mu);
     ED_CHECK_ARG(sum_ms && launches, "stack_launch_times: null pointer");
     Runtime* r = runtime_for_current_device();
+    std::unique_lock<std::mutex> lock;
+    if (r) lock = std::unique_lock<std::mutex>(r->mu);
     const int i = backward ? 1 : 0;
     ED_CHECK_ARG(r && r->stamps[i] && r->stamp_used[i] > 0,
                  "stack_launch_times: nothing recorded (edgedict_stack_time_launches(1) first)");
@@ -1062,9 +1087,10 @@ extern "C" int edgedict_stack_launch_times(int backward, float* sum_ms, int* lau
 }
 
 extern "C" int edgedict_stack_launch_stamps(int backward, unsigned long long* out, int max_launches, int* launches) {
-    std::lock_guard<std::mutex> lock(g_mu);
     ED_CHECK_ARG(out && launches && max_launches > 0, "stack_launch_stamps: bad arguments");
     Runtime* r = runtime_for_current_device();
+    std::unique_lock<std::mutex> lock;
+    if (r) lock = std::unique_lock<std::mutex>(r->mu);
     const int i = backward ? 1 : 0;
     ED_CHECK_ARG(r && r->stamps[i] && r->stamp_used[i] > 0,
                  "stack_launch_stamps: nothing recorded (edgedict_stack_time_launches(1) first)");
@@ -1076,7 +1102,6 @@ extern "C" int edgedict_stack_launch_stamps(int backward, unsigned long long* ou
 }
 
 extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* stream_) {
-    std::lock_guard<std::mutex> lock(g_mu);
     std::vector<Geom> g;
     ED_TRY(validate(d, g, true));
     ED_CHECK_ARG(d->dout && d->d_in_gamma && d->d_in_beta, "encoder_stack: null backward pointer in descriptor");

@@ -457,7 +457,17 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t lpw_rsrc(const void* p, unsign
 // (the memory counter retires in order; an explicit s_waitcnt vmcnt(0) stands in front of that barrier anyway).
 // Per accumulator the MFMA order, the order of the cross-wave sum and the cell math are unchanged: NS = 2 is
 // bit-identical to NS = 1 and to the launch-per-step kernel.
-template <bool TRACE, int NS>
+//
+// Data polling (DP, the default): the hand-off through a counter is three latencies in a row - the publisher waits
+// for its write-through stores to be acknowledged (1.3 us), bumps the counter, the readers' poll sees it (1.4 us with
+// the skew of 64 workgroups), and only THEN the gather starts its own round trip to memory.  But a frame's image is
+// written exactly once per pass (one image per frame), so the scheduler fills the images with a pattern no h value
+// can have (all ones: a bf16 NaN pair) before the pass, and the reader simply GATHERS - L2-bypassing loads - and
+// looks at what it got: a 16-byte chunk with an all-ones dword is not there yet (16-byte stores may tear at dword
+// granularity at worst, so every dword is checked), the wave sleeps and gathers again.  No drain, no counter, no poll
+// on the dependency chain: publish -> visible in memory -> gathered.  The arrival counters remain for the SIDE
+// streams (LayerNorm of the finished frames), bumped one step late behind a barrier that exists anyway.
+template <bool TRACE, int NS, bool DP>
 __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
     constexpr int TPS = 4 / NS;               // row tiles per sub-batch; sub-batch j = tiles [j TPS, (j + 1) TPS), owned by the waves of the same numbers
     __shared__ float4 hand[4][3][4][64];      // cross-wave K sum: [source wave][slot of the owner][gate][lane], 48 KB
@@ -530,7 +540,7 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
         const int t = S.t0 + s;
         unsigned* const cnt_j = S.counter + j * LPW_CNT_STRIDE;
         // ---- (1) every workgroup of this layer has published sub-batch j of h_{t-1}
-        if (s > 0 && tid == 0) {
+        if (!DP && s > 0 && tid == 0) {
             const unsigned want = S.base + (unsigned)(WGS * s);
             unsigned spins = 0;
             while (__hip_atomic_load(cnt_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
@@ -550,17 +560,42 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
         // ---- (2) h_{t-1} fragments of this wave's K quarter, the sub-batch's row tiles: image t, plain loads (the
         // address has never been touched before in this pass - nothing stale anywhere - and the first reader on an
         // XCD brings a line into that XCD's L2 for the others)
+        // Data polling: all of the sub-batch's fragments are requested, then looked at (a running maximum over their
+        // dwords: all ones = not written yet), then multiplied.  A gather that came too early - rare: the gate / c stores
+        // and the barrier above are delay enough (0.02 per step in the trace) - is simply done again.  (Using the
+        // fragments as they land and reading the verdict off the accumulators - NaN in, NaN out - needs 400 registers or,
+        // capped at the 368 that let a chunk product share the CU, spills into the cell update: 5.4 instead of 4.6 ms)
         bf16x8_t a[LPW_PER][TPS];
         {
             const unsigned soff_in = (unsigned)((long long)t * S.img_stride);
+            unsigned tries = 0;
+            for (;;) {
+                unsigned worst = 0u;
 #pragma unroll
-            for (int i = 0; i < LPW_PER; ++i) {
-                const int ks = min(ks_beg + i, KS - 1);
+                for (int i = 0; i < LPW_PER; ++i) {
+                    const int ks = min(ks_beg + i, KS - 1);
 #pragma unroll
-                for (int m = 0; m < TPS; ++m) {
-                    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(
-                        rimg, (unsigned)(((ks * MT + min(mt0 + j * TPS + m, MT - 1)) * 64 + lane) * 16), soff_in, 0);
-                    a[i][m] = *reinterpret_cast<const bf16x8_t*>(&v);
+                    for (int m = 0; m < TPS; ++m) {
+                        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(
+                            rimg, (unsigned)(((ks * MT + min(mt0 + j * TPS + m, MT - 1)) * 64 + lane) * 16), soff_in, DP ? 16 : 0);
+                        a[i][m] = *reinterpret_cast<const bf16x8_t*>(&v);
+                    }
+                }
+                if (!DP || s == 0) break;        // (step t0's image is complete since the launch before)
+#pragma unroll
+                for (int i = 0; i < LPW_PER; ++i)
+#pragma unroll
+                    for (int m = 0; m < TPS; ++m) {
+                        const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&a[i][m]);
+                        worst = max(worst, max(max(v[0], v[1]), max(v[2], v[3])));
+                    }
+                if (!__any(worst == 0xffffffffu)) break;
+                if (TRACE && tr) ph[4] += 100;   // (the trace's "arrive" column then reads: gathers repeated per step)
+                __builtin_amdgcn_s_sleep(2);
+                if (++tries > (1u << 19)) {                  // ~ a second: a peer never became resident
+                    if (L.err) atomicCAS(L.err, 0u, 700u + slot);
+                    bail_s = 1u;                             // (every wave still goes to the barrier below)
+                    break;
                 }
             }
         }
@@ -608,7 +643,8 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
         // in each wave's queue - are in memory: announce them behind this barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (NS > 1 && pend >= 0 && tid == 0)
+        if (DP && bail_s) break;
+        if ((NS > 1 || DP) && pend >= 0 && tid == 0)
             __hip_atomic_fetch_add(S.counter + pend * LPW_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         pend = j;
         if (NS == 1 || (wave / TPS) == j) {          // the waves that own this sub-batch's row tiles (wave-uniform)
@@ -671,7 +707,7 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
                     }
                 }
             }
-            if (NS == 1) {
+            if (NS == 1 && !DP) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 LPW_STAMP(3);
@@ -697,7 +733,7 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
         }
     }
 #undef LPW_STAMP
-    if (NS > 1 && pend >= 0 && !bail_s) {          // the last sub-iteration's publish
+    if ((NS > 1 || DP) && pend >= 0 && !bail_s) {          // the last sub-iteration's publish
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) __hip_atomic_fetch_add(S.counter + pend * LPW_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1667,8 +1703,10 @@ static int subs_for(int B, const char* env, int dflt) {
     while (n > 1 && MT <= 4 - 4 / n) n >>= 1;       // the last sub-batch must hold a live row tile (B <= 64; the forward's
     return n;                                       // second row group at B > 64 may idle in some)
 }
-int ed_stack_sk_subs(int B) { return subs_for(min(B, 64), "EDGEDICT_SK_SUB", 2); }
-int ed_stack_lpw_subs(int B) { return subs_for(min(B, 64), "EDGEDICT_LPW_SUB", 2); }
+// (default 1: with counters on the chain the sub-batches lose - the deferred arrival comes a whole product late, and a
+// gather of half the rows takes 2.3 of the 3.2 us of the full one - measured 5.1 -> 5.9 ms forward, 9.0 -> 9.2 ms BPTT)
+int ed_stack_sk_subs(int B) { return subs_for(min(B, 64), "EDGEDICT_SK_SUB", 1); }
+int ed_stack_lpw_subs(int B) { return subs_for(min(B, 64), "EDGEDICT_LPW_SUB", 1); }
 
 int ed_stack_launch_bwd_sk(const EdSkLaunch& L, hipStream_t s) {
     const int grid = L.nslot * (L.H >> 6) * 4;
@@ -1693,9 +1731,11 @@ int ed_stack_launch_fwd_lpw(const EdLpwLaunch& L, hipStream_t s) {
     const int grid = L.nslot * UB * RG;
     if (grid == 0) return ED_OK;
     ED_CHECK_ARG(L.nsub == 1 || L.nsub == 2 || L.nsub == 4, "stack_fwd_lpw: 1, 2 or 4 sub-batches");
-#define ED_LPW_LAUNCH(TR, NSUB) hipLaunchKernelGGL((stack_fwd_lpw_kernel<TR, NSUB>), dim3(grid), dim3(256), 0, s, L)
-    if (L.trace) { if (L.nsub == 4) ED_LPW_LAUNCH(true, 4); else if (L.nsub == 2) ED_LPW_LAUNCH(true, 2); else ED_LPW_LAUNCH(true, 1); }
-    else { if (L.nsub == 4) ED_LPW_LAUNCH(false, 4); else if (L.nsub == 2) ED_LPW_LAUNCH(false, 2); else ED_LPW_LAUNCH(false, 1); }
+#define ED_LPW_LAUNCH(TR, NSUB, DPOLL) hipLaunchKernelGGL((stack_fwd_lpw_kernel<TR, NSUB, DPOLL>), dim3(grid), dim3(256), 0, s, L)
+#define ED_LPW_LAUNCH_N(TR, DPOLL) do { if (L.nsub == 4) ED_LPW_LAUNCH(TR, 4, DPOLL); else if (L.nsub == 2) ED_LPW_LAUNCH(TR, 2, DPOLL); else ED_LPW_LAUNCH(TR, 1, DPOLL); } while (0)
+    if (L.trace) { if (L.data_poll) ED_LPW_LAUNCH_N(true, true); else ED_LPW_LAUNCH_N(true, false); }
+    else { if (L.data_poll) ED_LPW_LAUNCH_N(false, true); else ED_LPW_LAUNCH_N(false, false); }
+#undef ED_LPW_LAUNCH_N
 #undef ED_LPW_LAUNCH
     ED_CHECK_LAUNCH("stack_fwd_lpw_kernel");
     return ED_OK;

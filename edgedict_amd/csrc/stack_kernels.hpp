@@ -98,6 +98,8 @@ constexpr int LPW_MAX_SUB = 4;       // sub-batches per workgroup (counter lines
 struct EdLpwLaunch {
     EdLpwSlot slot[ED_STACK_MAX_SLOTS];
     int nslot;
+    int data_poll;               // 1: the images were filled with all-ones before the pass and the readers validate what they
+                                 // gather (no counter on the dependency chain); 0: the readers poll the arrival counters
     int nsub;                    // 1: the workgroup's 64 rows advance together; 2 / 4: as 32- / 16-row sub-batches, alternately
                                  // (ed_stack_lpw_subs), each with its own arrival counter - bit-identical results
     int B, H;

@@ -46,8 +46,10 @@ def _same(a, b, exact_bias=False):
 @pytest.mark.parametrize("case", CASES)
 @pytest.mark.parametrize("steps", [2, 4])
 @pytest.mark.parametrize("sub", [1, 2, 4])
-def test_lpw_forward_is_bit_identical_to_the_step_kernels(hip_lib, case, steps, sub):
-    """sub = sub-batches a workgroup's rows advance in (EDGEDICT_LPW_SUB; the library falls back to fewer when the
+@pytest.mark.parametrize("poll", [1, 0])
+def test_lpw_forward_is_bit_identical_to_the_step_kernels(hip_lib, case, steps, sub, poll):
+    """poll = 1 (default): no counter on the dependency chain - the readers gather and recognise chunks that are not
+    written yet by the fill pattern (EDGEDICT_LPW_POLL); 0: the readers poll the arrival counters.  sub = sub-batches a workgroup's rows advance in (EDGEDICT_LPW_SUB; the library falls back to fewer when the
     batch has too few 16-row tiles): deferred arrivals, one counter per sub-batch.  EDGEDICT_STACK_POISON fills the
     per-frame images with NaN first, so a read that overtakes its producer cannot pass on the previous run's values."""
     from edgedict_amd import encoder_stack
@@ -55,9 +57,9 @@ def test_lpw_forward_is_bit_identical_to_the_step_kernels(hip_lib, case, steps, 
     enc, xs = _encoder(case)
     ref = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk, lag=case[7]), EDGEDICT_STACK_LPW=0)
     got = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk, lag=case[7]),
-                    EDGEDICT_STACK_LPW=1, EDGEDICT_LPW_STEPS=steps, EDGEDICT_LPW_SUB=sub, EDGEDICT_STACK_POISON=1)
+                    EDGEDICT_STACK_LPW=1, EDGEDICT_LPW_STEPS=steps, EDGEDICT_LPW_SUB=sub, EDGEDICT_LPW_POLL=poll, EDGEDICT_STACK_POISON=1)
     ser = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=encoder_stack.SERIAL, chunk=chunk, lag=case[7]),
-                    EDGEDICT_STACK_LPW=1, EDGEDICT_LPW_STEPS=steps, EDGEDICT_LPW_SUB=sub, EDGEDICT_STACK_POISON=1)
+                    EDGEDICT_STACK_LPW=1, EDGEDICT_LPW_STEPS=steps, EDGEDICT_LPW_SUB=sub, EDGEDICT_LPW_POLL=poll, EDGEDICT_STACK_POISON=1)
     _same(ref, got)
     _same(ref, ser)
     encoder_stack.check_wsr_error()
@@ -70,8 +72,10 @@ SUB_CASES = [(64, 21, 16, 128, 3, [1], 4, 0), (37, 19, 24, 64, 2, [0], 3, 0), (4
 
 @pytest.mark.parametrize("case", SUB_CASES)
 @pytest.mark.parametrize("sub", [2, 4])
-def test_lpw_forward_sub_batches_are_bit_identical(hip_lib, case, sub):
+@pytest.mark.parametrize("poll", [1, 0])
+def test_lpw_forward_sub_batches_are_bit_identical(hip_lib, case, sub, poll, monkeypatch):
     from edgedict_amd import encoder_stack
+    monkeypatch.setenv("EDGEDICT_LPW_POLL", str(poll))
     chunk = 4 if case[6] < 4 else case[6]
     enc, xs = _encoder(case)
     ref = _with_env(lambda: _run(enc, xs, torch.bfloat16, flags=0, chunk=chunk), EDGEDICT_STACK_LPW=0)
@@ -84,11 +88,12 @@ def test_lpw_forward_sub_batches_are_bit_identical(hip_lib, case, sub):
     encoder_stack.check_wsr_error()
 
 
-@pytest.mark.parametrize("sub", [1, 2, 4])
-def test_lpw_forward_e6d2_full_size_bit_identical_and_carried_state(hip_lib, sub):
+@pytest.mark.parametrize("sub,poll", [(1, 1), (2, 1), (4, 1), (1, 0), (2, 0)])
+def test_lpw_forward_e6d2_full_size_bit_identical_and_carried_state(hip_lib, sub, poll, monkeypatch):
     """BASELINE config 2's encoder (B = 64, T0 = 401, 6 x 1024, 2x time reduction): 4 layer slots of 64
     workgroups fill the chip, the DEFAULT chunk / steps per launch; then chunked evaluation with carried state."""
     from edgedict_amd import config, encoder_stack
+    monkeypatch.setenv("EDGEDICT_LPW_POLL", str(poll))
     chunk = encoder_stack.CHUNK
     case = (64, 401, 240, 1024, 6, [1], chunk, 0)
     enc, xs = _encoder(case)
@@ -102,7 +107,7 @@ def test_lpw_forward_e6d2_full_size_bit_identical_and_carried_state(hip_lib, sub
         if "weight_ih" in n or "weight_hh" in n:
             assert torch.isfinite(got[3][n]).all(), n
     encoder_stack.check_wsr_error()
-    if sub != 2:
+    if sub != 1:
         return
 
     def chunked():

@@ -11,8 +11,8 @@ import torch  # noqa: E402
 from edgedict_amd import _lib, encoder_stack  # noqa: E402
 from edgedict_amd.models import Encoder  # noqa: E402
 
-steps = sys.argv[1] if len(sys.argv) > 1 else "6"
-encoder_stack.CHUNK = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+steps = sys.argv[1] if len(sys.argv) > 1 else "16"
+encoder_stack.CHUNK = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 os.environ["EDGEDICT_STACK_LPW"] = "1"
 os.environ["EDGEDICT_LPW_STEPS"] = steps
 torch.manual_seed(0)
@@ -32,8 +32,8 @@ with torch.no_grad():
     dt = time.perf_counter() - t0
     _lib.load().edgedict_stack_wsr_set_trace(None)
 tr = buf.cpu().view(-1, 8)[:6].double()
-names = ["wait", "loads+mfma", "handoff+cell", "publish+drain", "arrive", "trailing"]
-print("steps per launch %s, chunk %d, forward %.3f ms" % (steps, encoder_stack.CHUNK, dt * 1e3))
+names = ["wait", "loads+mfma", "handoff+cell", "publish(+drain)", "arrive", "trailing"]
+print("steps per launch %s, chunk %d, sub %s, poll %s, forward %.3f ms" % (steps, encoder_stack.CHUNK, os.environ.get("EDGEDICT_LPW_SUB", "-"), os.environ.get("EDGEDICT_LPW_POLL", "-"), dt * 1e3))
 for l in range(6):
     n, launches = tr[l, 6].item(), tr[l, 7].item()
     if n == 0:
