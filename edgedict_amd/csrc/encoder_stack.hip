@@ -214,14 +214,13 @@ struct WsLayout {
     size_t tmpW = 0, tmpB = 0, dX0 = 0, wsr_sync = 0, total = 0;
 };
 // sync region of the workspace, in 4-byte words: chunk flags of the forward / backward pass [8 layers][512 chunks] each,
-// arrival counters of the launch-persistent forward and of the split-K BPTT's layer-wide fallback [8 layers][LPW_MAX_SUB
-// sub-batches] lines of 256 bytes each, from 64 KB the unit-block and quarter counters of the split-K BPTT
-// [8 layers][SK_CNT_LINES] lines
+// arrival counters of the launch-persistent forward and of the split-K BPTT's layer-wide fallback [8 layers] lines of 256
+// bytes each, from 64 KB the unit-block and quarter counters of the split-K BPTT [8 layers][SK_CNT_LINES] lines
 constexpr size_t SYNC_FFLAG = 0, SYNC_BFLAG = 8 * 512, SYNC_FCNT = 2 * 8 * 512;
-constexpr size_t SYNC_BCNT = SYNC_FCNT + (size_t)8 * LPW_MAX_SUB * LPW_CNT_STRIDE;
+constexpr size_t SYNC_BCNT = SYNC_FCNT + (size_t)8 * LPW_CNT_STRIDE;
 constexpr size_t SYNC_GCNT = 16 * 1024;
 constexpr size_t WSR_SYNC_BYTES = (SYNC_GCNT + (size_t)8 * SK_CNT_LINES * 64) * 4;
-static_assert(SYNC_BCNT + (size_t)8 * LPW_MAX_SUB * LPW_CNT_STRIDE <= SYNC_GCNT, "sync region layout");
+static_assert(SYNC_BCNT + (size_t)8 * LPW_CNT_STRIDE <= SYNC_GCNT, "sync region layout");
 
 WsLayout ws_layout(const edgedict_stack_desc_t* d) {
     WsLayout w;
@@ -524,12 +523,11 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
     const long long BH = (long long)B * H;
     char* ws = (char*)d->ws;
     unsigned* fflag = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + SYNC_FFLAG;   // [8][512] chunk flags
-    unsigned* cnt = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + SYNC_FCNT;      // [8][LPW_MAX_SUB] arrival counter lines
-    const int NSUB = ed_stack_lpw_subs(B);                                          // sub-batches of a workgroup's rows
+    unsigned* cnt = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + SYNC_FCNT;      // [8] arrival counter lines
     unsigned* gerr = (st.rt && st.rt->wsr_err_dev) ? st.rt->wsr_err_dev + 2 : nullptr;
     for (int l = 0; l < L; ++l) ED_CHECK_ARG(g[l].nchunks <= 512, "encoder_stack: too many chunks for the flag table");
     ED_DEV(ed_stack_zero(fflag, (size_t)8 * 512 * sizeof(unsigned), st.C));
-    ED_DEV(ed_stack_zero(cnt, (size_t)8 * LPW_MAX_SUB * LPW_CNT_STRIDE * sizeof(unsigned), st.C));
+    ED_DEV(ed_stack_zero(cnt, (size_t)8 * LPW_CNT_STRIDE * sizeof(unsigned), st.C));
     ED_TRY(st.chain(st.C, st.R));
     for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.C, st.S[l]));
     // TWO side streams: what follows a full-rate layer (its LayerNorm, the next layer's product) runs on the
@@ -586,7 +584,6 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
         EdLpwLaunch Lc;
         Lc.nslot = 0;
         Lc.data_poll = lpw_data_poll() ? 1 : 0;
-        Lc.nsub = NSUB;
         Lc.B = B;
         Lc.H = H;
         Ran ran[ED_STACK_MAX_SLOTS];
@@ -616,7 +613,7 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
             sl.C_prev = y.Cx + (long long)t * BH;
             sl.C = y.Cx + (long long)(t + 1) * BH;
             sl.Wfrag = bptr(y.whh_f);
-            sl.counter = cnt + (size_t)l * LPW_MAX_SUB * LPW_CNT_STRIDE;
+            sl.counter = cnt + (size_t)l * LPW_CNT_STRIDE;
             sl.base = (unsigned)WGS * (unsigned)t;
             sl.wait_flag = (soft && opens) ? fflag + l * 512 + k : nullptr;
             sl.t0 = t;
@@ -677,17 +674,14 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
             }
             if (ni == 0) continue;
             if (soft) {
-                // order S behind this launch's steps through their arrival counters (every sub-batch's), not through
-                // an event
-                const unsigned* cp[ED_STACK_MAX_SLOTS * LPW_MAX_SUB];
-                unsigned tg[ED_STACK_MAX_SLOTS * LPW_MAX_SUB];
-                int nc = 0;
-                for (int j = 0; j < ni; ++j)
-                    for (int sb = 0; sb < NSUB; ++sb) {
-                        cp[nc] = cnt + ((size_t)ran[idx[j]].l * LPW_MAX_SUB + sb) * LPW_CNT_STRIDE;
-                        tg[nc++] = (unsigned)WGS * (unsigned)ran[idx[j]].t1;
-                    }
-                ED_DEV(ed_stack_wait_counters(cp, tg, nc, gerr, S));
+                // order S behind this launch's steps through their arrival counters, not through an event
+                const unsigned* cp[ED_STACK_MAX_SLOTS];
+                unsigned tg[ED_STACK_MAX_SLOTS];
+                for (int j = 0; j < ni; ++j) {
+                    cp[j] = cnt + (size_t)ran[idx[j]].l * LPW_CNT_STRIDE;
+                    tg[j] = (unsigned)WGS * (unsigned)ran[idx[j]].t1;
+                }
+                ED_DEV(ed_stack_wait_counters(cp, tg, ni, gerr, S));
             } else {
                 ED_TRY(st.chain(st.R, S));
             }
@@ -1140,7 +1134,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                 ED_DEV(ed_stack_fill(ws + wl.gimg[l], 0xff, (size_t)(d->layers[l].T + 1) * wl.gimg_stride, st.C));
                 ED_DEV(ed_stack_fill(ws + wl.skpart[l], 0xff, (size_t)2 * (H / 64) * 4 * 64 * 64 * sizeof(float), st.C));
             }
-        ED_DEV(ed_stack_zero(cntb, (size_t)8 * LPW_MAX_SUB * LPW_CNT_STRIDE * sizeof(unsigned), st.C));
+        ED_DEV(ed_stack_zero(cntb, (size_t)8 * LPW_CNT_STRIDE * sizeof(unsigned), st.C));
         ED_DEV(ed_stack_zero(gcnt, (size_t)8 * SK_CNT_LINES * 64 * sizeof(unsigned), st.C));
     }
     // ---- prologue: running dL/dc = 0
@@ -1296,14 +1290,12 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
         const int max_slots = max(1, min(ED_STACK_MAX_SLOTS, (g_trace ? 256 : n_cu) / WGS));
         const char* e_m = getenv("EDGEDICT_LPW_MARGIN_B");
         margin = (e_m && atoi(e_m) > 0) ? atoi(e_m) : 2;
-        const int NSUB = ed_stack_sk_subs(B);
         for (int w = 0;; ++w) {
             bool finished = true;
             for (int l = 0; l < L; ++l) finished = finished && next_t[l] >= g[l].T;
             if (finished) break;
             EdSkLaunch Ls;
             Ls.nslot = 0;
-            Ls.nsub = NSUB;
             Ls.B = B;
             Ls.H = H;
             Ls.trace = g_wsr_trace;
@@ -1339,7 +1331,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                 ss.dC = (float*)(ws + wl.dC[l]);
                 ss.Wsk = bptr(y.whh_s);
                 ss.part = (float*)(ws + wl.skpart[l]);
-                ss.counter = cntb + (size_t)l * LPW_MAX_SUB * LPW_CNT_STRIDE;
+                ss.counter = cntb + (size_t)l * LPW_CNT_STRIDE;
                 ss.gcounter = gcnt + (size_t)l * SK_CNT_LINES * 64;
                 ss.done = (unsigned)next_t[l];
                 ss.wait_flag = (soft && opens) ? bflag + l * 512 + k : nullptr;

@@ -369,7 +369,7 @@ __device__ __forceinline__ void soft_wait(const unsigned* flag, unsigned* err, u
 // that stream behind the steps WITHOUT an event record between the recurrence stream's launches (each record
 // cost ~3.5 us of inter-launch gap there).  What the waited-for steps published (write-through, drained before
 // the arrive) is in memory when the counter shows them; the kernels behind this one start with clean caches.
-constexpr int WAIT_COUNTERS_MAX = ED_STACK_MAX_SLOTS * LPW_MAX_SUB;
+constexpr int WAIT_COUNTERS_MAX = ED_STACK_MAX_SLOTS;
 struct WaitCountersArgs {
     const unsigned* counter[WAIT_COUNTERS_MAX];
     unsigned target[WAIT_COUNTERS_MAX];
@@ -447,16 +447,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t lpw_rsrc(const void* p, unsign
     return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, (int)bytes, 0x00020000);
 }
 
-// Sub-batches (NS = 2 above 32 rows): the step is one device-wide hand-off - publish h_t, drain, arrive, the
-// peers' poll - in series with the gather and the matrix work, and during the hand-off (2.7 of 7.3 us at E6D2)
-// the CU has nothing to do.  Rows are independent, so the workgroup's 4 row tiles are split into NS sub-batches
-// with their own arrival counters, advanced alternately: while sub-batch A's h_t travels, the workgroup gathers
-// and multiplies sub-batch B, W stationary for both.  What makes that pay is that NOBODY waits for a drain:
-// a sub-iteration issues its publish stores and goes on; the arrive is DEFERRED to the next sub-iteration's
-// barrier behind its matrix work - every wave has by then waited for loads that were issued after its stores
-// (the memory counter retires in order; an explicit s_waitcnt vmcnt(0) stands in front of that barrier anyway).
-// Per accumulator the MFMA order, the order of the cross-wave sum and the cell math are unchanged: NS = 2 is
-// bit-identical to NS = 1 and to the launch-per-step kernel.
+// (Round 4, measured and removed: the workgroup's four row tiles as 2 / 4 sub-batches with their own arrival counters,
+// advanced alternately with deferred arrivals - bit-identical, but 5.1 -> 5.9 / 8.2 ms per forward pass: a gather of half
+// the rows takes 2.3 of the 3.2 us of the full one, and an arrival deferred to the next sub-iteration comes too late.)
 //
 // Data polling (DP, the default): the hand-off through a counter is three latencies in a row - the publisher waits
 // for its write-through stores to be acknowledged (1.3 us), bumps the counter, the readers' poll sees it (1.4 us with
@@ -467,9 +460,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t lpw_rsrc(const void* p, unsign
 // granularity at worst, so every dword is checked), the wave sleeps and gathers again.  No drain, no counter, no poll
 // on the dependency chain: publish -> visible in memory -> gathered.  The arrival counters remain for the SIDE
 // streams (LayerNorm of the finished frames), bumped one step late behind a barrier that exists anyway.
-template <bool TRACE, int NS, bool DP>
+template <bool TRACE, bool DP>
 __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
-    constexpr int TPS = 4 / NS;               // row tiles per sub-batch; sub-batch j = tiles [j TPS, (j + 1) TPS), owned by the waves of the same numbers
     __shared__ float4 hand[4][3][4][64];      // cross-wave K sum: [source wave][slot of the owner][gate][lane], 48 KB
     if (ED_STEP_PRIO) __builtin_amdgcn_s_setprio(ED_STEP_PRIO);
     if (L.stamp && threadIdx.x == 0) atomicMin(&L.stamp[0], wall_clock64());
@@ -521,7 +513,7 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
 
     // debug trace (tools/lpw_trace.py): the first workgroup of every slot accumulates, per phase, the 100 MHz
     // ticks its lane 0 spent: [0] wait for the peers, [1] h loads + MFMA, [2] hand-off + cell update,
-    // [3] publish (+ drain with NS = 1), [4] arrive, [5] trailing stores; [6] steps, [7] launches
+    // [3] publish (+ drain, !DP), [4] arrive (!DP) / gathers repeated x 100 (DP), [5] trailing stores; [6] steps, [7] launches
     const bool tr = TRACE && L.trace != nullptr && rem == 0 && tid == 0;
     long long ph[6] = {0, 0, 0, 0, 0, 0};
     long long last_ = tr ? wall_clock64() : 0;
@@ -533,17 +525,14 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
             last_ = now_;                             \
         }                                             \
     } while (0)
-    int pend = -1;                              // sub-batch whose publish stores are out but not yet announced
-    const int niter = S.nsteps * NS;
-    for (int it = 0; it < niter; ++it) {
-        const int s = it / NS, j = it - s * NS;
+    bool pend = false;                          // DP: the step before published, the side streams have not been told yet
+    for (int s = 0; s < S.nsteps; ++s) {
         const int t = S.t0 + s;
-        unsigned* const cnt_j = S.counter + j * LPW_CNT_STRIDE;
-        // ---- (1) every workgroup of this layer has published sub-batch j of h_{t-1}
+        // ---- (1) !DP: every workgroup of this layer has published h_{t-1}
         if (!DP && s > 0 && tid == 0) {
             const unsigned want = S.base + (unsigned)(WGS * s);
             unsigned spins = 0;
-            while (__hip_atomic_load(cnt_j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            while (__hip_atomic_load(S.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
                 __builtin_amdgcn_s_sleep(1);
                 if (++spins > (1u << 21)) {                  // ~ a second: a peer never became resident
                     if (L.err) atomicCAS(L.err, 0u, 700u + slot);
@@ -557,15 +546,15 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (bail_s) break;
         LPW_STAMP(0);
-        // ---- (2) h_{t-1} fragments of this wave's K quarter, the sub-batch's row tiles: image t, plain loads (the
+        // ---- (2) h_{t-1} fragments of this wave's K quarter: image t, plain loads (the
         // address has never been touched before in this pass - nothing stale anywhere - and the first reader on an
         // XCD brings a line into that XCD's L2 for the others)
-        // Data polling: all of the sub-batch's fragments are requested, then looked at (a running maximum over their
+        // Data polling: all fragments are requested, then looked at (a running maximum over their
         // dwords: all ones = not written yet), then multiplied.  A gather that came too early - rare: the gate / c stores
         // and the barrier above are delay enough (0.02 per step in the trace) - is simply done again.  (Using the
         // fragments as they land and reading the verdict off the accumulators - NaN in, NaN out - needs 400 registers or,
         // capped at the 368 that let a chunk product share the CU, spills into the cell update: 5.4 instead of 4.6 ms)
-        bf16x8_t a[LPW_PER][TPS];
+        bf16x8_t a[LPW_PER][4];
         {
             const unsigned soff_in = (unsigned)((long long)t * S.img_stride);
             unsigned tries = 0;
@@ -575,9 +564,9 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
                 for (int i = 0; i < LPW_PER; ++i) {
                     const int ks = min(ks_beg + i, KS - 1);
 #pragma unroll
-                    for (int m = 0; m < TPS; ++m) {
+                    for (int m = 0; m < 4; ++m) {
                         const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(
-                            rimg, (unsigned)(((ks * MT + min(mt0 + j * TPS + m, MT - 1)) * 64 + lane) * 16), soff_in, DP ? 16 : 0);
+                            rimg, (unsigned)(((ks * MT + min(mt0 + m, MT - 1)) * 64 + lane) * 16), soff_in, DP ? 16 : 0);
                         a[i][m] = *reinterpret_cast<const bf16x8_t*>(&v);
                     }
                 }
@@ -585,7 +574,7 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
 #pragma unroll
                 for (int i = 0; i < LPW_PER; ++i)
 #pragma unroll
-                    for (int m = 0; m < TPS; ++m) {
+                    for (int m = 0; m < 4; ++m) {
                         const u32x4_t v = *reinterpret_cast<const u32x4_t*>(&a[i][m]);
                         worst = max(worst, max(max(v[0], v[1]), max(v[2], v[3])));
                     }
@@ -606,27 +595,26 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
         f32x4_t mine[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) mine[g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-        constexpr int PASSES = TPS > 2 ? 2 : 1, TPP = TPS / PASSES;      // tiles per MFMA pass
 #pragma unroll
-        for (int half = 0; half < PASSES; ++half) {
-            f32x4_t acc[TPP][4];
+        for (int half = 0; half < 2; ++half) {
+            f32x4_t acc[2][4];
 #pragma unroll
-            for (int mm = 0; mm < TPP; ++mm)
+            for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) acc[mm][g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < LPW_PER; ++i) {
                 if (ks_beg + i < ks_end) {
 #pragma unroll
-                    for (int mm = 0; mm < TPP; ++mm)
+                    for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
                         for (int g = 0; g < 4; ++g)
-                            acc[mm][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i][g], a[i][half * TPP + mm], acc[mm][g], 0, 0, 0);
+                            acc[mm][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[i][g], a[i][half * 2 + mm], acc[mm][g], 0, 0, 0);
                 }
             }
 #pragma unroll
-            for (int mm = 0; mm < TPP; ++mm) {
-                const int m = j * TPS + half * TPP + mm;
+            for (int mm = 0; mm < 2; ++mm) {
+                const int m = half * 2 + mm;
                 if (m != wave) {
                     const int sl = m < wave ? m : m - 1;
 #pragma unroll
@@ -639,15 +627,14 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
             }
         }
         LPW_STAMP(1);
-        // every load of this sub-iteration has landed in every wave, so the publish stores of the one before - older
-        // in each wave's queue - are in memory: announce them behind this barrier
+        // DP: every load of this step has landed in every wave, so the publish stores of the step before - older in each
+        // wave's queue - are in memory: tell the side streams behind this barrier
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (DP && bail_s) break;
-        if ((NS > 1 || DP) && pend >= 0 && tid == 0)
-            __hip_atomic_fetch_add(S.counter + pend * LPW_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        pend = j;
-        if (NS == 1 || (wave / TPS) == j) {          // the waves that own this sub-batch's row tiles (wave-uniform)
+        if (DP && pend && tid == 0) __hip_atomic_fetch_add(S.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pend = true;
+        {
 #pragma unroll
             for (int src = 0; src < 4; ++src) {
                 if (src != wave) {
@@ -707,7 +694,7 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
                     }
                 }
             }
-            if (NS == 1 && !DP) {
+            if (!DP) {
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __syncthreads();
                 LPW_STAMP(3);
@@ -733,10 +720,10 @@ __global__ __launch_bounds__(256, 1) void stack_fwd_lpw_kernel(EdLpwLaunch L) {
         }
     }
 #undef LPW_STAMP
-    if ((NS > 1 || DP) && pend >= 0 && !bail_s) {          // the last sub-iteration's publish
+    if (DP && pend && !bail_s) {          // the last step's publish
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (tid == 0) __hip_atomic_fetch_add(S.counter + pend * LPW_CNT_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_fetch_add(S.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (TRACE && tr) {
         long long* o = L.trace + S.layer * 8;
@@ -1037,9 +1024,9 @@ __global__ __launch_bounds__(256, ED_BWD_OCC) void stack_bwd_kernel(EdBwdLaunch 
 #ifndef ED_SK_ABLATE
 #define ED_SK_ABLATE 0      // timing experiments only (results wrong): 1 no dG stream, 2 no LDS reads / MFMA
 #endif
-constexpr int SK_GK = ED_SK_GK;             // LDS-DMA of 1 KB per wave and ring slot = k-steps per slot with one sub-batch
-constexpr int SK_SLOT = SK_GK * 4 * 1024;   // 16 KB: 16 pieces of 1 KB ([k-step][row tile of the sub-batch])
-static_assert(SK_GK == 4, "a ring slot is 16 pieces: 4 per wave");
+constexpr int SK_GK = ED_SK_GK;             // k-steps per ring slot
+constexpr int SK_SLOT = SK_GK * 4 * 1024;   // 16 KB: 4 k-steps x 4 row tiles x 1 KB
+constexpr int SK_MAXG = 32 / SK_GK;         // ring slots per step at H = 1024
 constexpr int SK_RING = ED_SK_RING;         // slots: RING - 1 of them in flight while one is consumed
 // s_waitcnt vmcnt(n * SK_GK): all but the n youngest slots of this wave's DMA have landed
 template <int N>
@@ -1058,19 +1045,14 @@ __device__ __forceinline__ void sk_wait_younger(int n) {
 static_assert(SK_RING >= 2 && SK_RING <= 8 && (SK_RING - 2) * SK_GK < 64, "ring depth");
 typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
 
-template <bool TRACE, int NS>
+// (Round 4, measured and removed: (a) the workgroup's rows as 2 / 4 sub-batches with their own counters, the arrival of
+// a partial deferred into the next product and the finishing block one product later - bit-identical, 9.0 -> 9.2 / 11.3 ms
+// per backward pass: a product of half the rows takes 60 % of the time of the full one and the deferred arrival comes a
+// whole product late; (b) data polling as in the forward kernel - dG images and a ring of partial buffers pre-filled with
+// NaN, every wave reading its own four LDS-DMA pieces back before the slot barrier: the ring phase went from 5.6 to
+// 9.2 us per step, the read-back serialises what the counted waits had pipelined.)
+template <bool TRACE>
 __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
-    // Sub-batches (NS = 2 or 4 above 32 / 48 rows, stack_kernels.hpp): a step has TWO device-wide hand-offs - the
-    // partial exchange inside the unit block and the dG image to the quarter's readers - in series with the product,
-    // 5.9 of 11.6 us with the matrix pipes idle.  The workgroup's 4 row tiles are split into NS sub-batches with their
-    // own counters: the products R_0 .. R_{NS-1} of a step run back to back (W stationary for all), the arrival that
-    // announces sub-batch j's partial is DEFERRED to the first ring barrier of R_{j+1} (every wave has by then passed
-    // a counted wait that retires its older stores), and the workgroup finishes ITS rows (tile kq, sub-batch
-    // jf = kq / TPS) one product later, behind R_{jf+1} - the exchange latency of sub-batch jf is R_{jf+1}'s time.
-    // Per accumulator the k order, and per cell the order of the four partials, are unchanged: every NS is bit-identical.
-    constexpr int TPS = 4 / NS;                 // row tiles per sub-batch
-    constexpr int GKS = SK_GK * NS;             // k-steps per ring slot: a slot is always 16 pieces of 1 KB = GKS k-steps x TPS row tiles
-    constexpr int MAXG = 32 / GKS;              // ring slots per sub-batch product at H = 1024
     extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];      // SK_RING * SK_SLOT bytes (dynamic)
     __shared__ unsigned bail_s;
     if (ED_STEP_PRIO) __builtin_amdgcn_s_setprio(ED_STEP_PRIO);
@@ -1082,41 +1064,31 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
     const EdSkSlot& S = L.slot[slot];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int KSq = H >> 5;                         // k-steps of this workgroup's quarter (<= 32)
-    const int KSqP = (KSq + SK_GK - 1) / SK_GK * SK_GK;       // ... padded to the unit of the rotation below
-    const int NGRP = (KSqP + GKS - 1) / GKS;        // ring slots per sub-batch product (<= MAXG)
+    const int NGRP = (KSq + SK_GK - 1) / SK_GK;     // ring slots per step (<= SK_MAXG)
     // the 8 workgroups of an XCD that read the same K quarter (same kq, same parity of ub) start their walk over the
-    // quarter's k-steps at (up to) 8 different places: the first window of each brings a different part of the image
+    // quarter's k-groups at 8 different places: the first window of each brings a different eighth of the image
     // into the XCD's L2, the later windows of all of them hit it (fresh write-through data is an L2 miss for the
-    // first reader; in lock-step every workgroup paid that miss on every window).  Walk position i <-> k-step
-    // (i + rot4) % KSqP, whatever the slot size: the order of the sums does not depend on NS
-    const int rot4 = ((ub >> 1) % (KSqP / SK_GK)) * SK_GK;
-    const bool full = KSq == KSqP;
+    // first reader; in lock-step every workgroup paid that miss on every window)
+    const int rot = (ub >> 1) % NGRP;
     const int MT = (B + 15) >> 4;
     const long long H4 = 4ll * H, BH = (long long)B * H;
     const __amdgpu_buffer_rsrc_t rimg = lpw_rsrc(S.img, (unsigned)S.img_bytes);
     const __amdgpu_buffer_rsrc_t rpart = lpw_rsrc(S.part, (unsigned)(2u * UBK * 4u * 64u * 64u * 4u));
-    // who waits for whom.  Unit-block counter (ub, j): the block's 4 workgroups, one arrival each per step once their
-    // partial of sub-batch j is in memory; the finisher of rows [16 kq, 16 kq + 16) - sub-batch jf - waits for it.
-    // Quarter kq of the gate columns is the 4 gates of units [kq H/4, (kq+1) H/4), i.e. of unit blocks
-    // [kq UBK/4, (kq+1) UBK/4): counter (quarter, j) takes one arrival per step from each of those blocks' finishers of
-    // sub-batch j (UBK / NS of them) when the blocks do not straddle quarters; otherwise the layer's counter of
-    // sub-batch j (WGS / NS arrivals per step).  Every counter has its own 256-byte line
-    const int jf = kq / TPS;
-    const int fpos = min(jf + 1, NS - 1);           // this workgroup finishes its rows behind product R_fpos
+    // who this workgroup waits for: quarter kq of the gate columns is the 4 gates of units
+    // [kq H/4, (kq+1) H/4), i.e. of unit blocks [kq UBK/4, (kq+1) UBK/4) - 16 of the layer's 64 workgroups at H = 1024.
+    // One arrival counter per quarter (a 256-byte line each, behind the unit-block counters) when the blocks do not
+    // straddle quarters; otherwise the layer's single counter
     const bool quarters = (UBK & 3) == 0;
-    unsigned* const gub = S.gcounter + (ub * NS) * 64;                                       // + j * 64
-    unsigned* const cnt_arrive = quarters ? S.gcounter + (SK_CNT_QUARTER + (ub / (UBK >> 2)) * NS + jf) * 64
-                                          : S.counter + jf * LPW_CNT_STRIDE;
-    const unsigned* const cnt_poll = quarters ? S.gcounter + (SK_CNT_QUARTER + kq * NS) * 64 : S.counter;   // + j * 64
-    const unsigned per_step = (unsigned)((quarters ? UBK : WGS) / NS);
+    unsigned* cnt_arrive = quarters ? S.gcounter + (SK_CNT_QUARTER + ub / (UBK >> 2)) * 64 : S.counter;
+    const unsigned* cnt_poll = quarters ? S.gcounter + (SK_CNT_QUARTER + kq) * 64 : S.counter;
 
-    // ---- stationary weights: unit tile `wave` of the (ub, kq) slice, every k-step of the quarter in walk order
+    // ---- stationary weights: unit tile `wave` of the (ub, kq) slice, every k-step of the quarter
     bf16x8_t w[32];
     {
         const bf16_t* wbase = S.Wsk + (((((long long)(ub * 4 + kq) * KSq) * 4) + wave) * 64 + lane) * 8;
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
-            const int ks = (min(i, KSqP - 1) + rot4) % KSqP;
+            const int ks = (min(i, NGRP * SK_GK - 1) + rot * SK_GK) % (NGRP * SK_GK);      // register i <-> k-step, rotated
             w[i] = ldfrag(wbase + (long long)min(ks, KSq - 1) * 4 * 512);
         }
     }
@@ -1134,8 +1106,8 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
     if (tid == 0) bail_s = 0u;
 
     // debug trace (tools/sk_trace.py): workgroup 0 of every slot accumulates the 100 MHz ticks its lane 0 spent in
-    // [0] waits for the quarter's producers, [1] dG ring + MFMA + partial stores, [2] drain + unit-block wait,
-    // [3] partial reads + cell, [4] publish + drain + arrive, [5] trailing stores; [6] steps, [7] launches
+    // [0] wait for the quarter's producers, [1] dG ring + MFMA + partial stores, [2] drain + unit-block wait + partial
+    // reads, [3] cell, [4] publish + drain + arrive, [5] trailing stores; [6] steps, [7] launches
     const bool tr = TRACE && L.trace != nullptr && rem == 0 && tid == 0;
     long long ph[6] = {0, 0, 0, 0, 0, 0};
     long long last_ = tr ? wall_clock64() : 0;
@@ -1147,9 +1119,9 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
             last_ = now_;                             \
         }                                             \
     } while (0)
-    // ---- a frame's cell operands (HBM: the forward pass wrote them long ago).  Requested at the END of the finishing
-    // block of the step before (and here for the first one): they are in flight under the next products, and the
-    // counted waits of the ring only get conservative by them
+    // ---- a frame's cell operands (HBM: the forward pass wrote them long ago).  Requested at the END of the step before
+    // (and here for the first one): the wait for the peers is their flight time, and nothing of this wave is outstanding
+    // in front of the first ring slot except loads that are about to land
     uint2 gq[4], dyq = make_uint2(0u, 0u);
     float4 ctq = make_float4(0.f, 0.f, 0.f, 0.f), cpq = ctq;
 #pragma unroll
@@ -1167,130 +1139,102 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
         }
     };
     request_operands(0);
-    unsigned pend = 0u;        // bit j: this workgroup's partial of sub-batch j is stored but not yet announced
-    // tid 0, behind a barrier that every wave reached with its older stores retired: announce them
-    auto flush_pending = [&]() {
-#pragma unroll
-        for (int j = 0; j < NS; ++j)
-            if (pend & (1u << j)) __hip_atomic_fetch_add(gub + j * 64, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-    bool dead = false;
-    for (int s = 0; s < S.nsteps && !dead; ++s) {
+    for (int s = 0; s < S.nsteps; ++s) {
         const int t = S.t0 - s;
-        const int par = t & 1;
-        const unsigned pbase = (unsigned)((((par * UBK + ub) * 4 + kq) * 64 * 64) * 4);
-        for (int j = 0; j < NS; ++j) {
-            // ---- (1) the finishers of sub-batch j have published their rows of dG_{t+1}
-            if (tid == 0) {
-                unsigned bail = 0u;
-                const unsigned want = per_step * (S.done + (unsigned)s);
-                const unsigned* cp = cnt_poll + j * 64;
-                unsigned spins = 0;
-                while (s > 0 && __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > (1u << 21)) {
-                        if (L.err) atomicCAS(L.err, 0u, 900u + slot);
-                        bail = 1u;
-                        break;
-                    }
+        // ---- (1) the producers of this quarter have published dG_{t+1}
+        if (tid == 0) {
+            unsigned bail = 0u;
+            const unsigned want = (quarters ? (unsigned)UBK : (unsigned)WGS) * (S.done + (unsigned)s);
+            unsigned spins = 0;
+            while (s > 0 && __hip_atomic_load(cnt_poll, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > (1u << 21)) {
+                    if (L.err) atomicCAS(L.err, 0u, 900u + slot);
+                    bail = 1u;
+                    break;
                 }
-                bail_s = bail;
             }
-            // (a raw barrier: __syncthreads() would make every wave wait for its own operand loads and stores here)
-            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-            if (bail_s) { dead = true; break; }
-            SK_STAMP(0);
-            f32x4_t acc[TPS];
+            bail_s = bail;
+        }
+        // (a raw barrier: __syncthreads() would make every wave wait for its own operand loads here)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (bail_s) break;
+        SK_STAMP(0);
+        const int pr = t & 1;
+        const unsigned pbase = (unsigned)((((pr * UBK + ub) * 4 + kq) * 64 * 64) * 4);
+        f32x4_t acc[4];
 #pragma unroll
-            for (int m = 0; m < TPS; ++m) acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-            if (t < S.T - 1) {
-                // ---- (2) partial product of this K quarter, the sub-batch's row tiles.  Ring slot = 16 pieces of 1 KB in
-                // [k-step][row tile] order; wave w brings pieces w, w + 4, w + 8, w + 12: one LDS-DMA per piece
-                const unsigned char* img = reinterpret_cast<const unsigned char*>(S.img) + (long long)(t + 1) * S.img_stride;
-                // piece ii * 4 + wave = k-step ii * NS + wave / TPS of the slot, row tile wave % TPS of the sub-batch:
-                // ONE row tile per wave (clamped to the batch) - one VGPR offset; the k-step goes into the scalar base
-                const int wv = __builtin_amdgcn_readfirstlane(wave);        // (uniform: the DMA's base address is a scalar)
-                const int kk0 = wv / TPS;
-                const unsigned avoff = (unsigned)(((kq * KSq * MT + min(j * TPS + wv % TPS, MT - 1)) * 64 + lane) * 16);
-                auto issue = [&](int g) {
-                    unsigned char* dst = ring + (g % SK_RING) * SK_SLOT + wave * 1024;
+        for (int m = 0; m < 4; ++m) acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        if (t < S.T - 1) {
+            // ---- (2) partial product of this K quarter.  Ring slot = 4 k-steps x 4 row tiles; wave w brings row tile
+            // w (clamped to the batch) of each k-step: one 1 KB LDS-DMA per (wave, k-step)
+            const unsigned char* img = reinterpret_cast<const unsigned char*>(S.img) + (long long)(t + 1) * S.img_stride;
+            const int mrow = min(wave, MT - 1);
+            const unsigned avoff = (unsigned)(((kq * KSq * MT + mrow) * 64 + lane) * 16);     // + scalar base: one VGPR
+            auto issue = [&](int g) {
+                unsigned char* dst = ring + (g % SK_RING) * SK_SLOT + wave * 1024;
 #pragma unroll
-                    for (int ii = 0; ii < 4; ++ii) {
-                        const int i = min(g * GKS + ii * NS + kk0, KSqP - 1);
-                        int ks = i + rot4;
-                        if (ks >= KSqP) ks -= KSqP;
-                        ks = min(ks, KSq - 1);
-                        // hand-written: the compiler makes every LDS read wait for ALL outstanding LDS-DMA it knows of
-                        // (vmcnt(0) right after the next slot's issue); the counted waits below are the real rule
-                        const unsigned m0v = __builtin_amdgcn_readfirstlane(
-                            (unsigned)(size_t)(__attribute__((address_space(3))) void*)(dst + ii * 4096));
-                        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
+                for (int j = 0; j < SK_GK; ++j) {
+                    int gr = g + rot;
+                    if (gr >= NGRP) gr -= NGRP;
+                    const int ks = min(gr * SK_GK + j, KSq - 1);
+                    // hand-written: the compiler makes every LDS read wait for ALL outstanding LDS-DMA it knows of
+                    // (vmcnt(0) right after the next slot's issue); the counted waits below are the real rule
+                    const unsigned m0v = __builtin_amdgcn_readfirstlane(
+                        (unsigned)(size_t)(__attribute__((address_space(3))) void*)(dst + j * 4096));
+                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
                                      ::"v"(avoff), "s"(m0v), "s"(img + (long long)ks * MT * 1024) : "memory", "m0");
-                    }
-                };
-                // (older loads / stores of this wave - cell operands, the partial before - only make the counted waits
-                // below conservative)
+                }
+            };
+            // (older loads of this wave - the cell operands - only make the counted waits below conservative)
 #pragma unroll
-                for (int g = 0; g < SK_RING - 1; ++g)
-                    if (ED_SK_ABLATE != 1 && g < NGRP) issue(g);
+            for (int g = 0; g < SK_RING - 1; ++g)
+                if (ED_SK_ABLATE != 1 && g < NGRP) issue(g);
 #pragma unroll
-                for (int g = 0; g < MAXG; ++g) {
-                    if (g < NGRP) {
-                        sk_wait_younger(min(SK_RING - 2, NGRP - 1 - g));
-                        asm volatile("s_barrier" ::: "memory");
-                        if (g == 0 && pend != 0u) {
-                            // every wave has passed a counted wait behind DMA issued AFTER its earlier partial stores
-                            if (tid == 0) flush_pending();
-                            pend = 0u;
+            for (int g = 0; g < SK_MAXG; ++g) {
+                if (g < NGRP) {
+                    sk_wait_younger(min(SK_RING - 2, NGRP - 1 - g));
+                    asm volatile("s_barrier" ::: "memory");
+                    if (ED_SK_ABLATE != 1 && g + SK_RING - 1 < NGRP) issue(g + SK_RING - 1);
+                    if (ED_SK_ABLATE == 2) continue;
+                    const unsigned char* src = ring + (g % SK_RING) * SK_SLOT + lane * 16;
+                    bf16x8_t af[2][4];
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) af[0][m] = *reinterpret_cast<const bf16x8_t*>(src + m * 1024);
+#pragma unroll
+                    for (int j = 0; j < SK_GK; ++j) {
+                        if (j + 1 < SK_GK) {
+#pragma unroll
+                            for (int m = 0; m < 4; ++m)
+                                af[(j + 1) & 1][m] = *reinterpret_cast<const bf16x8_t*>(src + (j + 1) * 4096 + m * 1024);
                         }
-                        if (ED_SK_ABLATE != 1 && g + SK_RING - 1 < NGRP) issue(g + SK_RING - 1);
-                        if (ED_SK_ABLATE == 2) continue;
-                        const unsigned char* src = ring + (g % SK_RING) * SK_SLOT + lane * 16;
-                        bf16x8_t af[2][TPS];
+                        if (KSq % SK_GK == 0 || ((g + rot) % NGRP) * SK_GK + j < KSq) {
 #pragma unroll
-                        for (int m = 0; m < TPS; ++m) af[0][m] = *reinterpret_cast<const bf16x8_t*>(src + m * 1024);
-#pragma unroll
-                        for (int kk = 0; kk < GKS; ++kk) {
-                            if (kk + 1 < GKS) {
-#pragma unroll
-                                for (int m = 0; m < TPS; ++m)
-                                    af[(kk + 1) & 1][m] = *reinterpret_cast<const bf16x8_t*>(src + ((kk + 1) * TPS + m) * 1024);
-                            }
-                            const int i = g * GKS + kk;
-                            bool valid = i < KSqP;
-                            if (!full) {
-                                int ks = i + rot4;
-                                if (ks >= KSqP) ks -= KSqP;
-                                valid = valid && ks < KSq;
-                            }
-                            if (valid) {
-#pragma unroll
-                                for (int m = 0; m < TPS; ++m)
-                                    acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g * GKS + kk], af[kk & 1][m], acc[m], 0, 0, 0);
-                            }
-                            __builtin_amdgcn_sched_barrier(0);
+                            for (int m = 0; m < 4; ++m)
+                                acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[g * SK_GK + j], af[j & 1][m], acc[m], 0, 0, 0);
                         }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
-            // ---- (3) publish the partial (zeros at the last frame: it has no dG_{t+1}; the exchange still runs - one
-            // rule for every step): rows 16 m + (lane & 15), 4 consecutive units per lane, write-through
+        }
+        // ---- (3) publish the partial (zeros at the last frame: it has no dG_{t+1}; the exchange still runs - one rule
+        // for every step): rows 16 m + (lane & 15), 4 consecutive units per lane, write-through
 #pragma unroll
-            for (int m = 0; m < TPS; ++m) {
-                const u32x4_t o = {__float_as_uint(acc[m][0]), __float_as_uint(acc[m][1]), __float_as_uint(acc[m][2]), __float_as_uint(acc[m][3])};
-                __builtin_amdgcn_raw_buffer_store_b128(o, rpart, pbase + pmine + (unsigned)((j * TPS + m) * 16 * 64 * 4), 0, 16);
-            }
-            pend |= 1u << j;
-            SK_STAMP(1);
-            if (j != fpos) continue;
-            // ================= finish rows [16 kq, 16 kq + 16) of frame t =================
-            // every storing wave drains; one lane announces what is pending and waits for the unit block's partials of
-            // sub-batch jf (announced by the others one product ago, except when jf is the last sub-batch)
+        for (int m = 0; m < 4; ++m) {
+            const u32x4_t o = {__float_as_uint(acc[m][0]), __float_as_uint(acc[m][1]), __float_as_uint(acc[m][2]), __float_as_uint(acc[m][3])};
+            __builtin_amdgcn_raw_buffer_store_b128(o, rpart, pbase + pmine + (unsigned)(m * 16 * 64 * 4), 0, 16);
+        }
+        SK_STAMP(1);
+        // ---- (4) dL/dh_t of this lane's cells: the four K parts in fixed order
+        float dh[4] = {0.f, 0.f, 0.f, 0.f};
+        {
+            // every storing wave drains; one lane arrives on the unit block's counter and waits for the other three
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
             if (tid == 0) {
-                flush_pending();
-                const unsigned* gc = gub + jf * 64;
+                unsigned* gc = S.gcounter + ub * 64;      // one 256-byte line per unit block
+                __hip_atomic_fetch_add(gc, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned want = 4u * (S.done + (unsigned)s + 1u);
                 unsigned spins = 0, bail = 0u;
                 while (__hip_atomic_load(gc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
@@ -1303,94 +1247,91 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
                 }
                 bail_s = bail;
             }
-            pend = 0u;
             __syncthreads();
-            if (bail_s) { dead = true; break; }
-            SK_STAMP(2);
-            // ---- (4) dL/dh_t of this lane's cells: the four K parts in fixed order (L2-served loads: the buffers are reused)
-            float dh[4] = {0.f, 0.f, 0.f, 0.f};
+            if (bail_s) break;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(
-                    rpart, (unsigned)((((((par * UBK + ub) * 4 + q) * 64 + crow) * 64) + quad * 4) * 4), 0, 16);
+                    rpart, (unsigned)((((((pr * UBK + ub) * 4 + q) * 64 + crow) * 64) + quad * 4) * 4), 0, 16);
                 dh[0] += __uint_as_float(v[0]); dh[1] += __uint_as_float(v[1]);
                 dh[2] += __uint_as_float(v[2]); dh[3] += __uint_as_float(v[3]);
             }
-            // ---- (5) cell backward in registers
-            uint2 outg[4];
-            {
-                const float ctv[4] = {ctq.x, ctq.y, ctq.z, ctq.w}, cpv[4] = {cpq.x, cpq.y, cpq.z, cpq.w};
-                float dcv[4] = {dc.x, dc.y, dc.z, dc.w};
-                float o[4][4];
+        }
+        SK_STAMP(2);
+        // ---- (5) cell backward in registers
+        uint2 outg[4];
+        {
+            const float ctv[4] = {ctq.x, ctq.y, ctq.z, ctq.w}, cpv[4] = {cpq.x, cpq.y, cpq.z, cpq.w};
+            float dcv[4] = {dc.x, dc.y, dc.z, dc.w};
+            float o[4][4];
 #pragma unroll
-                for (int jj = 0; jj < 4; ++jj) {
-                    auto pick = [&](const uint2& u) {
-                        const unsigned wd = (jj < 2) ? u.x : u.y;
-                        return __uint_as_float((jj & 1) ? (wd & 0xffff0000u) : (wd << 16));
-                    };
-                    const float ig = pick(gq[0]), fg = pick(gq[1]), gg = pick(gq[2]), og = pick(gq[3]);
-                    const float dht = pick(dyq) + dh[jj];
-                    const float tc = ftanh(ctv[jj]);
-                    const float dct = dcv[jj] + dht * og * (1.f - tc * tc);
-                    o[0][jj] = dct * gg * ig * (1.f - ig);
-                    o[1][jj] = dct * cpv[jj] * fg * (1.f - fg);
-                    o[2][jj] = dct * ig * (1.f - gg * gg);
-                    o[3][jj] = dht * tc * og * (1.f - og);
-                    dcv[jj] = dct * fg;
-                }
-                dc = make_float4(dcv[0], dcv[1], dcv[2], dcv[3]);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    outg[g].x = f32x2_to_bf16x2(o[g][0], o[g][1]);
-                    outg[g].y = f32x2_to_bf16x2(o[g][2], o[g][3]);
-                }
+            for (int j = 0; j < 4; ++j) {
+                auto pick = [&](const uint2& u) {
+                    const unsigned wd = (j < 2) ? u.x : u.y;
+                    return __uint_as_float((j & 1) ? (wd & 0xffff0000u) : (wd << 16));
+                };
+                const float ig = pick(gq[0]), fg = pick(gq[1]), gg = pick(gq[2]), og = pick(gq[3]);
+                const float dht = pick(dyq) + dh[j];
+                const float tc = ftanh(ctv[j]);
+                const float dct = dcv[j] + dht * og * (1.f - tc * tc);
+                o[0][j] = dct * gg * ig * (1.f - ig);
+                o[1][j] = dct * cpv[j] * fg * (1.f - fg);
+                o[2][j] = dct * ig * (1.f - gg * gg);
+                o[3][j] = dht * tc * og * (1.f - og);
+                dcv[j] = dct * fg;
             }
-            SK_STAMP(3);
-            // ---- (6) publish dG_t into image t.  Lanes l and l ^ 16 hold units u..u+3 and u+4..u+7 of one row: they swap
-            // two gates each, so every lane holds two whole 16-byte chunks (8 consecutive gate columns), stored write-through
-            u32x4_t v16[2];
-            const bool hi = (lane >> 4) & 1;
-            const int kc0 = (gcol0 & ~7) + (hi ? 32 : 0);        // first of the pair's 8 columns, gate 2 (hi) or 0
-            {
-                // (bit masks, not ?: - the compiler turns a select between two array elements into an indexed scratch load)
-                const unsigned himask = 0u - (unsigned)hi;
-                const unsigned g0x = (outg[0].x & himask) | (outg[2].x & ~himask), g0y = (outg[0].y & himask) | (outg[2].y & ~himask);
-                const unsigned g1x = (outg[1].x & himask) | (outg[3].x & ~himask), g1y = (outg[1].y & himask) | (outg[3].y & ~himask);
-                uint2 got[2];
-                got[0].x = __shfl_xor(g0x, 16); got[0].y = __shfl_xor(g0y, 16);
-                got[1].x = __shfl_xor(g1x, 16); got[1].y = __shfl_xor(g1y, 16);
+            dc = make_float4(dcv[0], dcv[1], dcv[2], dcv[3]);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                outg[g].x = f32x2_to_bf16x2(o[g][0], o[g][1]);
+                outg[g].y = f32x2_to_bf16x2(o[g][2], o[g][3]);
+            }
+        }
+        SK_STAMP(3);
+        // ---- (6) publish dG_t into image t.  Lanes l and l ^ 16 hold units u..u+3 and u+4..u+7 of one row: they swap
+        // two gates each, so every lane holds two whole 16-byte chunks (8 consecutive gate columns), stored write-through
+        u32x4_t v16[2];
+        const bool hi = (lane >> 4) & 1;
+        const int kc0 = (gcol0 & ~7) + (hi ? 32 : 0);        // first of the pair's 8 columns, gate 2 (hi) or 0
+        {
+            // (bit masks, not ?: - the compiler turns a select between two array elements into an indexed scratch load)
+            const unsigned himask = 0u - (unsigned)hi;
+            const unsigned g0x = (outg[0].x & himask) | (outg[2].x & ~himask), g0y = (outg[0].y & himask) | (outg[2].y & ~himask);
+            const unsigned g1x = (outg[1].x & himask) | (outg[3].x & ~himask), g1y = (outg[1].y & himask) | (outg[3].y & ~himask);
+            uint2 got[2];
+            got[0].x = __shfl_xor(g0x, 16); got[0].y = __shfl_xor(g0y, 16);
+            got[1].x = __shfl_xor(g1x, 16); got[1].y = __shfl_xor(g1y, 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                uint2 own;
+                own.x = (outg[2 + i].x & himask) | (outg[i].x & ~himask);
+                own.y = (outg[2 + i].y & himask) | (outg[i].y & ~himask);
+                v16[i] = hi ? (u32x4_t){got[i].x, got[i].y, own.x, own.y} : (u32x4_t){own.x, own.y, got[i].x, got[i].y};
+            }
+            if (t > 0 && live) {
+                const unsigned soff_out = (unsigned)((long long)t * S.img_stride);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    uint2 own;
-                    own.x = (outg[2 + i].x & himask) | (outg[i].x & ~himask);
-                    own.y = (outg[2 + i].y & himask) | (outg[i].y & ~himask);
-                    v16[i] = hi ? (u32x4_t){got[i].x, got[i].y, own.x, own.y} : (u32x4_t){own.x, own.y, got[i].x, got[i].y};
-                }
-                if (t > 0 && live) {
-                    const unsigned soff_out = (unsigned)((long long)t * S.img_stride);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int kc = kc0 + i * 16;
-                        const int ks = kc >> 5, kg = (kc >> 3) & 3;
-                        __builtin_amdgcn_raw_buffer_store_b128(
-                            v16[i], rimg, (unsigned)(((ks * MT + (crow >> 4)) * 64 + kg * 16 + (crow & 15)) * 16), soff_out, 16);
-                    }
+                    const int kc = kc0 + i * 16;
+                    const int ks = kc >> 5, kg = (kc >> 3) & 3;
+                    __builtin_amdgcn_raw_buffer_store_b128(
+                        v16[i], rimg, (unsigned)(((ks * MT + (crow >> 4)) * 64 + kg * 16 + (crow & 15)) * 16), soff_out, 16);
                 }
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) __hip_atomic_fetch_add(cnt_arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            SK_STAMP(4);
-            // ---- (7) off the chain: the dG rows the dX / weight-gradient products read (later kernels, ordered by an
-            // event behind this launch), the same two chunks; then the next frame's cell operands
-            if (live) {
-                bf16_t* G_t = S.G - (long long)s * B * H4 + (long long)crow * H4 + kc0;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4_t*>(G_t + i * 16) = v16[i];
-            }
-            if (s + 1 < S.nsteps) request_operands(s + 1);
-            SK_STAMP(5);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(cnt_arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        SK_STAMP(4);
+        // ---- (7) off the chain: the dG rows the dX / weight-gradient products read (later kernels, ordered by an event
+        // behind this launch), the same two chunks; then the next frame's cell operands
+        if (live) {
+            bf16_t* G_t = S.G - (long long)s * B * H4 + (long long)crow * H4 + kc0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4_t*>(G_t + i * 16) = v16[i];
+        }
+        if (s + 1 < S.nsteps) request_operands(s + 1);
+        SK_STAMP(5);
     }
 #undef SK_STAMP
     if (TRACE && tr) {
@@ -1400,11 +1341,6 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
         atomicAdd((unsigned long long*)(o + 7), 1ull);
     }
     if (live) *reinterpret_cast<float4*>(S.dC + (long long)crow * H + unit0) = dc;
-    // partials of the last products that nobody has been told about (sub-batches behind this workgroup's finishing
-    // block): their finishers are still waiting
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0 && !bail_s) flush_pending();
     if (L.stamp) {
         __syncthreads();
         if (threadIdx.x == 0) atomicMax(&L.stamp[1], wall_clock64());
@@ -1694,28 +1630,11 @@ int ed_stack_pack_sk(const float* w_hh, bf16_t* out, int H, hipStream_t s) {
     return ED_OK;
 }
 
-// sub-batches per workgroup: 16-row MFMA tiles cannot be split, so a batch of <= 32 rows advances as one
-static int subs_for(int B, const char* env, int dflt) {
-    const char* e = getenv(env);
-    int n = e ? atoi(e) : dflt;
-    if (n != 1 && n != 2 && n != 4) n = dflt;
-    const int MT = (B + 15) >> 4;
-    while (n > 1 && MT <= 4 - 4 / n) n >>= 1;       // the last sub-batch must hold a live row tile (B <= 64; the forward's
-    return n;                                       // second row group at B > 64 may idle in some)
-}
-// (default 1: with counters on the chain the sub-batches lose - the deferred arrival comes a whole product late, and a
-// gather of half the rows takes 2.3 of the 3.2 us of the full one - measured 5.1 -> 5.9 ms forward, 9.0 -> 9.2 ms BPTT)
-int ed_stack_sk_subs(int B) { return subs_for(min(B, 64), "EDGEDICT_SK_SUB", 1); }
-int ed_stack_lpw_subs(int B) { return subs_for(min(B, 64), "EDGEDICT_LPW_SUB", 1); }
-
 int ed_stack_launch_bwd_sk(const EdSkLaunch& L, hipStream_t s) {
     const int grid = L.nslot * (L.H >> 6) * 4;
     if (grid == 0) return ED_OK;
-    ED_CHECK_ARG(L.nsub == 1 || L.nsub == 2 || L.nsub == 4, "stack_bwd_sk: 1, 2 or 4 sub-batches");
-#define ED_SK_LAUNCH(TR, NSUB) hipLaunchKernelGGL((stack_bwd_sk_kernel<TR, NSUB>), dim3(grid), dim3(256), SK_RING * SK_SLOT, s, L)
-    if (L.trace) { if (L.nsub == 4) ED_SK_LAUNCH(true, 4); else if (L.nsub == 2) ED_SK_LAUNCH(true, 2); else ED_SK_LAUNCH(true, 1); }
-    else { if (L.nsub == 4) ED_SK_LAUNCH(false, 4); else if (L.nsub == 2) ED_SK_LAUNCH(false, 2); else ED_SK_LAUNCH(false, 1); }
-#undef ED_SK_LAUNCH
+    if (L.trace) hipLaunchKernelGGL(stack_bwd_sk_kernel<true>, dim3(grid), dim3(256), SK_RING * SK_SLOT, s, L);
+    else hipLaunchKernelGGL(stack_bwd_sk_kernel<false>, dim3(grid), dim3(256), SK_RING * SK_SLOT, s, L);
     ED_CHECK_LAUNCH("stack_bwd_sk_kernel");
     return ED_OK;
 }
@@ -1730,12 +1649,9 @@ int ed_stack_launch_fwd_lpw(const EdLpwLaunch& L, hipStream_t s) {
     const int UB = L.H >> 4, RG = (L.B + 63) >> 6;
     const int grid = L.nslot * UB * RG;
     if (grid == 0) return ED_OK;
-    ED_CHECK_ARG(L.nsub == 1 || L.nsub == 2 || L.nsub == 4, "stack_fwd_lpw: 1, 2 or 4 sub-batches");
-#define ED_LPW_LAUNCH(TR, NSUB, DPOLL) hipLaunchKernelGGL((stack_fwd_lpw_kernel<TR, NSUB, DPOLL>), dim3(grid), dim3(256), 0, s, L)
-#define ED_LPW_LAUNCH_N(TR, DPOLL) do { if (L.nsub == 4) ED_LPW_LAUNCH(TR, 4, DPOLL); else if (L.nsub == 2) ED_LPW_LAUNCH(TR, 2, DPOLL); else ED_LPW_LAUNCH(TR, 1, DPOLL); } while (0)
-    if (L.trace) { if (L.data_poll) ED_LPW_LAUNCH_N(true, true); else ED_LPW_LAUNCH_N(true, false); }
-    else { if (L.data_poll) ED_LPW_LAUNCH_N(false, true); else ED_LPW_LAUNCH_N(false, false); }
-#undef ED_LPW_LAUNCH_N
+#define ED_LPW_LAUNCH(TR, DPOLL) hipLaunchKernelGGL((stack_fwd_lpw_kernel<TR, DPOLL>), dim3(grid), dim3(256), 0, s, L)
+    if (L.trace) { if (L.data_poll) ED_LPW_LAUNCH(true, true); else ED_LPW_LAUNCH(true, false); }
+    else { if (L.data_poll) ED_LPW_LAUNCH(false, true); else ED_LPW_LAUNCH(false, false); }
 #undef ED_LPW_LAUNCH
     ED_CHECK_LAUNCH("stack_fwd_lpw_kernel");
     return ED_OK;

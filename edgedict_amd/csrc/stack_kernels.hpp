@@ -73,7 +73,8 @@ struct EdBwdLaunch {
 // counter and exchange h through the fragment images with write-through stores / L2-served loads.
 struct EdLpwSlot {
     bf16_t* G;                 // step t0: [B, 4H] interleaved (in pre-activations, out gates); step t0+s at + s*B*4H
-    bf16_t* img;               // h fragment images [T+1][H/32][B16/16][64][8], ONE PER FRAME: step t reads image t
+    bf16_t* img;               // h fragment images [T+1][H/32][B16/16][64][8], ONE PER FRAME (data polling: images 1 .. T hold
+                               // all ones before the pass - a reader recognises what is not written yet): step t reads image t
                                // (h_{t-1}), writes image t+1.  No address is written twice inside a forward
                                // pass, so no cache can hold a stale copy: readers use plain loads and the
                                // 8 workgroups of a layer that share an XCD fetch an image over the fabric once
@@ -84,9 +85,10 @@ struct EdLpwSlot {
     const float* C_prev;       // c_{t0-1} [B, H]
     float* C;                  // c rows of step t0; step t0+s at + s*B*H
     const bf16_t* Wfrag;       // W_hh B-fragment image (EdFwdStep::Wfrag)
-    unsigned* counter;         // arrivals of this layer's workgroups, one per finished step and SUB-BATCH: sub-batch j counts
-                               // on counter[j * LPW_CNT_STRIDE] (EdLpwLaunch::nsub of them, zeroed per call)
-    unsigned base;             // every counter once every step < t0 is done = workgroups_per_step * (steps done before)
+    unsigned* counter;         // arrivals of this layer's workgroups, one per finished step (zeroed per call).  Data polling:
+                               // only the side streams read it (stack_wait_counters_kernel), and the arrival of a step
+                               // comes one step late
+    unsigned base;             // *counter once every step < t0 is done = workgroups_per_step * (steps done before)
     const unsigned* wait_flag; // null, or: step t0 opens a chunk whose side-stream product is done when != 0
     int t0, nsteps;
     int layer;                 // for the debug trace only
@@ -94,14 +96,11 @@ struct EdLpwSlot {
 constexpr int LPW_CNT_STRIDE = 64;   // words between arrival counters: each has its own 256-byte line (the four layers of a
                                      // launch are polled by 256 lanes and bumped 256 times per step - in ONE line they queued
                                      // in one memory channel: 4-slot launches 80-127 us per 6 steps instead of 50-56)
-constexpr int LPW_MAX_SUB = 4;       // sub-batches per workgroup (counter lines per layer)
 struct EdLpwLaunch {
     EdLpwSlot slot[ED_STACK_MAX_SLOTS];
     int nslot;
     int data_poll;               // 1: the images were filled with all-ones before the pass and the readers validate what they
                                  // gather (no counter on the dependency chain); 0: the readers poll the arrival counters
-    int nsub;                    // 1: the workgroup's 64 rows advance together; 2 / 4: as 32- / 16-row sub-batches, alternately
-                                 // (ed_stack_lpw_subs), each with its own arrival counter - bit-identical results
     int B, H;
     unsigned long long* stamp;   // as EdFwdLaunch::stamp
     unsigned* err;               // host-visible give-up word (may be null)
@@ -124,7 +123,6 @@ struct EdChunkNorm {
 int ed_stack_wait_counters(const unsigned* const* counters, const unsigned* targets, int n, unsigned* err, hipStream_t s);
 int ed_stack_multi_norm(const EdChunkNorm* items, int n, int B, int H, float eps, hipStream_t s);
 int ed_stack_lpw_supported(int B, int H);     // 1 when the launch-persistent forward kernel covers this geometry
-int ed_stack_lpw_subs(int B);                 // sub-batches the forward kernel runs this batch in (EDGEDICT_LPW_SUB overrides)
 
 // ---- split-K, weights-stationary BPTT (stack_kernels.hip, stack_bwd_sk_kernel; needs B <= 64, H % 64 == 0,
 // H <= 1024).  The launch-per-step BPTT moves 512 KB into every CU per step (W_hh^T slice 256 KB + dG image
@@ -132,8 +130,8 @@ int ed_stack_lpw_subs(int B);                 // sub-batches the forward kernel 
 // columns) for all 64 rows: its W_hh^T slice is 128 KB and stays in 128 registers per lane for the whole launch,
 // the only dependent fetch of a step is its quarter of the dG image (128 KB).  The four workgroups of a unit
 // block exchange their partial sums (16 KB fp32 each, write-through) and each finishes 16 of the 64 rows.
-constexpr int SK_CNT_QUARTER = 64;    // first quarter-counter line of a layer's gcounter block (behind 16 unit blocks x 4 sub-batches)
-constexpr int SK_CNT_LINES = 96;      // 256-byte counter lines per layer: unit-block counters [0, 64), quarter counters [64, 80)
+constexpr int SK_CNT_QUARTER = 16;    // first quarter-counter line of a layer's gcounter block (behind the 16 unit blocks)
+constexpr int SK_CNT_LINES = 32;      // 256-byte counter lines per layer: unit-block counters [0, 16), quarter counters [16, 20)
 struct EdSkSlot {
     bf16_t* G;                 // frame t0 [B, 4H] interleaved (in gates, out dL/d(pre-activation)); frame t0-s at - s*B*4H
     bf16_t* img;               // dG fragment images [T + 1][4H/32][B16/16][64][8], one per frame: step t reads image t+1
@@ -144,10 +142,10 @@ struct EdSkSlot {
     float* dC;                 // [B, H] running dL/dc, in/out
     const bf16_t* Wsk;         // split-K fragment image of W_hh (edgedict_stack_pack_sk)
     float* part;               // [2][H/64][4][64][64] f32 partial sums, ping-pong by step parity
-    unsigned* counter;         // H % 256 != 0 only: the layer's finishers of sub-batch j arrive on counter[j * LPW_CNT_STRIDE]
-    unsigned* gcounter;        // lines of 64 words: [ub * nsub + j] the 4 workgroups of unit block ub, one arrival each per step
-                               // once their partial of sub-batch j is in memory; [SK_CNT_QUARTER + q * nsub + j] (H % 256 == 0)
-                               // the finishers of sub-batch j that write quarter q of the gate columns, one arrival per step
+    unsigned* counter;         // H % 256 != 0: the layer's workgroups, one arrival per finished step
+    unsigned* gcounter;        // lines of 64 words: [ub] the 4 workgroups of unit block ub, one arrival each per step once
+                               // their partial is in memory; [SK_CNT_QUARTER + q] (H % 256 == 0) the workgroups that write
+                               // quarter q of the gate columns, one arrival per step
     unsigned done;             // BPTT steps of this layer done before this launch (every counter is a multiple of it)
     const unsigned* wait_flag;
     int t0, nsteps, T, layer;
@@ -155,8 +153,6 @@ struct EdSkSlot {
 struct EdSkLaunch {
     EdSkSlot slot[ED_STACK_MAX_SLOTS];
     int nslot;
-    int nsub;                  // sub-batches (1, 2 or 4 = 64, 32 or 16 rows advanced alternately; ed_stack_sk_subs); every
-                               // value gives bit-identical results
     int B, H;
     unsigned long long* stamp;
     unsigned* err;
@@ -164,7 +160,6 @@ struct EdSkLaunch {
 };
 int ed_stack_launch_bwd_sk(const EdSkLaunch& L, hipStream_t s);
 int ed_stack_sk_supported(int B, int H);
-int ed_stack_sk_subs(int B);                  // sub-batches the split-K BPTT kernel runs this batch in (EDGEDICT_SK_SUB overrides)
 int ed_stack_pack_sk(const float* w_hh, bf16_t* out, int H, hipStream_t s);
 
 // kernels / launchers implemented in stack_kernels.hip

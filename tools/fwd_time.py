@@ -18,8 +18,8 @@ enc.compute_dtype = torch.bfloat16
 xs = torch.randn(B, T0, 240, device="cuda")
 for p in enc.parameters():          # gradients accumulate in place (flat-buffer training does the same)
     p.grad = torch.zeros_like(p)
-KEYS = {"LPW": "EDGEDICT_STACK_LPW", "STEPS": "EDGEDICT_LPW_STEPS", "MARGIN": "EDGEDICT_LPW_MARGIN", "SUB": "EDGEDICT_LPW_SUB", "POLL": "EDGEDICT_LPW_POLL", "SKPOLL": "EDGEDICT_SK_POLL",
-        "SK": "EDGEDICT_STACK_BWD_SK", "SKSTEPS": "EDGEDICT_SK_STEPS", "SKSUB": "EDGEDICT_SK_SUB", "MARGINB": "EDGEDICT_LPW_MARGIN_B"}
+KEYS = {"LPW": "EDGEDICT_STACK_LPW", "STEPS": "EDGEDICT_LPW_STEPS", "MARGIN": "EDGEDICT_LPW_MARGIN", "POLL": "EDGEDICT_LPW_POLL", 
+        "SK": "EDGEDICT_STACK_BWD_SK", "SKSTEPS": "EDGEDICT_SK_STEPS", "MARGINB": "EDGEDICT_LPW_MARGIN_B"}
 for spec in sys.argv[1:] or ["LPW=0"]:
     kv = dict(x.split("=") for x in spec.split(","))
     for k, v in kv.items():
