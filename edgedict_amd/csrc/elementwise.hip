@@ -661,3 +661,46 @@ extern "C" int edgedict_grad_clip_coef(const float* g, long long n, float max_no
     ED_CHECK_LAUNCH("grad_clip_coef");
     return ED_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// Measurement aid (tools/rccl_footprint.py, tests/test_dp_gpu.py): a stand-in for what a collective library's
+// resident kernels take from the chip while the launch-persistent recurrence kernels run - `workgroups` workgroups
+// of 512 threads that hold >= 128 registers per lane and stream `bytes` of `buf` (read, add 0, write) `passes`
+// times.  No 8-GPU node is available to the builder; this answers whether such a kernel on the auxiliary stream
+// starves a recurrence launch into its bounded-spin give-up.
+namespace {
+__global__ __launch_bounds__(512) void footprint_kernel(float4* __restrict__ buf, long long n16, int passes) {
+    float4 keep[32];                                   // 128 live registers per lane, as a ring kernel's staging
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 32; ++k) keep[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = 0; p < passes; ++p) {
+        for (long long i = i0; i < n16; i += stride * 32) {
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const long long j = i + (long long)k * stride;
+                if (j < n16) keep[k] = buf[j];
+            }
+#pragma unroll
+            for (int k = 0; k < 32; ++k) {
+                const long long j = i + (long long)k * stride;
+                if (j < n16) {
+                    float4 v = keep[k];
+                    v.x += 0.f; v.y += 0.f; v.z += 0.f; v.w += 0.f;
+                    buf[j] = v;
+                }
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int edgedict_debug_footprint(float* buf, long long n_floats, int workgroups, int passes, void* stream) {
+    ED_CHECK_ARG(buf && n_floats >= 4 && workgroups > 0 && passes > 0, "debug_footprint: bad arguments");
+    hipLaunchKernelGGL(footprint_kernel, dim3(workgroups), dim3(512), 0, (hipStream_t)stream,
+                       reinterpret_cast<float4*>(buf), n_floats / 4, passes);
+    ED_CHECK_LAUNCH("footprint_kernel");
+    return ED_OK;
+}
+

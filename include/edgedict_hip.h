@@ -437,6 +437,12 @@ int edgedict_adam_step_guarded(float* p, const float* g, float* m, float* v, lon
                                void* stream);
 int edgedict_grad_clip_coef(const float* g, long long n, float max_norm, float pre_scale,
                             float* sumsq_ws, float* coef, float* norm_out, void* stream);
+/* measurement aid, not on the hot path: a stand-in for a collective library's resident kernels - `workgroups`
+ * workgroups of 512 threads with >= 128 live registers per lane that read-modify-write buf[0, n_floats) `passes`
+ * times (values unchanged).  tools/rccl_footprint.py runs it on the auxiliary stream at every grads_final point of
+ * the backward pass (where cli/lightning.py:325-331's bucketed all-reduce would run) to see what the recurrence
+ * launches lose to it and that no bounded in-kernel wait gives up. */
+int edgedict_debug_footprint(float* buf, long long n_floats, int workgroups, int passes, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Log-mel filterbank front-end.  Replaces FilterbankFeatures.forward (rnnt/features.py:106-152,

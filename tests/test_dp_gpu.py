@@ -111,3 +111,93 @@ def test_two_ranks_equal_one_process_on_the_whole_batch(hip_lib):
         assert abs(both - losses[k]) <= 2e-2 * abs(losses[k]), (k, both, losses[k])
     diff = (got[0][1] - ref).abs().max().item()
     assert diff <= 5e-4, diff                                # two Adam steps of lr 1e-3, bf16 activations
+
+
+def _run_py(code, env_extra, timeout=600):
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=timeout, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    import json
+    return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+
+_ONE_RANK = """
+import json, os, sys, torch
+sys.path.insert(0, %r)
+import bench
+from edgedict_amd import encoder_stack, side
+from edgedict_amd.flags import make_flags
+from edgedict_amd.trainer import TrainEngine
+torch.cuda.set_device(0)
+dev = torch.device("cuda", 0)
+side.stream(dev)
+if os.environ.get("EDGEDICT_DP_FORCE") == "1":
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+flags = make_flags("E6D2", gradclip=None, dither=0.0)
+flags.preset_name = "E6D2"
+flags.sub_batch_size = 64
+torch.manual_seed(0)
+eng = TrainEngine(flags, device=dev, compute_dtype="bf16")
+eng.spec_augment = None                      # (random masks would differ between the two processes)
+data = bench.synth_batch(flags, 64, 15.0, 64, 1000, dev)
+losses = [float(eng.train_step(*data)) for _ in range(2)]
+torch.cuda.synchronize()
+encoder_stack.check_wsr_error()              # no bounded in-kernel wait gave up (the Adam steps were applied)
+red = eng.reducer
+p = eng.flat.data.double()
+print(json.dumps({"losses": losses, "sum": float(p.sum()), "sumsq": float((p * p).sum()),
+                  "probe": [float(x) for x in eng.flat.data[::1000003][:40]],
+                  "fwd_mode": encoder_stack.last_mode(False), "bwd_mode": encoder_stack.last_mode(True),
+                  "early": red.last_issued_early, "buckets": len(red.bounds), "by": list(red.last_early_by)}))
+"""
+
+
+@pytest.mark.timeout(900)
+def test_one_rank_rccl_with_the_default_kernels_equals_no_exchange(hip_lib):
+    """the DEFAULT kernels (launch-persistent forward, split-K BPTT: all workgroups of a layer must be
+    co-resident and wait for each other inside a launch) next to a real RCCL communicator - one rank, the only one a
+    one-GPU box can host, EDGEDICT_DP_FORCE=1 so that every bucket goes through the real issue path (hooks, ready()
+    from inside the backward pass on the auxiliary stream, finish()).  Full E6D2 size (B = 64 x 15 s: 256 resident
+    workgroups per recurrence launch), two training steps: no give-up word, both default kernels ran, the buckets
+    left during the backward pass, and the parameters equal those of the same two steps without any exchange
+    (a one-rank all-reduce is the identity, 1/N = 1)."""
+    from edgedict_amd import encoder_stack
+    code = _ONE_RANK % ROOT
+    port = 29800 + (os.getpid() % 1500)
+    ex = _run_py(code, {"EDGEDICT_DP_FORCE": "1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    ref = _run_py(code, {"EDGEDICT_DP_FORCE": "0"})
+    assert tuple(ex["fwd_mode"]) == (1, encoder_stack.CHUNK) and tuple(ex["bwd_mode"]) == (2, encoder_stack.CHUNK), ex
+    assert ex["buckets"] >= 8 and ex["early"] >= 7 and ex["by"].count("ready") >= 7, ex
+    assert ref["early"] == 0
+    for a, b in zip(ex["losses"], ref["losses"]):
+        assert abs(a - b) <= 1e-5 * abs(b), (ex["losses"], ref["losses"])
+    # fp32 atomics in a few small products order differently from run to run: equal to ~1e-6 of the values
+    assert abs(ex["sum"] - ref["sum"]) <= 1e-6 * abs(ref["sumsq"]) ** 0.5 + 1e-3, (ex["sum"], ref["sum"])
+    assert abs(ex["sumsq"] - ref["sumsq"]) <= 1e-6 * ref["sumsq"], (ex["sumsq"], ref["sumsq"])
+    for a, b in zip(ex["probe"], ref["probe"]):
+        assert abs(a - b) <= 1e-4 * max(abs(b), 1e-3), (a, b)
+
+
+@pytest.mark.timeout(900)
+def test_collective_footprint_stand_in_does_not_starve_the_recurrence_launches(hip_lib):
+    """32 workgroups x 512 threads x >= 128 registers streaming each layer's 34 MB gradient slice on the
+    auxiliary stream at every grads_final point (what RCCL's ring kernels would occupy while the BPTT of the layers
+    below runs): the training step still completes on the default kernels and no bounded wait gives up
+    (tools/rccl_footprint.py raises otherwise; the table for 0 / 16 / 32 / 64 workgroups is in DESIGN 7)."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rccl_footprint.py"), "0", "32"],
+                       capture_output=True, text=True, timeout=840, cwd=ROOT)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    import json
+    rows = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert [x["workgroups"] for x in rows] == [0, 32]
+    from edgedict_amd import encoder_stack
+    for x in rows:
+        assert tuple(x["fwd_mode"]) == (1, encoder_stack.CHUNK) and tuple(x["bwd_mode"]) == (2, encoder_stack.CHUNK), x
+    assert rows[1]["footprint_launches_per_step"] >= 7, rows
+    assert rows[1]["ms_per_step"] < 3.0 * rows[0]["ms_per_step"], rows
+
