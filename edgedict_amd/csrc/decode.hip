@@ -462,13 +462,70 @@ __global__ void beam_init(BeamPtrs p, int B, int W) {
     if (b == 0) { p.flags[0] = p.flags[1] = 0; *p.total_exp = 0; }
 }
 
+// ---- prefix=True (models.py:145-161): the prediction-network output of every expansion is kept per token-tree node
+// (the reference's Sequence.g), and at the start of a frame the host - which owns the list logic of that branch -
+// asks for log p(token | frame t, stored prediction) of a batch of (utterance, node, token) queries
+template <typename T>
+__global__ void beam_store_pred(BeamPtrs p, const T* __restrict__ dec_new, T* __restrict__ node_pred, int EM,
+                                int NODES, int P2) {
+    const int b = blockIdx.x;
+    if (!p.open[b]) return;
+    const int node = p.exp_node[b * EM + p.e_count[b]];        // -1 = the empty hypothesis: slot 0
+    T* dst = node_pred + ((size_t)b * (NODES + 1) + (node + 1)) * P2;
+    for (int i = threadIdx.x; i < P2; i += blockDim.x) dst[i] = dec_new[(size_t)b * P2 + i];
+}
+template <typename T>
+__global__ void beam_query_gather(const T* __restrict__ node_pred, const int32_t* __restrict__ q_row,
+                                  const int32_t* __restrict__ q_node, T* __restrict__ q_pred, int NODES, int P2) {
+    const int q = blockIdx.x;
+    const T* src = node_pred + ((size_t)q_row[q] * (NODES + 1) + (q_node[q] + 1)) * P2;
+    for (int i = threadIdx.x; i < P2; i += blockDim.x) q_pred[(size_t)q * P2 + i] = src[i];
+}
+// hid[q, :] = tanh(E1[row(q), frame t, :] + D1[q, :])
+template <typename T>
+__global__ void beam_query_hidden(const T* __restrict__ E1t, long long e_stride, const int32_t* __restrict__ q_row,
+                                  const T* __restrict__ D1, T* __restrict__ hid, int J) {
+    const int q = blockIdx.x;
+    const T* e = E1t + (long long)q_row[q] * e_stride;
+    for (int j = threadIdx.x; j < J; j += blockDim.x)
+        ElemIO<T>::store(hid + (size_t)q * J + j, tanhf(ElemIO<T>::load(e + j) + ElemIO<T>::load(D1 + (size_t)q * J + j)));
+}
+// out[q] = log_softmax(logits[q, :])[tok(q)], the arithmetic of beam_expand
+__global__ __launch_bounds__(256) void beam_query_logp(const float* __restrict__ logits, const int32_t* __restrict__ q_tok,
+                                                       float* __restrict__ out, int V) {
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const float* z = logits + (size_t)q * V;
+    __shared__ float sf[256];
+    float m = -INFINITY;
+    for (int v = tid; v < V; v += 256) m = fmaxf(m, z[v]);
+    sf[tid] = m;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) sf[tid] = fmaxf(sf[tid], sf[tid + off]);
+        __syncthreads();
+    }
+    m = sf[0];
+    __syncthreads();
+    float sm = 0.f;
+    for (int v = tid; v < V; v += 256) sm += expf(z[v] - m);
+    sf[tid] = sm;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) sf[tid] += sf[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) out[q] = (z[q_tok[q]] - m) - logf(sf[0]);
+}
+constexpr int BEAM_QMAX = 1024;      // queries per batch of the prefix branch
+
 struct BeamWs {
     Ws step;   // the greedy loop's per-iteration buffers (prediction-network step + joint)
     size_t h_state, c_state;
     size_t pool, bp_logp, bp_node, n_bp, bp_h0, bp_h1, bp_c0, bp_c1, bn_logp, bn_node, bn_ref, n_b, max_b,
         exp_node, exp_ref, exp_logp, e_count, f_h, f_c, nodes, n_nodes, open, lens, flags, total_exp, total;
+    size_t node_pred, q_row, q_node, q_tok, q_pred, q_D1, q_hid, q_logits, q_out;      // prefix = 1 only
 };
-inline BeamWs beam_layout(int esz, int B, int T, int J, int V, int E, int L, int H, int P2, int W, int EM) {
+inline BeamWs beam_layout(int esz, int B, int T, int J, int V, int E, int L, int H, int P2, int W, int EM, int prefix) {
     BeamWs w;
     w.step = ws_layout(esz, B, J, V, E, L, H, P2);
     size_t o = w.step.total;
@@ -501,6 +558,18 @@ inline BeamWs beam_layout(int esz, int B, int T, int J, int V, int E, int L, int
     w.lens = take((size_t)B * 4);
     w.flags = take(8);
     w.total_exp = take(8);
+    w.node_pred = w.q_row = w.q_node = w.q_tok = w.q_pred = w.q_D1 = w.q_hid = w.q_logits = w.q_out = 0;
+    if (prefix) {
+        w.node_pred = take((size_t)B * (NODES + 1) * P2 * esz);
+        w.q_row = take((size_t)BEAM_QMAX * 4);
+        w.q_node = take((size_t)BEAM_QMAX * 4);
+        w.q_tok = take((size_t)BEAM_QMAX * 4);
+        w.q_pred = take((size_t)BEAM_QMAX * P2 * esz);
+        w.q_D1 = take((size_t)BEAM_QMAX * J * esz);
+        w.q_hid = take((size_t)BEAM_QMAX * J * esz);
+        w.q_logits = take((size_t)BEAM_QMAX * V * 4);
+        w.q_out = take((size_t)BEAM_QMAX * 4);
+    }
     w.total = o;
     return w;
 }
@@ -508,9 +577,9 @@ inline BeamWs beam_layout(int esz, int B, int T, int J, int V, int E, int L, int
 }  // namespace
 
 extern "C" size_t edgedict_beam_workspace_bytes(int dtype, int B, int T, int J, int V, int E, int L,
-                                                int H, int P2, int W, int max_expansions) {
+                                                int H, int P2, int W, int max_expansions, int prefix) {
     if (B <= 0 || W <= 0 || max_expansions <= 0) return 0;
-    return beam_layout(dtype == ED_F32 ? 4 : 2, B, T < 0 ? 0 : T, J, V, E, L, H, P2, W, max_expansions).total;
+    return beam_layout(dtype == ED_F32 ? 4 : 2, B, T < 0 ? 0 : T, J, V, E, L, H, P2, W, max_expansions, prefix).total;
 }
 
 extern "C" int edgedict_beam_search(
@@ -519,7 +588,7 @@ extern "C" int edgedict_beam_search(
     const void* W2, const float* b2, int V, const void* emb, int emb_dtype, int E, int L,
     const void* const* w_ih, const void* const* w_hh, const float* const* b_ih,
     const float* const* b_hh, int H, const void* Wp, const float* bp, int blank, int bos, int W,
-    int max_expansions, int32_t* tokens_host, int max_tokens, int32_t* ntokens_host,
+    int max_expansions, int prefix, int32_t* tokens_host, int max_tokens, int32_t* ntokens_host,
     double* score_host, long long* expansions_host, void* workspace, void* stream_) {
     ED_CHECK_ARG(dtype == ED_F32 || dtype == ED_BF16, "beam_search: bad dtype");
     ED_CHECK_ARG(B > 0 && T >= 0 && J > 0 && V > 0 && L > 0 && H > 0 && P2 > 0 && E > 0 && W > 0 &&
@@ -534,7 +603,7 @@ extern "C" int edgedict_beam_search(
     hipStream_t s = (hipStream_t)stream_;
     const int esz = dtype == ED_F32 ? 4 : 2, EM = max_expansions;
     const int NODES = T * EM + 1;
-    const BeamWs w = beam_layout(esz, B, T, J, V, E, L, H, P2, W, EM);
+    const BeamWs w = beam_layout(esz, B, T, J, V, E, L, H, P2, W, EM, prefix);
     char* p = (char*)workspace;
     void* D1 = p + w.step.D1;
     void* hid = p + w.step.hid;
@@ -589,10 +658,122 @@ extern "C" int edgedict_beam_search(
     int maxlen = 0;
     for (int b = 0; b < B; ++b) maxlen = lens_host[b] > maxlen ? lens_host[b] : maxlen;
 
+    // ---- prefix = 1: host mirrors for the list logic of models.py:145-161
+    long long prefix_steps = 0;                 // prediction-network steps the reference spends in that branch
+    std::vector<int32_t> nbp_h, node_h, nn_h, qrow, qnode, qtok;
+    std::vector<double> logp_h;
+    std::vector<int2> nodes_h;
+    std::vector<float> qout;
+    void* node_pred = prefix ? (void*)(p + w.node_pred) : nullptr;
+    auto prefix_merge = [&](int t, const char* e1t) -> int {
+        nbp_h.resize(B); node_h.resize((size_t)B * W); logp_h.resize((size_t)B * W); nn_h.resize(B);
+        ED_CHECK_HIP(hipMemcpyAsync(nbp_h.data(), q.n_bp, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+        ED_CHECK_HIP(hipStreamSynchronize(s));
+        bool any = false;
+        for (int b = 0; b < B; ++b) any = any || (t < lens_host[b] && nbp_h[b] > 1);
+        if (!any) return ED_OK;
+        nodes_h.resize((size_t)B * NODES);
+        ED_CHECK_HIP(hipMemcpyAsync(node_h.data(), q.bp_node, node_h.size() * 4, hipMemcpyDeviceToHost, s));
+        ED_CHECK_HIP(hipMemcpyAsync(logp_h.data(), q.bp_logp, logp_h.size() * 8, hipMemcpyDeviceToHost, s));
+        ED_CHECK_HIP(hipMemcpyAsync(nn_h.data(), q.n_nodes, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+        ED_CHECK_HIP(hipMemcpyAsync(nodes_h.data(), q.nodes, nodes_h.size() * 8, hipMemcpyDeviceToHost, s));
+        ED_CHECK_HIP(hipStreamSynchronize(s));
+        // every (j, i > j) with A[i] a proper prefix of A[j]: the tokens of A[j] behind A[i], each with the prediction
+        // stored at the node before it on A[j]'s path (g; the first one is the prediction of A[i]'s sequence)
+        struct Pair { int b, j, i, q0, nq; };
+        std::vector<Pair> pairs;
+        qrow.clear(); qnode.clear(); qtok.clear();
+        std::vector<std::vector<int>> paths(W);                   // per list entry: its nodes, last token first
+        for (int b = 0; b < B; ++b) {
+            if (t >= lens_host[b]) continue;
+            const int n = nbp_h[b];
+            const int2* nd = nodes_h.data() + (size_t)b * NODES;
+            for (int j = 0; j < n; ++j) {
+                paths[j].clear();
+                for (int x = node_h[(size_t)b * W + j]; x >= 0; x = nd[x].x) paths[j].push_back(x);
+            }
+            for (int j = 0; j + 1 < n; ++j) {
+                const std::vector<int>& pj = paths[j];
+                const int lj = (int)pj.size();
+                for (int i = j + 1; i < n; ++i) {
+                    // isprefix(A[i].k, A[j].k), by VALUE: the same token sequence can sit in the list twice, as two
+                    // nodes (a hypothesis that survived as a blank child AND was re-created from its parent)
+                    const std::vector<int>& pi = paths[i];
+                    const int li = (int)pi.size();
+                    if (li >= lj) continue;
+                    bool pre = true;
+                    for (int d = 0; d < li && pre; ++d) pre = nd[pi[li - 1 - d]].y == nd[pj[lj - 1 - d]].y;
+                    if (!pre) continue;
+                    Pair pr{b, j, i, (int)qrow.size(), lj - li};
+                    for (int d = lj - li - 1; d >= 0; --d) {      // tokens of A[j] behind A[i], in order
+                        qrow.push_back(b);
+                        qnode.push_back(nd[pj[d]].x);             // g: the prediction stored at the node before it (-1: root)
+                        qtok.push_back(nd[pj[d]].y);
+                    }
+                    pairs.push_back(pr);
+                }
+            }
+        }
+        if (pairs.empty()) return ED_OK;
+        const int NQ = (int)qrow.size();
+        qout.resize(NQ);
+        int32_t* d_row = (int32_t*)(p + w.q_row);
+        int32_t* d_node = (int32_t*)(p + w.q_node);
+        int32_t* d_tok = (int32_t*)(p + w.q_tok);
+        void* d_pred = p + w.q_pred;
+        void* d_D1 = p + w.q_D1;
+        void* d_hid = p + w.q_hid;
+        float* d_logits = (float*)(p + w.q_logits);
+        float* d_out = (float*)(p + w.q_out);
+        for (int q0 = 0; q0 < NQ; q0 += BEAM_QMAX) {
+            const int nq = std::min(BEAM_QMAX, NQ - q0);
+            int rc;
+            ED_CHECK_HIP(hipMemcpyAsync(d_row, qrow.data() + q0, (size_t)nq * 4, hipMemcpyHostToDevice, s));
+            ED_CHECK_HIP(hipMemcpyAsync(d_node, qnode.data() + q0, (size_t)nq * 4, hipMemcpyHostToDevice, s));
+            ED_CHECK_HIP(hipMemcpyAsync(d_tok, qtok.data() + q0, (size_t)nq * 4, hipMemcpyHostToDevice, s));
+            if (dtype == ED_F32)
+                hipLaunchKernelGGL(beam_query_gather<float>, dim3(nq), dim3(64), 0, s, (const float*)node_pred, d_row,
+                                   d_node, (float*)d_pred, NODES, P2);
+            else
+                hipLaunchKernelGGL(beam_query_gather<bf16_t>, dim3(nq), dim3(64), 0, s, (const bf16_t*)node_pred, d_row,
+                                   d_node, (bf16_t*)d_pred, NODES, P2);
+            if ((rc = edgedict_gemm(dtype, dtype, d_pred, P2, 1, W1d, ldw1, 1, d_D1, J, nq, J, P2, b1, nullptr, 0, 1, s)))
+                return rc;
+            if (dtype == ED_F32)
+                hipLaunchKernelGGL(beam_query_hidden<float>, dim3(nq), dim3(128), 0, s, (const float*)e1t, e_row_stride,
+                                   d_row, (const float*)d_D1, (float*)d_hid, J);
+            else
+                hipLaunchKernelGGL(beam_query_hidden<bf16_t>, dim3(nq), dim3(128), 0, s, (const bf16_t*)e1t, e_row_stride,
+                                   d_row, (const bf16_t*)d_D1, (bf16_t*)d_hid, J);
+            if ((rc = edgedict_gemm(dtype, ED_F32, d_hid, J, 1, W2, J, 1, d_logits, V, nq, V, J, b2, nullptr, 0, 1, s)))
+                return rc;
+            hipLaunchKernelGGL(beam_query_logp, dim3(nq), dim3(256), 0, s, d_logits, d_tok, d_out, V);
+            ED_CHECK_HIP(hipMemcpyAsync(qout.data() + q0, d_out, (size_t)nq * 4, hipMemcpyDeviceToHost, s));
+            ED_CHECK_HIP(hipStreamSynchronize(s));
+        }
+        // A[j].logp = log_aplusb(A[j].logp, A[i].logp + sum): j ascending, i ascending; A[i] (i > j) still holds the
+        // value it had when the frame began (its own turn as a "j" comes later)
+        for (const Pair& pr : pairs) {
+            double cur = logp_h[(size_t)pr.b * W + pr.i];
+            for (int k = 0; k < pr.nq; ++k) cur += (double)qout[pr.q0 + k];
+            double& a = logp_h[(size_t)pr.b * W + pr.j];
+            const double hi = a > cur ? a : cur;
+            a = hi + log1p(exp(-fabs(a - cur)));
+            ++prefix_steps;
+        }
+        ED_CHECK_HIP(hipMemcpyAsync(q.bp_logp, logp_h.data(), logp_h.size() * 8, hipMemcpyHostToDevice, s));
+        ED_CHECK_HIP(hipStreamSynchronize(s));       // (logp_h is reused by the next frame)
+        return ED_OK;
+    };
+
     int cur = 0;
     for (int t = 0; t < maxlen; ++t) {
-        hipLaunchKernelGGL(beam_frame_begin, dim3(B), dim3(64), 0, s, q, t, W, EM * V);
         const char* e1t = (const char*)E1 + (size_t)t * e_frame_stride * esz;
+        if (prefix && t > 0) {
+            const int rc = prefix_merge(t, e1t);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL(beam_frame_begin, dim3(B), dim3(64), 0, s, q, t, W, EM * V);
         for (int it = 0;; ++it) {
             int rc;
             hipLaunchKernelGGL(beam_pop, dim3(B), dim3(256), 0, s, q, cur, W, V, EM, L, H, B, NODES,
@@ -617,6 +798,14 @@ extern "C" int edgedict_beam_search(
             if ((rc = edgedict_gemm(dtype, dtype, xin, H, 1, Wp, H, 1, dec_new, P2, B, P2, H, bp,
                                     nullptr, 0, 1, s)))
                 return rc;
+            if (prefix) {        // Sequence.g of the children (models.py:183): this expansion's prediction, kept per node
+                if (dtype == ED_F32)
+                    hipLaunchKernelGGL(beam_store_pred<float>, dim3(B), dim3(64), 0, s, q, (const float*)dec_new,
+                                       (float*)node_pred, EM, NODES, P2);
+                else
+                    hipLaunchKernelGGL(beam_store_pred<bf16_t>, dim3(B), dim3(64), 0, s, q, (const bf16_t*)dec_new,
+                                       (bf16_t*)node_pred, EM, NODES, P2);
+            }
             // joint(x_t, pred) (models.py:165): D1 = pred W1d^T + b1; hid = tanh(E1[:,t] + D1); logits
             if ((rc = edgedict_gemm(dtype, dtype, dec_new, P2, 1, W1d, ldw1, 1, D1, J, B, J, P2, b1,
                                     nullptr, 0, 1, s)))
@@ -661,7 +850,7 @@ extern "C" int edgedict_beam_search(
     ED_CHECK_HIP(hipStreamSynchronize(s));
     ED_CHECK_ARG(!flags[0], "beam_search: an utterance needed more than max_expansions = %d expansions in one frame", EM);
     ED_CHECK_ARG(!flags[1], "beam_search: token tree overflow");
-    if (expansions_host) *expansions_host = total;
+    if (expansions_host) *expansions_host = total + prefix_steps;
     std::vector<int32_t> rev;
     for (int b = 0; b < B; ++b) {
         rev.clear();

@@ -95,10 +95,11 @@ def greedy_decode_batch(model, xs, xlen):
     return [seq[:int(n)] for seq, n in zip(toks, lens)], score
 
 
-def beam_search_batch(model, xs, xlen=None, W=10, max_expansions=None):
+def beam_search_batch(model, xs, xlen=None, W=10, max_expansions=None, prefix=False):
     """Graves (2012) beam search as the reference's legacy ``Transducer.beam_search`` runs it
-    (models.py:121-202 with ``prefix=False``), batched: every utterance keeps its own A / B sets
-    and all open utterances advance one expansion per lockstep iteration on the device.
+    (models.py:121-202), batched: every utterance keeps its own A / B sets and all open utterances
+    advance one expansion per lockstep iteration on the device.  ``prefix=True`` is the reference's
+    prefix-sum variant (:145-161): see ``edgedict_beam_search`` in include/edgedict_hip.h.
 
     xs [B, T0, I]; xlen (host or device int tensor, stacked frames) or None for "all frames".
     Returns ``(list of int64 arrays (tokens, no blanks), fp64 tensor [B] = -log p)``: per
@@ -134,7 +135,7 @@ def beam_search_batch(model, xs, xlen=None, W=10, max_expansions=None):
     b_ih = [dec.lstm.layer(k)[2].detach() for k in range(L)]
     b_hh = [dec.lstm.layer(k)[3].detach() for k in range(L)]
     lib = _lib.load()
-    nbytes = lib.edgedict_beam_workspace_bytes(dtype_code(cd), B, T, J, V, E, L, H, P2, W, EM)
+    nbytes = lib.edgedict_beam_workspace_bytes(dtype_code(cd), B, T, J, V, E, L, H, P2, W, EM, int(bool(prefix)))
     ws = torch.empty(nbytes, dtype=torch.uint8, device=enc_out.device)
     max_tokens = T * EM + 1
     tokens = np.zeros((B, max_tokens), dtype=np.int32)
@@ -149,7 +150,7 @@ def beam_search_batch(model, xs, xlen=None, W=10, max_expansions=None):
         _lib.ptr(l1.bias.detach()), P2, _lib.ptr(w2c), _lib.ptr(l2.bias.detach()), V,
         _lib.ptr(dec.embed.weight.detach()), dtype_code(dec.embed.weight.dtype), E, L,
         _ptr_array(w_ih), _ptr_array(w_hh), _ptr_array(b_ih), _ptr_array(b_hh), H, _lib.ptr(wpc),
-        _lib.ptr(dec.proj.bias.detach()), int(model.blank), int(BOS), int(W), EM,
+        _lib.ptr(dec.proj.bias.detach()), int(model.blank), int(BOS), int(W), EM, int(bool(prefix)),
         tokens.ctypes.data_as(ctypes.c_void_p), max_tokens, ntok.ctypes.data_as(ctypes.c_void_p),
         score.ctypes.data_as(ctypes.c_void_p), ctypes.byref(nexp), _lib.ptr(ws), _lib.stream_ptr())
     _lib.check(rc, "beam_search")

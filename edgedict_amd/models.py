@@ -924,12 +924,9 @@ class Transducer(nn.Module):
 
     def beam_search(self, xs, xlen=None, W=10, prefix=False, max_expansions=None):
         """Beam search of the reference's legacy model (models.py:121-202), batched; see
-        ``decode.beam_search_batch``.  ``prefix=True`` (the prefix-sum variant, :145-161) is not
-        implemented."""
-        if prefix:
-            raise NotImplementedError("beam_search(prefix=True) is not implemented")
+        ``decode.beam_search_batch``.  ``prefix=True`` is its prefix-sum variant (:145-161)."""
         from .decode import beam_search_batch
-        return beam_search_batch(self, xs, xlen, W, max_expansions)
+        return beam_search_batch(self, xs, xlen, W, max_expansions, prefix=prefix)
 
 
 class _CausalConvFn(torch.autograd.Function):

@@ -560,21 +560,28 @@ int edgedict_gelu_groupnorm_bwd(int dtype, const void* y, const void* dout, cons
 long long edgedict_blaslt_calls(void);
 
 /* ------------------------------------------------------------------------------------
- * Batched beam search: the reference's legacy Transducer.beam_search (models.py:121-202,
- * prefix=False; Sequence models.py:212-224) for B utterances in lockstep, over the maintained
- * model's prediction network and joint.  Operands as edgedict_greedy_decode, plus
+ * Batched beam search: the reference's legacy Transducer.beam_search (models.py:121-202; Sequence
+ * models.py:212-224) for B utterances in lockstep, over the maintained model's prediction network and
+ * joint.  Operands as edgedict_greedy_decode, plus
  *   lens_host        HOST int32 [B]: encoder frames of each utterance (<= T)
  *   bos              the token the empty hypothesis feeds first (BOS = 2, zero state)
  *   W                beam width;  max_expansions >= W: cap on pops per utterance and frame
  *                    (exceeding it is an error, never a silent truncation)
  *   tokens_host      HOST int32 [B, max_tokens]: tokens of B[0] (no blanks, no BOS)
  *   ntokens_host     HOST int32 [B];  score_host HOST fp64 [B] = -log p of that hypothesis
- *   expansions_host  HOST, nullable: total number of expansions (pops) performed
+ *   prefix           0 / 1: the `prefix` argument of the reference method.  1 = models.py:145-161: at the start of every
+ *                    frame the probability of reaching a hypothesis A[j] through a later list entry A[i] that is a
+ *                    proper prefix of it (the missing tokens emitted on this frame, each from the prediction-network
+ *                    output stored when that position was expanded - Sequence.g) is folded into logp(A[j]) with
+ *                    log_aplusb, pairs in the reference's order.  The list logic runs on the host (the call already
+ *                    synchronises every lockstep iteration), the joint evaluations as one batched device pass per frame
+ *   expansions_host  HOST, nullable: total number of prediction-network steps (pops; with prefix = 1 also one per
+ *                    merged pair, as the reference spends them)
  * Scores are accumulated in fp64 from fp32 log-softmax values, as the reference's Python floats
  * are.  The call synchronises the stream (the loop's stop test is data dependent).
  */
 size_t edgedict_beam_workspace_bytes(int dtype, int B, int T, int J, int V, int E, int L, int H,
-                                     int P2, int W, int max_expansions);
+                                     int P2, int W, int max_expansions, int prefix);
 int edgedict_beam_search(int dtype, const void* E1, long long e_row_stride,
                          long long e_frame_stride, int B, int T, const int32_t* lens_host, int J,
                          const void* W1d, long long ldw1, const float* b1, int P2, const void* W2,
@@ -582,7 +589,7 @@ int edgedict_beam_search(int dtype, const void* E1, long long e_row_stride,
                          const void* const* w_ih, const void* const* w_hh,
                          const float* const* b_ih, const float* const* b_hh, int H,
                          const void* Wp, const float* bp, int blank, int bos, int W,
-                         int max_expansions, int32_t* tokens_host, int max_tokens,
+                         int max_expansions, int prefix, int32_t* tokens_host, int max_tokens,
                          int32_t* ntokens_host, double* score_host, long long* expansions_host,
                          void* workspace, void* stream);
 

@@ -92,7 +92,7 @@ class _LegacySelf:
         return self.m.joint(x, pred)
 
 
-def reference_search(cfg, sd, xs, xlen, W):
+def reference_search(cfg, sd, xs, xlen, W, prefix=False):
     import warnings
     from oracle.make_golden import reference_model
     m = reference_model(cfg, sd)
@@ -105,7 +105,7 @@ def reference_search(cfg, sd, xs, xlen, W):
         for b in range(xs.shape[0]):
             stub = _LegacySelf(m, M.NUL, cfg["vocab_size"])
             stub.frames = int(lens[b])
-            k, neg = fn(stub, xs[b:b + 1], W=W)
+            k, neg = fn(stub, xs[b:b + 1], W=W, prefix=prefix)
             assert k[0] == 1                  # the legacy start token
             seqs.append(np.array(k[1:], dtype=np.int64))
             scores.append(float(neg))
@@ -163,6 +163,25 @@ def main():
         out["W%d_expansions" % W] = np.array([n])
         out["ref_W%d_score" % W] = rscores
         out["ref_W%d_expansions" % W] = np.array([rn])
+    # ---- the prefix=True branch (models.py:145-161): the same two searches with the flag set
+    for W in WIDTHS[1:]:
+        seqs, scores, n = beam_ref.beam_search(sd, xs, xlen, W=W, prefix=True)
+        rseqs, rscores, rn = reference_search(CFG, sd, xs, xlen, W, prefix=True)
+        plain = [out["W%d_seq%d" % (W, b)].tolist() for b in range(len(seqs))]
+        print("prefix W=%d" % W, [s.tolist() for s in seqs], scores, "expansions", n, "| reference-executed:",
+              [s.tolist() for s in rseqs], rscores, rn, "| differs from prefix=False:",
+              [s.tolist() for s in seqs] != plain or not np.allclose(scores, out["W%d_score" % W], rtol=1e-9))
+        for a, b in zip(seqs, rseqs):
+            assert np.array_equal(a, b), (W, a, b)
+        assert (np.abs(scores - rscores) / np.abs(rscores)).max() < 1e-6, (W, scores, rscores)
+        assert n == rn, (W, n, rn)
+        for b, sq in enumerate(seqs):
+            out["P_W%d_seq%d" % (W, b)] = sq
+            out["ref_P_W%d_seq%d" % (W, b)] = rseqs[b]
+        out["P_W%d_score" % W] = scores
+        out["P_W%d_expansions" % W] = np.array([n])
+        out["ref_P_W%d_score" % W] = rscores
+        out["ref_P_W%d_expansions" % W] = np.array([rn])
     g, gs = M.greedy_decode(sd, xs, xlen)
     print("greedy", [[int(t) for t in s if t != 0] for s in g], "labels", [y[:n].tolist() for y, n in zip(ys, ylen)])
     np.savez_compressed(path, **out)

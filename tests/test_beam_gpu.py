@@ -53,6 +53,34 @@ def test_beam_matches_committed_oracle_vectors(hip_lib, W):
     assert decode.beam_search_batch.last_expansions == int(G["ref_W%d_expansions" % W][0])
 
 
+@pytest.mark.parametrize("W", [2, 4, 10])
+def test_beam_prefix_branch_matches_the_reference_executed_vectors(hip_lib, W):
+    """``beam_search(prefix=True)`` (models.py:145-161): tokens and the number of prediction-network steps equal to
+    what the reference's own function returned when executed with the flag (``ref_P_*``), scores as for prefix=False."""
+    from edgedict_amd import decode
+    sd, xs, xlen = _golden()
+    m = _engine(sd)
+    with torch.no_grad():
+        seqs, scores = m.beam_search(xs.cuda(), xlen, W=W, prefix=True)
+    for b, s in enumerate(seqs):
+        assert np.array_equal(s, G["ref_P_W%d_seq%d" % (W, b)]), (W, b, s)
+    np.testing.assert_allclose(scores.numpy(), G["ref_P_W%d_score" % W], rtol=2e-4, atol=2e-4)
+    assert decode.beam_search_batch.last_expansions == int(G["ref_P_W%d_expansions" % W][0])
+
+
+def test_beam_prefix_branch_random_model_ragged_batch_matches_oracle(hip_lib):
+    sd = M.make_state_dict(CFG, 3)
+    xs, ys, xlen, ylen = M.make_batch(CFG, 4, 5, 17, 4)
+    xlen = torch.tensor([17, 9, 17, 3, 12], dtype=torch.int32)
+    m = _engine(sd)
+    with torch.no_grad():
+        seqs, scores = m.beam_search(xs.cuda(), xlen, W=3, max_expansions=400, prefix=True)
+    rs, rsc, _ = beam_ref.beam_search(sd, xs, xlen, W=3, prefix=True)
+    for a, b in zip(seqs, rs):
+        assert np.array_equal(a, b)
+    np.testing.assert_allclose(scores.numpy(), rsc, rtol=2e-4, atol=2e-4)
+
+
 def test_beam_random_model_ragged_batch_matches_oracle(hip_lib):
     sd = M.make_state_dict(CFG, 3)
     xs, ys, xlen, ylen = M.make_batch(CFG, 4, 5, 17, 4)
@@ -84,8 +112,6 @@ def test_beam_expansion_cap_is_an_error_not_a_truncation(hip_lib):
     m = _engine(sd)
     with pytest.raises(RuntimeError, match="max_expansions"):
         m.beam_search(xs.cuda(), xlen, W=1, max_expansions=1)
-    with pytest.raises(NotImplementedError):
-        m.beam_search(xs.cuda(), xlen, W=2, prefix=True)
 
 
 def test_beam_bf16_runs_and_returns_valid_tokens(hip_lib):

@@ -41,6 +41,22 @@ def test_oracle_reproduces_the_reference_executed_search(W):
     assert n == int(G["ref_W%d_expansions" % W][0])
 
 
+@pytest.mark.parametrize("W", WIDTHS[1:])
+def test_oracle_prefix_branch_reproduces_the_reference_executed_search(W):
+    """``prefix=True`` (models.py:145-161), the lifted reference function run with the flag set: tokens and the number
+    of prediction-network steps exactly, scores to 1e-6; and the branch is not a no-op on these vectors (the scores
+    move by 0.15 - 1.1 against prefix=False)."""
+    sd, xs, xlen = load()
+    seqs, scores, n = beam_ref.beam_search(sd, xs, xlen, W=W, prefix=True)
+    for b, s in enumerate(seqs):
+        assert np.array_equal(s, G["ref_P_W%d_seq%d" % (W, b)])
+        assert np.array_equal(s, G["P_W%d_seq%d" % (W, b)])
+    np.testing.assert_allclose(scores, G["ref_P_W%d_score" % W], rtol=1e-6)
+    assert n == int(G["ref_P_W%d_expansions" % W][0]) == int(G["P_W%d_expansions" % W][0])
+    assert np.abs(G["ref_P_W%d_score" % W] - G["ref_W%d_score" % W]).max() > 0.1
+    assert n > int(G["ref_W%d_expansions" % W][0])
+
+
 def test_score_is_the_log_probability_of_one_alignment():
     """-score must be <= the total log-probability of the returned label sequence (it is the
     probability of a single path through the lattice), and for W = 10 the trained model recovers
