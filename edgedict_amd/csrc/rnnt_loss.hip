@@ -9,10 +9,10 @@
 // Three HBM-/latency-shaped kernels, none of them GEMM-shaped (no MFMA here on purpose):
 //   1. rnnt_lse_gather : one wave64 per lattice cell row (V logits), 16-byte coalesced loads,
 //                        online max/sum, writes denominator + blank/label log-probs.   HBM-bound.
-//   2. rnnt_alpha_beta : one workgroup per (utterance, direction); one lane per label position,
-//                        anti-diagonal sweep, u-1 / u+1 neighbour exchanged through a
-//                        double-buffered LDS line, next diagonal's log-probs prefetched
-//                        before the barrier.                                   latency-bound.
+//   2. rnnt_alpha_beta : one WAVE per (utterance, direction); a lane owns ceil(U1/64) label columns and
+//                        runs one row behind its left neighbour, whose hand-over arrives by a DPP
+//                        shuffle (no LDS, no barrier), next row's log-probs requested a step ahead.
+//                                                                              latency-bound.
 //   3. rnnt_grad       : one wave64 per row again; reads logits once, writes grads once. HBM-bound.
 #include "common.hpp"
 
@@ -151,121 +151,124 @@ __global__ __launch_bounds__(256) void rnnt_lse_from_parts(
 }
 
 // log(exp(a)+exp(b)) with float64 carry: only the add/sub/max are fp64, the correction term
-// log1p(exp(-|a-b|)) in [0, ln 2] is evaluated in fp32 (abs error ~1e-7).
+// log(1 + exp(-|a-b|)) in [0, ln 2] is evaluated in fp32 on the hardware transcendental units (v_exp_f32 /
+// v_log_f32, ~1 ulp each: abs error ~1e-7, the same order as libm's log1pf(expf(.)) - whose ~100 dependent
+// instructions were 90 % of a lattice step: the recurrence is a chain of T + U of these)
 __device__ __forceinline__ double log_add64(double a, double b) {
     const double m = fmax(a, b);
     if (m == -(double)INFINITY) return m;
     const float d = (float)(fmin(a, b) - m);  // <= 0, may be -inf
-    return m + (double)log1pf(expf(d));
+    return m + (double)__logf(1.f + __expf(d));
 }
 
 // ------------------------------------------------------------------ kernel 2
-// blockIdx.x = 2*b + dir  (dir 0: alpha, dir 1: beta).  blockDim.x = roundup(U1, 64).
-// Thread u owns lattice column u.  At diagonal d the live cell of column u is t = d - u
-// (alpha) or the mirrored one (beta).
-__global__ void rnnt_alpha_beta(const float* __restrict__ lpb, const float* __restrict__ lpl,
-                                const int32_t* __restrict__ act_lens,
-                                const int32_t* __restrict__ label_lens, int Tm, int U1,
-                                double* __restrict__ alphas, double* __restrict__ betas,
-                                double* __restrict__ ll) {
-    extern __shared__ __attribute__((aligned(16))) double xch[];  // [2][blockDim.x + 2]
+// ONE WAVE per (utterance, direction): blockIdx.x = 2*b + dir (dir 0: alpha, dir 1: beta), 64 threads.  Lane l owns
+// the C = ceil(U1 / 64) consecutive label columns [C l, C l + C) (beta: counted from the right end) and walks them
+// down the frames one row per step, one step behind lane l - 1: at step s it is in row s - l.  What a cell needs from
+// the column to its left (alpha: a(t,u-1) + lp_label(t,u-1); beta: b(t,u+1)) was produced by the SAME lane one
+// statement earlier or by lane l - 1 in the step before - a register handed up one lane with a DPP shuffle; what it
+// needs from the row above is the lane's own value of the step before.  No LDS, no barrier: T + ceil(U1/C) - 1 steps
+// of C dependent log-adds each (E6D2: 233 steps of 2, against 265 diagonals with a workgroup barrier and an LDS round
+// trip each: 0.17 -> 0.03 ms).  Per cell the arithmetic and its operand order are those of the barrier kernel it
+// replaces (fp64 carry, fp32 correction term): alphas, betas and the likelihoods are bit-identical.
+template <int C>
+__global__ __launch_bounds__(64) void rnnt_alpha_beta(const float* __restrict__ lpb, const float* __restrict__ lpl,
+                                                      const int32_t* __restrict__ act_lens,
+                                                      const int32_t* __restrict__ label_lens, int Tm, int U1,
+                                                      double* __restrict__ alphas, double* __restrict__ betas,
+                                                      double* __restrict__ ll) {
+    // log-probabilities are requested D steps ahead of their use (a step is ~0.3 us of dependent arithmetic, an L2
+    // round trip ~1 us: one step ahead the recurrence waited for its loads on every row - 0.30 instead of 0.17 ms)
+    constexpr int D = C <= 2 ? 8 : (C <= 4 ? 4 : (C <= 8 ? 2 : 1));
     const int b = blockIdx.x >> 1;
     const int dir = blockIdx.x & 1;
-    const int u = threadIdx.x;
+    const int lane = threadIdx.x;
     // clamped exactly as rnnt_lse_gather / rnnt_grad clamp them: malformed lengths (the Python shim
-    // rejects them, a raw C-ABI caller may not) can neither index past the [Tm, U1] slab nor past
-    // the exchange buffer; an empty utterance (Tb <= 0) has likelihood 0 => cost +inf, never garbage
+    // rejects them, a raw C-ABI caller may not) cannot index past the [Tm, U1] slab; an empty utterance
+    // (Tb <= 0) has likelihood 0 => cost +inf, never garbage
     const int Tb = max(0, min(act_lens[b], Tm)), Ub = max(0, min(label_lens[b], U1 - 1));
     if (Tb == 0) {
-        if (threadIdx.x == 0) ll[2 * b + dir] = -(double)INFINITY;
+        if (lane == 0) ll[2 * b + dir] = -(double)INFINITY;
         return;
     }
-    const int stride = blockDim.x + 2;
     const long long base = (long long)b * Tm * U1;
-    const bool col_ok = (u <= Ub);
-    const int ndiag = Tb + Ub;  // diagonals 0 .. Tb+Ub-1
-
-    // both buffers start at -inf so that out-of-lattice neighbours contribute nothing
-    for (int i = threadIdx.x; i < 2 * stride; i += blockDim.x) xch[i] = -(double)INFINITY;
-    __syncthreads();
-
-    if (dir == 0) {
-        // ---------------- alpha: a(t,u) = lse(a(t-1,u)+lpb(t-1,u), a(t,u-1)+lpl(t,u-1))
-        double stay = -(double)INFINITY;  // a(t-1,u) + lpb(t-1,u), carried in a register
-        // prefetch log-probs of this column's first live cell (t = 0 at diagonal d = u)
-        float nb = 0.f, nl = 0.f;
-        if (col_ok && Tb > 0) {
-            nb = lpb[base + u];
-            nl = lpl[base + u];
-        }
-        for (int d = 0; d < ndiag; ++d) {
-            const int t = d - u;
-            const bool live = col_ok && t >= 0 && t < Tb;
-            double* cur = xch + (d & 1) * stride;
-            const double* prev = xch + ((d + 1) & 1) * stride;
-            if (live) {
-                const float cb = nb, cl = nl;
-                // prefetch (t+1, u) for the next diagonal
-                if (t + 1 < Tb) {
-                    const long long nidx = base + (long long)(t + 1) * U1 + u;
-                    nb = lpb[nidx];
-                    nl = lpl[nidx];
-                }
-                double a;
-                if (t == 0 && u == 0) {
-                    a = 0.0;
-                } else {
-                    const double from_left = prev[u];  // a(t,u-1)+lpl(t,u-1); slot u holds column u-1
-                    a = log_add64(stay, from_left);
-                }
-                alphas[base + (long long)t * U1 + u] = a;
-                stay = a + cb;
-                cur[u + 1] = (u < Ub) ? a + cl : -(double)INFINITY;
-                if (t == Tb - 1 && u == Ub) ll[2 * b] = a + cb;
-            } else {
-                cur[u + 1] = -(double)INFINITY;
+    const int nlanes = (Ub + C) / C;                 // lanes that own a column <= Ub
+    const int nsteps = Tb + nlanes - 1;
+    const double NEG = -(double)INFINITY;
+    double keep[C];                                  // alpha: a(t-1,u) + lp_blank(t-1,u);  beta: b(t+1,u)
+#pragma unroll
+    for (int c = 0; c < C; ++c) keep[c] = NEG;
+    double out_last = NEG;                           // what the lane to the right needs from this lane's last step
+    // column of slot c: alpha u = C lane + c; beta u = Ub - (C lane + c); row number r of this lane -> frame
+    auto col = [&](int c) { return dir == 0 ? C * lane + c : Ub - (C * lane + c); };
+    auto frame = [&](int r) { return dir == 0 ? r : Tb - 1 - r; };
+    float qb[D][C], ql[D][C];                        // ring by STEP: slot s % D holds the row this lane is in at step s
+    auto request = [&](int j, int r) {               // (static j)
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const int u = col(c);
+            float vb = 0.f, vl = 0.f;
+            if (lane < nlanes && r >= 0 && r < Tb && u >= 0 && u <= Ub) {
+                const long long idx = base + (long long)frame(r) * U1 + u;
+                vb = lpb[idx];
+                vl = lpl[idx];
             }
-            __syncthreads();
+            qb[j][c] = vb;
+            ql[j][c] = vl;
         }
-    } else {
-        // ---------------- beta: b(t,u) = lse(b(t+1,u)+lpb(t,u), b(t,u+1)+lpl(t,u))
-        // mirrored diagonal index e = (Tb-1-t) + (Ub-u)
-        double up = -(double)INFINITY;  // b(t+1,u)
-        float nb = 0.f, nl = 0.f;
-        if (col_ok && Tb > 0) {
-            const long long idx = base + (long long)(Tb - 1) * U1 + u;
-            nb = lpb[idx];
-            nl = lpl[idx];
-        }
-        for (int e = 0; e < ndiag; ++e) {
-            const int t = Tb - 1 - (e - (Ub - u));
-            const bool live = col_ok && t >= 0 && t < Tb;
-            double* cur = xch + (e & 1) * stride;
-            const double* prev = xch + ((e + 1) & 1) * stride;
+    };
+#pragma unroll
+    for (int j = 0; j < D; ++j) request(j, j - lane);
+    for (int s0 = 0; s0 < nsteps; s0 += D) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            const int s = s0 + j;
+            if (s >= nsteps) break;
+            const int r = s - lane;                  // rows done before this one
+            const bool live = lane < nlanes && r >= 0 && r < Tb;
+            // lane l - 1's hand-over of the step before (same row): a whole-wave shift by one lane as two DPP moves
+            // (wave_shr:1 - __shfl_up goes through the LDS crossbar and waits for it on every step)
+            double side = __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(out_last), 0x138, 0xf, 0xf, false),
+                                           __builtin_amdgcn_update_dpp(0, __double2loint(out_last), 0x138, 0xf, 0xf, false));
+            if (lane == 0) side = NEG;
+            float cb[C], cl[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) { cb[c] = qb[j][c]; cl[c] = ql[j][c]; }
+            request(j, r + D);                       // the row of step s + D
             if (live) {
-                const float cb = nb, cl = nl;
-                if (t - 1 >= 0) {
-                    const long long nidx = base + (long long)(t - 1) * U1 + u;
-                    nb = lpb[nidx];
-                    nl = lpl[nidx];
+                const int t = frame(r);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const int u = col(c);
+                    if (u < 0 || u > Ub) continue;
+                    const long long idx = base + (long long)t * U1 + u;
+                    if (dir == 0) {
+                        // a(t,u) = lse(a(t-1,u) + lpb(t-1,u), a(t,u-1) + lpl(t,u-1))
+                        const double a = (t == 0 && u == 0) ? 0.0 : log_add64(keep[c], side);
+                        alphas[idx] = a;
+                        keep[c] = a + cb[c];
+                        side = (u < Ub) ? a + cl[c] : NEG;
+                        if (t == Tb - 1 && u == Ub) ll[2 * b] = a + cb[c];
+                    } else {
+                        // b(t,u) = lse(b(t+1,u) + lpb(t,u), b(t,u+1) + lpl(t,u))
+                        double bv;
+                        if (t == Tb - 1 && u == Ub) {
+                            bv = cb[c];
+                        } else {
+                            const double via_label = (u < Ub) ? side + cl[c] : NEG;
+                            const double via_blank = (t < Tb - 1) ? keep[c] + cb[c] : NEG;
+                            bv = log_add64(via_blank, via_label);
+                        }
+                        betas[idx] = bv;
+                        keep[c] = bv;
+                        side = bv;
+                        if (t == 0 && u == 0) ll[2 * b + 1] = bv;
+                    }
                 }
-                double bv;
-                if (t == Tb - 1 && u == Ub) {
-                    bv = cb;
-                } else {
-                    const double right = prev[u + 1];  // b(t,u+1) published by column u+1
-                    const double via_label = (u < Ub) ? right + cl : -(double)INFINITY;
-                    const double via_blank = (t < Tb - 1) ? up + cb : -(double)INFINITY;
-                    bv = log_add64(via_blank, via_label);
-                }
-                betas[base + (long long)t * U1 + u] = bv;
-                up = bv;
-                cur[u] = bv;
-                if (t == 0 && u == 0) ll[2 * b + 1] = bv;
+                out_last = side;
             } else {
-                cur[u] = -(double)INFINITY;
+                out_last = NEG;
             }
-            __syncthreads();
         }
     }
 }
@@ -453,10 +456,18 @@ static int loss_forward(const void* acts, int acts_dtype, const int32_t* labels,
                            denom, lpb, lpl, vec_ok, pk_off);
     ED_CHECK_LAUNCH("rnnt_lse_gather");
 
-    const int threads = ((U1 + 63) / 64) * 64;
-    const size_t lds = (size_t)2 * (threads + 2) * sizeof(double);
-    hipLaunchKernelGGL(rnnt_alpha_beta, dim3(2 * B), dim3(threads), lds, stream, lpb, lpl,
-                       act_lens, label_lens, T, U1, alphas, betas, ll);
+    // one wave per (utterance, direction), C = ceil(U1 / 64) label columns per lane (rounded up to a power of two)
+    ED_CHECK_ARG(U1 <= 64 * 32, "rnnt_loss_forward: more than 2047 labels per utterance (U1 = %d)", U1);
+#define ED_AB_LAUNCH(CC) hipLaunchKernelGGL(rnnt_alpha_beta<CC>, dim3(2 * B), dim3(64), 0, stream, lpb, lpl, act_lens, \
+                                            label_lens, T, U1, alphas, betas, ll)
+    const int cols = (U1 + 63) / 64;
+    if (cols <= 1) ED_AB_LAUNCH(1);
+    else if (cols <= 2) ED_AB_LAUNCH(2);
+    else if (cols <= 4) ED_AB_LAUNCH(4);
+    else if (cols <= 8) ED_AB_LAUNCH(8);
+    else if (cols <= 16) ED_AB_LAUNCH(16);
+    else ED_AB_LAUNCH(32);
+#undef ED_AB_LAUNCH
     ED_CHECK_LAUNCH("rnnt_alpha_beta");
     hipLaunchKernelGGL(rnnt_costs, dim3(1), dim3(256), 0, stream, ll, costs, B, reduced,
                        reduce_scale);
