@@ -256,15 +256,39 @@ def decode_rates(engine, flags, batch, device):
                 dt = (time.perf_counter() - t0) / reps
                 res["greedy_decode_" + name] = {"utterances_per_s": B / dt, "ms_per_batch": 1e3 * dt,
                                                 "x_real_time": B * seconds / dt, "batch": B}
-            same = sum(int((a == b).sum()) for a, b in zip(toks["bf16"], toks["fp32"]))
-            total = sum(len(a) for a in toks["fp32"])
-            nonblank = sum(int((a != 0).sum()) for a in toks["fp32"])
-            res["bf16_greedy_agreement"] = {
-                "frames": total, "equal": same, "fraction": same / max(1, total),
-                "nonblank_fraction_fp32": nonblank / max(1, total),
-                "utterances_identical": sum(int(np.array_equal(a, b)) for a, b in zip(toks["bf16"], toks["fp32"])),
-                "note": "greedy tokens (blanks included) of the bench batch, bf16 throughput mode vs fp32 parity mode "
-                        "(the mode pinned bit-exactly on the reference), engine weights after the timed steps"}
+            def agreement(tb, tf, what):
+                same = sum(int((a == b).sum()) for a, b in zip(tb, tf))
+                total = sum(len(a) for a in tf)
+                nonblank = sum(int((a != 0).sum()) for a in tf)
+                # frame of the first differing token per utterance (greedy search feeds its own output back: one flip
+                # changes the prediction-network state of everything behind it), as a histogram over 10 % bins of the
+                # utterance; "never" = identical
+                first = []
+                for a, b in zip(tb, tf):
+                    d = np.nonzero(np.asarray(a) != np.asarray(b))[0]
+                    first.append(None if len(d) == 0 else float(d[0]) / max(1, len(a)))
+                hist = [0] * 10
+                for f in first:
+                    if f is not None:
+                        hist[min(9, int(f * 10))] += 1
+                return {"frames": total, "equal": same, "fraction": same / max(1, total),
+                        "nonblank_fraction_fp32": nonblank / max(1, total),
+                        "utterances_identical": sum(f is None for f in first),
+                        "first_divergence_histogram_by_tenth_of_utterance": hist,
+                        "note": "greedy tokens (blanks included) of the bench batch, bf16 throughput mode vs fp32 parity "
+                                "mode (the mode pinned bit-exactly on the reference), " + what}
+            res["bf16_greedy_agreement"] = agreement(toks["bf16"], toks["fp32"], "engine weights after the timed steps")
+            # ... and on the SEEDED INITIAL weights (torch.manual_seed(0) model of this preset: a state every run of
+            # this file shares, unlike "after K noisy steps on random labels")
+            torch.manual_seed(0)
+            m0 = Transducer(**model_kwargs(flags, vocab_size=flags.bpe_size)).to(device).eval()
+            t0k = {}
+            for name in ("fp32", "bf16"):
+                m0.compute_dtype = name
+                t0k[name], _ = m0.greedy_decode(xs, xlen)
+            res["bf16_greedy_agreement_initial_weights"] = agreement(t0k["bf16"], t0k["fp32"],
+                                                                     "seeded initial weights (torch.manual_seed(0))")
+            del m0
     finally:
         model.compute_dtype = cd0
         model.train(was_training)
@@ -398,6 +422,15 @@ def main():
     dt = time.perf_counter() - t0
     timers = ops.timer_summary()
     ops.TIMERS = None
+    # host time of ONE step that starts on an idle device and is not waited for: what the host needs to enqueue a step
+    # when no full queue throttles it (inside the timed loop the host runs a queue ahead and blocks on its depth)
+    host_unthrottled = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        engine.train_step(*batch)
+        host_unthrottled.append(time.perf_counter() - h0)
+    barrier()
     left_early = engine.reducer.last_issued_early
     # world > 1: AFTER the timed region the same K steps run once more in the OTHER exchange mode (every bucket sent
     # after the backward pass, EDGEDICT_DP_OVERLAP=0), so that one multi-GPU run answers DESIGN 7's open question -
@@ -608,6 +641,7 @@ def main():
             },
             "kernel_ms": {k: round(v[1], 4) for k, v in sorted(timers.items())},
             "host_enqueue_ms_per_step": round(1e3 * host_s / args.steps, 3),
+            "host_unthrottled_ms": round(1e3 * min(host_unthrottled), 3),
             "host_call_ms": {k: round(v[1], 3) for k, v in sorted(ops.host_summary().items())},
         }
         out["roofline"] = stack if stack is not None else out["roofline_mfma"]

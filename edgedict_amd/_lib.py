@@ -58,6 +58,7 @@ def load():
         lib.edgedict_rnnt_workspace_view.restype = ctypes.c_void_p
         lib.edgedict_greedy_workspace_bytes.restype = ctypes.c_size_t
         lib.edgedict_beam_workspace_bytes.restype = ctypes.c_size_t
+        lib.edgedict_stream_encoder_workspace_bytes.restype = ctypes.c_size_t
         lib.edgedict_blaslt_calls.restype = ctypes.c_longlong
         lib.edgedict_gelu_groupnorm_bwd_workspace_bytes.restype = ctypes.c_size_t
         lib.edgedict_lstm_workspace_bytes.restype = ctypes.c_size_t

@@ -53,6 +53,11 @@ PACKED_LATTICE = os.environ.get("EDGEDICT_PACKED_LATTICE", "1") != "0"
 # (csrc/gemm_nt256.hip) instead of a separate pass over the logits (rnnt_lse_gather)
 FUSED_LSE = os.environ.get("EDGEDICT_FUSED_LSE", "1") != "0"
 
+# bf16 inference on a chunk shorter than STACK_MIN_FRAMES (the streaming decoder): one native call with a fused launch
+# per layer-frame instead of the per-layer kernels (EDGEDICT_STREAM_ENCODER_STEP=0 restores them)
+STREAM_ENCODER_STEP = os.environ.get("EDGEDICT_STREAM_ENCODER_STEP", "1") != "0"
+STREAM_STEP_MAX_ROWS = int(os.environ.get("EDGEDICT_STREAM_STEP_MAX_ROWS", "16"))
+
 # inputs shorter than this many frames use the per-layer path even in bf16 (see Encoder.forward)
 STACK_MIN_FRAMES = int(os.environ.get("EDGEDICT_STACK_MIN_FRAMES", "24"))
 

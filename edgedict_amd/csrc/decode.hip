@@ -15,6 +15,16 @@
 
 #include <vector>
 
+// decode_fused.hip: the bf16 frame as five fused launches
+bool ed_decode_fused_ok(int dtype, int J, int V, int E, int H, int P2);
+int ed_decode_fused_frame(const void* E1t, long long e_row_stride, int B, int J, const void* W1d, long long ldw1,
+                          const float* b1, int P2, const void* W2, const float* b2, int V, const void* emb,
+                          int emb_dtype, int E, int L, const void* const* w_ih, const void* const* w_hh,
+                          const float* const* b_ih, const float* const* b_hh, int H, const void* Wp, const float* bp,
+                          float* h_state, float* c_state, void* dec_out, int blank, int unk, int32_t* tokens_out,
+                          long long tok_stride, int t, float* score, void* hid, void* parts, int32_t* pred,
+                          float* h_new, float* c_new, void* Y0, void* Y1, hipStream_t s);
+
 namespace {
 
 // hid[b, :] = tanh(E1[b*e_stride + :] + D1[b, :])
@@ -170,8 +180,20 @@ extern "C" int edgedict_greedy_decode(
     float* c_new = (float*)(p + w.c_new);
     void* dec_new = p + w.dec_new;
 
+    // bf16: a frame is five fused launches (decode_fused.hip; the slice partials live in the logits buffer, which the
+    // fused frame never fills); fp32 parity mode and odd shapes: composed from the general kernels below
+    const bool fused = ed_decode_fused_ok(dtype, J, V, E, H, P2) && (size_t)V * 4 >= (size_t)((V + 255) / 256) * 32;
     for (int t = 0; t < T; ++t) {
         int rc;
+        if (fused) {
+            const char* e1f = (const char*)E1 + (size_t)t * e_frame_stride * esz;
+            if ((rc = ed_decode_fused_frame(e1f, e_row_stride, B, J, W1d, ldw1, b1, P2, W2, b2, V, emb, emb_dtype, E, L,
+                                            w_ih, w_hh, b_ih, b_hh, H, Wp, bp, h_state, c_state, dec_out, blank, unk,
+                                            tokens_out, tok_stride, t, score, hid, logits, pred, h_new, c_new, Y[0],
+                                            Y[1], s)))
+                return rc;
+            continue;
+        }
         // joint on frame t:  D1 = dec_out W1d^T + b1;  hid = tanh(E1[:,t] + D1);  logits (fp32)
         if ((rc = edgedict_gemm(dtype, dtype, dec_out, P2, 1, W1d, ldw1, 1, D1, J, B, J, P2, b1,
                                 nullptr, 0, 1, s)))

@@ -1,0 +1,519 @@
+// Fused per-frame kernels of the greedy / streaming RNN-T search (bf16 mode), gfx950.
+//
+// One search frame (Transducer.greedy_decode rnnt/models.py:254-263, PytorchStreamDecoder.decode
+// rnnt/stream.py:102-119) is a chain of small products over B rows - joint hidden [B x J x P2], logits
+// [B x V x J], the prediction network's L LSTM steps, its projection - each followed by a few elementwise ops.
+// Composed from the general kernels that is 11 launches per frame (decode.hip: product, add + tanh, product, pick,
+// embedding, L x (product + cell), product, commit), ~7 us each, with nothing else to overlap them: the loop was
+// launch-bound (80 us per frame, 2-3 % of what one pass over the 4.7 MB of weights costs).  Here a frame is FIVE
+// launches, each a product with its whole epilogue:
+//   1. dec_joint_hidden   hid = tanh(E1[:, t] + dec_out W1d^T + b1)
+//   2. dec_logits_pick    logits = hid W2^T + b2 in registers -> per row and 256-column slice: arg-max, arg-max
+//                         without <unk>, sum of exponentials (the logits never reach memory)
+//   3. dec_lstm_step      (first layer) final pick from the slices (+ the stream decoder's <unk> rule, + score),
+//                         token out, embedding, x W_ih^T + h W_hh^T + b, LSTM cell
+//   4. dec_lstm_step      (further layers)
+//   5. dec_proj_commit    dec_new = h W_p^T + b_p; where the symbol is not blank: dec_out, h, c <- new
+// Operands go straight from L2 into MFMA fragments (v_mfma_f32_16x16x32_bf16, the weights as the FIRST operand so
+// that a lane ends up with 4 consecutive output columns of one row): no LDS staging - every operand is used once per
+// workgroup.  Rows are independent and a row's arithmetic does not depend on its position in the batch, so S
+// concurrent streams equal S single-stream decoders bit for bit (tests/test_stream_gpu.py).
+// The fp32 parity mode keeps the composed path (exact-f32 products, pinned token-exact on the reference goldens).
+#include "common.hpp"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+
+__device__ __forceinline__ bf16x8_t ld8(const bf16_t* p) { return *reinterpret_cast<const bf16x8_t*>(p); }
+__device__ __forceinline__ bf16x8_t ld8_f32(const float* p) {       // 8 fp32 -> bf16 fragment
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    union { unsigned u[4]; bf16x8_t v; } r;
+    r.u[0] = f32x2_to_bf16x2(a.x, a.y); r.u[1] = f32x2_to_bf16x2(a.z, a.w);
+    r.u[2] = f32x2_to_bf16x2(b.x, b.y); r.u[3] = f32x2_to_bf16x2(b.z, b.w);
+    return r.v;
+}
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
+__device__ __forceinline__ float tanh_fast(float x) {
+    const float e = __expf(-2.f * fabsf(x));
+    const float t = (1.f - e) / (1.f + e);
+    return x < 0.f ? -t : t;
+}
+
+// acc[n] (+)= W[col0 + 16 n + .. 16][k] x X[row][k] over K (multiple of 32): lane (r16 = lane & 15, q = lane >> 4)
+// ends with acc[n][e] = out[row0 + r16][col0 + 16 n + 4 q + e].  Rows / columns past the end are clamped (their
+// results are garbage that the caller masks).
+template <int NT, typename XT>
+__device__ __forceinline__ void tile_product(f32x4_t (&acc)[NT], const XT* __restrict__ X, long long ldx, int row,
+                                             const bf16_t* __restrict__ W, long long ldw, int col0, int ncols, int K,
+                                             int lane) {
+    const int r16 = lane & 15, kq = lane >> 4;
+    const XT* xp = X + (long long)row * ldx + kq * 8;
+    const bf16_t* wp[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) wp[n] = W + (long long)min(col0 + n * 16 + r16, ncols - 1) * ldw + kq * 8;
+    // the operands of CH k-steps are requested together (these kernels run a wave or four per CU: nothing else hides
+    // an L2 round trip), then multiplied
+    constexpr int CH = NT == 1 ? 8 : 4;
+    for (int k0 = 0; k0 < K; k0 += 32 * CH) {
+        bf16x8_t a[CH], b[CH][NT];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int k = min(k0 + 32 * c, K - 32);          // (clamped: a repeated k-step is masked below)
+            if constexpr (sizeof(XT) == 4) a[c] = ld8_f32(reinterpret_cast<const float*>(xp) + k);
+            else a[c] = ld8(reinterpret_cast<const bf16_t*>(xp) + k);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) b[c][n] = ld8(wp[n] + k);
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (k0 + 32 * c < K) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[c][n], a[c], acc[n], 0, 0, 0);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- 1
+// hid[b, j] = tanh(E1[b, t, j] + bf16(dec_out[b] . W1d[j] + b1[j]));  one wave per (16 rows, 64 columns)
+__global__ __launch_bounds__(64) void dec_joint_hidden(const bf16_t* __restrict__ E1t, long long e_row_stride,
+                                                       const bf16_t* __restrict__ dec_out, int P2,
+                                                       const bf16_t* __restrict__ W1d, long long ldw1,
+                                                       const float* __restrict__ b1, bf16_t* __restrict__ hid,
+                                                       int B, int J) {
+    const int lane = threadIdx.x, r16 = lane & 15, q = lane >> 4;
+    const int row = blockIdx.x * 16 + r16, col0 = blockIdx.y * 64;
+    f32x4_t acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    tile_product<4>(acc, dec_out, P2, min(row, B - 1), W1d, ldw1, col0, J, P2, lane);
+    if (row >= B) return;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+        const int c = col0 + n * 16 + q * 4;
+        if (c >= J) continue;                      // (J % 4 == 0: a lane's 4 columns are in or out together)
+        const uint2 e = *reinterpret_cast<const uint2*>(E1t + (long long)row * e_row_stride + c);
+        const float ev[4] = {__uint_as_float(e.x << 16), __uint_as_float(e.x & 0xffff0000u),
+                             __uint_as_float(e.y << 16), __uint_as_float(e.y & 0xffff0000u)};
+        float h[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) h[i] = tanhf(ev[i] + bf16_to_f32(f32_to_bf16(acc[n][i] + b1[c + i])));
+        uint2 o;
+        o.x = f32x2_to_bf16x2(h[0], h[1]);
+        o.y = f32x2_to_bf16x2(h[2], h[3]);
+        *reinterpret_cast<uint2*>(hid + (long long)row * J + c) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- 2
+// per row and 256-column slice of the logits: (max, first arg-max), the same without column `unk`, sum of
+// exp(z - max).  4 waves = 4 x 64 columns of 16 rows.
+struct PickPart {
+    float m; int a;          // max over the slice, lowest index on ties
+    float mx; int ax;        // ... over the slice without column unk (-inf / INT_MAX if nothing is left)
+    float se;                // sum exp(z - m)
+    int pad[3];
+};
+__device__ __forceinline__ void pick_merge(float& m, int& a, float om, int oa) {
+    if (om > m || (om == m && oa < a)) { m = om; a = oa; }
+}
+__global__ __launch_bounds__(256) void dec_logits_pick(const bf16_t* __restrict__ hid, int J,
+                                                       const bf16_t* __restrict__ W2, const float* __restrict__ b2,
+                                                       int V, int unk, int want_sum, PickPart* __restrict__ parts,
+                                                       int B) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+    const int row = blockIdx.x * 16 + r16, col0 = blockIdx.y * 256 + wave * 64;
+    f32x4_t acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    tile_product<4>(acc, hid, J, min(row, B - 1), W2, J, col0, V, J, lane);
+    float m = -INFINITY, mx = -INFINITY;
+    int a = 0x7fffffff, ax = 0x7fffffff;
+    float z[16];
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = col0 + n * 16 + q * 4 + i;
+            const float v = c < V ? acc[n][i] + b2[c] : -INFINITY;
+            z[n * 4 + i] = v;
+            if (v > m) { m = v; a = c; }                       // ascending c within a lane: strict > keeps the first
+            if (c != unk && v > mx) { mx = v; ax = c; }
+        }
+    // the 4 lanes that hold this row (q = 0..3), then the 4 waves
+#pragma unroll
+    for (int off = 16; off <= 32; off <<= 1) {
+        pick_merge(m, a, __shfl_xor(m, off, 64), __shfl_xor(a, off, 64));
+        pick_merge(mx, ax, __shfl_xor(mx, off, 64), __shfl_xor(ax, off, 64));
+    }
+    __shared__ float s_m[4][16], s_mx[4][16], s_se[4][16];
+    __shared__ int s_a[4][16], s_ax[4][16];
+    if (q == 0) { s_m[wave][r16] = m; s_a[wave][r16] = a; s_mx[wave][r16] = mx; s_ax[wave][r16] = ax; }
+    __syncthreads();
+    float gm = s_m[0][r16];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) gm = fmaxf(gm, s_m[w][r16]);
+    if (want_sum) {
+        float se = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) se += __expf(z[i] - gm);    // (-inf columns add 0; gm is finite: V > 0)
+        se += __shfl_xor(se, 16, 64);
+        se += __shfl_xor(se, 32, 64);
+        if (q == 0) s_se[wave][r16] = se;
+        __syncthreads();
+    }
+    if (threadIdx.x < 16 && row < B) {
+        PickPart p;
+        p.m = s_m[0][r16]; p.a = s_a[0][r16]; p.mx = s_mx[0][r16]; p.ax = s_ax[0][r16];
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            pick_merge(p.m, p.a, s_m[w][r16], s_a[w][r16]);
+            pick_merge(p.mx, p.ax, s_mx[w][r16], s_ax[w][r16]);
+        }
+        p.se = want_sum ? s_se[0][r16] + s_se[1][r16] + s_se[2][r16] + s_se[3][r16] : 0.f;
+        p.pad[0] = p.pad[1] = p.pad[2] = 0;
+        parts[(long long)row * gridDim.y + blockIdx.y] = p;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- 3 / 4
+// One LSTM step of one layer for 16 rows x 16 units per workgroup (wave g = gate g).  first != 0: the layer input is
+// the embedding of the symbol picked from `parts` (which this kernel finishes: every workgroup for its own rows, the
+// unit-block-0 workgroups write it out); otherwise x = y_prev (bf16 rows of the layer below).
+struct LstmStepArgs {
+    const PickPart* parts; int nslices; int unk; int blank;
+    int32_t* pred; int32_t* tokens; long long tok_stride; int t; float* score;
+    const void* emb; int emb_f32; int E;
+    const bf16_t* x_prev;                 // [B, H] (layers > 0)
+    const bf16_t* w_ih; const bf16_t* w_hh; const float* b_ih; const float* b_hh;
+    const float* h_in; const float* c_in;  // [B, H] fp32 state of this layer
+    float* h_out; float* c_out;            // [B, H] fp32 candidates
+    bf16_t* y_out;                         // [B, H] bf16 copy of h_out (next layer / projection operand)
+    int B, H, Kx;
+};
+__global__ __launch_bounds__(256) void dec_lstm_step(LstmStepArgs A, int first) {
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
+    const int row = row0 + r16, rowc = min(row, A.B - 1);
+    __shared__ int s_pred[16];
+    __shared__ float s_gate[4][16][17];
+    if (first) {
+        if (threadIdx.x < 16) {
+            const int rr = min(row0 + (int)threadIdx.x, A.B - 1);
+            const PickPart* p = A.parts + (long long)rr * A.nslices;
+            float m = -INFINITY, mx = -INFINITY;
+            int a = 0x7fffffff, ax = 0x7fffffff;
+            for (int s = 0; s < A.nslices; ++s) {
+                pick_merge(m, a, p[s].m, p[s].a);
+                pick_merge(mx, ax, p[s].mx, p[s].ax);
+            }
+            int pick = a;
+            // rnnt/stream.py:105-108: an arg-max that is <unk> has its logit set to 0 and the arg-max is retaken
+            if (A.unk >= 0 && a == A.unk) pick = (0.f > mx || (0.f == mx && A.unk < ax)) ? A.unk : ax;
+            s_pred[threadIdx.x] = pick;
+            if (blockIdx.y == 0 && row0 + (int)threadIdx.x < A.B) {
+                A.pred[rr] = pick;
+                if (A.tokens) A.tokens[(long long)rr * A.tok_stride + A.t] = pick;
+                if (A.score) {                     // -(max log p) = log sum exp(z - max)   (greedy mode: unk < 0)
+                    float se = 0.f;
+                    for (int s = 0; s < A.nslices; ++s) se += p[s].se * __expf(p[s].m - m);
+                    A.score[rr] += logf(se);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    f32x4_t acc[1];
+    acc[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int col0 = g * A.H + j0;                 // W rows of this gate's 16 units
+    if (first) {
+        const int tok = s_pred[r16];
+        if (A.emb_f32) tile_product<1>(acc, reinterpret_cast<const float*>(A.emb), A.E, tok, A.w_ih, A.Kx, col0, 4 * A.H, A.Kx, lane);
+        else tile_product<1>(acc, reinterpret_cast<const bf16_t*>(A.emb), A.E, tok, A.w_ih, A.Kx, col0, 4 * A.H, A.Kx, lane);
+    } else {
+        tile_product<1>(acc, A.x_prev, A.H, rowc, A.w_ih, A.Kx, col0, 4 * A.H, A.Kx, lane);
+    }
+    tile_product<1>(acc, A.h_in, A.H, rowc, A.w_hh, A.H, col0, 4 * A.H, A.H, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int u = q * 4 + i;
+        s_gate[g][r16][u] = acc[0][i] + A.b_ih[col0 + u] + A.b_hh[col0 + u];
+    }
+    __syncthreads();
+    // cells: thread <-> (row tid & 15, unit tid >> 4)
+    const int cr = threadIdx.x & 15, cu = threadIdx.x >> 4;
+    const int crow = row0 + cr;
+    if (crow < A.B) {
+        const float ig = sigm(s_gate[0][cr][cu]), fg = sigm(s_gate[1][cr][cu]);
+        const float gg = tanh_fast(s_gate[2][cr][cu]), og = sigm(s_gate[3][cr][cu]);
+        const long long o = (long long)crow * A.H + j0 + cu;
+        const float c = fg * A.c_in[o] + ig * gg;
+        const float h = og * tanh_fast(c);
+        A.c_out[o] = c;
+        A.h_out[o] = h;
+        A.y_out[o] = f32_to_bf16(h);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- 5
+// dec_new = y W_p^T + b_p for 16 rows x 64 columns per wave; rows whose symbol is not blank take dec_new and the new
+// prediction-network state (each block moves its share of the L x H state values of its rows)
+__global__ __launch_bounds__(64) void dec_proj_commit(const bf16_t* __restrict__ y, int H, const bf16_t* __restrict__ Wp,
+                                                      const float* __restrict__ bp, int P2,
+                                                      const int32_t* __restrict__ pred, int blank,
+                                                      bf16_t* __restrict__ dec_out, float* __restrict__ h_state,
+                                                      const float* __restrict__ h_new, float* __restrict__ c_state,
+                                                      const float* __restrict__ c_new, int L, int B) {
+    const int lane = threadIdx.x, r16 = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.x * 16, row = row0 + r16, col0 = blockIdx.y * 64;
+    f32x4_t acc[4];
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    tile_product<4>(acc, y, H, min(row, B - 1), Wp, H, col0, P2, H, lane);
+    const bool keep = row < B && pred[min(row, B - 1)] != blank;
+    if (keep) {
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+            const int c = col0 + n * 16 + q * 4;
+            if (c >= P2) continue;
+            uint2 o;
+            o.x = f32x2_to_bf16x2(acc[n][0] + bp[c], acc[n][1] + bp[c + 1]);
+            o.y = f32x2_to_bf16x2(acc[n][2] + bp[c + 2], acc[n][3] + bp[c + 3]);
+            *reinterpret_cast<uint2*>(dec_out + (long long)row * P2 + c) = o;
+        }
+    }
+    // state commit: this block's slice of [L][16 rows][H]
+    const int per = (L * H + gridDim.y - 1) / gridDim.y;
+    const int lo = blockIdx.y * per, hi = min(L * H, lo + per);
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = row0 + rr;
+        if (r >= B || pred[r] == blank) continue;
+        for (int i = lo + lane; i < hi; i += 64) {
+            const int l = i / H, j = i - l * H;
+            const long long o = ((long long)l * B + r) * H + j;
+            h_state[o] = h_new[o];
+            c_state[o] = c_new[o];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- stream encoder
+// One LSTM time step of one encoder layer for 16 RT rows x 16 units per workgroup (wave g = gate g): the streaming
+// decoder's encoder advances S streams by a frame or two per chunk, and composed from the per-layer kernels (input
+// product, kernel-per-step recurrence) that was ~4 launches per layer-frame plus their host glue.  The W fragment of a
+// k-step is loaded once and used for all RT row tiles.
+template <int RT>
+__global__ __launch_bounds__(256) void enc_lstm_step(const bf16_t* __restrict__ x, long long ldx, int Kx,
+                                                     const bf16_t* __restrict__ w_ih, const bf16_t* __restrict__ w_hh,
+                                                     const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                                     const float* __restrict__ h_in, const float* __restrict__ c_in,
+                                                     float* __restrict__ h_out, float* __restrict__ c_out,
+                                                     bf16_t* __restrict__ y, long long ldy, int B, int H) {
+    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4, kq = q;
+    const int row0 = blockIdx.x * 16 * RT, j0 = blockIdx.y * 16;
+    __shared__ float s_gate[4][16 * RT][17];
+    f32x4_t acc[RT];
+#pragma unroll
+    for (int m = 0; m < RT; ++m) acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    const int col = g * H + j0 + r16;                       // this lane's W row (gate g, unit j0 + r16)
+    int rows[RT];
+#pragma unroll
+    for (int m = 0; m < RT; ++m) rows[m] = min(row0 + m * 16 + r16, B - 1);
+    // K % 8 == 0 (the encoder's first layer has K = 240): the k-groups of the last k-step that lie past K are zeros.
+    // Software-pipelined: the operands of the next CH k-steps are requested before the current ones are multiplied (a
+    // workgroup per CU, four waves: nothing else hides the L2 round trip - without it 48 of the 60 us of a layer-frame
+    // at S = 256 were 32 exposed round trips)
+    constexpr int CH = RT >= 4 ? 2 : 4;                     // k-steps per stage
+    auto product = [&](auto xload, const bf16_t* W, int K) {
+        const bf16_t* wp = W + (long long)col * K + kq * 8;
+        const int KP = (K + 31) & ~31;
+        const int nst = (KP / 32 + CH - 1) / CH;            // stages
+        bf16x8_t a[2][CH][RT], b[2][CH];
+        auto request = [&](int buf, int st) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) {
+                const int k = min((st * CH + c) * 32, KP - 32);
+                const bool in = k + kq * 8 < K;
+                union { unsigned u[4]; bf16x8_t v; } z;
+                z.u[0] = z.u[1] = z.u[2] = z.u[3] = 0u;
+                b[buf][c] = in ? ld8(wp + k) : z.v;
+#pragma unroll
+                for (int m = 0; m < RT; ++m) a[buf][c][m] = in ? xload(rows[m], k + kq * 8) : z.v;
+            }
+        };
+        auto multiply = [&](int buf, int st) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c)
+                if ((st * CH + c) * 32 < KP) {
+#pragma unroll
+                    for (int m = 0; m < RT; ++m)
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[buf][c], a[buf][c][m], acc[m], 0, 0, 0);
+                }
+        };
+        request(0, 0);
+        for (int st = 0; st < nst; st += 2) {
+            if (st + 1 < nst) request(1, st + 1);
+            multiply(0, st);
+            if (st + 2 < nst) request(0, st + 2);
+            if (st + 1 < nst) multiply(1, st + 1);
+        }
+    };
+    product([&](int r, int k) { return ld8(x + (long long)r * ldx + k); }, w_ih, Kx);
+    product([&](int r, int k) { return ld8_f32(h_in + (long long)r * H + k); }, w_hh, H);
+#pragma unroll
+    for (int m = 0; m < RT; ++m)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int u = q * 4 + i;
+            s_gate[g][m * 16 + r16][u] = acc[m][i] + b_ih[g * H + j0 + u] + b_hh[g * H + j0 + u];
+        }
+    __syncthreads();
+    for (int cell = threadIdx.x; cell < 256 * RT; cell += 256) {
+        const int cr = cell % (16 * RT), cu = cell / (16 * RT);
+        const int crow = row0 + cr;
+        if (crow >= B) continue;
+        const float ig = sigm(s_gate[0][cr][cu]), fg = sigm(s_gate[1][cr][cu]);
+        const float gg = tanh_fast(s_gate[2][cr][cu]), og = sigm(s_gate[3][cr][cu]);
+        const long long o = (long long)crow * H + j0 + cu;
+        const float c = fg * c_in[o] + ig * gg;
+        const float h = og * tanh_fast(c);
+        c_out[o] = c;
+        h_out[o] = h;
+        y[(long long)crow * ldy + j0 + cu] = f32_to_bf16(h);
+    }
+}
+
+inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
+
+}  // namespace
+
+// ---- C ABI: the streaming encoder step (rnnt/stream.py:93-100: `self.encoder(xs, (enc_h, enc_c))` on a chunk of a
+// few frames).  Encoder.forward rnnt/models.py:131-136 / ResLayerNormLSTM.forward :55-75 for T <= a few frames, bf16:
+// input LayerNorm, then per layer T fused LSTM steps + residual / LayerNorm / TimeReduction; ONE native call.
+extern "C" size_t edgedict_stream_encoder_workspace_bytes(int B, int T, int I0, int H, int L) {
+    if (B <= 0 || T <= 0 || L <= 0) return 0;
+    const size_t D = (size_t)(I0 > H ? I0 : H);
+    // X0 (normalised input), two activation buffers, Y, two state scratch buffers, statistics
+    return 4 * align256((size_t)B * T * D * 2) + 2 * align256((size_t)B * H * 4) + 2 * align256((size_t)B * T * 4);
+}
+
+extern "C" int edgedict_stream_encoder_step(const void* xs, int x_dtype, int B, int T, int I0, int H, int L,
+                                            const float* in_gamma, const float* in_beta,
+                                            const void* const* w_ih, const void* const* w_hh,
+                                            const float* const* b_ih, const float* const* b_hh,
+                                            const float* const* ln_gamma, const float* const* ln_beta,
+                                            const int* reduce, float* h_state, float* c_state, void* out,
+                                            int* T_out, void* workspace, void* stream_) {
+    ED_CHECK_ARG(xs && in_gamma && in_beta && w_ih && w_hh && b_ih && b_hh && ln_gamma && ln_beta && reduce && h_state &&
+                     c_state && out && workspace && T_out, "stream_encoder_step: null pointer");
+    ED_CHECK_ARG(B > 0 && T > 0 && L > 0 && H % 32 == 0 && I0 % 8 == 0, "stream_encoder_step: need H %% 32 == 0 and "
+                 "I0 %% 8 == 0 (B=%d T=%d I0=%d H=%d)", B, T, I0, H);
+    ED_CHECK_ARG(x_dtype == ED_F32 || x_dtype == ED_BF16, "stream_encoder_step: bad input dtype");
+    hipStream_t s = (hipStream_t)stream_;
+    const size_t D = (size_t)(I0 > H ? I0 : H);
+    char* p = (char*)workspace;
+    const size_t act = align256((size_t)B * T * D * 2);
+    bf16_t* X = (bf16_t*)p;                    // layer input  [B, T_l, K_l]
+    bf16_t* Xn = (bf16_t*)(p + act);           // next layer's input
+    bf16_t* Y = (bf16_t*)(p + 2 * act);        // h rows       [B, T_l, H]
+    bf16_t* Xc = (bf16_t*)(p + 3 * act);       // bf16 copy of an fp32 input
+    float* hs = (float*)(p + 4 * act);
+    float* cs = (float*)(p + 4 * act + align256((size_t)B * H * 4));
+    float* mean = (float*)(p + 4 * act + 2 * align256((size_t)B * H * 4));
+    float* rstd = (float*)((char*)mean + align256((size_t)B * T * 4));
+    int rc;
+    const void* x_in = xs;
+    if (x_dtype == ED_F32) {                   // the feature front-end hands over fp32
+        if ((rc = edgedict_cast(ED_F32, xs, ED_BF16, Xc, (long long)B * T * I0, s))) return rc;
+        x_in = Xc;
+    }
+    if ((rc = edgedict_layernorm_fwd(ED_BF16, x_in, nullptr, in_gamma, in_beta, X, mean, rstd, B, T, I0, 1, 1e-5f, s)))
+        return rc;
+    int Tl = T, K = I0;
+    for (int l = 0; l < L; ++l) {
+        ED_CHECK_ARG(reduce[l] == 1 || reduce[l] == 2, "stream_encoder_step: time reduction must be 1 or 2");
+        float* hl = h_state + (size_t)l * B * H;
+        float* cl = c_state + (size_t)l * B * H;
+        const float* hin = hl; const float* cin = cl;
+        for (int t = 0; t < Tl; ++t) {
+            float* hout = (t & 1) ? hl : hs;
+            float* cout = (t & 1) ? cl : cs;
+            const dim3 grid1((B + 15) / 16, H / 16), grid4((B + 63) / 64, H / 16);
+            if (B <= 16)
+                hipLaunchKernelGGL(enc_lstm_step<1>, grid1, dim3(256), 0, s, X + (size_t)t * K, (long long)Tl * K, K,
+                                   (const bf16_t*)w_ih[l], (const bf16_t*)w_hh[l], b_ih[l], b_hh[l], hin, cin, hout, cout,
+                                   Y + (size_t)t * H, (long long)Tl * H, B, H);
+            else
+                hipLaunchKernelGGL(enc_lstm_step<4>, grid4, dim3(256), 0, s, X + (size_t)t * K, (long long)Tl * K, K,
+                                   (const bf16_t*)w_ih[l], (const bf16_t*)w_hh[l], b_ih[l], b_hh[l], hin, cin, hout, cout,
+                                   Y + (size_t)t * H, (long long)Tl * H, B, H);
+            hin = hout; cin = cout;
+        }
+        if (Tl & 1) {                           // the last step wrote the scratch buffers
+            ED_CHECK_HIP(hipMemcpyAsync(hl, hs, (size_t)B * H * 4, hipMemcpyDeviceToDevice, s));
+            ED_CHECK_HIP(hipMemcpyAsync(cl, cs, (size_t)B * H * 4, hipMemcpyDeviceToDevice, s));
+        }
+        const int Tn = (Tl + reduce[l] - 1) / reduce[l];
+        void* dst = (l == L - 1) ? out : (void*)Xn;
+        if ((rc = edgedict_layernorm_fwd(ED_BF16, Y, l > 0 ? X : nullptr, ln_gamma[l], ln_beta[l], dst, mean, rstd, B, Tl,
+                                         H, reduce[l], 1e-5f, s)))
+            return rc;
+        bf16_t* tmp = X; X = Xn; Xn = tmp;
+        Tl = Tn;
+        K = H;
+    }
+    *T_out = Tl;
+    ED_CHECK_LAUNCH("stream_encoder_step");
+    return ED_OK;
+}
+
+namespace {
+
+}  // namespace
+
+// shapes the fused frame covers (otherwise decode.hip composes the frame from the general kernels)
+bool ed_decode_fused_ok(int dtype, int J, int V, int E, int H, int P2) {
+    static const int on = [] { const char* e = getenv("EDGEDICT_DECODE_FUSED"); return e ? atoi(e) : 1; }();
+    return on && dtype == ED_BF16 && J % 32 == 0 && P2 % 32 == 0 && E % 32 == 0 && H % 32 == 0 && H % 16 == 0 &&
+           V % 4 == 0 && J % 4 == 0 && P2 % 4 == 0;
+}
+size_t ed_decode_fused_ws_bytes(int B, int V) {
+    return align256((size_t)B * ((V + 255) / 256) * sizeof(PickPart));
+}
+
+// one frame of the search: see the file header.  hid [B, J] bf16, parts = ed_decode_fused_ws_bytes(B, V) bytes,
+// h_new / c_new [L, B, H] fp32, Y [2][B, H] bf16 (ping-pong between layers); pred [B] out
+int ed_decode_fused_frame(const void* E1t, long long e_row_stride, int B, int J, const void* W1d, long long ldw1,
+                          const float* b1, int P2, const void* W2, const float* b2, int V, const void* emb,
+                          int emb_dtype, int E, int L, const void* const* w_ih, const void* const* w_hh,
+                          const float* const* b_ih, const float* const* b_hh, int H, const void* Wp, const float* bp,
+                          float* h_state, float* c_state, void* dec_out, int blank, int unk, int32_t* tokens_out,
+                          long long tok_stride, int t, float* score, void* hid, void* parts, int32_t* pred,
+                          float* h_new, float* c_new, void* Y0, void* Y1, hipStream_t s) {
+    const int RB = (B + 15) / 16, NS = (V + 255) / 256;
+    hipLaunchKernelGGL(dec_joint_hidden, dim3(RB, (J + 63) / 64), dim3(64), 0, s, (const bf16_t*)E1t, e_row_stride,
+                       (const bf16_t*)dec_out, P2, (const bf16_t*)W1d, ldw1, b1, (bf16_t*)hid, B, J);
+    hipLaunchKernelGGL(dec_logits_pick, dim3(RB, NS), dim3(256), 0, s, (const bf16_t*)hid, J, (const bf16_t*)W2, b2, V,
+                       unk, score ? 1 : 0, (PickPart*)parts, B);
+    void* Y[2] = {Y0, Y1};
+    for (int k = 0; k < L; ++k) {
+        LstmStepArgs A;
+        A.parts = (const PickPart*)parts; A.nslices = NS; A.unk = unk; A.blank = blank;
+        A.pred = pred; A.tokens = tokens_out; A.tok_stride = tok_stride; A.t = t; A.score = score;
+        A.emb = emb; A.emb_f32 = emb_dtype == ED_F32 ? 1 : 0; A.E = E;
+        A.x_prev = k > 0 ? (const bf16_t*)Y[(k - 1) & 1] : nullptr;
+        A.w_ih = (const bf16_t*)w_ih[k]; A.w_hh = (const bf16_t*)w_hh[k]; A.b_ih = b_ih[k]; A.b_hh = b_hh[k];
+        A.h_in = h_state + (size_t)k * B * H; A.c_in = c_state + (size_t)k * B * H;
+        A.h_out = h_new + (size_t)k * B * H; A.c_out = c_new + (size_t)k * B * H;
+        A.y_out = (bf16_t*)Y[k & 1];
+        A.B = B; A.H = H; A.Kx = k == 0 ? E : H;
+        hipLaunchKernelGGL(dec_lstm_step, dim3(RB, H / 16), dim3(256), 0, s, A, k == 0 ? 1 : 0);
+    }
+    hipLaunchKernelGGL(dec_proj_commit, dim3(RB, (P2 + 63) / 64), dim3(64), 0, s, (const bf16_t*)Y[(L - 1) & 1], H,
+                       (const bf16_t*)Wp, bp, P2, pred, blank, (bf16_t*)dec_out, h_state, h_new, c_state, c_new, L, B);
+    ED_CHECK_LAUNCH("decode_fused_frame");
+    return ED_OK;
+}

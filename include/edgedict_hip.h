@@ -560,6 +560,25 @@ int edgedict_gelu_groupnorm_bwd(int dtype, const void* y, const void* dout, cons
 long long edgedict_blaslt_calls(void);
 
 /* ------------------------------------------------------------------------------------
+ * Streaming encoder step (bf16): PytorchStreamDecoder.decode's `self.encoder(xs, (enc_h, enc_c))`
+ * (rnnt/stream.py:93-100) on a chunk of a few frames for B concurrent streams - Encoder.forward
+ * rnnt/models.py:131-136 without its output projection: input LayerNorm, then per layer T fused LSTM steps
+ * (input product + recurrent product + cell in one launch per frame) and the residual / LayerNorm / TimeReduction
+ * of ResLayerNormLSTM.forward :55-75.  One native call instead of ~4 launches per layer-frame plus host glue.
+ *   xs            [B, T, I0] x_dtype (ED_F32 or ED_BF16), I0 % 8 == 0;  H % 32 == 0
+ *   w_ih / w_hh   HOST arrays [L] of bf16 DEVICE matrices [4H, K_l] / [4H, H] (PyTorch gate order i,f,g,o)
+ *   b_ih / b_hh / ln_gamma / ln_beta  HOST arrays [L] of fp32 DEVICE vectors;  reduce HOST int [L] in {1, 2}
+ *   h_state / c_state  fp32 [L, B, H], updated in place;  out bf16 [B, T_out, H], T_out returned through *T_out
+ */
+size_t edgedict_stream_encoder_workspace_bytes(int B, int T, int I0, int H, int L);
+int edgedict_stream_encoder_step(const void* xs, int x_dtype, int B, int T, int I0, int H, int L,
+                                 const float* in_gamma, const float* in_beta, const void* const* w_ih,
+                                 const void* const* w_hh, const float* const* b_ih, const float* const* b_hh,
+                                 const float* const* ln_gamma, const float* const* ln_beta, const int* reduce,
+                                 float* h_state, float* c_state, void* out, int* T_out, void* workspace,
+                                 void* stream);
+
+/* ------------------------------------------------------------------------------------
  * Batched beam search: the reference's legacy Transducer.beam_search (models.py:121-202; Sequence
  * models.py:212-224) for B utterances in lockstep, over the maintained model's prediction network and
  * joint.  Operands as edgedict_greedy_decode, plus

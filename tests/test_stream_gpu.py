@@ -181,3 +181,44 @@ def test_256_streams_in_lock_step_equal_single_stream_decoders_and_reference_gol
     print("\n[stream_256 %s] %d of %d frame tokens equal the single-stream decoders (%d non-blank)"
           % (dtype, same, total, emitted))
     assert same >= 0.98 * total
+
+
+@pytest.mark.parametrize("B,T,H,L,red", [(1, 1, 64, 3, [1]), (37, 2, 64, 3, [1]), (70, 3, 128, 4, [0, 2]), (5, 5, 64, 2, [])])
+def test_fused_stream_encoder_step_matches_the_per_layer_path_and_is_row_independent(hip_lib, B, T, H, L, red):
+    """edgedict_stream_encoder_step (csrc/decode_fused.hip: the streaming decoder's encoder call, rnnt/stream.py:93-100 ->
+    Encoder.forward rnnt/models.py:131-136, as ONE native call with a fused launch per layer-frame) against the
+    per-layer bf16 kernels it replaces for short chunks: outputs and carried states within bf16 rounding, two
+    consecutive chunks with carried state, and - bit for bit - independent of how many streams share the batch."""
+    from edgedict_amd import config
+    from edgedict_amd.models import Encoder
+    torch.manual_seed(3)
+    enc = Encoder(input_size=240, hidden_size=H, num_layers=L, dropout=0.0, proj_size=48, time_reductions=red).cuda().eval()
+    enc.compute_dtype = torch.bfloat16
+    g = torch.Generator(device="cpu").manual_seed(4)
+    x1 = torch.randn(B, T, 240, generator=g).cuda()
+    x2 = torch.randn(B, T, 240, generator=g).cuda()
+
+    def run(fused, a, b):
+        old = (config.STREAM_ENCODER_STEP, config.STREAM_STEP_MAX_ROWS)
+        config.STREAM_ENCODER_STEP, config.STREAM_STEP_MAX_ROWS = fused, 1 << 20     # (the kernel itself at any batch)
+        try:
+            with torch.no_grad():
+                y1, (h1, c1) = enc(a)
+                y2, (h2, c2) = enc(b, (h1, c1))
+            torch.cuda.synchronize()
+            return [t.float() for t in (y1, h1, c1, y2, h2, c2)]
+        finally:
+            config.STREAM_ENCODER_STEP, config.STREAM_STEP_MAX_ROWS = old
+    new, ref = run(True, x1, x2), run(False, x1, x2)
+    for a, b in zip(new, ref):
+        assert a.shape == b.shape
+        assert torch.isfinite(a).all()
+        scale = max(b.abs().max().item(), 1e-3)
+        assert (a - b).abs().max().item() <= 4e-2 * scale, ((a - b).abs().max().item(), scale)
+        assert (a - b).norm().item() <= 1e-2 * max(b.norm().item(), 1e-6)
+    if B > 1:
+        # row 0 alone == row 0 inside the batch, bit for bit (a stream must not depend on its neighbours)
+        alone = run(True, x1[:1].contiguous(), x2[:1].contiguous())
+        for a, b in zip(alone, new):
+            sub = b[:, :1] if b.dim() == 3 and b.shape[1] == B and b.shape[0] != B else b[:1]
+            assert torch.equal(a, sub), (a.shape, sub.shape)
