@@ -24,6 +24,12 @@ int ed_decode_fused_frame(const void* E1t, long long e_row_stride, int B, int J,
                           float* h_state, float* c_state, void* dec_out, int blank, int unk, int32_t* tokens_out,
                           long long tok_stride, int t, float* score, void* hid, void* parts, int32_t* pred,
                           float* h_new, float* c_new, void* Y0, void* Y1, hipStream_t s);
+int ed_decode_fused_beam_step(const void* E1t, long long e_row_stride, int B, int J, const void* W1d, long long ldw1,
+                              const float* b1, int P2, const void* emb, int emb_dtype, int E, int L,
+                              const void* const* w_ih, const void* const* w_hh, const float* const* b_ih,
+                              const float* const* b_hh, int H, const void* Wp, const float* bp, const float* h_state,
+                              const float* c_state, const int32_t* pred, void* dec_new, void* hid, float* h_new,
+                              float* c_new, void* Y0, void* Y1, hipStream_t s);
 
 namespace {
 
@@ -788,6 +794,7 @@ extern "C" int edgedict_beam_search(
         return ED_OK;
     };
 
+    const bool fused_step = ed_decode_fused_ok(dtype, J, V, E, H, P2);
     int cur = 0;
     for (int t = 0; t < maxlen; ++t) {
         const char* e1t = (const char*)E1 + (size_t)t * e_frame_stride * esz;
@@ -800,6 +807,20 @@ extern "C" int edgedict_beam_search(
             int rc;
             hipLaunchKernelGGL(beam_pop, dim3(B), dim3(256), 0, s, q, cur, W, V, EM, L, H, B, NODES,
                                bos, pred, h_state, c_state);
+            if (fused_step) {
+                // bf16: prediction-network step + projection + joint hidden as 2 + L fused launches (decode_fused.hip)
+                if ((rc = ed_decode_fused_beam_step(e1t, e_row_stride, B, J, W1d, ldw1, b1, P2, emb, emb_dtype, E, L, w_ih,
+                                                    w_hh, b_ih, b_hh, H, Wp, bp, h_state, c_state, pred, dec_new, hid,
+                                                    h_new, c_new, Y[0], Y[1], s)))
+                    return rc;
+                if (prefix)
+                    hipLaunchKernelGGL(beam_store_pred<bf16_t>, dim3(B), dim3(64), 0, s, q, (const bf16_t*)dec_new,
+                                       (bf16_t*)node_pred, EM, NODES, P2);
+                if ((rc = edgedict_gemm(dtype, ED_F32, hid, J, 1, W2, J, 1, logits, V, B, V, J, b2, nullptr, 0, 1, s)))
+                    return rc;
+                hipLaunchKernelGGL(beam_expand, dim3(B), dim3(256), 0, s, q, logits, h_new, c_new, W, V, EM, L, H, B,
+                                   blank);
+            } else {
             // prediction-network step on y*'s last token from y*'s state (models.py:164,126-132)
             if ((rc = edgedict_embedding_fwd(dtype, emb_dtype, pred, 1, emb, x, B, 1, E, V, 0, 0, s)))
                 return rc;
@@ -845,6 +866,7 @@ extern "C" int edgedict_beam_search(
                 return rc;
             hipLaunchKernelGGL(beam_expand, dim3(B), dim3(256), 0, s, q, logits, h_new, c_new, W, V,
                                EM, L, H, B, blank);
+            }
             if (it + 1 >= W) {   // B cannot hold W hypotheses before W expansions
                 ED_CHECK_HIP(hipMemcpyAsync(open_h.data(), q.open, (size_t)B * 4, hipMemcpyDeviceToHost, s));
                 ED_CHECK_HIP(hipStreamSynchronize(s));

@@ -200,7 +200,10 @@ __global__ __launch_bounds__(256) void dec_lstm_step(LstmStepArgs A, int first) 
     const int row = row0 + r16, rowc = min(row, A.B - 1);
     __shared__ int s_pred[16];
     __shared__ float s_gate[4][16][17];
-    if (first) {
+    if (first == 2) {                              // beam search: the symbol is the popped hypothesis' last token
+        if (threadIdx.x < 16) s_pred[threadIdx.x] = A.pred[min(row0 + (int)threadIdx.x, A.B - 1)];
+        __syncthreads();
+    } else if (first) {
         if (threadIdx.x < 16) {
             const int rr = min(row0 + (int)threadIdx.x, A.B - 1);
             const PickPart* p = A.parts + (long long)rr * A.nslices;
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(64) void dec_proj_commit(const bf16_t* __restrict__
 #pragma unroll
     for (int n = 0; n < 4; ++n) acc[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     tile_product<4>(acc, y, H, min(row, B - 1), Wp, H, col0, P2, H, lane);
-    const bool keep = row < B && pred[min(row, B - 1)] != blank;
+    const bool keep = row < B && (pred == nullptr || pred[min(row, B - 1)] != blank);   // (pred == null: every row)
     if (keep) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
@@ -285,6 +288,7 @@ __global__ __launch_bounds__(64) void dec_proj_commit(const bf16_t* __restrict__
             *reinterpret_cast<uint2*>(dec_out + (long long)row * P2 + c) = o;
         }
     }
+    if (pred == nullptr) return;
     // state commit: this block's slice of [L][16 rows][H]
     const int per = (L * H + gridDim.y - 1) / gridDim.y;
     const int lo = blockIdx.y * per, hi = min(L * H, lo + per);
@@ -482,6 +486,38 @@ bool ed_decode_fused_ok(int dtype, int J, int V, int E, int H, int P2) {
 }
 size_t ed_decode_fused_ws_bytes(int B, int V) {
     return align256((size_t)B * ((V + 255) / 256) * sizeof(PickPart));
+}
+
+// beam search (decode.hip): prediction-network step on pred[b] from (h_state, c_state) -> h_new / c_new, dec_new, and the
+// joint's hidden vector of frame t for every row - 2 + L launches instead of 4 + 2 L; the caller multiplies hid by W2
+int ed_decode_fused_beam_step(const void* E1t, long long e_row_stride, int B, int J, const void* W1d, long long ldw1,
+                              const float* b1, int P2, const void* emb, int emb_dtype, int E, int L,
+                              const void* const* w_ih, const void* const* w_hh, const float* const* b_ih,
+                              const float* const* b_hh, int H, const void* Wp, const float* bp, const float* h_state,
+                              const float* c_state, const int32_t* pred, void* dec_new, void* hid, float* h_new,
+                              float* c_new, void* Y0, void* Y1, hipStream_t s) {
+    const int RB = (B + 15) / 16;
+    void* Y[2] = {Y0, Y1};
+    for (int k = 0; k < L; ++k) {
+        LstmStepArgs A;
+        A.parts = nullptr; A.nslices = 0; A.unk = -1; A.blank = -1;
+        A.pred = const_cast<int32_t*>(pred); A.tokens = nullptr; A.tok_stride = 0; A.t = 0; A.score = nullptr;
+        A.emb = emb; A.emb_f32 = emb_dtype == ED_F32 ? 1 : 0; A.E = E;
+        A.x_prev = k > 0 ? (const bf16_t*)Y[(k - 1) & 1] : nullptr;
+        A.w_ih = (const bf16_t*)w_ih[k]; A.w_hh = (const bf16_t*)w_hh[k]; A.b_ih = b_ih[k]; A.b_hh = b_hh[k];
+        A.h_in = h_state + (size_t)k * B * H; A.c_in = c_state + (size_t)k * B * H;
+        A.h_out = h_new + (size_t)k * B * H; A.c_out = c_new + (size_t)k * B * H;
+        A.y_out = (bf16_t*)Y[k & 1];
+        A.B = B; A.H = H; A.Kx = k == 0 ? E : H;
+        hipLaunchKernelGGL(dec_lstm_step, dim3(RB, H / 16), dim3(256), 0, s, A, k == 0 ? 2 : 0);
+    }
+    hipLaunchKernelGGL(dec_proj_commit, dim3(RB, (P2 + 63) / 64), dim3(64), 0, s, (const bf16_t*)Y[(L - 1) & 1], H,
+                       (const bf16_t*)Wp, bp, P2, (const int32_t*)nullptr, 0, (bf16_t*)dec_new, (float*)nullptr,
+                       (const float*)nullptr, (float*)nullptr, (const float*)nullptr, L, B);
+    hipLaunchKernelGGL(dec_joint_hidden, dim3(RB, (J + 63) / 64), dim3(64), 0, s, (const bf16_t*)E1t, e_row_stride,
+                       (const bf16_t*)dec_new, P2, (const bf16_t*)W1d, ldw1, b1, (bf16_t*)hid, B, J);
+    ED_CHECK_LAUNCH("decode_fused_beam_step");
+    return ED_OK;
 }
 
 // one frame of the search: see the file header.  hid [B, J] bf16, parts = ed_decode_fused_ws_bytes(B, V) bytes,
