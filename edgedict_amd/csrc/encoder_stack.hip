@@ -259,14 +259,16 @@ WsLayout ws_layout(const edgedict_stack_desc_t* d) {
         off += (size_t)(d->layers[l].T + 1) * w.himg_stride;
     }
     // ... and one dG image per frame for the launch-persistent BPTT: T x B16 x 4H bf16 (205 MB per full-rate E6D2 layer)
+    // (nothing of it for a descriptor that promises no backward pass: 0.8 GB at E6D2 / 15 s / B = 64)
+    const bool infer = (d->flags & EDGEDICT_STACK_INFERENCE) != 0;
     w.gimg_stride = align256(B16 * 4 * d->H * sizeof(bf16_t));
     for (int l = 0; l < d->L; ++l) {
         w.gimg.push_back(off);
-        off += (size_t)(d->layers[l].T + 1) * w.gimg_stride;
+        if (!infer) off += (size_t)(d->layers[l].T + 1) * w.gimg_stride;
     }
     for (int l = 0; l < d->L; ++l) {
         w.skpart.push_back(off);
-        off += align256((size_t)2 * (d->H / 64 + 1) * 4 * 64 * 64 * sizeof(float));
+        if (!infer) off += align256((size_t)2 * (d->H / 64 + 1) * 4 * 64 * 64 * sizeof(float));
     }
     w.total = off;
     return w;
@@ -492,6 +494,11 @@ namespace {
 
 long long* g_wsr_trace = nullptr;   // debug: device buffer registered by edgedict_stack_wsr_set_trace (tools/lpw_trace.py, tools/sk_trace.py)
 
+int device_cus() {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+    return n;
+}
 bool lpw_data_poll() {
     // default: no counter on the dependency chain - the images are filled before the pass and the readers validate what
     // they gather; 0: the readers poll the arrival counters (round 3's protocol: 7.9 instead of 7.1 us per step)
@@ -717,6 +724,15 @@ int lpw_steps(const edgedict_stack_desc_t* d) {
     const char* e_n = getenv("EDGEDICT_LPW_STEPS");
     const int on = e_on ? atoi(e_on) : 1, want = e_n ? atoi(e_n) : min(d->chunk, 16);      // default: a chunk per launch
     if (!on || !ed_stack_lpw_supported(d->B, d->H)) return 0;
+    // the kernel addresses a layer's images through ONE 32-bit buffer descriptor, and all workgroups of a layer must be
+    // resident at once (they wait for each other inside the launch): otherwise the launch-per-step kernels
+    {
+        const size_t B16 = (size_t)(d->B + 15) / 16 * 16;
+        const size_t stride = align256(B16 * d->H * sizeof(bf16_t));
+        for (int l = 0; l < d->L; ++l)
+            if ((size_t)(d->layers[l].T + 1) * stride >= (1ull << 32)) return 0;
+        if (!g_trace && device_cus() < (d->H >> 4) * ((d->B + 63) >> 6)) return 0;
+    }
     bool reduces = false;
     for (int l = 0; l < d->L; ++l) reduces = reduces || d->layers[l].reduce == 2;
     int ns = max(1, min(want, d->chunk));
@@ -733,6 +749,13 @@ int sk_bwd_steps(const edgedict_stack_desc_t* d) {
     if (!on || !ed_stack_sk_supported(d->B, d->H)) return 0;
     for (int l = 0; l < d->L; ++l)
         if (!d->layers[l].whh_s) return 0;
+    {   // as lpw_steps: 32-bit image range, and the layer's (H / 64) x 4 workgroups co-resident (two fit a CU)
+        const size_t B16 = (size_t)(d->B + 15) / 16 * 16;
+        const size_t stride = align256(B16 * 4 * d->H * sizeof(bf16_t));
+        for (int l = 0; l < d->L; ++l)
+            if ((size_t)(d->layers[l].T + 1) * stride >= (1ull << 32)) return 0;
+        if (!g_trace && 2 * device_cus() < (d->H >> 6) * 4) return 0;
+    }
     int ns = max(1, min(want, d->chunk));
     while (ns > 1 && d->chunk % ns != 0) --ns;
     return ns;
@@ -1099,6 +1122,7 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     std::vector<Geom> g;
     ED_TRY(validate(d, g, true));
     ED_CHECK_ARG(d->dout && d->d_in_gamma && d->d_in_beta, "encoder_stack: null backward pointer in descriptor");
+    ED_CHECK_ARG(!(d->flags & EDGEDICT_STACK_INFERENCE), "encoder_stack: backward on a descriptor flagged EDGEDICT_STACK_INFERENCE");
     const int B = d->B, H = d->H, L = d->L;
     const long long BH = (long long)B * H;
     const WsLayout wl = ws_layout(d);

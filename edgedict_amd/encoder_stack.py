@@ -49,6 +49,7 @@ GRADS_FINAL_CB = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_void_p)
 SERIAL = 1
 DW_AT_END = 2
 ACCUM_GRADS = 8
+INFERENCE = 64     # no backward pass will follow (torch.no_grad): no dG images / split-K partials in the workspace
 
 # schedule knobs (env overrides are for tuning runs; the defaults are what bench.py measures)
 # output-rate frames per chunk (= steps per launch of the launch-persistent kernels).  E6D2 training step, round 3:
@@ -326,8 +327,9 @@ class EncoderStackFn(torch.autograd.Function):
         x = xs.contiguous()
         if x.dtype not in (F32, BF16):
             x = x.float()
+        needs_bwd = any(ctx.needs_input_grad)        # (grad mode is off inside forward(); this is what autograd knows)
         plan = _Plan(x, (in_g, in_b), layers, list(reductions), h0, c0,
-                     FLAGS if flags is None else flags)
+                     (FLAGS if flags is None else flags) | (0 if needs_bwd else INFERENCE))
         with ops.timed("enc_stack_fwd_T%d_L%d" % (x.shape[1], len(layers))):
             plan.forward()
         hN, cN = plan.final_states()

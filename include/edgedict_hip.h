@@ -265,6 +265,8 @@ typedef struct edgedict_stack_layer {
 #define EDGEDICT_STACK_SERIAL 1     /* run everything on the caller's stream (debug / bit-exact check) */
 #define EDGEDICT_STACK_DW_AT_END 2  /* weight gradients after the BPTT instead of under it */
 #define EDGEDICT_STACK_ACCUM_GRADS 8 /* dW_ih / dW_hh / db / db_hh are existing gradient buffers: += instead of = */
+#define EDGEDICT_STACK_INFERENCE 64 /* no backward pass will follow this forward: the workspace carries no dG images /
+   split-K partials (edgedict_stack_workspace_bytes is smaller), edgedict_stack_backward refuses the descriptor */
 #define EDGEDICT_STACK_SIDE_STREAM_PER_LAYER 4 /* experiment: chunk GEMMs on one side stream PER LAYER.
    Measured 2x SLOWER end to end: more streams than hardware queues serialises everything. */
 
