@@ -15,21 +15,23 @@
 
 #include <vector>
 
-// decode_fused.hip: the bf16 frame as five fused launches
-bool ed_decode_fused_ok(int dtype, int J, int V, int E, int H, int P2);
-int ed_decode_fused_frame(const void* E1t, long long e_row_stride, int B, int J, const void* W1d, long long ldw1,
-                          const float* b1, int P2, const void* W2, const float* b2, int V, const void* emb,
-                          int emb_dtype, int E, int L, const void* const* w_ih, const void* const* w_hh,
-                          const float* const* b_ih, const float* const* b_hh, int H, const void* Wp, const float* bp,
-                          float* h_state, float* c_state, void* dec_out, int blank, int unk, int32_t* tokens_out,
-                          long long tok_stride, int t, float* score, void* hid, void* parts, int32_t* pred,
-                          float* h_new, float* c_new, void* Y0, void* Y1, hipStream_t s);
-int ed_decode_fused_beam_step(const void* E1t, long long e_row_stride, int B, int J, const void* W1d, long long ldw1,
-                              const float* b1, int P2, const void* emb, int emb_dtype, int E, int L,
-                              const void* const* w_ih, const void* const* w_hh, const float* const* b_ih,
-                              const float* const* b_hh, int H, const void* Wp, const float* bp, const float* h_state,
-                              const float* c_state, const int32_t* pred, void* dec_new, void* hid, float* h_new,
-                              float* c_new, void* Y0, void* Y1, hipStream_t s);
+// decode_fused.hip: a frame as five fused launches (bf16 and fp32)
+bool ed_decode_fused_ok(int dtype, int emb_dtype, int J, int V, int E, int H, int P2);
+size_t ed_decode_fused_ws_bytes(int B, int V);
+int ed_decode_fused_frame(int dtype, const void* E1t, long long e_row_stride, int B, int J, const void* W1d,
+                          long long ldw1, const float* b1, int P2, const void* W2, const float* b2, int V,
+                          const void* emb, int emb_dtype, int E, int L, const void* const* w_ih,
+                          const void* const* w_hh, const float* const* b_ih, const float* const* b_hh, int H,
+                          const void* Wp, const float* bp, float* h_state, float* c_state, void* dec_out, int blank,
+                          int unk, int32_t* tokens_out, long long tok_stride, int t, float* score, void* hid, void* parts,
+                          int32_t* pred, float* h_new, float* c_new, void* Y0, void* Y1, hipStream_t s);
+int ed_decode_fused_beam_step(int dtype, const void* E1t, long long e_row_stride, int B, int J, const void* W1d,
+                              long long ldw1, const float* b1, int P2, const void* W2, const float* b2, int V,
+                              const void* emb, int emb_dtype, int E, int L, const void* const* w_ih,
+                              const void* const* w_hh, const float* const* b_ih, const float* const* b_hh, int H,
+                              const void* Wp, const float* bp, const float* h_state, const float* c_state,
+                              const int32_t* pred, void* dec_new, void* hid, float* logits, float* h_new, float* c_new,
+                              void* Y0, void* Y1, hipStream_t s);
 
 namespace {
 
@@ -186,14 +188,15 @@ extern "C" int edgedict_greedy_decode(
     float* c_new = (float*)(p + w.c_new);
     void* dec_new = p + w.dec_new;
 
-    // bf16: a frame is five fused launches (decode_fused.hip; the slice partials live in the logits buffer, which the
-    // fused frame never fills); fp32 parity mode and odd shapes: composed from the general kernels below
-    const bool fused = ed_decode_fused_ok(dtype, J, V, E, H, P2) && (size_t)V * 4 >= (size_t)((V + 255) / 256) * 32;
+    // a frame is five fused launches (decode_fused.hip; the slice partials live in the logits buffer, which the fused
+    // frame never fills); odd shapes: composed from the general kernels below
+    const bool fused = ed_decode_fused_ok(dtype, emb_dtype, J, V, E, H, P2) &&
+                       align256((size_t)B * V * 4) >= ed_decode_fused_ws_bytes(B, V);
     for (int t = 0; t < T; ++t) {
         int rc;
         if (fused) {
             const char* e1f = (const char*)E1 + (size_t)t * e_frame_stride * esz;
-            if ((rc = ed_decode_fused_frame(e1f, e_row_stride, B, J, W1d, ldw1, b1, P2, W2, b2, V, emb, emb_dtype, E, L,
+            if ((rc = ed_decode_fused_frame(dtype, e1f, e_row_stride, B, J, W1d, ldw1, b1, P2, W2, b2, V, emb, emb_dtype, E, L,
                                             w_ih, w_hh, b_ih, b_hh, H, Wp, bp, h_state, c_state, dec_out, blank, unk,
                                             tokens_out, tok_stride, t, score, hid, logits, pred, h_new, c_new, Y[0],
                                             Y[1], s)))
@@ -794,7 +797,7 @@ extern "C" int edgedict_beam_search(
         return ED_OK;
     };
 
-    const bool fused_step = ed_decode_fused_ok(dtype, J, V, E, H, P2);
+    const bool fused_step = ed_decode_fused_ok(dtype, emb_dtype, J, V, E, H, P2);
     int cur = 0;
     for (int t = 0; t < maxlen; ++t) {
         const char* e1t = (const char*)E1 + (size_t)t * e_frame_stride * esz;
@@ -808,16 +811,19 @@ extern "C" int edgedict_beam_search(
             hipLaunchKernelGGL(beam_pop, dim3(B), dim3(256), 0, s, q, cur, W, V, EM, L, H, B, NODES,
                                bos, pred, h_state, c_state);
             if (fused_step) {
-                // bf16: prediction-network step + projection + joint hidden as 2 + L fused launches (decode_fused.hip)
-                if ((rc = ed_decode_fused_beam_step(e1t, e_row_stride, B, J, W1d, ldw1, b1, P2, emb, emb_dtype, E, L, w_ih,
-                                                    w_hh, b_ih, b_hh, H, Wp, bp, h_state, c_state, pred, dec_new, hid,
-                                                    h_new, c_new, Y[0], Y[1], s)))
+                // prediction-network step + projection + joint hidden + logits as 3 + L fused launches (decode_fused.hip)
+                if ((rc = ed_decode_fused_beam_step(dtype, e1t, e_row_stride, B, J, W1d, ldw1, b1, P2, W2, b2, V, emb,
+                                                    emb_dtype, E, L, w_ih, w_hh, b_ih, b_hh, H, Wp, bp, h_state, c_state,
+                                                    pred, dec_new, hid, logits, h_new, c_new, Y[0], Y[1], s)))
                     return rc;
-                if (prefix)
-                    hipLaunchKernelGGL(beam_store_pred<bf16_t>, dim3(B), dim3(64), 0, s, q, (const bf16_t*)dec_new,
-                                       (bf16_t*)node_pred, EM, NODES, P2);
-                if ((rc = edgedict_gemm(dtype, ED_F32, hid, J, 1, W2, J, 1, logits, V, B, V, J, b2, nullptr, 0, 1, s)))
-                    return rc;
+                if (prefix) {
+                    if (dtype == ED_F32)
+                        hipLaunchKernelGGL(beam_store_pred<float>, dim3(B), dim3(64), 0, s, q, (const float*)dec_new,
+                                           (float*)node_pred, EM, NODES, P2);
+                    else
+                        hipLaunchKernelGGL(beam_store_pred<bf16_t>, dim3(B), dim3(64), 0, s, q, (const bf16_t*)dec_new,
+                                           (bf16_t*)node_pred, EM, NODES, P2);
+                }
                 hipLaunchKernelGGL(beam_expand, dim3(B), dim3(256), 0, s, q, logits, h_new, c_new, W, V, EM, L, H, B,
                                    blank);
             } else {

@@ -1,24 +1,29 @@
-// Fused per-frame kernels of the greedy / streaming RNN-T search (bf16 mode), gfx950.
+// Fused per-frame kernels of the greedy / streaming / beam RNN-T search (bf16 and fp32 modes), gfx950.
 //
 // One search frame (Transducer.greedy_decode rnnt/models.py:254-263, PytorchStreamDecoder.decode
 // rnnt/stream.py:102-119) is a chain of small products over B rows - joint hidden [B x J x P2], logits
 // [B x V x J], the prediction network's L LSTM steps, its projection - each followed by a few elementwise ops.
 // Composed from the general kernels that is 11 launches per frame (decode.hip: product, add + tanh, product, pick,
-// embedding, L x (product + cell), product, commit), ~7 us each, with nothing else to overlap them: the loop was
-// launch-bound (80 us per frame, 2-3 % of what one pass over the 4.7 MB of weights costs).  Here a frame is FIVE
-// launches, each a product with its whole epilogue:
+// embedding, L x (product + cell), product, commit), ~7 us each in bf16 and 15-70 us each in fp32 (the general GEMM
+// on 2-16 tiles), with nothing else to overlap them.  Here a frame is FIVE launches, each a product with its whole
+// epilogue:
 //   1. dec_joint_hidden   hid = tanh(E1[:, t] + dec_out W1d^T + b1)
-//   2. dec_logits_pick    logits = hid W2^T + b2 in registers -> per row and 256-column slice: arg-max, arg-max
+//   2. dec_logits_pick    logits = hid W2^T + b2 in registers -> per row and 64-column slice: arg-max, arg-max
 //                         without <unk>, sum of exponentials (the logits never reach memory)
 //   3. dec_lstm_step      (first layer) final pick from the slices (+ the stream decoder's <unk> rule, + score),
 //                         token out, embedding, x W_ih^T + h W_hh^T + b, LSTM cell
 //   4. dec_lstm_step      (further layers)
 //   5. dec_proj_commit    dec_new = h W_p^T + b_p; where the symbol is not blank: dec_out, h, c <- new
-// Operands go straight from L2 into MFMA fragments (v_mfma_f32_16x16x32_bf16, the weights as the FIRST operand so
-// that a lane ends up with 4 consecutive output columns of one row): no LDS staging - every operand is used once per
-// workgroup.  Rows are independent and a row's arithmetic does not depend on its position in the batch, so S
-// concurrent streams equal S single-stream decoders bit for bit (tests/test_stream_gpu.py).
-// The fp32 parity mode keeps the composed path (exact-f32 products, pinned token-exact on the reference goldens).
+// Operands go straight from L2 into MFMA fragments, the weights as the FIRST operand so that a lane ends up with 4
+// consecutive output columns of one row; no LDS staging - every operand is used once per workgroup.  These kernels
+// are LATENCY-bound (a wave or four per CU, nothing else to hide an L2 round trip behind), so the rule is: one wave =
+// ONE 16 x 16 output tile, every operand fragment of its K loop requested at once (up to 20 k-steps = 160 registers),
+// a second round trip only where the data dependence forces one (the embedding row of the symbol just picked).
+//   bf16: v_mfma_f32_16x16x32_bf16, a lane's 16-byte load = 8 k of one k-step;
+//   fp32 (the parity mode, pinned token-exact on the reference's goldens): v_mfma_f32_16x16x4_f32, a lane's 16-byte load
+//         = 4 k that feed FOUR MFMA steps (the same k permutation on both operands - see lstm.hip f32_product16).
+// Rows are independent and a row's arithmetic does not depend on its position in the batch, so S concurrent streams
+// equal S single-stream decoders bit for bit (tests/test_stream_gpu.py).
 #include "common.hpp"
 
 namespace {
@@ -41,76 +46,109 @@ __device__ __forceinline__ float tanh_fast(float x) {
     return x < 0.f ? -t : t;
 }
 
-// acc[n] (+)= W[col0 + 16 n + .. 16][k] x X[row][k] over K (multiple of 32): lane (r16 = lane & 15, q = lane >> 4)
-// ends with acc[n][e] = out[row0 + r16][col0 + 16 n + 4 q + e].  Rows / columns past the end are clamped (their
-// results are garbage that the caller masks).
-template <int NT, typename XT>
-__device__ __forceinline__ void tile_product(f32x4_t (&acc)[NT], const XT* __restrict__ X, long long ldx, int row,
-                                             const bf16_t* __restrict__ W, long long ldw, int col0, int ncols, int K,
-                                             int lane) {
-    const int r16 = lane & 15, kq = lane >> 4;
-    const XT* xp = X + (long long)row * ldx + kq * 8;
-    const bf16_t* wp[NT];
-#pragma unroll
-    for (int n = 0; n < NT; ++n) wp[n] = W + (long long)min(col0 + n * 16 + r16, ncols - 1) * ldw + kq * 8;
-    // the operands of CH k-steps are requested together (these kernels run a wave or four per CU: nothing else hides
-    // an L2 round trip), then multiplied
-    constexpr int CH = NT == 1 ? 8 : 4;
-    for (int k0 = 0; k0 < K; k0 += 32 * CH) {
-        bf16x8_t a[CH], b[CH][NT];
+// ---- the two arithmetic modes.  ET = element type of the weights and of the activations between the kernels.
+// KS = k per "k-step" (one 16-byte load per lane and operand), LK = k per lane.
+template <typename ET> struct Mode;
+template <> struct Mode<bf16_t> {
+    static constexpr int KS = 32, LK = 8;
+    typedef bf16x8_t frag;
+    static __device__ __forceinline__ frag ldw(const bf16_t* p) { return ld8(p); }
+    static __device__ __forceinline__ frag ldx(const bf16_t* p) { return ld8(p); }
+    static __device__ __forceinline__ frag ldx(const float* p) { return ld8_f32(p); }
+    static __device__ __forceinline__ void mma(f32x4_t& acc, const frag& w, const frag& x) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, x, acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float act(float v) { return bf16_to_f32(f32_to_bf16(v)); }   // value as stored
+    static __device__ __forceinline__ float ld1(const bf16_t* p) { return bf16_to_f32(*p); }
+    static __device__ __forceinline__ void st4(bf16_t* p, float a, float b, float c, float d) {
+        uint2 o;
+        o.x = f32x2_to_bf16x2(a, b);
+        o.y = f32x2_to_bf16x2(c, d);
+        *reinterpret_cast<uint2*>(p) = o;
+    }
+    static __device__ __forceinline__ void ld4(const bf16_t* p, float (&v)[4]) {
+        const uint2 e = *reinterpret_cast<const uint2*>(p);
+        v[0] = __uint_as_float(e.x << 16); v[1] = __uint_as_float(e.x & 0xffff0000u);
+        v[2] = __uint_as_float(e.y << 16); v[3] = __uint_as_float(e.y & 0xffff0000u);
+    }
+    static __device__ __forceinline__ void st1(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+    static __device__ __forceinline__ float sig(float x) { return sigm(x); }
+    static __device__ __forceinline__ float tnh(float x) { return tanh_fast(x); }
+};
+template <> struct Mode<float> {
+    static constexpr int KS = 16, LK = 4;
+    typedef float4 frag;
+    static __device__ __forceinline__ frag ldw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ __forceinline__ frag ldx(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ __forceinline__ void mma(f32x4_t& acc, const frag& w, const frag& x) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.x, x.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.y, x.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.z, x.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(w.w, x.w, acc, 0, 0, 0);
+    }
+    static __device__ __forceinline__ float act(float v) { return v; }
+    static __device__ __forceinline__ float ld1(const float* p) { return *p; }
+    static __device__ __forceinline__ void st4(float* p, float a, float b, float c, float d) {
+        *reinterpret_cast<float4*>(p) = make_float4(a, b, c, d);
+    }
+    static __device__ __forceinline__ void ld4(const float* p, float (&v)[4]) {
+        const float4 e = *reinterpret_cast<const float4*>(p);
+        v[0] = e.x; v[1] = e.y; v[2] = e.z; v[3] = e.w;
+    }
+    static __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+    // the parity mode keeps the exact functions of the composed path (lstm.hip lstm_step_fwd<float>)
+    static __device__ __forceinline__ float sig(float x) { return 1.f / (1.f + expf(-x)); }
+    static __device__ __forceinline__ float tnh(float x) { return tanhf(x); }
+};
+
+// acc (+)= W[wrow][k] x X[xrow][k] over K (a multiple of KS): lane (r16 = lane & 15, q = lane >> 4) ends with
+// acc[e] = out[xrow of lane r16][column of W row 4 q + e].  wp / xp point at this lane's W row / X row (+ q * LK).
+// CH k-steps are requested together, then multiplied, k ascending (the order of the sums does not depend on CH).
+template <typename ET, int CH, typename XT>
+__device__ __forceinline__ void wave_product(f32x4_t& acc, const XT* __restrict__ xp, const ET* __restrict__ wp, int K) {
+    typedef Mode<ET> Md;
+    for (int k0 = 0; k0 < K; k0 += Md::KS * CH) {
+        typename Md::frag a[CH], b[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const int k = min(k0 + 32 * c, K - 32);          // (clamped: a repeated k-step is masked below)
-            if constexpr (sizeof(XT) == 4) a[c] = ld8_f32(reinterpret_cast<const float*>(xp) + k);
-            else a[c] = ld8(reinterpret_cast<const bf16_t*>(xp) + k);
-#pragma unroll
-            for (int n = 0; n < NT; ++n) b[c][n] = ld8(wp[n] + k);
+            const int k = min(k0 + Md::KS * c, K - Md::KS);      // (clamped: a repeated k-step is skipped below)
+            b[c] = Md::ldw(wp + k);
+            a[c] = Md::ldx(xp + k);
         }
 #pragma unroll
-        for (int c = 0; c < CH; ++c) {
-            if (k0 + 32 * c < K) {
-#pragma unroll
-                for (int n = 0; n < NT; ++n)
-                    acc[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[c][n], a[c], acc[n], 0, 0, 0);
-            }
-        }
+        for (int c = 0; c < CH; ++c)
+            if (k0 + Md::KS * c < K) Md::mma(acc, b[c], a[c]);
     }
 }
 
 // ---------------------------------------------------------------------------------------------- 1
-// hid[b, j] = tanh(E1[b, t, j] + bf16(dec_out[b] . W1d[j] + b1[j]));  one wave per (16 rows, 64 columns)
-__global__ __launch_bounds__(64) void dec_joint_hidden(const bf16_t* __restrict__ E1t, long long e_row_stride,
-                                                       const bf16_t* __restrict__ dec_out, int P2,
-                                                       const bf16_t* __restrict__ W1d, long long ldw1,
-                                                       const float* __restrict__ b1, bf16_t* __restrict__ hid,
-                                                       int B, int J) {
-    const int lane = threadIdx.x, r16 = lane & 15, q = lane >> 4;
-    const int row = blockIdx.x * 16 + r16, col0 = blockIdx.y * 64;
-    f32x4_t acc[4];
+// hid[b, j] = tanh(E1[b, t, j] + act(dec_out[b] . W1d[j] + b1[j]));  one wave per (16 rows, 16 columns), 4 waves
+template <typename ET>
+__global__ __launch_bounds__(256) void dec_joint_hidden(const ET* __restrict__ E1t, long long e_row_stride,
+                                                        const ET* __restrict__ dec_out, int P2,
+                                                        const ET* __restrict__ W1d, long long ldw1,
+                                                        const float* __restrict__ b1, ET* __restrict__ hid,
+                                                        int B, int J) {
+    typedef Mode<ET> Md;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+    const int row = blockIdx.x * 16 + r16, col0 = blockIdx.y * 64 + wave * 16;
+    if (col0 >= J) return;
+    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    wave_product<ET, 20>(acc, dec_out + (long long)min(row, B - 1) * P2 + q * Md::LK,
+                         W1d + (long long)min(col0 + r16, J - 1) * ldw1 + q * Md::LK, P2);
+    const int c = col0 + q * 4;
+    if (row >= B || c >= J) return;               // (J % 4 == 0: a lane's 4 columns are in or out together)
+    float ev[4], h[4];
+    Md::ld4(E1t + (long long)row * e_row_stride + c, ev);
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    tile_product<4>(acc, dec_out, P2, min(row, B - 1), W1d, ldw1, col0, J, P2, lane);
-    if (row >= B) return;
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-        const int c = col0 + n * 16 + q * 4;
-        if (c >= J) continue;                      // (J % 4 == 0: a lane's 4 columns are in or out together)
-        const uint2 e = *reinterpret_cast<const uint2*>(E1t + (long long)row * e_row_stride + c);
-        const float ev[4] = {__uint_as_float(e.x << 16), __uint_as_float(e.x & 0xffff0000u),
-                             __uint_as_float(e.y << 16), __uint_as_float(e.y & 0xffff0000u)};
-        float h[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) h[i] = tanhf(ev[i] + bf16_to_f32(f32_to_bf16(acc[n][i] + b1[c + i])));
-        uint2 o;
-        o.x = f32x2_to_bf16x2(h[0], h[1]);
-        o.y = f32x2_to_bf16x2(h[2], h[3]);
-        *reinterpret_cast<uint2*>(hid + (long long)row * J + c) = o;
-    }
+    for (int i = 0; i < 4; ++i) h[i] = tanhf(ev[i] + Md::act(acc[i] + b1[c + i]));
+    Md::st4(hid + (long long)row * J + c, h[0], h[1], h[2], h[3]);
 }
 
 // ---------------------------------------------------------------------------------------------- 2
-// per row and 256-column slice of the logits: (max, first arg-max), the same without column `unk`, sum of
-// exp(z - max).  4 waves = 4 x 64 columns of 16 rows.
+// per row and 64-column slice of the logits: (max, first arg-max), the same without column `unk`, sum of
+// exp(z - max).  4 waves = 4 x 16 columns of 16 rows.  With logits_out the logits are written instead (fp32 [B, V]:
+// the beam search expands every symbol).
 struct PickPart {
     float m; int a;          // max over the slice, lowest index on ties
     float mx; int ax;        // ... over the slice without column unk (-inf / INT_MAX if nothing is left)
@@ -120,29 +158,35 @@ struct PickPart {
 __device__ __forceinline__ void pick_merge(float& m, int& a, float om, int oa) {
     if (om > m || (om == m && oa < a)) { m = om; a = oa; }
 }
-__global__ __launch_bounds__(256) void dec_logits_pick(const bf16_t* __restrict__ hid, int J,
-                                                       const bf16_t* __restrict__ W2, const float* __restrict__ b2,
-                                                       int V, int unk, int want_sum, PickPart* __restrict__ parts,
+template <typename ET>
+__global__ __launch_bounds__(256) void dec_logits_pick(const ET* __restrict__ hid, int J, const ET* __restrict__ W2,
+                                                       const float* __restrict__ b2, int V, int unk, int want_sum,
+                                                       PickPart* __restrict__ parts, float* __restrict__ logits_out,
                                                        int B) {
+    typedef Mode<ET> Md;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
-    const int row = blockIdx.x * 16 + r16, col0 = blockIdx.y * 256 + wave * 64;
-    f32x4_t acc[4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n) acc[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    tile_product<4>(acc, hid, J, min(row, B - 1), W2, J, col0, V, J, lane);
+    const int row = blockIdx.x * 16 + r16, col0 = blockIdx.y * 64 + wave * 16;
+    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    wave_product<ET, 20>(acc, hid + (long long)min(row, B - 1) * J + q * Md::LK,
+                         W2 + (long long)min(col0 + r16, V - 1) * J + q * Md::LK, J);
+    float z[4];
     float m = -INFINITY, mx = -INFINITY;
     int a = 0x7fffffff, ax = 0x7fffffff;
-    float z[16];
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int c = col0 + n * 16 + q * 4 + i;
-            const float v = c < V ? acc[n][i] + b2[c] : -INFINITY;
-            z[n * 4 + i] = v;
-            if (v > m) { m = v; a = c; }                       // ascending c within a lane: strict > keeps the first
-            if (c != unk && v > mx) { mx = v; ax = c; }
+    for (int i = 0; i < 4; ++i) {
+        const int c = col0 + q * 4 + i;
+        const float v = c < V ? acc[i] + b2[c] : -INFINITY;
+        z[i] = v;
+        if (v > m) { m = v; a = c; }                       // ascending c within a lane: strict > keeps the first
+        if (c != unk && v > mx) { mx = v; ax = c; }
+    }
+    if (logits_out) {
+        const int c = col0 + q * 4;
+        if (row < B && c < V) {                            // (V % 4 == 0)
+            *reinterpret_cast<float4*>(logits_out + (long long)row * V + c) = make_float4(z[0], z[1], z[2], z[3]);
         }
+        return;
+    }
     // the 4 lanes that hold this row (q = 0..3), then the 4 waves
 #pragma unroll
     for (int off = 16; off <= 32; off <<= 1) {
@@ -159,7 +203,7 @@ __global__ __launch_bounds__(256) void dec_logits_pick(const bf16_t* __restrict_
     if (want_sum) {
         float se = 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) se += __expf(z[i] - gm);    // (-inf columns add 0; gm is finite: V > 0)
+        for (int i = 0; i < 4; ++i) se += __expf(z[i] - gm);     // (-inf columns add 0; gm is finite: V > 0)
         se += __shfl_xor(se, 16, 64);
         se += __shfl_xor(se, 32, 64);
         if (q == 0) s_se[wave][r16] = se;
@@ -182,125 +226,172 @@ __global__ __launch_bounds__(256) void dec_logits_pick(const bf16_t* __restrict_
 // ---------------------------------------------------------------------------------------------- 3 / 4
 // One LSTM step of one layer for 16 rows x 16 units per workgroup (wave g = gate g).  first != 0: the layer input is
 // the embedding of the symbol picked from `parts` (which this kernel finishes: every workgroup for its own rows, the
-// unit-block-0 workgroups write it out); otherwise x = y_prev (bf16 rows of the layer below).
+// unit-block-0 workgroups write it out); otherwise x = y_prev (rows of the layer below).
+// Everything that does not depend on the pick - W_ih, W_hh, h - is requested BEFORE the slices are merged (16 lanes per
+// row, each a share of the slices, a butterfly over the 16), the embedding rows right behind it: two L2 round trips
+// per launch where the serial merge + two products made 3 + nslices.
+template <typename ET>
 struct LstmStepArgs {
     const PickPart* parts; int nslices; int unk; int blank;
     int32_t* pred; int32_t* tokens; long long tok_stride; int t; float* score;
     const void* emb; int emb_f32; int E;
-    const bf16_t* x_prev;                 // [B, H] (layers > 0)
-    const bf16_t* w_ih; const bf16_t* w_hh; const float* b_ih; const float* b_hh;
+    const ET* x_prev;                      // [B, H] (layers > 0)
+    const ET* w_ih; const ET* w_hh; const float* b_ih; const float* b_hh;
     const float* h_in; const float* c_in;  // [B, H] fp32 state of this layer
     float* h_out; float* c_out;            // [B, H] fp32 candidates
-    bf16_t* y_out;                         // [B, H] bf16 copy of h_out (next layer / projection operand)
+    ET* y_out;                             // [B, H] copy of h_out in the mode's type (next layer / projection operand)
     int B, H, Kx;
 };
-__global__ __launch_bounds__(256) void dec_lstm_step(LstmStepArgs A, int first) {
+template <typename ET>
+__global__ __launch_bounds__(256) void dec_lstm_step(LstmStepArgs<ET> A, int first) {
+    typedef Mode<ET> Md;
+    constexpr int CH = 8;
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
     const int row0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
     const int row = row0 + r16, rowc = min(row, A.B - 1);
     __shared__ int s_pred[16];
     __shared__ float s_gate[4][16][17];
-    if (first == 2) {                              // beam search: the symbol is the popped hypothesis' last token
-        if (threadIdx.x < 16) s_pred[threadIdx.x] = A.pred[min(row0 + (int)threadIdx.x, A.B - 1)];
-        __syncthreads();
-    } else if (first) {
-        if (threadIdx.x < 16) {
-            const int rr = min(row0 + (int)threadIdx.x, A.B - 1);
+    const int col0 = g * A.H + j0;                 // W rows of this gate's 16 units
+    const ET* wip = A.w_ih + (long long)(col0 + r16) * A.Kx + q * Md::LK;
+    const ET* whp = A.w_hh + (long long)(col0 + r16) * A.H + q * Md::LK;
+    const float* hp = A.h_in + (long long)rowc * A.H + q * Md::LK;
+    // ---- batch 0 (the first CH k-steps) of both products, requested up front
+    typename Md::frag wi[CH], wh[CH], hx[CH], xx[CH];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        wi[c] = Md::ldw(wip + min(c * Md::KS, A.Kx - Md::KS));
+        wh[c] = Md::ldw(whp + min(c * Md::KS, A.H - Md::KS));
+        hx[c] = Md::ldx(hp + min(c * Md::KS, A.H - Md::KS));
+    }
+    const ET* xp = nullptr;                        // this lane's x row (layers > 0) ...
+    const float* xpf = nullptr;                    // ... or embedding row (fp32 table)
+    if (!first) {
+        xp = A.x_prev + (long long)rowc * A.H + q * Md::LK;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) xx[c] = Md::ldx(xp + min(c * Md::KS, A.Kx - Md::KS));
+    } else {
+        if (first == 2) {                          // beam search: the symbol is the popped hypothesis' last token
+            if (threadIdx.x < 16) s_pred[threadIdx.x] = A.pred[min(row0 + (int)threadIdx.x, A.B - 1)];
+        } else {
+            // thread <-> (row tid >> 4, slice share tid & 15)
+            const int pr = threadIdx.x >> 4, ps = threadIdx.x & 15;
+            const int rr = min(row0 + pr, A.B - 1);
             const PickPart* p = A.parts + (long long)rr * A.nslices;
             float m = -INFINITY, mx = -INFINITY;
             int a = 0x7fffffff, ax = 0x7fffffff;
-            for (int s = 0; s < A.nslices; ++s) {
+            for (int s = ps; s < A.nslices; s += 16) {
                 pick_merge(m, a, p[s].m, p[s].a);
                 pick_merge(mx, ax, p[s].mx, p[s].ax);
+            }
+#pragma unroll
+            for (int off = 1; off <= 8; off <<= 1) {
+                pick_merge(m, a, __shfl_xor(m, off, 64), __shfl_xor(a, off, 64));
+                pick_merge(mx, ax, __shfl_xor(mx, off, 64), __shfl_xor(ax, off, 64));
             }
             int pick = a;
             // rnnt/stream.py:105-108: an arg-max that is <unk> has its logit set to 0 and the arg-max is retaken
             if (A.unk >= 0 && a == A.unk) pick = (0.f > mx || (0.f == mx && A.unk < ax)) ? A.unk : ax;
-            s_pred[threadIdx.x] = pick;
-            if (blockIdx.y == 0 && row0 + (int)threadIdx.x < A.B) {
-                A.pred[rr] = pick;
-                if (A.tokens) A.tokens[(long long)rr * A.tok_stride + A.t] = pick;
+            if (ps == 0) s_pred[pr] = pick;
+            if (blockIdx.y == 0 && row0 + pr < A.B) {
+                if (ps == 0) {
+                    A.pred[rr] = pick;
+                    if (A.tokens) A.tokens[(long long)rr * A.tok_stride + A.t] = pick;
+                }
                 if (A.score) {                     // -(max log p) = log sum exp(z - max)   (greedy mode: unk < 0)
                     float se = 0.f;
-                    for (int s = 0; s < A.nslices; ++s) se += p[s].se * __expf(p[s].m - m);
-                    A.score[rr] += logf(se);
+                    for (int s = ps; s < A.nslices; s += 16) se += p[s].se * __expf(p[s].m - m);
+#pragma unroll
+                    for (int off = 1; off <= 8; off <<= 1) se += __shfl_xor(se, off, 64);
+                    if (ps == 0) A.score[rr] += logf(se);
                 }
             }
         }
         __syncthreads();
-    }
-    f32x4_t acc[1];
-    acc[0] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    const int col0 = g * A.H + j0;                 // W rows of this gate's 16 units
-    if (first) {
         const int tok = s_pred[r16];
-        if (A.emb_f32) tile_product<1>(acc, reinterpret_cast<const float*>(A.emb), A.E, tok, A.w_ih, A.Kx, col0, 4 * A.H, A.Kx, lane);
-        else tile_product<1>(acc, reinterpret_cast<const bf16_t*>(A.emb), A.E, tok, A.w_ih, A.Kx, col0, 4 * A.H, A.Kx, lane);
-    } else {
-        tile_product<1>(acc, A.x_prev, A.H, rowc, A.w_ih, A.Kx, col0, 4 * A.H, A.Kx, lane);
+        if (A.emb_f32) {
+            xpf = reinterpret_cast<const float*>(A.emb) + (long long)tok * A.E + q * Md::LK;
+#pragma unroll
+            for (int c = 0; c < CH; ++c) xx[c] = Md::ldx(xpf + min(c * Md::KS, A.Kx - Md::KS));
+        } else {
+            if constexpr (sizeof(ET) == 2) {
+                xp = reinterpret_cast<const ET*>(A.emb) + (long long)tok * A.E + q * Md::LK;
+#pragma unroll
+                for (int c = 0; c < CH; ++c) xx[c] = Md::ldx(xp + min(c * Md::KS, A.Kx - Md::KS));
+            }
+        }
     }
-    tile_product<1>(acc, A.h_in, A.H, rowc, A.w_hh, A.H, col0, 4 * A.H, A.H, lane);
+    // ---- x W_ih^T, then h W_hh^T, k ascending
+    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+        if (c * Md::KS < A.Kx) Md::mma(acc, wi[c], xx[c]);
+    if (A.Kx > CH * Md::KS) {
+        const int k0 = CH * Md::KS;
+        if (xpf) wave_product<ET, CH>(acc, xpf + k0, wip + k0, A.Kx - k0);
+        else wave_product<ET, CH>(acc, xp + k0, wip + k0, A.Kx - k0);
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+        if (c * Md::KS < A.H) Md::mma(acc, wh[c], hx[c]);
+    if (A.H > CH * Md::KS) wave_product<ET, CH>(acc, hp + CH * Md::KS, whp + CH * Md::KS, A.H - CH * Md::KS);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int u = q * 4 + i;
-        s_gate[g][r16][u] = acc[0][i] + A.b_ih[col0 + u] + A.b_hh[col0 + u];
+        s_gate[g][r16][u] = acc[i] + A.b_ih[col0 + u] + A.b_hh[col0 + u];
     }
     __syncthreads();
     // cells: thread <-> (row tid & 15, unit tid >> 4)
     const int cr = threadIdx.x & 15, cu = threadIdx.x >> 4;
     const int crow = row0 + cr;
     if (crow < A.B) {
-        const float ig = sigm(s_gate[0][cr][cu]), fg = sigm(s_gate[1][cr][cu]);
-        const float gg = tanh_fast(s_gate[2][cr][cu]), og = sigm(s_gate[3][cr][cu]);
+        const float ig = Md::sig(s_gate[0][cr][cu]), fg = Md::sig(s_gate[1][cr][cu]);
+        const float gg = Md::tnh(s_gate[2][cr][cu]), og = Md::sig(s_gate[3][cr][cu]);
         const long long o = (long long)crow * A.H + j0 + cu;
         const float c = fg * A.c_in[o] + ig * gg;
-        const float h = og * tanh_fast(c);
+        const float h = og * Md::tnh(c);
         A.c_out[o] = c;
         A.h_out[o] = h;
-        A.y_out[o] = f32_to_bf16(h);
+        Md::st1(A.y_out + o, h);
     }
 }
 
 // ---------------------------------------------------------------------------------------------- 5
-// dec_new = y W_p^T + b_p for 16 rows x 64 columns per wave; rows whose symbol is not blank take dec_new and the new
-// prediction-network state (each block moves its share of the L x H state values of its rows)
-__global__ __launch_bounds__(64) void dec_proj_commit(const bf16_t* __restrict__ y, int H, const bf16_t* __restrict__ Wp,
-                                                      const float* __restrict__ bp, int P2,
-                                                      const int32_t* __restrict__ pred, int blank,
-                                                      bf16_t* __restrict__ dec_out, float* __restrict__ h_state,
-                                                      const float* __restrict__ h_new, float* __restrict__ c_state,
-                                                      const float* __restrict__ c_new, int L, int B) {
-    const int lane = threadIdx.x, r16 = lane & 15, q = lane >> 4;
-    const int row0 = blockIdx.x * 16, row = row0 + r16, col0 = blockIdx.y * 64;
-    f32x4_t acc[4];
-#pragma unroll
-    for (int n = 0; n < 4; ++n) acc[n] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    tile_product<4>(acc, y, H, min(row, B - 1), Wp, H, col0, P2, H, lane);
-    const bool keep = row < B && (pred == nullptr || pred[min(row, B - 1)] != blank);   // (pred == null: every row)
-    if (keep) {
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-            const int c = col0 + n * 16 + q * 4;
-            if (c >= P2) continue;
-            uint2 o;
-            o.x = f32x2_to_bf16x2(acc[n][0] + bp[c], acc[n][1] + bp[c + 1]);
-            o.y = f32x2_to_bf16x2(acc[n][2] + bp[c + 2], acc[n][3] + bp[c + 3]);
-            *reinterpret_cast<uint2*>(dec_out + (long long)row * P2 + c) = o;
-        }
+// dec_new = y W_p^T + b_p for 16 rows x 64 columns per workgroup (a wave = 16 columns); rows whose symbol is not blank
+// take dec_new and the new prediction-network state (each block moves its share of the L x H state values of its rows)
+template <typename ET>
+__global__ __launch_bounds__(256) void dec_proj_commit(const ET* __restrict__ y, int H, const ET* __restrict__ Wp,
+                                                       const float* __restrict__ bp, int P2,
+                                                       const int32_t* __restrict__ pred, int blank,
+                                                       ET* __restrict__ dec_out, float* __restrict__ h_state,
+                                                       const float* __restrict__ h_new, float* __restrict__ c_state,
+                                                       const float* __restrict__ c_new, int L, int B) {
+    typedef Mode<ET> Md;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.x * 16, row = row0 + r16, col0 = blockIdx.y * 64 + wave * 16;
+    __shared__ int s_keep[16];
+    if (threadIdx.x < 16) {
+        const int r = row0 + (int)threadIdx.x;
+        s_keep[threadIdx.x] = r < B && (pred == nullptr || pred[r] != blank);          // (pred == null: every row)
     }
+    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (col0 < P2)
+        wave_product<ET, 16>(acc, y + (long long)min(row, B - 1) * H + q * Md::LK,
+                             Wp + (long long)min(col0 + r16, P2 - 1) * H + q * Md::LK, H);
+    __syncthreads();
+    const int c = col0 + q * 4;
+    if (s_keep[r16] && c < P2)
+        Md::st4(dec_out + (long long)row * P2 + c, acc[0] + bp[c], acc[1] + bp[c + 1], acc[2] + bp[c + 2], acc[3] + bp[c + 3]);
     if (pred == nullptr) return;
-    // state commit: this block's slice of [L][16 rows][H]
+    // state commit: this block's slice of [L][16 rows][H], one value per thread and pass
     const int per = (L * H + gridDim.y - 1) / gridDim.y;
-    const int lo = blockIdx.y * per, hi = min(L * H, lo + per);
-    for (int rr = 0; rr < 16; ++rr) {
-        const int r = row0 + rr;
-        if (r >= B || pred[r] == blank) continue;
-        for (int i = lo + lane; i < hi; i += 64) {
-            const int l = i / H, j = i - l * H;
-            const long long o = ((long long)l * B + r) * H + j;
-            h_state[o] = h_new[o];
-            c_state[o] = c_new[o];
-        }
+    const int lo = blockIdx.y * per, n = min(L * H, lo + per) - lo;
+    for (int idx = threadIdx.x; idx < 16 * n; idx += 256) {
+        const int rr = idx / n, i = lo + idx - rr * n;
+        if (!s_keep[rr]) continue;
+        const int l = i / H, j = i - l * H;
+        const long long o = ((long long)l * B + row0 + rr) * H + j;
+        h_state[o] = h_new[o];
+        c_state[o] = c_new[o];
     }
 }
 
@@ -474,82 +565,120 @@ extern "C" int edgedict_stream_encoder_step(const void* xs, int x_dtype, int B, 
     return ED_OK;
 }
 
+// shapes the fused frame covers (otherwise decode.hip composes the frame from the general kernels)
+bool ed_decode_fused_ok(int dtype, int emb_dtype, int J, int V, int E, int H, int P2) {
+    static const int on = [] { const char* e = getenv("EDGEDICT_DECODE_FUSED"); return e ? atoi(e) : 1; }();
+    return on && (dtype == ED_BF16 || (dtype == ED_F32 && emb_dtype == ED_F32)) && J % 32 == 0 && P2 % 32 == 0 &&
+           E % 32 == 0 && H % 32 == 0 && V % 4 == 0;
+}
+// slice partials of one frame: [B][ceil(V / 64)] PickPart (32 bytes each: V / 2 bytes per row - they fit the fp32
+// logits buffer of the composed path, which the fused frame never fills)
+size_t ed_decode_fused_ws_bytes(int B, int V) {
+    return align256((size_t)B * ((V + 63) / 64) * sizeof(PickPart));
+}
+
 namespace {
+
+template <typename ET>
+void launch_lstm_steps(int first_mode, const PickPart* parts, int NS, int unk, int blank, int32_t* pred, int32_t* tokens,
+                       long long tok_stride, int t, float* score, const void* emb, int emb_dtype, int E, int L,
+                       const void* const* w_ih, const void* const* w_hh, const float* const* b_ih,
+                       const float* const* b_hh, int H, const float* h_state, const float* c_state, float* h_new,
+                       float* c_new, void* const* Y, int B, hipStream_t s) {
+    const int RB = (B + 15) / 16;
+    for (int k = 0; k < L; ++k) {
+        LstmStepArgs<ET> A;
+        A.parts = parts; A.nslices = NS; A.unk = unk; A.blank = blank;
+        A.pred = pred; A.tokens = tokens; A.tok_stride = tok_stride; A.t = t; A.score = score;
+        A.emb = emb; A.emb_f32 = emb_dtype == ED_F32 ? 1 : 0; A.E = E;
+        A.x_prev = k > 0 ? (const ET*)Y[(k - 1) & 1] : nullptr;
+        A.w_ih = (const ET*)w_ih[k]; A.w_hh = (const ET*)w_hh[k]; A.b_ih = b_ih[k]; A.b_hh = b_hh[k];
+        A.h_in = h_state + (size_t)k * B * H; A.c_in = c_state + (size_t)k * B * H;
+        A.h_out = h_new + (size_t)k * B * H; A.c_out = c_new + (size_t)k * B * H;
+        A.y_out = (ET*)Y[k & 1];
+        A.B = B; A.H = H; A.Kx = k == 0 ? E : H;
+        hipLaunchKernelGGL(dec_lstm_step<ET>, dim3(RB, H / 16), dim3(256), 0, s, A, k == 0 ? first_mode : 0);
+    }
+}
+
+template <typename ET>
+int beam_step_t(const void* E1t, long long e_row_stride, int B, int J, const void* W1d, long long ldw1, const float* b1,
+                int P2, const void* W2, const float* b2, int V, const void* emb, int emb_dtype, int E, int L,
+                const void* const* w_ih, const void* const* w_hh, const float* const* b_ih, const float* const* b_hh,
+                int H, const void* Wp, const float* bp, const float* h_state, const float* c_state, const int32_t* pred,
+                void* dec_new, void* hid, float* logits, float* h_new, float* c_new, void* Y0, void* Y1, hipStream_t s) {
+    const int RB = (B + 15) / 16;
+    void* Y[2] = {Y0, Y1};
+    launch_lstm_steps<ET>(2, nullptr, 0, -1, -1, const_cast<int32_t*>(pred), nullptr, 0, 0, nullptr, emb, emb_dtype, E, L,
+                          w_ih, w_hh, b_ih, b_hh, H, h_state, c_state, h_new, c_new, Y, B, s);
+    hipLaunchKernelGGL(dec_proj_commit<ET>, dim3(RB, (P2 + 63) / 64), dim3(256), 0, s, (const ET*)Y[(L - 1) & 1], H,
+                       (const ET*)Wp, bp, P2, (const int32_t*)nullptr, 0, (ET*)dec_new, (float*)nullptr,
+                       (const float*)nullptr, (float*)nullptr, (const float*)nullptr, L, B);
+    hipLaunchKernelGGL(dec_joint_hidden<ET>, dim3(RB, (J + 63) / 64), dim3(256), 0, s, (const ET*)E1t, e_row_stride,
+                       (const ET*)dec_new, P2, (const ET*)W1d, ldw1, b1, (ET*)hid, B, J);
+    hipLaunchKernelGGL(dec_logits_pick<ET>, dim3(RB, (V + 63) / 64), dim3(256), 0, s, (const ET*)hid, J, (const ET*)W2,
+                       b2, V, -1, 0, (PickPart*)nullptr, logits, B);
+    return ED_OK;
+}
+
+template <typename ET>
+int frame_t(const void* E1t, long long e_row_stride, int B, int J, const void* W1d, long long ldw1, const float* b1,
+            int P2, const void* W2, const float* b2, int V, const void* emb, int emb_dtype, int E, int L,
+            const void* const* w_ih, const void* const* w_hh, const float* const* b_ih, const float* const* b_hh, int H,
+            const void* Wp, const float* bp, float* h_state, float* c_state, void* dec_out, int blank, int unk,
+            int32_t* tokens_out, long long tok_stride, int t, float* score, void* hid, void* parts, int32_t* pred,
+            float* h_new, float* c_new, void* Y0, void* Y1, hipStream_t s) {
+    const int RB = (B + 15) / 16, NS = (V + 63) / 64;
+    hipLaunchKernelGGL(dec_joint_hidden<ET>, dim3(RB, (J + 63) / 64), dim3(256), 0, s, (const ET*)E1t, e_row_stride,
+                       (const ET*)dec_out, P2, (const ET*)W1d, ldw1, b1, (ET*)hid, B, J);
+    hipLaunchKernelGGL(dec_logits_pick<ET>, dim3(RB, NS), dim3(256), 0, s, (const ET*)hid, J, (const ET*)W2, b2, V,
+                       unk, score ? 1 : 0, (PickPart*)parts, (float*)nullptr, B);
+    void* Y[2] = {Y0, Y1};
+    launch_lstm_steps<ET>(1, (const PickPart*)parts, NS, unk, blank, pred, tokens_out, tok_stride, t, score, emb, emb_dtype,
+                          E, L, w_ih, w_hh, b_ih, b_hh, H, h_state, c_state, h_new, c_new, Y, B, s);
+    hipLaunchKernelGGL(dec_proj_commit<ET>, dim3(RB, (P2 + 63) / 64), dim3(256), 0, s, (const ET*)Y[(L - 1) & 1], H,
+                       (const ET*)Wp, bp, P2, pred, blank, (ET*)dec_out, h_state, h_new, c_state, c_new, L, B);
+    return ED_OK;
+}
 
 }  // namespace
 
-// shapes the fused frame covers (otherwise decode.hip composes the frame from the general kernels)
-bool ed_decode_fused_ok(int dtype, int J, int V, int E, int H, int P2) {
-    static const int on = [] { const char* e = getenv("EDGEDICT_DECODE_FUSED"); return e ? atoi(e) : 1; }();
-    return on && dtype == ED_BF16 && J % 32 == 0 && P2 % 32 == 0 && E % 32 == 0 && H % 32 == 0 && H % 16 == 0 &&
-           V % 4 == 0 && J % 4 == 0 && P2 % 4 == 0;
-}
-size_t ed_decode_fused_ws_bytes(int B, int V) {
-    return align256((size_t)B * ((V + 255) / 256) * sizeof(PickPart));
-}
-
-// beam search (decode.hip): prediction-network step on pred[b] from (h_state, c_state) -> h_new / c_new, dec_new, and the
-// joint's hidden vector of frame t for every row - 2 + L launches instead of 4 + 2 L; the caller multiplies hid by W2
-int ed_decode_fused_beam_step(const void* E1t, long long e_row_stride, int B, int J, const void* W1d, long long ldw1,
-                              const float* b1, int P2, const void* emb, int emb_dtype, int E, int L,
-                              const void* const* w_ih, const void* const* w_hh, const float* const* b_ih,
-                              const float* const* b_hh, int H, const void* Wp, const float* bp, const float* h_state,
-                              const float* c_state, const int32_t* pred, void* dec_new, void* hid, float* h_new,
-                              float* c_new, void* Y0, void* Y1, hipStream_t s) {
-    const int RB = (B + 15) / 16;
-    void* Y[2] = {Y0, Y1};
-    for (int k = 0; k < L; ++k) {
-        LstmStepArgs A;
-        A.parts = nullptr; A.nslices = 0; A.unk = -1; A.blank = -1;
-        A.pred = const_cast<int32_t*>(pred); A.tokens = nullptr; A.tok_stride = 0; A.t = 0; A.score = nullptr;
-        A.emb = emb; A.emb_f32 = emb_dtype == ED_F32 ? 1 : 0; A.E = E;
-        A.x_prev = k > 0 ? (const bf16_t*)Y[(k - 1) & 1] : nullptr;
-        A.w_ih = (const bf16_t*)w_ih[k]; A.w_hh = (const bf16_t*)w_hh[k]; A.b_ih = b_ih[k]; A.b_hh = b_hh[k];
-        A.h_in = h_state + (size_t)k * B * H; A.c_in = c_state + (size_t)k * B * H;
-        A.h_out = h_new + (size_t)k * B * H; A.c_out = c_new + (size_t)k * B * H;
-        A.y_out = (bf16_t*)Y[k & 1];
-        A.B = B; A.H = H; A.Kx = k == 0 ? E : H;
-        hipLaunchKernelGGL(dec_lstm_step, dim3(RB, H / 16), dim3(256), 0, s, A, k == 0 ? 2 : 0);
-    }
-    hipLaunchKernelGGL(dec_proj_commit, dim3(RB, (P2 + 63) / 64), dim3(64), 0, s, (const bf16_t*)Y[(L - 1) & 1], H,
-                       (const bf16_t*)Wp, bp, P2, (const int32_t*)nullptr, 0, (bf16_t*)dec_new, (float*)nullptr,
-                       (const float*)nullptr, (float*)nullptr, (const float*)nullptr, L, B);
-    hipLaunchKernelGGL(dec_joint_hidden, dim3(RB, (J + 63) / 64), dim3(64), 0, s, (const bf16_t*)E1t, e_row_stride,
-                       (const bf16_t*)dec_new, P2, (const bf16_t*)W1d, ldw1, b1, (bf16_t*)hid, B, J);
+// beam search (decode.hip): prediction-network step on pred[b] from (h_state, c_state) -> h_new / c_new, dec_new, the
+// joint's hidden vector of frame t and the logits (fp32 [B, V]) of every row - 3 + L launches instead of 5 + 2 L
+int ed_decode_fused_beam_step(int dtype, const void* E1t, long long e_row_stride, int B, int J, const void* W1d,
+                              long long ldw1, const float* b1, int P2, const void* W2, const float* b2, int V,
+                              const void* emb, int emb_dtype, int E, int L, const void* const* w_ih,
+                              const void* const* w_hh, const float* const* b_ih, const float* const* b_hh, int H,
+                              const void* Wp, const float* bp, const float* h_state, const float* c_state,
+                              const int32_t* pred, void* dec_new, void* hid, float* logits, float* h_new, float* c_new,
+                              void* Y0, void* Y1, hipStream_t s) {
+    if (dtype == ED_F32)
+        beam_step_t<float>(E1t, e_row_stride, B, J, W1d, ldw1, b1, P2, W2, b2, V, emb, emb_dtype, E, L, w_ih, w_hh, b_ih,
+                           b_hh, H, Wp, bp, h_state, c_state, pred, dec_new, hid, logits, h_new, c_new, Y0, Y1, s);
+    else
+        beam_step_t<bf16_t>(E1t, e_row_stride, B, J, W1d, ldw1, b1, P2, W2, b2, V, emb, emb_dtype, E, L, w_ih, w_hh, b_ih,
+                            b_hh, H, Wp, bp, h_state, c_state, pred, dec_new, hid, logits, h_new, c_new, Y0, Y1, s);
     ED_CHECK_LAUNCH("decode_fused_beam_step");
     return ED_OK;
 }
 
-// one frame of the search: see the file header.  hid [B, J] bf16, parts = ed_decode_fused_ws_bytes(B, V) bytes,
-// h_new / c_new [L, B, H] fp32, Y [2][B, H] bf16 (ping-pong between layers); pred [B] out
-int ed_decode_fused_frame(const void* E1t, long long e_row_stride, int B, int J, const void* W1d, long long ldw1,
-                          const float* b1, int P2, const void* W2, const float* b2, int V, const void* emb,
-                          int emb_dtype, int E, int L, const void* const* w_ih, const void* const* w_hh,
-                          const float* const* b_ih, const float* const* b_hh, int H, const void* Wp, const float* bp,
-                          float* h_state, float* c_state, void* dec_out, int blank, int unk, int32_t* tokens_out,
-                          long long tok_stride, int t, float* score, void* hid, void* parts, int32_t* pred,
-                          float* h_new, float* c_new, void* Y0, void* Y1, hipStream_t s) {
-    const int RB = (B + 15) / 16, NS = (V + 255) / 256;
-    hipLaunchKernelGGL(dec_joint_hidden, dim3(RB, (J + 63) / 64), dim3(64), 0, s, (const bf16_t*)E1t, e_row_stride,
-                       (const bf16_t*)dec_out, P2, (const bf16_t*)W1d, ldw1, b1, (bf16_t*)hid, B, J);
-    hipLaunchKernelGGL(dec_logits_pick, dim3(RB, NS), dim3(256), 0, s, (const bf16_t*)hid, J, (const bf16_t*)W2, b2, V,
-                       unk, score ? 1 : 0, (PickPart*)parts, B);
-    void* Y[2] = {Y0, Y1};
-    for (int k = 0; k < L; ++k) {
-        LstmStepArgs A;
-        A.parts = (const PickPart*)parts; A.nslices = NS; A.unk = unk; A.blank = blank;
-        A.pred = pred; A.tokens = tokens_out; A.tok_stride = tok_stride; A.t = t; A.score = score;
-        A.emb = emb; A.emb_f32 = emb_dtype == ED_F32 ? 1 : 0; A.E = E;
-        A.x_prev = k > 0 ? (const bf16_t*)Y[(k - 1) & 1] : nullptr;
-        A.w_ih = (const bf16_t*)w_ih[k]; A.w_hh = (const bf16_t*)w_hh[k]; A.b_ih = b_ih[k]; A.b_hh = b_hh[k];
-        A.h_in = h_state + (size_t)k * B * H; A.c_in = c_state + (size_t)k * B * H;
-        A.h_out = h_new + (size_t)k * B * H; A.c_out = c_new + (size_t)k * B * H;
-        A.y_out = (bf16_t*)Y[k & 1];
-        A.B = B; A.H = H; A.Kx = k == 0 ? E : H;
-        hipLaunchKernelGGL(dec_lstm_step, dim3(RB, H / 16), dim3(256), 0, s, A, k == 0 ? 1 : 0);
-    }
-    hipLaunchKernelGGL(dec_proj_commit, dim3(RB, (P2 + 63) / 64), dim3(64), 0, s, (const bf16_t*)Y[(L - 1) & 1], H,
-                       (const bf16_t*)Wp, bp, P2, pred, blank, (bf16_t*)dec_out, h_state, h_new, c_state, c_new, L, B);
+// one frame of the search: see the file header.  hid [B, J], parts = ed_decode_fused_ws_bytes(B, V) bytes,
+// h_new / c_new [L, B, H] fp32, Y [2][B, H] (ping-pong between layers); pred [B] out
+int ed_decode_fused_frame(int dtype, const void* E1t, long long e_row_stride, int B, int J, const void* W1d,
+                          long long ldw1, const float* b1, int P2, const void* W2, const float* b2, int V,
+                          const void* emb, int emb_dtype, int E, int L, const void* const* w_ih,
+                          const void* const* w_hh, const float* const* b_ih, const float* const* b_hh, int H,
+                          const void* Wp, const float* bp, float* h_state, float* c_state, void* dec_out, int blank,
+                          int unk, int32_t* tokens_out, long long tok_stride, int t, float* score, void* hid, void* parts,
+                          int32_t* pred, float* h_new, float* c_new, void* Y0, void* Y1, hipStream_t s) {
+    if (dtype == ED_F32)
+        frame_t<float>(E1t, e_row_stride, B, J, W1d, ldw1, b1, P2, W2, b2, V, emb, emb_dtype, E, L, w_ih, w_hh, b_ih, b_hh,
+                       H, Wp, bp, h_state, c_state, dec_out, blank, unk, tokens_out, tok_stride, t, score, hid, parts,
+                       pred, h_new, c_new, Y0, Y1, s);
+    else
+        frame_t<bf16_t>(E1t, e_row_stride, B, J, W1d, ldw1, b1, P2, W2, b2, V, emb, emb_dtype, E, L, w_ih, w_hh, b_ih, b_hh,
+                        H, Wp, bp, h_state, c_state, dec_out, blank, unk, tokens_out, tok_stride, t, score, hid, parts,
+                        pred, h_new, c_new, Y0, Y1, s);
     ED_CHECK_LAUNCH("decode_fused_frame");
     return ED_OK;
 }

@@ -56,6 +56,42 @@ template <> struct MK<float> { static constexpr int K = 4, LANE_K = 1; };
 
 constexpr int UNITS = 4;  // hidden units per forward workgroup (x 4 gates = one 16-wide N tile)
 
+// fp32 operands, K slice [kbeg, kend) a multiple of 16 long, rows 16-byte aligned: ONE 16-byte load per lane and operand
+// feeds FOUR 16x16x4 MFMA steps - lane (r, kq) holds k = 16 c + 4 kq + j (j = 0..3) of chunk c, and MFMA j of the chunk
+// takes element j of every lane: the same permutation of k on both operands, i.e. the same dot product summed in
+// another order.  CHK chunks of both operands are requested together.  (The scalar form below issues one dependent L2
+// round trip per MFMA step: 64 per wave at H = 1024 - the fp32 step took 46 us, 3 us of them arithmetic; this is what
+// made the exact mode's encoder 7 x slower than it has to be.)
+template <int M>
+__device__ __forceinline__ void f32_product16(f32x4_t (&acc)[M], const float* const (&ap)[M], const float* wp,
+                                              int kbeg, int kend, int lane) {
+    constexpr int CHK = M >= 4 ? 8 : 16;
+    const int ko = (lane >> 4) * 4;
+    for (int k = kbeg; k < kend; k += 16 * CHK) {
+        float4 bq[CHK], aq[CHK][M];
+#pragma unroll
+        for (int c = 0; c < CHK; ++c) {
+            const int kk = min(k + 16 * c, kend - 16) + ko;          // (clamped: a repeated chunk is skipped below)
+            bq[c] = *reinterpret_cast<const float4*>(wp + kk);
+#pragma unroll
+            for (int m = 0; m < M; ++m) aq[c][m] = *reinterpret_cast<const float4*>(ap[m] + kk);
+        }
+#pragma unroll
+        for (int c = 0; c < CHK; ++c) {
+            if (k + 16 * c < kend) {
+                const float bv[4] = {bq[c].x, bq[c].y, bq[c].z, bq[c].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int m = 0; m < M; ++m) {
+                        const float av[4] = {aq[c][m].x, aq[c][m].y, aq[c][m].z, aq[c][m].w};
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], bv[j], acc[m], 0, 0, 0);
+                    }
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void lstm_step_fwd(
     T* __restrict__ G, T* __restrict__ Hprev, T* __restrict__ Y, float* __restrict__ Cst,
@@ -90,6 +126,21 @@ __global__ __launch_bounds__(256) void lstm_step_fwd(
         a_ok[m] = b < B;
         aptr[m] = Hprev + ((long long)min(b, B - 1) * Tn + t) * H;
     }
+    if constexpr (sizeof(T) == 4) {
+        if ((H & 63) == 0) {       // wave slices of H / 4, a multiple of 16 (rows past B: clamped, never stored)
+            const float* ap[4] = {(const float*)aptr[0], (const float*)aptr[1], (const float*)aptr[2], (const float*)aptr[3]};
+            f32_product16<4>(acc, ap, (const float*)wptr, kbeg, kend, lane);
+        } else {
+            for (int k = kbeg; k < kend; k += MKK) {
+                const auto bf = load_frag(wptr, k + koff, H, w_ok);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const auto af = load_frag(aptr[m], k + koff, H, a_ok[m]);
+                    acc[m] = mma(af, bf, acc[m]);
+                }
+            }
+        }
+    } else
     for (int k = kbeg; k < kend; k += MKK) {
         const auto bf = load_frag(wptr, k + koff, H, w_ok);
 #pragma unroll
@@ -174,6 +225,15 @@ __global__ __launch_bounds__(256) void lstm_step_bwd(
         const int koff = (lane >> 4) * LK;
         f32x4_t acc2 = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         int k = kbeg;
+        if constexpr (sizeof(T) == 4) {
+            if ((H & 15) == 0) {   // wave slices of H
+                f32x4_t a1[1] = {acc};
+                const float* ap[1] = {(const float*)aptr};
+                f32_product16<1>(a1, ap, (const float*)wptr, kbeg, kend, lane);
+                acc = a1[0];
+                k = kend;
+            }
+        }
         for (; k + MKK < kend; k += 2 * MKK) {  // two independent accumulation chains
             const auto a0 = load_frag(aptr, k + koff, K, a_ok);
             const auto w0 = load_frag(wptr, k + koff, K, w_ok);

@@ -121,3 +121,50 @@ def test_beam_bf16_runs_and_returns_valid_tokens(hip_lib):
         seqs, scores = m.beam_search(xs.cuda(), xlen, W=4)
     assert all(((s > 0) & (s < CFG["vocab_size"])).all() for s in seqs)
     assert torch.isfinite(scores).all() and (scores >= 0).all()
+
+
+# every dimension a multiple of 32 (V of 4): the shapes csrc/decode_fused.hip covers - the prediction-network step, the
+# projection, the joint's hidden vector and the logits of an expansion as 3 + L fused launches, in fp32 as in bf16
+CFG32 = dict(vocab_embed_size=32, vocab_size=64, input_size=24, enc_hidden_size=32, enc_layers=2,
+             enc_proj_size=32, dec_hidden_size=32, dec_layers=2, dec_proj_size=32, joint_size=32)
+
+
+def _engine32(sd, dtype="fp32"):
+    from edgedict_amd.models import Transducer
+    m = Transducer(enc_dropout=0.0, dec_dropout=0.0, output_loss=False, **CFG32)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    m.compute_dtype = dtype
+    return m
+
+
+@pytest.mark.parametrize("prefix", [False, True])
+def test_beam_fused_step_fp32_matches_oracle(hip_lib, prefix):
+    sd = M.make_state_dict(CFG32, 5)
+    xs, ys, xlen, ylen = M.make_batch(CFG32, 6, 19, 15, 4)        # 19 utterances: two row tiles, the second ragged
+    xlen = torch.tensor([15, 9, 15, 3, 12, 15, 1, 7, 15, 15, 4, 11, 15, 2, 15, 13, 15, 6, 10], dtype=torch.int32)
+    m = _engine32(sd)
+    with torch.no_grad():
+        seqs, scores = m.beam_search(xs.cuda(), xlen, W=3, max_expansions=600, prefix=prefix)
+    rs, rsc, _ = beam_ref.beam_search(sd, xs, xlen, W=3, prefix=prefix)
+    for a, b in zip(seqs, rs):
+        assert np.array_equal(a, b)
+    np.testing.assert_allclose(scores.numpy(), rsc, rtol=2e-4, atol=2e-4)
+
+
+def test_greedy_fused_frame_fp32_matches_oracle_and_bf16_runs(hip_lib):
+    """Transducer.greedy_decode rnnt/models.py:243-269 through the five fused launches per frame in the fp32 parity mode
+    (the E4D1 / E6D2 reference goldens of tests/test_models_gpu.py run through the same kernels at full size)."""
+    sd = M.make_state_dict(CFG32, 7)
+    xs, ys, xlen, ylen = M.make_batch(CFG32, 8, 37, 21, 4)        # 37 rows: three row tiles, the last ragged
+    m = _engine32(sd)
+    with torch.no_grad():
+        tokens, score = m.greedy_decode(xs.cuda(), xlen.cuda())
+    rt, rs = M.greedy_decode(sd, xs, xlen)
+    for b, t in enumerate(tokens):
+        assert np.array_equal(t, np.asarray(rt[b])[:len(t)]), b
+    np.testing.assert_allclose(score.cpu().numpy(), np.asarray(rs), rtol=1e-4, atol=1e-4)
+    mb = _engine32(sd, "bf16")
+    with torch.no_grad():
+        tb, sb = mb.greedy_decode(xs.cuda(), xlen.cuda())
+    assert all(((t >= 0) & (t < CFG32["vocab_size"])).all() for t in tb) and torch.isfinite(sb).all()

@@ -78,7 +78,8 @@ if __name__ == "__main__":
     else:
         print(__doc__.split("usage:")[0])
         for variant, env in (("default", {}), ("stack weight grads at end", {"EDGEDICT_STACK_FLAGS": "2"}),
-                             ("nodefer", {}), ("forward one launch per step (EDGEDICT_STACK_LPW=0)", {"EDGEDICT_STACK_LPW": "0"})):
+                             ("nodefer", {}), ("forward hand-off through arrival counters (EDGEDICT_LPW_POLL=0)", {"EDGEDICT_LPW_POLL": "0"}),
+                             ("forward one launch per step (EDGEDICT_STACK_LPW=0)", {"EDGEDICT_STACK_LPW": "0"})):
             e = dict(os.environ)
             e.update(env)
             arg = "nodefer" if variant == "nodefer" else variant
