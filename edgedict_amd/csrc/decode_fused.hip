@@ -396,84 +396,82 @@ __global__ __launch_bounds__(256) void dec_proj_commit(const ET* __restrict__ y,
 }
 
 // ---------------------------------------------------------------------------------------------- stream encoder
-// One LSTM time step of one encoder layer for 16 RT rows x 16 units per workgroup (wave g = gate g): the streaming
-// decoder's encoder advances S streams by a frame or two per chunk, and composed from the per-layer kernels (input
-// product, kernel-per-step recurrence) that was ~4 launches per layer-frame plus their host glue.  The W fragment of a
-// k-step is loaded once and used for all RT row tiles.
+// One LSTM time step of one encoder layer for 16 RT rows x 16 units per workgroup: the streaming decoder's encoder
+// advances S streams by a frame or two per chunk, and composed from the per-layer kernels (LayerNorm, input product,
+// state copy, kernel-per-step recurrence) that was 4 launches and ~35 us per layer-frame plus their host glue.
+// 8 waves: wave (g, half) = gate g of the 16 units, half 0 the input product x W_ih^T, half 1 the recurrent product
+// h W_hh^T (h as bf16: the previous step's y row, or the bf16 copy of the carried state made once per call - the same
+// values the conversion at load time would produce) - two independent K loops side by side, 8 k-steps of both operands
+// requested at once (one L2 round trip per 256 k), the W fragment of a k-step used for all RT row tiles.
+// Loads are never conditional (a predicated load is its own exec-masked block and the compiler waits for each - the first
+// version of this kernel spent 48 of its 60 us at S = 256 in 32 exposed round trips): addresses are clamped into the
+// row and the W fragment of a k-group past K is zeroed after the load (the encoder's first layer has K = 240).
+template <int RT, int CH>
+__device__ __forceinline__ void rows_product(f32x4_t (&acc)[RT], const bf16_t* const (&xp)[RT], const bf16_t* wp, int K,
+                                             int kq) {
+    const int KP = (K + 31) & ~31;
+    for (int k0 = 0; k0 < KP; k0 += 32 * CH) {
+        bf16x8_t a[CH][RT], b[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const int k = min(k0 + 32 * c, KP - 32);
+            const int kk = min(k + kq * 8, K - 8);           // K % 8 == 0: the last whole 8-group of the row
+            b[c] = ld8(wp + kk);
+#pragma unroll
+            for (int m = 0; m < RT; ++m) a[c][m] = ld8(xp[m] + kk);
+        }
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            if (k0 + 32 * c < KP) {
+                union { unsigned u[4]; bf16x8_t v; } z;
+                z.v = b[c];
+                if (k0 + 32 * c + kq * 8 >= K) z.u[0] = z.u[1] = z.u[2] = z.u[3] = 0u;
+#pragma unroll
+                for (int m = 0; m < RT; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(z.v, a[c][m], acc[m], 0, 0, 0);
+            }
+        }
+    }
+}
+
 template <int RT>
-__global__ __launch_bounds__(256) void enc_lstm_step(const bf16_t* __restrict__ x, long long ldx, int Kx,
+__global__ __launch_bounds__(512) void enc_lstm_step(const bf16_t* __restrict__ x, long long ldx, int Kx,
                                                      const bf16_t* __restrict__ w_ih, const bf16_t* __restrict__ w_hh,
                                                      const float* __restrict__ b_ih, const float* __restrict__ b_hh,
-                                                     const float* __restrict__ h_in, const float* __restrict__ c_in,
-                                                     float* __restrict__ h_out, float* __restrict__ c_out,
-                                                     bf16_t* __restrict__ y, long long ldy, int B, int H) {
-    const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4, kq = q;
+                                                     const bf16_t* __restrict__ hb, long long ldh,
+                                                     const float* __restrict__ c_in, float* __restrict__ h_out,
+                                                     float* __restrict__ c_out, bf16_t* __restrict__ y, long long ldy,
+                                                     int B, int H) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = wave & 3, half = wave >> 2;
+    const int r16 = lane & 15, q = lane >> 4;
     const int row0 = blockIdx.x * 16 * RT, j0 = blockIdx.y * 16;
-    __shared__ float s_gate[4][16 * RT][17];
+    __shared__ float s_gate[2][4][16 * RT][17];
     f32x4_t acc[RT];
 #pragma unroll
     for (int m = 0; m < RT; ++m) acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     const int col = g * H + j0 + r16;                       // this lane's W row (gate g, unit j0 + r16)
-    int rows[RT];
+    const bf16_t* xp[RT];
+    const bf16_t* src = half ? hb : x;
+    const long long ld = half ? ldh : ldx;
+    const int K = half ? H : Kx;
 #pragma unroll
-    for (int m = 0; m < RT; ++m) rows[m] = min(row0 + m * 16 + r16, B - 1);
-    // K % 8 == 0 (the encoder's first layer has K = 240): the k-groups of the last k-step that lie past K are zeros.
-    // Software-pipelined: the operands of the next CH k-steps are requested before the current ones are multiplied (a
-    // workgroup per CU, four waves: nothing else hides the L2 round trip - without it 48 of the 60 us of a layer-frame
-    // at S = 256 were 32 exposed round trips)
-    constexpr int CH = RT >= 4 ? 2 : 4;                     // k-steps per stage
-    auto product = [&](auto xload, const bf16_t* W, int K) {
-        const bf16_t* wp = W + (long long)col * K + kq * 8;
-        const int KP = (K + 31) & ~31;
-        const int nst = (KP / 32 + CH - 1) / CH;            // stages
-        bf16x8_t a[2][CH][RT], b[2][CH];
-        auto request = [&](int buf, int st) {
-#pragma unroll
-            for (int c = 0; c < CH; ++c) {
-                const int k = min((st * CH + c) * 32, KP - 32);
-                const bool in = k + kq * 8 < K;
-                union { unsigned u[4]; bf16x8_t v; } z;
-                z.u[0] = z.u[1] = z.u[2] = z.u[3] = 0u;
-                b[buf][c] = in ? ld8(wp + k) : z.v;
-#pragma unroll
-                for (int m = 0; m < RT; ++m) a[buf][c][m] = in ? xload(rows[m], k + kq * 8) : z.v;
-            }
-        };
-        auto multiply = [&](int buf, int st) {
-#pragma unroll
-            for (int c = 0; c < CH; ++c)
-                if ((st * CH + c) * 32 < KP) {
-#pragma unroll
-                    for (int m = 0; m < RT; ++m)
-                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[buf][c], a[buf][c][m], acc[m], 0, 0, 0);
-                }
-        };
-        request(0, 0);
-        for (int st = 0; st < nst; st += 2) {
-            if (st + 1 < nst) request(1, st + 1);
-            multiply(0, st);
-            if (st + 2 < nst) request(0, st + 2);
-            if (st + 1 < nst) multiply(1, st + 1);
-        }
-    };
-    product([&](int r, int k) { return ld8(x + (long long)r * ldx + k); }, w_ih, Kx);
-    product([&](int r, int k) { return ld8_f32(h_in + (long long)r * H + k); }, w_hh, H);
+    for (int m = 0; m < RT; ++m) xp[m] = src + (long long)min(row0 + m * 16 + r16, B - 1) * ld;
+    rows_product<RT, RT >= 4 ? 8 : 16>(acc, xp, (half ? w_hh : w_ih) + (long long)col * K, K, q);
 #pragma unroll
     for (int m = 0; m < RT; ++m)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int u = q * 4 + i;
-            s_gate[g][m * 16 + r16][u] = acc[m][i] + b_ih[g * H + j0 + u] + b_hh[g * H + j0 + u];
-        }
+        for (int i = 0; i < 4; ++i) s_gate[half][g][m * 16 + r16][q * 4 + i] = acc[m][i];
     __syncthreads();
-    for (int cell = threadIdx.x; cell < 256 * RT; cell += 256) {
+    for (int cell = threadIdx.x; cell < 256 * RT; cell += 512) {
         const int cr = cell % (16 * RT), cu = cell / (16 * RT);
         const int crow = row0 + cr;
         if (crow >= B) continue;
-        const float ig = sigm(s_gate[0][cr][cu]), fg = sigm(s_gate[1][cr][cu]);
-        const float gg = tanh_fast(s_gate[2][cr][cu]), og = sigm(s_gate[3][cr][cu]);
+        float pre[4];
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg)
+            pre[gg] = (s_gate[0][gg][cr][cu] + s_gate[1][gg][cr][cu]) + b_ih[gg * H + j0 + cu] + b_hh[gg * H + j0 + cu];
+        const float ig = sigm(pre[0]), fg = sigm(pre[1]), gt = tanh_fast(pre[2]), og = sigm(pre[3]);
         const long long o = (long long)crow * H + j0 + cu;
-        const float c = fg * c_in[o] + ig * gg;
+        const float c = fg * c_in[o] + ig * gt;
         const float h = og * tanh_fast(c);
         c_out[o] = c;
         h_out[o] = h;
@@ -492,7 +490,8 @@ extern "C" size_t edgedict_stream_encoder_workspace_bytes(int B, int T, int I0, 
     if (B <= 0 || T <= 0 || L <= 0) return 0;
     const size_t D = (size_t)(I0 > H ? I0 : H);
     // X0 (normalised input), two activation buffers, Y, two state scratch buffers, statistics
-    return 4 * align256((size_t)B * T * D * 2) + 2 * align256((size_t)B * H * 4) + 2 * align256((size_t)B * T * 4);
+    return 4 * align256((size_t)B * T * D * 2) + 2 * align256((size_t)B * H * 4) + 2 * align256((size_t)B * T * 4) +
+           align256((size_t)L * B * H * 2);      // + the bf16 copy of the carried h
 }
 
 extern "C" int edgedict_stream_encoder_step(const void* xs, int x_dtype, int B, int T, int I0, int H, int L,
@@ -519,7 +518,9 @@ extern "C" int edgedict_stream_encoder_step(const void* xs, int x_dtype, int B, 
     float* cs = (float*)(p + 4 * act + align256((size_t)B * H * 4));
     float* mean = (float*)(p + 4 * act + 2 * align256((size_t)B * H * 4));
     float* rstd = (float*)((char*)mean + align256((size_t)B * T * 4));
+    bf16_t* HB = (bf16_t*)((char*)rstd + align256((size_t)B * T * 4));
     int rc;
+    if ((rc = edgedict_cast(ED_F32, h_state, ED_BF16, HB, (long long)L * B * H, s))) return rc;
     const void* x_in = xs;
     if (x_dtype == ED_F32) {                   // the feature front-end hands over fp32
         if ((rc = edgedict_cast(ED_F32, xs, ED_BF16, Xc, (long long)B * T * I0, s))) return rc;
@@ -532,20 +533,22 @@ extern "C" int edgedict_stream_encoder_step(const void* xs, int x_dtype, int B, 
         ED_CHECK_ARG(reduce[l] == 1 || reduce[l] == 2, "stream_encoder_step: time reduction must be 1 or 2");
         float* hl = h_state + (size_t)l * B * H;
         float* cl = c_state + (size_t)l * B * H;
-        const float* hin = hl; const float* cin = cl;
+        const float* cin = cl;
         for (int t = 0; t < Tl; ++t) {
             float* hout = (t & 1) ? hl : hs;
             float* cout = (t & 1) ? cl : cs;
             const dim3 grid1((B + 15) / 16, H / 16), grid4((B + 63) / 64, H / 16);
+            const bf16_t* hb = t == 0 ? HB + (size_t)l * B * H : Y + (size_t)(t - 1) * H;
+            const long long ldh = t == 0 ? (long long)H : (long long)Tl * H;
             if (B <= 16)
-                hipLaunchKernelGGL(enc_lstm_step<1>, grid1, dim3(256), 0, s, X + (size_t)t * K, (long long)Tl * K, K,
-                                   (const bf16_t*)w_ih[l], (const bf16_t*)w_hh[l], b_ih[l], b_hh[l], hin, cin, hout, cout,
+                hipLaunchKernelGGL(enc_lstm_step<1>, grid1, dim3(512), 0, s, X + (size_t)t * K, (long long)Tl * K, K,
+                                   (const bf16_t*)w_ih[l], (const bf16_t*)w_hh[l], b_ih[l], b_hh[l], hb, ldh, cin, hout, cout,
                                    Y + (size_t)t * H, (long long)Tl * H, B, H);
             else
-                hipLaunchKernelGGL(enc_lstm_step<4>, grid4, dim3(256), 0, s, X + (size_t)t * K, (long long)Tl * K, K,
-                                   (const bf16_t*)w_ih[l], (const bf16_t*)w_hh[l], b_ih[l], b_hh[l], hin, cin, hout, cout,
+                hipLaunchKernelGGL(enc_lstm_step<4>, grid4, dim3(512), 0, s, X + (size_t)t * K, (long long)Tl * K, K,
+                                   (const bf16_t*)w_ih[l], (const bf16_t*)w_hh[l], b_ih[l], b_hh[l], hb, ldh, cin, hout, cout,
                                    Y + (size_t)t * H, (long long)Tl * H, B, H);
-            hin = hout; cin = cout;
+            cin = cout;
         }
         if (Tl & 1) {                           // the last step wrote the scratch buffers
             ED_CHECK_HIP(hipMemcpyAsync(hl, hs, (size_t)B * H * 4, hipMemcpyDeviceToDevice, s));

@@ -17,7 +17,7 @@ from edgedict_amd.stream import BatchedStreamDecoder, chunk_geometry  # noqa: E4
 flags = make_flags("E6D2")
 torch.manual_seed(0)
 m = Transducer(**model_kwargs(flags, vocab_size=2048)).cuda().eval()
-for dtype in ("bf16", "fp32"):
+for dtype in (sys.argv[1:] or ("bf16", "fp32")):
     m.compute_dtype = dtype
     for step_n_frame in (2, 8):
         win, hop = chunk_geometry(flags, step_n_frame)
