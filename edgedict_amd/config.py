@@ -56,6 +56,11 @@ FUSED_LSE = os.environ.get("EDGEDICT_FUSED_LSE", "1") != "0"
 # bf16 inference on a chunk shorter than STACK_MIN_FRAMES (the streaming decoder): one native call with a fused launch
 # per layer-frame instead of the per-layer kernels (EDGEDICT_STREAM_ENCODER_STEP=0 restores them)
 STREAM_ENCODER_STEP = os.environ.get("EDGEDICT_STREAM_ENCODER_STEP", "1") != "0"
+# ... for up to this many streams when the chunk is one or two encoder frames (the reference-native 75 ms chunk), and up
+# to STREAM_STEP_MAX_ROWS streams for longer chunks - measured (tools/stream_bench.py, fused vs per-layer kernels, ms per
+# chunk step): 1 frame, S = 64 / 256 / 1024: 0.47 / 0.49 / 1.55 vs 0.62 / 0.61 / 0.76; 4 frames, S = 1 / 64 / 256: 0.62 /
+# 1.53 / 1.63 vs 0.62 / 0.74 / 0.90 (the per-layer kernels batch the input product over the frames)
+STREAM_STEP_MAX_ROWS_SHORT = int(os.environ.get("EDGEDICT_STREAM_STEP_MAX_ROWS_SHORT", "256"))
 STREAM_STEP_MAX_ROWS = int(os.environ.get("EDGEDICT_STREAM_STEP_MAX_ROWS", "16"))
 
 # inputs shorter than this many frames use the per-layer path even in bf16 (see Encoder.forward)

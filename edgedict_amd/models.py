@@ -747,13 +747,12 @@ class Encoder(nn.Module):
             hiddens = (h, c)
         elif (isinstance(lstm, ResLayerNormLSTM) and xs.dim() == 3 and cd == torch.bfloat16
               and not torch.is_grad_enabled() and 0 < xs.shape[1] < config.STACK_MIN_FRAMES
-              and xs.shape[0] <= config.STREAM_STEP_MAX_ROWS
+              and xs.shape[0] <= (config.STREAM_STEP_MAX_ROWS_SHORT if xs.shape[1] <= 2 else config.STREAM_STEP_MAX_ROWS)
               and lstm.hidden_size % 32 == 0 and xs.shape[2] % 8 == 0 and config.STREAM_ENCODER_STEP):
             # streaming chunks of a FEW streams (rnnt/stream.py:93-100: a frame or two per call): ONE native call, a
             # fused launch per layer-frame (csrc/decode_fused.hip, edgedict_stream_encoder_step) - 0.39 instead of
-            # 0.67 ms per chunk for one stream.  From ~64 streams on the per-layer kernels are as fast or faster
-            # (S = 256: 0.61 vs 0.65 ms; chunks of 4 frames: 0.93 vs 2.2 ms - they batch the input product over the
-            # frames and stream W_hh once per step for all rows)
+            # 0.67 ms per chunk for one stream, 0.49 instead of 0.61 for 256; longer chunks of many streams stay on the
+            # per-layer kernels, which batch the input product over the frames (config.STREAM_STEP_MAX_ROWS*)
             xs, hiddens = _stream_encoder_step(self, xs, hiddens)
         else:
             xs = _InputNormFn.apply(xs, self.norm.weight, self.norm.bias, cd)

@@ -14,6 +14,7 @@ import time
 import torch
 
 
+from . import encoder_stack
 from .decode import init_search_state, run_search
 from .features import StackedLogFbank
 from .flags import model_kwargs
@@ -82,6 +83,7 @@ class BatchedStreamDecoder(StreamTransducerDecoder):
         """frames: float32 [S, win_size] on the device -> int32 [S, k] token ids (0 = blank),
         k = encoder frames produced by this chunk."""
         t0 = time.time()
+        encoder_stack.check_wsr_error()      # a bounded in-kernel wait of an EARLIER chunk that gave up (host word, no sync)
         xs, _ = self.transform(frames)
         enc_out, (self.enc_h, self.enc_c) = self.model.encoder(xs, (self.enc_h, self.enc_c))
         self.encoder_elapsed.append(time.time() - t0)
