@@ -25,13 +25,6 @@ int ed_decode_fused_frame(int dtype, const void* E1t, long long e_row_stride, in
                           const void* Wp, const float* bp, float* h_state, float* c_state, void* dec_out, int blank,
                           int unk, int32_t* tokens_out, long long tok_stride, int t, float* score, void* hid, void* parts,
                           int32_t* pred, float* h_new, float* c_new, void* Y0, void* Y1, hipStream_t s);
-int ed_decode_persistent(int dtype, const void* E1, long long e_row_stride, long long e_frame_stride, int B, int T, int J,
-                         const void* W1d, long long ldw1, const float* b1, int P2, const void* W2, const float* b2, int V,
-                         const void* emb, int emb_dtype, int E, int L, const void* const* w_ih, const void* const* w_hh,
-                         const float* const* b_ih, const float* const* b_hh, int H, const void* Wp, const float* bp,
-                         float* h_state, float* c_state, void* dec_out, int blank, int unk, int32_t* tokens_out,
-                         long long tok_stride, float* score, void* hid, void* parts, int32_t* pred, float* h_new,
-                         float* c_new, void* Y0, void* Y1, unsigned* counter, hipStream_t s);
 int ed_decode_fused_beam_step(int dtype, const void* E1t, long long e_row_stride, int B, int J, const void* W1d,
                               long long ldw1, const float* b1, int P2, const void* W2, const float* b2, int V,
                               const void* emb, int emb_dtype, int E, int L, const void* const* w_ih,
@@ -133,7 +126,7 @@ __global__ void commit_kernel(const int32_t* __restrict__ pred, int blank, T* __
 inline size_t align256(size_t x) { return (x + 255) / 256 * 256; }
 
 struct Ws {
-    size_t D1, hid, logits, pred, x, G, Hprev, Y0, Y1, Cst, h_new, c_new, dec_new, sync, total;
+    size_t D1, hid, logits, pred, x, G, Hprev, Y0, Y1, Cst, h_new, c_new, dec_new, total;
 };
 inline Ws ws_layout(int esz, int B, int J, int V, int E, int L, int H, int P2) {
     Ws w;
@@ -152,7 +145,6 @@ inline Ws ws_layout(int esz, int B, int J, int V, int E, int L, int H, int P2) {
     w.h_new = take((size_t)L * B * H * 4);
     w.c_new = take((size_t)L * B * H * 4);
     w.dec_new = take((size_t)B * P2 * esz);
-    w.sync = take(256);
     w.total = o;
     return w;
 }
@@ -200,15 +192,6 @@ extern "C" int edgedict_greedy_decode(
     // frame never fills); odd shapes: composed from the general kernels below
     const bool fused = ed_decode_fused_ok(dtype, emb_dtype, J, V, E, H, P2) &&
                        align256((size_t)B * V * 4) >= ed_decode_fused_ws_bytes(B, V);
-    if (fused && T > 0) {
-        // the whole frame loop as one launch where the device takes it (decode_fused.hip, dec_persistent)
-        const int rc = ed_decode_persistent(dtype, E1, e_row_stride, e_frame_stride, B, T, J, W1d, ldw1, b1, P2, W2, b2, V, emb,
-                                            emb_dtype, E, L, w_ih, w_hh, b_ih, b_hh, H, Wp, bp, h_state, c_state, dec_out,
-                                            blank, unk, tokens_out, tok_stride, score, hid, logits, pred, h_new, c_new, Y[0],
-                                            Y[1], (unsigned*)(p + w.sync), s);
-        if (rc < 0) return rc;
-        if (rc == 1) return ED_OK;
-    }
     for (int t = 0; t < T; ++t) {
         int rc;
         if (fused) {

@@ -101,92 +101,19 @@ template <> struct Mode<float> {
     static __device__ __forceinline__ float tnh(float x) { return tanhf(x); }
 };
 
-// ---- where activations come from / go to.  CC = false: plain pointers (a kernel per phase: the kernel boundary orders
-// producer and consumer).  CC = true (the persistent frame-loop kernel): every tensor that one workgroup writes and
-// another reads inside the launch goes through write-through stores and L2-bypassing loads (`sc1`), the G16 recipe of the
-// HIP guide that the encoder's launch-persistent kernels use; weights and the encoder's projections are read-only for
-// the launch and stay plain (L2-resident).
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4_t;
-typedef __attribute__((ext_vector_type(2))) unsigned u32x2_t;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
-    const unsigned long long a = (unsigned long long)p;
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a);
-    const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, 0x7fffffff, 0x00020000);
-}
-template <bool CC> struct Buf;
-template <> struct Buf<false> {
-    char* p;
-    __device__ __forceinline__ explicit Buf(const void* q) : p((char*)q) {}
-    __device__ __forceinline__ u32x4_t ld16(unsigned o) const { return *reinterpret_cast<const u32x4_t*>(p + o); }
-    __device__ __forceinline__ u32x2_t ld8b(unsigned o) const { return *reinterpret_cast<const u32x2_t*>(p + o); }
-    __device__ __forceinline__ unsigned ld4b(unsigned o) const { return *reinterpret_cast<const unsigned*>(p + o); }
-    __device__ __forceinline__ unsigned ld2b(unsigned o) const { return *reinterpret_cast<const unsigned short*>(p + o); }
-    __device__ __forceinline__ void st16(unsigned o, u32x4_t v) const { *reinterpret_cast<u32x4_t*>(p + o) = v; }
-    __device__ __forceinline__ void st8b(unsigned o, u32x2_t v) const { *reinterpret_cast<u32x2_t*>(p + o) = v; }
-    __device__ __forceinline__ void st4b(unsigned o, unsigned v) const { *reinterpret_cast<unsigned*>(p + o) = v; }
-    __device__ __forceinline__ void st2b(unsigned o, unsigned v) const { *reinterpret_cast<unsigned short*>(p + o) = (unsigned short)v; }
-};
-template <> struct Buf<true> {
-    __amdgpu_buffer_rsrc_t r;
-    __device__ __forceinline__ explicit Buf(const void* q) : r(make_rsrc(q)) {}
-    __device__ __forceinline__ u32x4_t ld16(unsigned o) const { return __builtin_amdgcn_raw_buffer_load_b128(r, o, 0, 16); }
-    __device__ __forceinline__ u32x2_t ld8b(unsigned o) const { return __builtin_amdgcn_raw_buffer_load_b64(r, o, 0, 16); }
-    __device__ __forceinline__ unsigned ld4b(unsigned o) const { return __builtin_amdgcn_raw_buffer_load_b32(r, o, 0, 16); }
-    __device__ __forceinline__ unsigned ld2b(unsigned o) const { return __builtin_amdgcn_raw_buffer_load_b16(r, o, 0, 16); }
-    __device__ __forceinline__ void st16(unsigned o, u32x4_t v) const { __builtin_amdgcn_raw_buffer_store_b128(v, r, o, 0, 16); }
-    __device__ __forceinline__ void st8b(unsigned o, u32x2_t v) const { __builtin_amdgcn_raw_buffer_store_b64(v, r, o, 0, 16); }
-    __device__ __forceinline__ void st4b(unsigned o, unsigned v) const { __builtin_amdgcn_raw_buffer_store_b32(v, r, o, 0, 16); }
-    __device__ __forceinline__ void st2b(unsigned o, unsigned v) const { __builtin_amdgcn_raw_buffer_store_b16((unsigned short)v, r, o, 0, 16); }
-};
-// element access on a Buf in the mode's activation type
-template <typename ET> struct Io;
-template <> struct Io<bf16_t> {
-    template <typename B> static __device__ __forceinline__ bf16x8_t frag(const B& b, unsigned o) {      // bf16 rows
-        union { u32x4_t u; bf16x8_t v; } r; r.u = b.ld16(o); return r.v;
-    }
-    template <typename B> static __device__ __forceinline__ bf16x8_t frag_f32(const B& b, unsigned o) {  // fp32 rows -> bf16
-        const u32x4_t lo = b.ld16(o), hi = b.ld16(o + 16);
-        union { unsigned u[4]; bf16x8_t v; } r;
-        r.u[0] = f32x2_to_bf16x2(__uint_as_float(lo[0]), __uint_as_float(lo[1]));
-        r.u[1] = f32x2_to_bf16x2(__uint_as_float(lo[2]), __uint_as_float(lo[3]));
-        r.u[2] = f32x2_to_bf16x2(__uint_as_float(hi[0]), __uint_as_float(hi[1]));
-        r.u[3] = f32x2_to_bf16x2(__uint_as_float(hi[2]), __uint_as_float(hi[3]));
-        return r.v;
-    }
-    template <typename B> static __device__ __forceinline__ void st4(const B& b, unsigned o, float x, float y, float z, float w) {
-        b.st8b(o, (u32x2_t){f32x2_to_bf16x2(x, y), f32x2_to_bf16x2(z, w)});
-    }
-    template <typename B> static __device__ __forceinline__ void st1(const B& b, unsigned o, float v) { b.st2b(o, f32_to_bf16(v)); }
-};
-template <> struct Io<float> {
-    template <typename B> static __device__ __forceinline__ float4 frag(const B& b, unsigned o) {
-        const u32x4_t v = b.ld16(o);
-        return make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
-    }
-    template <typename B> static __device__ __forceinline__ float4 frag_f32(const B& b, unsigned o) { return frag(b, o); }
-    template <typename B> static __device__ __forceinline__ void st4(const B& b, unsigned o, float x, float y, float z, float w) {
-        b.st16(o, (u32x4_t){__float_as_uint(x), __float_as_uint(y), __float_as_uint(z), __float_as_uint(w)});
-    }
-    template <typename B> static __device__ __forceinline__ void st1(const B& b, unsigned o, float v) { b.st4b(o, __float_as_uint(v)); }
-};
-
 // acc (+)= W[wrow][k] x X[xrow][k] over K (a multiple of KS): lane (r16 = lane & 15, q = lane >> 4) ends with
-// acc[e] = out[xrow of lane r16][column of W row 4 q + e].  wp points at this lane's W row (+ q * LK elements), xo is the
-// byte offset of this lane's X row (+ q * LK elements) in xb; XF32: the X rows are fp32 whatever the mode.
+// acc[e] = out[xrow of lane r16][column of W row 4 q + e].  wp / xp point at this lane's W row / X row (+ q * LK).
 // CH k-steps are requested together, then multiplied, k ascending (the order of the sums does not depend on CH).
-template <typename ET, int CH, bool XF32, typename B>
-__device__ __forceinline__ void wave_product(f32x4_t& acc, const B& xb, unsigned xo, const ET* __restrict__ wp, int K) {
+template <typename ET, int CH, typename XT>
+__device__ __forceinline__ void wave_product(f32x4_t& acc, const XT* __restrict__ xp, const ET* __restrict__ wp, int K) {
     typedef Mode<ET> Md;
-    constexpr unsigned XE = XF32 ? 4u : (unsigned)sizeof(ET);
     for (int k0 = 0; k0 < K; k0 += Md::KS * CH) {
         typename Md::frag a[CH], b[CH];
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
             const int k = min(k0 + Md::KS * c, K - Md::KS);      // (clamped: a repeated k-step is skipped below)
             b[c] = Md::ldw(wp + k);
-            if constexpr (XF32) a[c] = Io<ET>::frag_f32(xb, xo + (unsigned)k * XE);
-            else a[c] = Io<ET>::frag(xb, xo + (unsigned)k * XE);
+            a[c] = Md::ldx(xp + k);
         }
 #pragma unroll
         for (int c = 0; c < CH; ++c)
@@ -195,25 +122,30 @@ __device__ __forceinline__ void wave_product(f32x4_t& acc, const B& xb, unsigned
 }
 
 // ---------------------------------------------------------------------------------------------- 1
-// hid[b, j] = tanh(E1[b, t, j] + act(dec_out[b] . W1d[j] + b1[j]));  one wave per (16 rows rt, 16 columns ct)
-template <typename ET, bool CC>
-__device__ __forceinline__ void phase_hidden(const ET* __restrict__ E1t, long long e_row_stride, const ET* dec_out, int P2,
-                                             const ET* __restrict__ W1d, long long ldw1, const float* __restrict__ b1,
-                                             ET* hid, int B, int J, int rt, int ct, int lane) {
+// hid[b, j] = tanh(E1[b, t, j] + act(dec_out[b] . W1d[j] + b1[j]));  one wave per (16 rows, 16 columns), 4 waves
+template <typename ET>
+__global__ __launch_bounds__(256) void dec_joint_hidden(const ET* __restrict__ E1t, long long e_row_stride,
+                                                        const ET* __restrict__ dec_out, int P2,
+                                                        const ET* __restrict__ W1d, long long ldw1,
+                                                        const float* __restrict__ b1, ET* __restrict__ hid,
+                                                        int B, int J) {
     typedef Mode<ET> Md;
-    const int r16 = lane & 15, q = lane >> 4;
-    const int row = rt * 16 + r16, col0 = ct * 16;
-    const Buf<CC> xb(dec_out), hb(hid);
-    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    wave_product<ET, 20, false>(acc, xb, (unsigned)((min(row, B - 1) * P2 + q * Md::LK) * sizeof(ET)),
-                                W1d + (long long)min(col0 + r16, J - 1) * ldw1 + q * Md::LK, P2);
-    const int c = col0 + q * 4;
-    if (row >= B || c >= J) return;               // (J % 4 == 0: a lane's 4 columns are in or out together)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+    const int row = blockIdx.x * 16 + r16, col0 = blockIdx.y * 64 + wave * 16;
+    if (col0 >= J) return;
+    // (everything the epilogue needs is requested BEFORE the product: behind it, it would be one more L2 round trip)
+    const int c = min(col0 + q * 4, J - 4);       // (J % 4 == 0: a lane's 4 columns are in or out together)
     float ev[4], h[4];
-    Md::ld4(E1t + (long long)row * e_row_stride + c, ev);
+    Md::ld4(E1t + (long long)min(row, B - 1) * e_row_stride + c, ev);
+    const float4 bv = *reinterpret_cast<const float4*>(b1 + c);
+    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    wave_product<ET, 20>(acc, dec_out + (long long)min(row, B - 1) * P2 + q * Md::LK,
+                         W1d + (long long)min(col0 + r16, J - 1) * ldw1 + q * Md::LK, P2);
+    if (row >= B || col0 + q * 4 >= J) return;
+    const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) h[i] = tanhf(ev[i] + Md::act(acc[i] + b1[c + i]));
-    Io<ET>::st4(hb, (unsigned)((row * J + c) * sizeof(ET)), h[0], h[1], h[2], h[3]);
+    for (int i = 0; i < 4; ++i) h[i] = tanhf(ev[i] + Md::act(acc[i] + bb[i]));
+    Md::st4(hid + (long long)row * J + c, h[0], h[1], h[2], h[3]);
 }
 
 // ---------------------------------------------------------------------------------------------- 2
@@ -229,36 +161,35 @@ struct PickPart {
 __device__ __forceinline__ void pick_merge(float& m, int& a, float om, int oa) {
     if (om > m || (om == m && oa < a)) { m = om; a = oa; }
 }
-struct PickShared {
-    float m[4][16], mx[4][16], se[4][16];
-    int a[4][16], ax[4][16];
-};
-template <typename ET, bool CC>
-__device__ __forceinline__ void phase_logits(const ET* hid, int J, const ET* __restrict__ W2, const float* __restrict__ b2,
-                                             int V, int unk, int want_sum, PickPart* parts, int nslices,
-                                             float* __restrict__ logits_out, int B, int rt, int slice, PickShared& sh) {
+template <typename ET>
+__global__ __launch_bounds__(256) void dec_logits_pick(const ET* __restrict__ hid, int J, const ET* __restrict__ W2,
+                                                       const float* __restrict__ b2, int V, int unk, int want_sum,
+                                                       PickPart* __restrict__ parts, float* __restrict__ logits_out,
+                                                       int B) {
     typedef Mode<ET> Md;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
-    const int row = rt * 16 + r16, col0 = slice * 64 + wave * 16;
-    const Buf<CC> xb(hid), pb(parts);
+    const int row = blockIdx.x * 16 + r16, col0 = blockIdx.y * 64 + wave * 16;
+    const float4 bv = *reinterpret_cast<const float4*>(b2 + min(col0 + q * 4, V - 4));     // (V % 4 == 0), before the product
     f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    wave_product<ET, 20, false>(acc, xb, (unsigned)((min(row, B - 1) * J + q * Md::LK) * sizeof(ET)),
-                                W2 + (long long)min(col0 + r16, V - 1) * J + q * Md::LK, J);
+    wave_product<ET, 20>(acc, hid + (long long)min(row, B - 1) * J + q * Md::LK,
+                         W2 + (long long)min(col0 + r16, V - 1) * J + q * Md::LK, J);
+    const float bb[4] = {bv.x, bv.y, bv.z, bv.w};
     float z[4];
     float m = -INFINITY, mx = -INFINITY;
     int a = 0x7fffffff, ax = 0x7fffffff;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int c = col0 + q * 4 + i;
-        const float v = c < V ? acc[i] + b2[c] : -INFINITY;
+        const float v = c < V ? acc[i] + bb[i] : -INFINITY;
         z[i] = v;
         if (v > m) { m = v; a = c; }                       // ascending c within a lane: strict > keeps the first
         if (c != unk && v > mx) { mx = v; ax = c; }
     }
     if (logits_out) {
         const int c = col0 + q * 4;
-        if (row < B && c < V)                              // (V % 4 == 0)
+        if (row < B && c < V) {                            // (V % 4 == 0)
             *reinterpret_cast<float4*>(logits_out + (long long)row * V + c) = make_float4(z[0], z[1], z[2], z[3]);
+        }
         return;
     }
     // the 4 lanes that hold this row (q = 0..3), then the 4 waves
@@ -267,38 +198,39 @@ __device__ __forceinline__ void phase_logits(const ET* hid, int J, const ET* __r
         pick_merge(m, a, __shfl_xor(m, off, 64), __shfl_xor(a, off, 64));
         pick_merge(mx, ax, __shfl_xor(mx, off, 64), __shfl_xor(ax, off, 64));
     }
-    if (q == 0) { sh.m[wave][r16] = m; sh.a[wave][r16] = a; sh.mx[wave][r16] = mx; sh.ax[wave][r16] = ax; }
+    __shared__ float s_m[4][16], s_mx[4][16], s_se[4][16];
+    __shared__ int s_a[4][16], s_ax[4][16];
+    if (q == 0) { s_m[wave][r16] = m; s_a[wave][r16] = a; s_mx[wave][r16] = mx; s_ax[wave][r16] = ax; }
     __syncthreads();
-    float gm = sh.m[0][r16];
+    float gm = s_m[0][r16];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) gm = fmaxf(gm, sh.m[w][r16]);
+    for (int w = 1; w < 4; ++w) gm = fmaxf(gm, s_m[w][r16]);
     if (want_sum) {
         float se = 0.f;
 #pragma unroll
         for (int i = 0; i < 4; ++i) se += __expf(z[i] - gm);     // (-inf columns add 0; gm is finite: V > 0)
         se += __shfl_xor(se, 16, 64);
         se += __shfl_xor(se, 32, 64);
-        if (q == 0) sh.se[wave][r16] = se;
+        if (q == 0) s_se[wave][r16] = se;
         __syncthreads();
     }
     if (threadIdx.x < 16 && row < B) {
-        float pm = sh.m[0][r16], pmx = sh.mx[0][r16];
-        int pa = sh.a[0][r16], pax = sh.ax[0][r16];
+        PickPart p;
+        p.m = s_m[0][r16]; p.a = s_a[0][r16]; p.mx = s_mx[0][r16]; p.ax = s_ax[0][r16];
 #pragma unroll
         for (int w = 1; w < 4; ++w) {
-            pick_merge(pm, pa, sh.m[w][r16], sh.a[w][r16]);
-            pick_merge(pmx, pax, sh.mx[w][r16], sh.ax[w][r16]);
+            pick_merge(p.m, p.a, s_m[w][r16], s_a[w][r16]);
+            pick_merge(p.mx, p.ax, s_mx[w][r16], s_ax[w][r16]);
         }
-        const float pse = want_sum ? sh.se[0][r16] + sh.se[1][r16] + sh.se[2][r16] + sh.se[3][r16] : 0.f;
-        const unsigned o = (unsigned)((row * nslices + slice) * (int)sizeof(PickPart));
-        pb.st16(o, (u32x4_t){__float_as_uint(pm), (unsigned)pa, __float_as_uint(pmx), (unsigned)pax});
-        pb.st16(o + 16, (u32x4_t){__float_as_uint(pse), 0u, 0u, 0u});
+        p.se = want_sum ? s_se[0][r16] + s_se[1][r16] + s_se[2][r16] + s_se[3][r16] : 0.f;
+        p.pad[0] = p.pad[1] = p.pad[2] = 0;
+        parts[(long long)row * gridDim.y + blockIdx.y] = p;
     }
 }
 
 // ---------------------------------------------------------------------------------------------- 3 / 4
 // One LSTM step of one layer for 16 rows x 16 units per workgroup (wave g = gate g).  first != 0: the layer input is
-// the embedding of the symbol picked from `parts` (which this phase finishes: every workgroup for its own rows, the
+// the embedding of the symbol picked from `parts` (which this kernel finishes: every workgroup for its own rows, the
 // unit-block-0 workgroups write it out); otherwise x = y_prev (rows of the layer below).
 // Everything that does not depend on the pick - W_ih, W_hh, h - is requested BEFORE the slices are merged (16 lanes per
 // row, each a share of the slices, a butterfly over the 16), the embedding rows right behind it: two L2 round trips
@@ -315,50 +247,52 @@ struct LstmStepArgs {
     ET* y_out;                             // [B, H] copy of h_out in the mode's type (next layer / projection operand)
     int B, H, Kx;
 };
-struct LstmShared {
-    int pred[16];
-    float gate[4][16][17];
-};
-template <typename ET, bool CC>
-__device__ __forceinline__ void phase_lstm(const LstmStepArgs<ET>& A, int first, int rt, int jt, LstmShared& sh) {
+template <typename ET>
+__global__ __launch_bounds__(256) void dec_lstm_step(LstmStepArgs<ET> A, int first) {
     typedef Mode<ET> Md;
     constexpr int CH = 8;
     const int lane = threadIdx.x & 63, g = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
-    const int row0 = rt * 16, j0 = jt * 16;
+    const int row0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
     const int row = row0 + r16, rowc = min(row, A.B - 1);
+    __shared__ int s_pred[16];
+    __shared__ float s_gate[4][16][17];
     const int col0 = g * A.H + j0;                 // W rows of this gate's 16 units
     const ET* wip = A.w_ih + (long long)(col0 + r16) * A.Kx + q * Md::LK;
     const ET* whp = A.w_hh + (long long)(col0 + r16) * A.H + q * Md::LK;
-    const Buf<CC> hb(A.h_in), cb(A.c_in), xb(A.x_prev), pb(A.parts), prb(A.pred), hob(A.h_out), cob(A.c_out), yb(A.y_out);
-    const Buf<false> eb(A.emb);
-    const unsigned ho = (unsigned)((rowc * A.H + q * Md::LK) * 4);
-    // ---- batch 0 (the first CH k-steps) of both products, requested up front
+    const float* hp = A.h_in + (long long)rowc * A.H + q * Md::LK;
+    // ---- the epilogue's operands first (behind the products they would be one more L2 round trip each) ...
+    const float4 bi4 = *reinterpret_cast<const float4*>(A.b_ih + col0 + q * 4), bh4 = *reinterpret_cast<const float4*>(A.b_hh + col0 + q * 4);
+    const int cr = threadIdx.x & 15, cu = threadIdx.x >> 4;          // cells: thread <-> (row tid & 15, unit tid >> 4)
+    const int crow = row0 + cr;
+    const long long co = (long long)min(crow, A.B - 1) * A.H + j0 + cu;
+    const float c_prev = A.c_in[co];
+    // ---- ... then batch 0 (the first CH k-steps) of both products
     typename Md::frag wi[CH], wh[CH], hx[CH], xx[CH];
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
         wi[c] = Md::ldw(wip + min(c * Md::KS, A.Kx - Md::KS));
         wh[c] = Md::ldw(whp + min(c * Md::KS, A.H - Md::KS));
-        hx[c] = Io<ET>::frag_f32(hb, ho + (unsigned)min(c * Md::KS, A.H - Md::KS) * 4u);
+        hx[c] = Md::ldx(hp + min(c * Md::KS, A.H - Md::KS));
     }
-    unsigned xo = 0;                               // byte offset of this lane's x row (layers > 0: in x_prev; else in emb)
+    const ET* xp = nullptr;                        // this lane's x row (layers > 0) ...
+    const float* xpf = nullptr;                    // ... or embedding row (fp32 table)
     if (!first) {
-        xo = (unsigned)((rowc * A.H + q * Md::LK) * sizeof(ET));
+        xp = A.x_prev + (long long)rowc * A.H + q * Md::LK;
 #pragma unroll
-        for (int c = 0; c < CH; ++c) xx[c] = Io<ET>::frag(xb, xo + (unsigned)min(c * Md::KS, A.Kx - Md::KS) * (unsigned)sizeof(ET));
+        for (int c = 0; c < CH; ++c) xx[c] = Md::ldx(xp + min(c * Md::KS, A.Kx - Md::KS));
     } else {
         if (first == 2) {                          // beam search: the symbol is the popped hypothesis' last token
-            if (threadIdx.x < 16) sh.pred[threadIdx.x] = (int)prb.ld4b((unsigned)min(row0 + (int)threadIdx.x, A.B - 1) * 4u);
+            if (threadIdx.x < 16) s_pred[threadIdx.x] = A.pred[min(row0 + (int)threadIdx.x, A.B - 1)];
         } else {
             // thread <-> (row tid >> 4, slice share tid & 15)
             const int pr = threadIdx.x >> 4, ps = threadIdx.x & 15;
             const int rr = min(row0 + pr, A.B - 1);
-            const unsigned po = (unsigned)(rr * A.nslices * (int)sizeof(PickPart));
+            const PickPart* p = A.parts + (long long)rr * A.nslices;
             float m = -INFINITY, mx = -INFINITY;
             int a = 0x7fffffff, ax = 0x7fffffff;
             for (int s = ps; s < A.nslices; s += 16) {
-                const u32x4_t v = pb.ld16(po + (unsigned)s * 32u);
-                pick_merge(m, a, __uint_as_float(v[0]), (int)v[1]);
-                pick_merge(mx, ax, __uint_as_float(v[2]), (int)v[3]);
+                pick_merge(m, a, p[s].m, p[s].a);
+                pick_merge(mx, ax, p[s].mx, p[s].ax);
             }
 #pragma unroll
             for (int off = 1; off <= 8; off <<= 1) {
@@ -368,18 +302,15 @@ __device__ __forceinline__ void phase_lstm(const LstmStepArgs<ET>& A, int first,
             int pick = a;
             // rnnt/stream.py:105-108: an arg-max that is <unk> has its logit set to 0 and the arg-max is retaken
             if (A.unk >= 0 && a == A.unk) pick = (0.f > mx || (0.f == mx && A.unk < ax)) ? A.unk : ax;
-            if (ps == 0) sh.pred[pr] = pick;
-            if (jt == 0 && row0 + pr < A.B) {
+            if (ps == 0) s_pred[pr] = pick;
+            if (blockIdx.y == 0 && row0 + pr < A.B) {
                 if (ps == 0) {
-                    prb.st4b((unsigned)rr * 4u, (unsigned)pick);
+                    A.pred[rr] = pick;
                     if (A.tokens) A.tokens[(long long)rr * A.tok_stride + A.t] = pick;
                 }
                 if (A.score) {                     // -(max log p) = log sum exp(z - max)   (greedy mode: unk < 0)
                     float se = 0.f;
-                    for (int s = ps; s < A.nslices; s += 16) {
-                        const u32x4_t v = pb.ld16(po + (unsigned)s * 32u);
-                        se += __uint_as_float(pb.ld4b(po + (unsigned)s * 32u + 16u)) * __expf(__uint_as_float(v[0]) - m);
-                    }
+                    for (int s = ps; s < A.nslices; s += 16) se += p[s].se * __expf(p[s].m - m);
 #pragma unroll
                     for (int off = 1; off <= 8; off <<= 1) se += __shfl_xor(se, off, 64);
                     if (ps == 0) A.score[rr] += logf(se);
@@ -387,16 +318,16 @@ __device__ __forceinline__ void phase_lstm(const LstmStepArgs<ET>& A, int first,
             }
         }
         __syncthreads();
-        const int tok = sh.pred[r16];
+        const int tok = s_pred[r16];
         if (A.emb_f32) {
-            xo = (unsigned)((tok * A.E + q * Md::LK) * 4);
+            xpf = reinterpret_cast<const float*>(A.emb) + (long long)tok * A.E + q * Md::LK;
 #pragma unroll
-            for (int c = 0; c < CH; ++c) xx[c] = Io<ET>::frag_f32(eb, xo + (unsigned)min(c * Md::KS, A.Kx - Md::KS) * 4u);
+            for (int c = 0; c < CH; ++c) xx[c] = Md::ldx(xpf + min(c * Md::KS, A.Kx - Md::KS));
         } else {
             if constexpr (sizeof(ET) == 2) {
-                xo = (unsigned)((tok * A.E + q * Md::LK) * 2);
+                xp = reinterpret_cast<const ET*>(A.emb) + (long long)tok * A.E + q * Md::LK;
 #pragma unroll
-                for (int c = 0; c < CH; ++c) xx[c] = Io<ET>::frag(eb, xo + (unsigned)min(c * Md::KS, A.Kx - Md::KS) * 2u);
+                for (int c = 0; c < CH; ++c) xx[c] = Md::ldx(xp + min(c * Md::KS, A.Kx - Md::KS));
             }
         }
     }
@@ -407,98 +338,34 @@ __device__ __forceinline__ void phase_lstm(const LstmStepArgs<ET>& A, int first,
         if (c * Md::KS < A.Kx) Md::mma(acc, wi[c], xx[c]);
     if (A.Kx > CH * Md::KS) {
         const int k0 = CH * Md::KS;
-        if (!first) wave_product<ET, CH, false>(acc, xb, xo + (unsigned)k0 * (unsigned)sizeof(ET), wip + k0, A.Kx - k0);
-        else if (A.emb_f32) wave_product<ET, CH, true>(acc, eb, xo + (unsigned)k0 * 4u, wip + k0, A.Kx - k0);
-        else wave_product<ET, CH, false>(acc, eb, xo + (unsigned)k0 * (unsigned)sizeof(ET), wip + k0, A.Kx - k0);
+        if (xpf) wave_product<ET, CH>(acc, xpf + k0, wip + k0, A.Kx - k0);
+        else wave_product<ET, CH>(acc, xp + k0, wip + k0, A.Kx - k0);
     }
 #pragma unroll
     for (int c = 0; c < CH; ++c)
         if (c * Md::KS < A.H) Md::mma(acc, wh[c], hx[c]);
-    if (A.H > CH * Md::KS)
-        wave_product<ET, CH, true>(acc, hb, ho + (unsigned)(CH * Md::KS) * 4u, whp + CH * Md::KS, A.H - CH * Md::KS);
+    if (A.H > CH * Md::KS) wave_product<ET, CH>(acc, hp + CH * Md::KS, whp + CH * Md::KS, A.H - CH * Md::KS);
+    {
+        const float bi[4] = {bi4.x, bi4.y, bi4.z, bi4.w}, bh[4] = {bh4.x, bh4.y, bh4.z, bh4.w};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int u = q * 4 + i;
-        sh.gate[g][r16][u] = acc[i] + A.b_ih[col0 + u] + A.b_hh[col0 + u];
+        for (int i = 0; i < 4; ++i) s_gate[g][r16][q * 4 + i] = acc[i] + bi[i] + bh[i];
     }
     __syncthreads();
-    // cells: thread <-> (row tid & 15, unit tid >> 4)
-    const int cr = threadIdx.x & 15, cu = threadIdx.x >> 4;
-    const int crow = row0 + cr;
     if (crow < A.B) {
-        const float ig = Md::sig(sh.gate[0][cr][cu]), fg = Md::sig(sh.gate[1][cr][cu]);
-        const float gg = Md::tnh(sh.gate[2][cr][cu]), og = Md::sig(sh.gate[3][cr][cu]);
-        const unsigned o = (unsigned)(crow * A.H + j0 + cu);
-        const float c = fg * __uint_as_float(cb.ld4b(o * 4u)) + ig * gg;
+        const float ig = Md::sig(s_gate[0][cr][cu]), fg = Md::sig(s_gate[1][cr][cu]);
+        const float gg = Md::tnh(s_gate[2][cr][cu]), og = Md::sig(s_gate[3][cr][cu]);
+        const long long o = co;
+        const float c = fg * c_prev + ig * gg;
         const float h = og * Md::tnh(c);
-        cob.st4b(o * 4u, __float_as_uint(c));
-        hob.st4b(o * 4u, __float_as_uint(h));
-        Io<ET>::st1(yb, o * (unsigned)sizeof(ET), h);
+        A.c_out[o] = c;
+        A.h_out[o] = h;
+        Md::st1(A.y_out + o, h);
     }
 }
 
 // ---------------------------------------------------------------------------------------------- 5
 // dec_new = y W_p^T + b_p for 16 rows x 64 columns per workgroup (a wave = 16 columns); rows whose symbol is not blank
-// take dec_new and the new prediction-network state (each tile moves its share of the L x H state values of its rows)
-template <typename ET, bool CC>
-__device__ __forceinline__ void phase_proj(const ET* y, int H, const ET* __restrict__ Wp, const float* __restrict__ bp, int P2,
-                                           const int32_t* pred, int blank, ET* dec_out, float* h_state, const float* h_new,
-                                           float* c_state, const float* c_new, int L, int B, int rt, int slice, int nslices,
-                                           int (&s_keep)[16]) {
-    typedef Mode<ET> Md;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
-    const int row0 = rt * 16, row = row0 + r16, col0 = slice * 64 + wave * 16;
-    const Buf<CC> yb(y), prb(pred), db(dec_out), hsb(h_state), hnb(h_new), csb(c_state), cnb(c_new);
-    if (threadIdx.x < 16) {
-        const int r = row0 + (int)threadIdx.x;
-        s_keep[threadIdx.x] = r < B && (pred == nullptr || (int)prb.ld4b((unsigned)r * 4u) != blank);   // (pred == null: every row)
-    }
-    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    if (col0 < P2)
-        wave_product<ET, 16, false>(acc, yb, (unsigned)((min(row, B - 1) * H + q * Md::LK) * sizeof(ET)),
-                                    Wp + (long long)min(col0 + r16, P2 - 1) * H + q * Md::LK, H);
-    __syncthreads();
-    const int c = col0 + q * 4;
-    if (s_keep[r16] && c < P2)
-        Io<ET>::st4(db, (unsigned)((row * P2 + c) * sizeof(ET)), acc[0] + bp[c], acc[1] + bp[c + 1], acc[2] + bp[c + 2],
-                    acc[3] + bp[c + 3]);
-    if (pred == nullptr) return;
-    // state commit: this tile's slice of [L][16 rows][H], one value per thread and pass
-    const int per = (L * H + nslices - 1) / nslices;
-    const int lo = slice * per, n = min(L * H, lo + per) - lo;
-    for (int idx = threadIdx.x; idx < 16 * n; idx += 256) {
-        const int rr = idx / n, i = lo + idx - rr * n;
-        if (!s_keep[rr]) continue;
-        const int l = i / H, j = i - l * H;
-        const unsigned o = (unsigned)((l * B + row0 + rr) * H + j) * 4u;
-        hsb.st4b(o, hnb.ld4b(o));
-        csb.st4b(o, cnb.ld4b(o));
-    }
-}
-
-// ---- a kernel per phase (the stream decoder's one-frame chunks, the beam search's expansions, shapes the persistent kernel
-// does not take)
-template <typename ET>
-__global__ __launch_bounds__(256) void dec_joint_hidden(const ET* __restrict__ E1t, long long e_row_stride,
-                                                        const ET* __restrict__ dec_out, int P2,
-                                                        const ET* __restrict__ W1d, long long ldw1,
-                                                        const float* __restrict__ b1, ET* __restrict__ hid, int B, int J) {
-    const int ct = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (ct * 16 >= J) return;
-    phase_hidden<ET, false>(E1t, e_row_stride, dec_out, P2, W1d, ldw1, b1, hid, B, J, blockIdx.x, ct, threadIdx.x & 63);
-}
-template <typename ET>
-__global__ __launch_bounds__(256) void dec_logits_pick(const ET* __restrict__ hid, int J, const ET* __restrict__ W2,
-                                                       const float* __restrict__ b2, int V, int unk, int want_sum,
-                                                       PickPart* __restrict__ parts, float* __restrict__ logits_out, int B) {
-    __shared__ PickShared sh;
-    phase_logits<ET, false>(hid, J, W2, b2, V, unk, want_sum, parts, gridDim.y, logits_out, B, blockIdx.x, blockIdx.y, sh);
-}
-template <typename ET>
-__global__ __launch_bounds__(256) void dec_lstm_step(LstmStepArgs<ET> A, int first) {
-    __shared__ LstmShared sh;
-    phase_lstm<ET, false>(A, first, blockIdx.x, blockIdx.y, sh);
-}
+// take dec_new and the new prediction-network state (each block moves its share of the L x H state values of its rows)
 template <typename ET>
 __global__ __launch_bounds__(256) void dec_proj_commit(const ET* __restrict__ y, int H, const ET* __restrict__ Wp,
                                                        const float* __restrict__ bp, int P2,
@@ -506,99 +373,34 @@ __global__ __launch_bounds__(256) void dec_proj_commit(const ET* __restrict__ y,
                                                        ET* __restrict__ dec_out, float* __restrict__ h_state,
                                                        const float* __restrict__ h_new, float* __restrict__ c_state,
                                                        const float* __restrict__ c_new, int L, int B) {
+    typedef Mode<ET> Md;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r16 = lane & 15, q = lane >> 4;
+    const int row0 = blockIdx.x * 16, row = row0 + r16, col0 = blockIdx.y * 64 + wave * 16;
     __shared__ int s_keep[16];
-    phase_proj<ET, false>(y, H, Wp, bp, P2, pred, blank, dec_out, h_state, h_new, c_state, c_new, L, B, blockIdx.x, blockIdx.y,
-                          gridDim.y, s_keep);
-}
-
-// ---------------------------------------------------------------------------------------------- the persistent frame loop
-// ONE launch for all T frames of a greedy search (Transducer.greedy_decode rnnt/models.py:254-263: `for t in range(T)`):
-// G <= #CUs workgroups, all resident, walk the five phases of every frame; between two phases the grid meets on a
-// monotonic arrival counter (every storing wave drains its write-through stores, one lane per workgroup arrives and polls:
-// the hand-off of the encoder's launch-persistent kernels, ~2 us instead of a kernel boundary's launch + cache flush
-// + refill).  Weights are read with plain loads and stay in the L2s for the whole search; what the phases hand to each
-// other - hid, the slice partials, the picked symbols, the LSTM rows and states, dec_out - goes through `sc1` accesses.
-// A wait is bounded (2^22 polls): the launch gives up, sets the host-visible word and every workgroup leaves.
-constexpr int PERSIST_MAX_L = 4;
-template <typename ET>
-struct PersistArgs {
-    const ET* E1; long long e_row_stride, e_frame_stride;
-    const ET* W1d; long long ldw1; const float* b1;
-    const ET* W2; const float* b2;
-    const void* emb; int emb_f32; int E;
-    const ET* w_ih[PERSIST_MAX_L]; const ET* w_hh[PERSIST_MAX_L];
-    const float* b_ih[PERSIST_MAX_L]; const float* b_hh[PERSIST_MAX_L];
-    const ET* Wp; const float* bp;
-    float* h_state; float* c_state; ET* dec_out;
-    ET* hid; PickPart* parts; int32_t* pred; float* h_new; float* c_new; ET* Y0; ET* Y1;
-    int32_t* tokens; long long tok_stride; float* score;
-    int B, T, J, V, P2, H, L, blank, unk;
-    unsigned* counter; unsigned* err;
-};
-__device__ __forceinline__ bool grid_meet(unsigned* counter, unsigned target, unsigned* err, unsigned code, unsigned& bail_s) {
-    // every wave's write-through stores have been acknowledged before its workgroup arrives
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0, bail = 0u;
-        while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 22) || (err && (spins & 1023u) == 0u && __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
-                if (err) atomicCAS(err, 0u, code);
-                bail = 1u;
-                break;
-            }
-        }
-        bail_s = bail;
+    if (threadIdx.x < 16) {
+        const int r = row0 + (int)threadIdx.x;
+        s_keep[threadIdx.x] = r < B && (pred == nullptr || pred[r] != blank);          // (pred == null: every row)
     }
+    const int c = col0 + q * 4;
+    const float4 bv = *reinterpret_cast<const float4*>(bp + min(c, P2 - 4));       // (P2 % 4 == 0), before the product
+    f32x4_t acc = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (col0 < P2)
+        wave_product<ET, 16>(acc, y + (long long)min(row, B - 1) * H + q * Md::LK,
+                             Wp + (long long)min(col0 + r16, P2 - 1) * H + q * Md::LK, H);
     __syncthreads();
-    return bail_s == 0u;
-}
-template <typename ET>
-__global__ __launch_bounds__(256) void dec_persistent(PersistArgs<ET> A) {
-    __shared__ PickShared psh;
-    __shared__ LstmShared lsh;
-    __shared__ int s_keep[16];
-    __shared__ unsigned bail_s;
-    const int G = gridDim.x, wg = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int RB = (A.B + 15) / 16, CT = (A.J + 15) / 16, NS = (A.V + 63) / 64, UB = A.H / 16, PS = (A.P2 + 63) / 64;
-    unsigned epoch = 0;
-    const unsigned base = 0u;              // the host clears the counter before the launch (never read it here: a late
-                                           // workgroup would see its peers' first arrivals)
-    for (int t = 0; t < A.T; ++t) {
-        const ET* E1t = A.E1 + (long long)t * A.e_frame_stride;
-        for (int tile = wg * 4 + wave; tile < RB * CT; tile += G * 4)
-            phase_hidden<ET, true>(E1t, A.e_row_stride, A.dec_out, A.P2, A.W1d, A.ldw1, A.b1, A.hid, A.B, A.J, tile / CT, tile % CT, lane);
-        if (!grid_meet(A.counter, base + (unsigned)G * ++epoch, A.err, 1100u, bail_s)) return;
-        for (int tile = wg; tile < RB * NS; tile += G) {
-            phase_logits<ET, true>(A.hid, A.J, A.W2, A.b2, A.V, A.unk, A.score ? 1 : 0, A.parts, NS, nullptr, A.B, tile / NS, tile % NS, psh);
-            __syncthreads();
-        }
-        if (!grid_meet(A.counter, base + (unsigned)G * ++epoch, A.err, 1101u, bail_s)) return;
-        for (int k = 0; k < A.L; ++k) {
-            LstmStepArgs<ET> S;
-            S.parts = A.parts; S.nslices = NS; S.unk = A.unk; S.blank = A.blank;
-            S.pred = A.pred; S.tokens = A.tokens; S.tok_stride = A.tok_stride; S.t = t; S.score = A.score;
-            S.emb = A.emb; S.emb_f32 = A.emb_f32; S.E = A.E;
-            S.x_prev = k > 0 ? (((k - 1) & 1) ? A.Y1 : A.Y0) : nullptr;
-            S.w_ih = A.w_ih[k]; S.w_hh = A.w_hh[k]; S.b_ih = A.b_ih[k]; S.b_hh = A.b_hh[k];
-            S.h_in = A.h_state + (size_t)k * A.B * A.H; S.c_in = A.c_state + (size_t)k * A.B * A.H;
-            S.h_out = A.h_new + (size_t)k * A.B * A.H; S.c_out = A.c_new + (size_t)k * A.B * A.H;
-            S.y_out = (k & 1) ? A.Y1 : A.Y0;
-            S.B = A.B; S.H = A.H; S.Kx = k == 0 ? A.E : A.H;
-            for (int tile = wg; tile < RB * UB; tile += G) {
-                phase_lstm<ET, true>(S, k == 0 ? 1 : 0, tile / UB, tile % UB, lsh);
-                __syncthreads();
-            }
-            if (!grid_meet(A.counter, base + (unsigned)G * ++epoch, A.err, 1102u + k, bail_s)) return;
-        }
-        for (int tile = wg; tile < RB * PS; tile += G) {
-            phase_proj<ET, true>(((A.L - 1) & 1) ? A.Y1 : A.Y0, A.H, A.Wp, A.bp, A.P2, A.pred, A.blank, A.dec_out, A.h_state, A.h_new,
-                                 A.c_state, A.c_new, A.L, A.B, tile / PS, tile % PS, PS, s_keep);
-            __syncthreads();
-        }
-        if (t + 1 < A.T && !grid_meet(A.counter, base + (unsigned)G * ++epoch, A.err, 1110u, bail_s)) return;
+    if (s_keep[r16] && c < P2)
+        Md::st4(dec_out + (long long)row * P2 + c, acc[0] + bv.x, acc[1] + bv.y, acc[2] + bv.z, acc[3] + bv.w);
+    if (pred == nullptr) return;
+    // state commit: this block's slice of [L][16 rows][H], one value per thread and pass
+    const int per = (L * H + gridDim.y - 1) / gridDim.y;
+    const int lo = blockIdx.y * per, n = min(L * H, lo + per) - lo;
+    for (int idx = threadIdx.x; idx < 16 * n; idx += 256) {
+        const int rr = idx / n, i = lo + idx - rr * n;
+        if (!s_keep[rr]) continue;
+        const int l = i / H, j = i - l * H;
+        const long long o = ((long long)l * B + row0 + rr) * H + j;
+        h_state[o] = h_new[o];
+        c_state[o] = c_new[o];
     }
 }
 
@@ -851,74 +653,7 @@ int frame_t(const void* E1t, long long e_row_stride, int B, int J, const void* W
     return ED_OK;
 }
 
-template <typename ET>
-int persistent_t(int G, const void* E1, long long e_row_stride, long long e_frame_stride, int B, int T, int J, const void* W1d,
-                 long long ldw1, const float* b1, int P2, const void* W2, const float* b2, int V, const void* emb,
-                 int emb_dtype, int E, int L, const void* const* w_ih, const void* const* w_hh, const float* const* b_ih,
-                 const float* const* b_hh, int H, const void* Wp, const float* bp, float* h_state, float* c_state,
-                 void* dec_out, int blank, int unk, int32_t* tokens_out, long long tok_stride, float* score, void* hid,
-                 void* parts, int32_t* pred, float* h_new, float* c_new, void* Y0, void* Y1, unsigned* counter,
-                 unsigned* err, hipStream_t s) {
-    PersistArgs<ET> A;
-    A.E1 = (const ET*)E1; A.e_row_stride = e_row_stride; A.e_frame_stride = e_frame_stride;
-    A.W1d = (const ET*)W1d; A.ldw1 = ldw1; A.b1 = b1; A.W2 = (const ET*)W2; A.b2 = b2;
-    A.emb = emb; A.emb_f32 = emb_dtype == ED_F32 ? 1 : 0; A.E = E;
-    for (int k = 0; k < PERSIST_MAX_L; ++k) {
-        A.w_ih[k] = k < L ? (const ET*)w_ih[k] : nullptr; A.w_hh[k] = k < L ? (const ET*)w_hh[k] : nullptr;
-        A.b_ih[k] = k < L ? b_ih[k] : nullptr; A.b_hh[k] = k < L ? b_hh[k] : nullptr;
-    }
-    A.Wp = (const ET*)Wp; A.bp = bp; A.h_state = h_state; A.c_state = c_state; A.dec_out = (ET*)dec_out;
-    A.hid = (ET*)hid; A.parts = (PickPart*)parts; A.pred = pred; A.h_new = h_new; A.c_new = c_new; A.Y0 = (ET*)Y0; A.Y1 = (ET*)Y1;
-    A.tokens = tokens_out; A.tok_stride = tok_stride; A.score = score;
-    A.B = B; A.T = T; A.J = J; A.V = V; A.P2 = P2; A.H = H; A.L = L; A.blank = blank; A.unk = unk;
-    A.counter = counter; A.err = err;
-    hipLaunchKernelGGL(dec_persistent<ET>, dim3(G), dim3(256), 0, s, A);
-    return ED_OK;
-}
-
 }  // namespace
-
-extern "C" void* edgedict_stack_error_words(int host);
-
-// The whole frame loop of a greedy search as ONE launch (dec_persistent above).  Returns 1 if it was launched, 0 if the
-// shape / device does not qualify (the caller then issues the frames one by one), < 0 on error.  `counter` is a device word
-// this call zeroes on the stream.
-int ed_decode_persistent(int dtype, const void* E1, long long e_row_stride, long long e_frame_stride, int B, int T, int J,
-                         const void* W1d, long long ldw1, const float* b1, int P2, const void* W2, const float* b2, int V,
-                         const void* emb, int emb_dtype, int E, int L, const void* const* w_ih, const void* const* w_hh,
-                         const float* const* b_ih, const float* const* b_hh, int H, const void* Wp, const float* bp,
-                         float* h_state, float* c_state, void* dec_out, int blank, int unk, int32_t* tokens_out,
-                         long long tok_stride, float* score, void* hid, void* parts, int32_t* pred, float* h_new,
-                         float* c_new, void* Y0, void* Y1, unsigned* counter, hipStream_t s) {
-    const char* e_on = getenv("EDGEDICT_DECODE_PERSIST");       // (read per call: tests flip it)
-    const int on = e_on ? atoi(e_on) : 1;
-    static const int n_cu = [] {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-        return n;
-    }();
-    if (!on || T < 1 || L > PERSIST_MAX_L || n_cu < 8) return 0;
-    // every tensor the phases exchange is addressed with 32-bit byte offsets
-    const long long big = (long long)B * ((long long)V / 2 + 4ll * (long long)(J > P2 ? J : P2) + 4ll * L * H);
-    if (big >= (1ll << 31)) return 0;
-    unsigned* err = (unsigned*)edgedict_stack_error_words(0);
-    if (!err) return 0;
-    const int RB = (B + 15) / 16;
-    int tiles = RB * ((V + 63) / 64);
-    tiles = tiles > RB * (H / 16) ? tiles : RB * (H / 16);
-    const int G = tiles < n_cu ? tiles : n_cu;          // one workgroup per CU at most: all of them are resident
-    ED_CHECK_HIP(hipMemsetAsync(counter, 0, sizeof(unsigned), s));
-    if (dtype == ED_F32)
-        persistent_t<float>(G, E1, e_row_stride, e_frame_stride, B, T, J, W1d, ldw1, b1, P2, W2, b2, V, emb, emb_dtype, E, L, w_ih,
-                            w_hh, b_ih, b_hh, H, Wp, bp, h_state, c_state, dec_out, blank, unk, tokens_out, tok_stride, score,
-                            hid, parts, pred, h_new, c_new, Y0, Y1, counter, err + 2, s);
-    else
-        persistent_t<bf16_t>(G, E1, e_row_stride, e_frame_stride, B, T, J, W1d, ldw1, b1, P2, W2, b2, V, emb, emb_dtype, E, L,
-                             w_ih, w_hh, b_ih, b_hh, H, Wp, bp, h_state, c_state, dec_out, blank, unk, tokens_out, tok_stride,
-                             score, hid, parts, pred, h_new, c_new, Y0, Y1, counter, err + 2, s);
-    ED_CHECK_LAUNCH("decode_persistent");
-    return 1;
-}
 
 // beam search (decode.hip): prediction-network step on pred[b] from (h_state, c_state) -> h_new / c_new, dec_new, the
 // joint's hidden vector of frame t and the logits (fp32 [B, V]) of every row - 3 + L launches instead of 5 + 2 L

@@ -139,11 +139,6 @@ def check_wsr_error():
                            "of the side stream (code %d: %s pass, launch slot %d); the results of that call are "
                            "garbage. EDGEDICT_STACK_SOFT_WAIT=0 orders the streams with events instead"
                            % (code, "forward" if code < 600 else "backward", code % 100))
-    if 1100 <= code < 1200:
-        raise RuntimeError("edgedict_amd: the persistent frame-loop kernel of the greedy search gave up waiting for its peers "
-                           "(code %d: phase %d of a frame; csrc/decode_fused.hip dec_persistent); the tokens of that call are "
-                           "garbage. EDGEDICT_DECODE_PERSIST=0 issues the frames as separate launches (e.g. when two "
-                           "processes share the device)" % (code, code - 1100))
     if code:
         raise RuntimeError("edgedict_amd: a launch-persistent encoder launch gave up waiting for its peers (code %d); "
                            "the results of that call are garbage. EDGEDICT_STACK_LPW=0 / EDGEDICT_STACK_BWD_SK=0 "

@@ -168,29 +168,3 @@ def test_greedy_fused_frame_fp32_matches_oracle_and_bf16_runs(hip_lib):
     with torch.no_grad():
         tb, sb = mb.greedy_decode(xs.cuda(), xlen.cuda())
     assert all(((t >= 0) & (t < CFG32["vocab_size"])).all() for t in tb) and torch.isfinite(sb).all()
-
-
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_persistent_frame_loop_equals_the_frame_by_frame_launches(hip_lib, dtype, monkeypatch):
-    """csrc/decode_fused.hip dec_persistent (the whole `for t in range(T)` of rnnt/models.py:254-263 as ONE launch, the
-    phases of a frame meeting on a grid-wide arrival counter, exchanged tensors through write-through stores and
-    L2-bypassing loads) against the same phases as five launches per frame: the arithmetic is the same code, so tokens
-    (blanks included) and scores must be bit-identical; no bounded wait gave up."""
-    from edgedict_amd import encoder_stack
-    sd = M.make_state_dict(CFG32, 11)
-    xs, ys, xlen, ylen = M.make_batch(CFG32, 12, 70, 33, 4)       # 70 rows: five row tiles, the last ragged; 33 frames
-    m = _engine32(sd, dtype)
-    out = {}
-    for persist in ("1", "0"):
-        monkeypatch.setenv("EDGEDICT_DECODE_PERSIST", persist)
-        with torch.no_grad():
-            tok, sc = m.greedy_decode(xs.cuda(), xlen.cuda())
-        out[persist] = (tok, sc.cpu())
-        encoder_stack.check_wsr_error()
-    for a, b in zip(out["1"][0], out["0"][0]):
-        assert np.array_equal(a, b)
-    assert torch.equal(out["1"][1], out["0"][1])
-    if dtype == "fp32":
-        rt, rs = M.greedy_decode(sd, xs, xlen)
-        for b, t in enumerate(out["1"][0]):
-            assert np.array_equal(t, np.asarray(rt[b])[:len(t)]), b
