@@ -289,6 +289,8 @@ struct BeamPtrs {
     int32_t* bn_ref;
     int32_t* n_b;        // [B]      len(B)
     double* max_b;       // [B]
+    double* blk_max;     // [B][1 + EM]  max of pool segment 0 (the survivors) / 1 + e (children of expansion e) ...
+    int32_t* blk_arg;    // [B][1 + EM]  ... and its first position in the pool (INT_MAX: nothing left)
     int32_t* exp_node;   // [B][EM]  node / state reference / score of the e-th popped hypothesis
     int32_t* exp_ref;
     double* exp_logp;
@@ -303,7 +305,42 @@ struct BeamPtrs {
     long long* total_exp;// [1]
 };
 
-__global__ void beam_frame_begin(BeamPtrs p, int t, int W, int EMV) {
+// (max, first position) of a workgroup's per-thread candidates: butterfly inside a wave, the four waves through LDS.
+// Ties go to the lower position, -inf candidates carry INT_MAX.  Every thread gets the result.
+__device__ __forceinline__ void block_argmax(double& v, int& a, double* s_v, int* s_a) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double ov = __shfl_xor(v, off, 64);
+        const int oa = __shfl_xor(a, off, 64);
+        if (ov > v || (ov == v && oa < a)) { v = ov; a = oa; }
+    }
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();                       // (s_v / s_a may still be read from a previous use)
+    if ((threadIdx.x & 63) == 0) { s_v[wave] = v; s_a[wave] = a; }
+    __syncthreads();
+    v = s_v[0]; a = s_a[0];
+    for (int w = 1; w < nw; ++w)
+        if (s_v[w] > v || (s_v[w] == v && s_a[w] < a)) { v = s_v[w]; a = s_a[w]; }
+}
+__device__ __forceinline__ float block_sum_max(float x, bool is_max, float* s_f) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float o = __shfl_xor(x, off, 64);
+        x = is_max ? fmaxf(x, o) : x + o;
+    }
+    const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s_f[wave] = x;
+    __syncthreads();
+    x = s_f[0];
+    for (int w = 1; w < nw; ++w) x = is_max ? fmaxf(x, s_f[w]) : x + s_f[w];
+    return x;
+}
+
+// A pool of W + expansions x V fp64 scores per utterance is searched twice per iteration (arg-max for the pop, max for
+// the stop test): 20 k scores after ten expansions.  Each segment - the survivors, the V children of one expansion -
+// therefore keeps its (max, first position); a pop or an expansion rescans ONE segment and then only the segment maxima.
+__global__ __launch_bounds__(64) void beam_frame_begin(BeamPtrs p, int t, int W, int EM, int V) {
     const int b = blockIdx.x;
     const bool act = t < p.lens[b];
     if (threadIdx.x == 0) {
@@ -314,9 +351,25 @@ __global__ void beam_frame_begin(BeamPtrs p, int t, int W, int EMV) {
             p.max_b[b] = -INFINITY;
         }
     }
-    if (act)
-        for (int i = threadIdx.x; i < W; i += blockDim.x)
-            p.pool[(size_t)b * (W + EMV) + i] = i < p.n_bp[b] ? p.bp_logp[b * W + i] : -INFINITY;
+    if (!act) return;
+    double best = -INFINITY;
+    int arg = 0x7fffffff;
+    const int nbp = p.n_bp[b];
+    for (int i = threadIdx.x; i < W; i += 64) {
+        const double v = i < nbp ? p.bp_logp[b * W + i] : -INFINITY;
+        p.pool[(size_t)b * (W + (size_t)EM * V) + i] = v;
+        if (v > best) { best = v; arg = i; }
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const double ov = __shfl_xor(best, off, 64);
+        const int oa = __shfl_xor(arg, off, 64);
+        if (ov > best || (ov == best && oa < arg)) { best = ov; arg = oa; }
+    }
+    if (threadIdx.x == 0) {
+        p.blk_max[(size_t)b * (EM + 1)] = best;
+        p.blk_arg[(size_t)b * (EM + 1)] = arg;
+    }
 }
 
 // y* = max(A) (first on ties), removed from A; its last token -> pred, its state -> h/c_state
@@ -327,29 +380,42 @@ __global__ __launch_bounds__(256) void beam_pop(BeamPtrs p, int cur, int W, int 
     const int b = blockIdx.x, tid = threadIdx.x;
     if (!p.open[b]) return;
     double* pool = p.pool + (size_t)b * (W + (size_t)EM * V);
-    const int n = W + p.e_count[b] * V;
+    const int e_n = p.e_count[b];
+    double* bmax = p.blk_max + (size_t)b * (EM + 1);
+    int32_t* barg = p.blk_arg + (size_t)b * (EM + 1);
+    __shared__ double sb[4];
+    __shared__ int sa[4];
+    __shared__ int s_ref;
+    // arg-max over the segment maxima (segments are in pool order, so the first position of the lowest segment wins ties)
     double best = -INFINITY;
     int arg = 0x7fffffff;
-    for (int i = tid; i < n; i += 256) {
-        const double v = pool[i];
-        if (v > best) { best = v; arg = i; }
+    for (int i = tid; i <= e_n; i += 256) {
+        const double v = bmax[i];
+        const int a = barg[i];
+        if (v > best || (v == best && a < arg)) { best = v; arg = a; }
     }
-    __shared__ double sb[256];
-    __shared__ int sa[256];
-    __shared__ int s_ref;
-    sb[tid] = best; sa[tid] = arg;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) {
-            const double ob = sb[tid + off];
-            const int oa = sa[tid + off];
-            if (ob > sb[tid] || (ob == sb[tid] && oa < sa[tid])) { sb[tid] = ob; sa[tid] = oa; }
+    block_argmax(best, arg, sb, sa);
+    const int idx = arg;
+    const double popped = best;
+    if (idx == 0x7fffffff) {                 // nothing left in A (cannot happen: a frame starts with >= 1 survivor)
+        if (tid == 0) { p.flags[0] = 1; p.open[b] = 0; }
+        return;
+    }
+    // the popped entry leaves A: rescan its segment
+    {
+        const int seg = idx < W ? 0 : 1 + (idx - W) / V;
+        const int lo = seg == 0 ? 0 : W + (seg - 1) * V, n = seg == 0 ? W : V;
+        double v2 = -INFINITY;
+        int a2 = 0x7fffffff;
+        for (int i = tid; i < n; i += 256) {
+            const double v = (lo + i == idx) ? -INFINITY : pool[lo + i];
+            if (v > v2) { v2 = v; a2 = lo + i; }
         }
-        __syncthreads();
+        block_argmax(v2, a2, sb, sa);
+        if (tid == 0) { bmax[seg] = v2; barg[seg] = v2 == -INFINITY ? 0x7fffffff : a2; }
     }
     if (tid == 0) {
-        const int idx = sa[0];
-        const int e = p.e_count[b];
+        const int e = e_n;
         int node, ref, tok;
         if (idx < W) {
             node = p.bp_node[b * W + idx];
@@ -367,7 +433,7 @@ __global__ __launch_bounds__(256) void beam_pop(BeamPtrs p, int cur, int W, int 
         pool[idx] = -INFINITY;
         p.exp_node[b * EM + e] = node;
         p.exp_ref[b * EM + e] = ref;
-        p.exp_logp[b * EM + e] = sb[0];
+        p.exp_logp[b * EM + e] = popped;
         pred[b] = tok;
         s_ref = ref;
     }
@@ -392,33 +458,28 @@ __global__ __launch_bounds__(256) void beam_expand(BeamPtrs p, const float* __re
     const int b = blockIdx.x, tid = threadIdx.x;
     if (!p.open[b]) return;
     const float* z = logits + (size_t)b * V;
-    __shared__ float sf[256];
-    __shared__ double sd[256];
+    __shared__ float sf[4];
+    __shared__ double sd[4];
+    __shared__ int si[4];
     float m = -INFINITY;
     for (int v = tid; v < V; v += 256) m = fmaxf(m, z[v]);
-    sf[tid] = m;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) sf[tid] = fmaxf(sf[tid], sf[tid + off]);
-        __syncthreads();
-    }
-    m = sf[0];
-    __syncthreads();
+    m = block_sum_max(m, true, sf);
     float s = 0.f;
     for (int v = tid; v < V; v += 256) s += expf(z[v] - m);
-    sf[tid] = s;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) sf[tid] += sf[tid + off];
-        __syncthreads();
-    }
-    const float logs = logf(sf[0]);
+    s = block_sum_max(s, false, sf);
+    const float logs = logf(s);
     const int e = p.e_count[b];
     const double base = p.exp_logp[b * EM + e];
     double* pool = p.pool + (size_t)b * (W + (size_t)EM * V);
-    double* seg = pool + W + (size_t)e * V;
-    for (int v = tid; v < V; v += 256)
-        seg[v] = v == blank ? -INFINITY : base + (double)((z[v] - m) - logs);
+    const int lo = W + e * V;
+    double* seg = pool + lo;
+    double best = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int v = tid; v < V; v += 256) {
+        const double c = v == blank ? -INFINITY : base + (double)((z[v] - m) - logs);
+        seg[v] = c;
+        if (c > best) { best = c; arg = lo + v; }
+    }
     const size_t LH = (size_t)L * H;
     float* dh = p.f_h + ((size_t)b * EM + e) * LH;
     float* dc = p.f_c + ((size_t)b * EM + e) * LH;
@@ -427,17 +488,17 @@ __global__ __launch_bounds__(256) void beam_expand(BeamPtrs p, const float* __re
         dh[i] = h_new[((size_t)l * B + b) * H + j];
         dc[i] = c_new[((size_t)l * B + b) * H + j];
     }
-    __syncthreads();
-    // max(A) after this expansion
-    const int n = W + (e + 1) * V;
-    double best = -INFINITY;
-    for (int i = tid; i < n; i += 256) best = fmax(best, pool[i]);
-    sd[tid] = best;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) sd[tid] = fmax(sd[tid], sd[tid + off]);
-        __syncthreads();
+    // the new segment's (max, first position), then max(A) = max over the segment maxima
+    block_argmax(best, arg, sd, si);
+    double* bmax = p.blk_max + (size_t)b * (EM + 1);
+    if (tid == 0) {
+        bmax[e + 1] = best;
+        p.blk_arg[(size_t)b * (EM + 1) + e + 1] = arg;
     }
+    double amax = best;
+    int dummy = 0;
+    for (int i = tid; i <= e; i += 256) amax = fmax(amax, bmax[i]);       // (segments 0 .. e: written by earlier kernels)
+    block_argmax(amax, dummy, sd, si);
     if (tid == 0) {
         const double lpb = base + (double)((z[blank] - m) - logs);
         const int j = p.n_b[b];
@@ -451,7 +512,7 @@ __global__ __launch_bounds__(256) void beam_expand(BeamPtrs p, const float* __re
         p.max_b[b] = mb;
         p.e_count[b] = e + 1;
         atomicAdd((unsigned long long*)p.total_exp, 1ull);
-        if (j + 1 >= W && mb >= sd[0]) {
+        if (j + 1 >= W && mb >= amax) {
             p.open[b] = 0;
         } else if (e + 1 >= EM) {
             p.flags[0] = 1;
@@ -552,7 +613,7 @@ constexpr int BEAM_QMAX = 1024;      // queries per batch of the prefix branch
 struct BeamWs {
     Ws step;   // the greedy loop's per-iteration buffers (prediction-network step + joint)
     size_t h_state, c_state;
-    size_t pool, bp_logp, bp_node, n_bp, bp_h0, bp_h1, bp_c0, bp_c1, bn_logp, bn_node, bn_ref, n_b, max_b,
+    size_t pool, bp_logp, bp_node, n_bp, bp_h0, bp_h1, bp_c0, bp_c1, bn_logp, bn_node, bn_ref, n_b, max_b, blk_max, blk_arg,
         exp_node, exp_ref, exp_logp, e_count, f_h, f_c, nodes, n_nodes, open, lens, flags, total_exp, total;
     size_t node_pred, q_row, q_node, q_tok, q_pred, q_D1, q_hid, q_logits, q_out;      // prefix = 1 only
 };
@@ -577,6 +638,8 @@ inline BeamWs beam_layout(int esz, int B, int T, int J, int V, int E, int L, int
     w.bn_ref = take((size_t)B * W * 4);
     w.n_b = take((size_t)B * 4);
     w.max_b = take((size_t)B * 8);
+    w.blk_max = take((size_t)B * (EM + 1) * 8);
+    w.blk_arg = take((size_t)B * (EM + 1) * 4);
     w.exp_node = take((size_t)B * EM * 4);
     w.exp_ref = take((size_t)B * EM * 4);
     w.exp_logp = take((size_t)B * EM * 8);
@@ -662,6 +725,8 @@ extern "C" int edgedict_beam_search(
     q.bn_ref = (int32_t*)(p + w.bn_ref);
     q.n_b = (int32_t*)(p + w.n_b);
     q.max_b = (double*)(p + w.max_b);
+    q.blk_max = (double*)(p + w.blk_max);
+    q.blk_arg = (int32_t*)(p + w.blk_arg);
     q.exp_node = (int32_t*)(p + w.exp_node);
     q.exp_ref = (int32_t*)(p + w.exp_ref);
     q.exp_logp = (double*)(p + w.exp_logp);
@@ -805,7 +870,7 @@ extern "C" int edgedict_beam_search(
             const int rc = prefix_merge(t, e1t);
             if (rc) return rc;
         }
-        hipLaunchKernelGGL(beam_frame_begin, dim3(B), dim3(64), 0, s, q, t, W, EM * V);
+        hipLaunchKernelGGL(beam_frame_begin, dim3(B), dim3(64), 0, s, q, t, W, EM, V);
         for (int it = 0;; ++it) {
             int rc;
             hipLaunchKernelGGL(beam_pop, dim3(B), dim3(256), 0, s, q, cur, W, V, EM, L, H, B, NODES,
