@@ -58,9 +58,11 @@ FUSED_LSE = os.environ.get("EDGEDICT_FUSED_LSE", "1") != "0"
 STREAM_ENCODER_STEP = os.environ.get("EDGEDICT_STREAM_ENCODER_STEP", "1") != "0"
 # ... for up to this many streams when the chunk is one or two encoder frames (the reference-native 75 ms chunk), and up
 # to STREAM_STEP_MAX_ROWS streams for longer chunks - measured (tools/stream_bench.py, fused vs per-layer kernels, ms per
-# chunk step): 1 frame, S = 64 / 256 / 1024: 0.47 / 0.49 / 1.55 vs 0.62 / 0.61 / 0.76; 4 frames, S = 1 / 64 / 256: 0.62 /
-# 1.53 / 1.63 vs 0.62 / 0.74 / 0.90 (the per-layer kernels batch the input product over the frames)
-STREAM_STEP_MAX_ROWS_SHORT = int(os.environ.get("EDGEDICT_STREAM_STEP_MAX_ROWS_SHORT", "256"))
+# chunk step through the module path): 1 frame, S = 64 / 256 / 1024: 0.34 / 0.33 / 0.64 vs 0.62 / 0.61 / 0.77; 4 frames,
+# S = 64 / 256 / 1024: 0.84 / 0.94 / 2.20 vs 0.75 / 0.90 / 2.43 (the per-layer kernels batch the input product over the frames)
+STREAM_STEP_MAX_ROWS_SHORT = int(os.environ.get("EDGEDICT_STREAM_STEP_MAX_ROWS_SHORT", "4096"))
+# BatchedStreamDecoder: the native calls of a chunk step with pre-bound arguments and buffers (stream._ChunkPlan)
+STREAM_FAST_CHUNK = os.environ.get("EDGEDICT_STREAM_FAST_CHUNK", "1") != "0"
 STREAM_STEP_MAX_ROWS = int(os.environ.get("EDGEDICT_STREAM_STEP_MAX_ROWS", "16"))
 
 # inputs shorter than this many frames use the per-layer path even in bf16 (see Encoder.forward)

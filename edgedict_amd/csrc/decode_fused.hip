@@ -447,8 +447,8 @@ __global__ __launch_bounds__(512) void enc_lstm_step(const bf16_t* __restrict__ 
                                                      const bf16_t* __restrict__ w_ih, const bf16_t* __restrict__ w_hh,
                                                      const float* __restrict__ b_ih, const float* __restrict__ b_hh,
                                                      const bf16_t* __restrict__ hb, long long ldh,
-                                                     const float* __restrict__ c_in, float* __restrict__ h_out,
-                                                     float* __restrict__ c_out, bf16_t* __restrict__ y, long long ldy,
+                                                     const float* c_in, float* __restrict__ h_out, float* c_out,
+                                                     bf16_t* __restrict__ y, long long ldy,
                                                      int B, int H) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = wave & 3, half = wave >> 2;
     const int r16 = lane & 15, q = lane >> 4;
@@ -478,6 +478,123 @@ __global__ __launch_bounds__(512) void enc_lstm_step(const bf16_t* __restrict__ 
 #pragma unroll
         for (int gg = 0; gg < 4; ++gg)
             pre[gg] = (s_gate[0][gg][cr][cu] + s_gate[1][gg][cr][cu]) + b_ih[gg * H + j0 + cu] + b_hh[gg * H + j0 + cu];
+        const float ig = sigm(pre[0]), fg = sigm(pre[1]), gt = tanh_fast(pre[2]), og = sigm(pre[3]);
+        const long long o = (long long)crow * H + j0 + cu;
+        const float c = fg * c_in[o] + ig * gt;
+        const float h = og * tanh_fast(c);
+        c_out[o] = c;
+        h_out[o] = h;
+        y[(long long)crow * ldy + j0 + cu] = f32_to_bf16(h);
+    }
+}
+
+// The same layer-frame for MANY rows (17 .. thousands of streams): a 64-row x (16 units x 4 gates) output tile per
+// workgroup with both operands staged through LDS - the one-tile-per-wave form above re-reads the 64-row X / h block
+// once per gate wave (1.3 MB per workgroup at S = 256: 42 us per layer-frame at the 49 GB/s a CU pulls), here every
+// operand byte enters the CU once (512 KB: ~11 us).  The K loop is gemm_nt_ring64's (gemm_nt.hip): ring of three
+// 64-k stages filled by LDS-DMA (global_load_lds_dwordx4, wave w brings pieces w and w + 4 of both operands), counted
+// `s_waitcnt vmcnt(4)` + raw barrier, XOR-swizzled 16-byte chunks; it runs over [x | h] x [W_ih | W_hh]^T as two K
+// segments with SEPARATE accumulators, summed as (x part + h part) + b_ih + b_hh - bit for bit what enc_lstm_step<1>
+// computes for the same row, so a stream's state does not depend on how many streams share its batch.  K tails (the
+// first layer's K = 240): chunks past K are fetched from a 16-byte zero block.
+__device__ const uint4 ed_zero16 = {0u, 0u, 0u, 0u};
+__device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+__global__ __launch_bounds__(256, 2) void enc_lstm_tile(const bf16_t* __restrict__ x, long long ldx, int Kx,
+                                                        const bf16_t* __restrict__ w_ih, const bf16_t* __restrict__ w_hh,
+                                                        const float* __restrict__ b_ih, const float* __restrict__ b_hh,
+                                                        const bf16_t* __restrict__ hb, long long ldh, const float* c_in,
+                                                        float* __restrict__ h_out, float* c_out, bf16_t* __restrict__ y,
+                                                        long long ldy, int B, int H) {
+    constexpr int BKK = 64, NS = 3, A_BYTES = 64 * BKK * 2, BUF_BYTES = 2 * A_BYTES;      // 16 KB per stage
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * BUF_BYTES];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int m0 = blockIdx.x * 64, j0 = blockIdx.y * 16;
+    const int KT0 = (Kx + BKK - 1) / BKK, KT = KT0 + (H + BKK - 1) / BKK;
+    const int prow = lane >> 3;
+    const int chunk = (lane & 7) ^ prow;
+    const bf16_t* ax[2];
+    const bf16_t* ah[2];
+    const bf16_t* bx[2];
+    const bf16_t* bh[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = (i * 4 + wave) * 8 + prow;                       // row of the tile / local gate column
+        const long long row = min(m0 + r, B - 1);
+        const long long wrow = (long long)(r >> 4) * H + j0 + (r & 15);   // W row of (gate r >> 4, unit j0 + (r & 15))
+        ax[i] = x + row * ldx + chunk * 8;
+        ah[i] = hb + row * ldh + chunk * 8;
+        bx[i] = w_ih + wrow * Kx + chunk * 8;
+        bh[i] = w_hh + wrow * H + chunk * 8;
+    }
+    auto issue = [&](int q) {
+        unsigned char* base = smem + (q % NS) * BUF_BYTES;
+        const bool seg = q >= KT0;
+        const int k0 = (seg ? q - KT0 : q) * BKK;
+        const bool in = k0 + chunk * 8 < (seg ? H : Kx);               // (K % 8 == 0: a chunk is in or out as a whole)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            glds16(in ? (const void*)((seg ? ah[i] : ax[i]) + k0) : (const void*)&ed_zero16, base + (i * 4 + wave) * 1024);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            glds16(in ? (const void*)((seg ? bh[i] : bx[i]) + k0) : (const void*)&ed_zero16, base + A_BYTES + (i * 4 + wave) * 1024);
+    };
+    f32x4_t accx[2][2], acch[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) accx[i][j] = acch[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    auto stage = [&](int q, f32x4_t (&acc)[2][2]) {
+        if (q + 1 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_barrier" ::: "memory");          // stage q landed everywhere; stage q - 1 is read out
+        if (q + 2 < KT) issue(q + 2);
+        const unsigned char* sA = smem + (q % NS) * BUF_BYTES;
+        const unsigned char* sB = sA + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < BKK / 32; ++ks) {
+            bf16x8_t a[2], b[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ra = wm * 32 + i * 16 + r16;
+                a[i] = *reinterpret_cast<const bf16x8_t*>(sA + ra * 128 + (((ks * 4 + kq) ^ (ra & 7)) << 4));
+                const int rb = wn * 32 + i * 16 + r16;
+                b[i] = *reinterpret_cast<const bf16x8_t*>(sB + rb * 128 + (((ks * 4 + kq) ^ (rb & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        }
+    };
+    issue(0);
+    if (KT > 1) issue(1);
+    for (int q = 0; q < KT0; ++q) stage(q, accx);
+    for (int q = KT0; q < KT; ++q) stage(q, acch);
+    __syncthreads();
+    float* sg = reinterpret_cast<float*>(smem);           // [64 rows][65]: x part + h part of every pre-activation
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int nl = wn * 32 + j * 16 + kq * 4, ml = wm * 32 + i * 16 + r16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sg[ml * 65 + nl + e] = accx[i][j][e] + acch[i][j][e];
+        }
+    __syncthreads();
+    for (int cell = threadIdx.x; cell < 64 * 16; cell += 256) {
+        const int cr = cell & 63, cu = cell >> 6;
+        const int crow = m0 + cr;
+        if (crow >= B) continue;
+        float pre[4];
+#pragma unroll
+        for (int gg = 0; gg < 4; ++gg)
+            pre[gg] = sg[cr * 65 + gg * 16 + cu] + b_ih[gg * H + j0 + cu] + b_hh[gg * H + j0 + cu];
         const float ig = sigm(pre[0]), fg = sigm(pre[1]), gt = tanh_fast(pre[2]), og = sigm(pre[3]);
         const long long o = (long long)crow * H + j0 + cu;
         const float c = fg * c_in[o] + ig * gt;
@@ -523,8 +640,6 @@ extern "C" int edgedict_stream_encoder_step(const void* xs, int x_dtype, int B, 
     bf16_t* Xn = (bf16_t*)(p + act);           // next layer's input
     bf16_t* Y = (bf16_t*)(p + 2 * act);        // h rows       [B, T_l, H]
     bf16_t* Xc = (bf16_t*)(p + 3 * act);       // bf16 copy of an fp32 input
-    float* hs = (float*)(p + 4 * act);
-    float* cs = (float*)(p + 4 * act + align256((size_t)B * H * 4));
     float* mean = (float*)(p + 4 * act + 2 * align256((size_t)B * H * 4));
     float* rstd = (float*)((char*)mean + align256((size_t)B * T * 4));
     bf16_t* HB = (bf16_t*)((char*)rstd + align256((size_t)B * T * 4));
@@ -542,26 +657,20 @@ extern "C" int edgedict_stream_encoder_step(const void* xs, int x_dtype, int B, 
         ED_CHECK_ARG(reduce[l] == 1 || reduce[l] == 2, "stream_encoder_step: time reduction must be 1 or 2");
         float* hl = h_state + (size_t)l * B * H;
         float* cl = c_state + (size_t)l * B * H;
-        const float* cin = cl;
+        // the carried state is updated IN PLACE: a cell's c is read and written by the same thread, and the recurrent
+        // product reads the bf16 copy of h (HB / the previous step's y row), never h_state itself
         for (int t = 0; t < Tl; ++t) {
-            float* hout = (t & 1) ? hl : hs;
-            float* cout = (t & 1) ? cl : cs;
             const dim3 grid1((B + 15) / 16, H / 16), grid4((B + 63) / 64, H / 16);
             const bf16_t* hb = t == 0 ? HB + (size_t)l * B * H : Y + (size_t)(t - 1) * H;
             const long long ldh = t == 0 ? (long long)H : (long long)Tl * H;
             if (B <= 16)
                 hipLaunchKernelGGL(enc_lstm_step<1>, grid1, dim3(512), 0, s, X + (size_t)t * K, (long long)Tl * K, K,
-                                   (const bf16_t*)w_ih[l], (const bf16_t*)w_hh[l], b_ih[l], b_hh[l], hb, ldh, cin, hout, cout,
+                                   (const bf16_t*)w_ih[l], (const bf16_t*)w_hh[l], b_ih[l], b_hh[l], hb, ldh, cl, hl, cl,
                                    Y + (size_t)t * H, (long long)Tl * H, B, H);
             else
-                hipLaunchKernelGGL(enc_lstm_step<4>, grid4, dim3(512), 0, s, X + (size_t)t * K, (long long)Tl * K, K,
-                                   (const bf16_t*)w_ih[l], (const bf16_t*)w_hh[l], b_ih[l], b_hh[l], hb, ldh, cin, hout, cout,
+                hipLaunchKernelGGL(enc_lstm_tile, grid4, dim3(256), 0, s, X + (size_t)t * K, (long long)Tl * K, K,
+                                   (const bf16_t*)w_ih[l], (const bf16_t*)w_hh[l], b_ih[l], b_hh[l], hb, ldh, cl, hl, cl,
                                    Y + (size_t)t * H, (long long)Tl * H, B, H);
-            cin = cout;
-        }
-        if (Tl & 1) {                           // the last step wrote the scratch buffers
-            ED_CHECK_HIP(hipMemcpyAsync(hl, hs, (size_t)B * H * 4, hipMemcpyDeviceToDevice, s));
-            ED_CHECK_HIP(hipMemcpyAsync(cl, cs, (size_t)B * H * 4, hipMemcpyDeviceToDevice, s));
         }
         const int Tn = (Tl + reduce[l] - 1) / reduce[l];
         void* dst = (l == L - 1) ? out : (void*)Xn;

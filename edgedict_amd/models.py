@@ -751,7 +751,7 @@ class Encoder(nn.Module):
               and lstm.hidden_size % 32 == 0 and xs.shape[2] % 8 == 0 and config.STREAM_ENCODER_STEP):
             # streaming chunks of a FEW streams (rnnt/stream.py:93-100: a frame or two per call): ONE native call, a
             # fused launch per layer-frame (csrc/decode_fused.hip, edgedict_stream_encoder_step) - 0.39 instead of
-            # 0.67 ms per chunk for one stream, 0.49 instead of 0.61 for 256; longer chunks of many streams stay on the
+            # 0.67 ms per chunk for one stream, 0.33 instead of 0.61 for 256; longer chunks of many streams stay on the
             # per-layer kernels, which batch the input product over the frames (config.STREAM_STEP_MAX_ROWS*)
             xs, hiddens = _stream_encoder_step(self, xs, hiddens)
         else:

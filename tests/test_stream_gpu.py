@@ -222,3 +222,48 @@ def test_fused_stream_encoder_step_matches_the_per_layer_path_and_is_row_indepen
         for a, b in zip(alone, new):
             sub = b[:, :1] if b.dim() == 3 and b.shape[1] == B and b.shape[0] != B else b[:1]
             assert torch.equal(a, sub), (a.shape, sub.shape)
+
+
+@pytest.mark.parametrize("S,dither", [(1, 0.0), (37, 1e-5)])
+def test_pre_bound_chunk_plan_equals_the_module_path(hip_lib, S, dither):
+    """stream._ChunkPlan (the six native calls of a chunk step with their arguments and buffers bound once) against the
+    module path it short-cuts (transform -> Encoder.forward -> run_search): same kernels, same arguments, same order, so
+    tokens AND the carried encoder / prediction-network states are bit-identical after every chunk, across a masked
+    reset, with dither on (the same seed sequence); a changed parameter rebuilds the plan."""
+    from edgedict_amd import config
+    from edgedict_amd.stream import BatchedStreamDecoder, chunk_geometry
+    flags, sd, m = _setup()
+    m.compute_dtype = "bf16"
+    win, hop = chunk_geometry(flags, 2)
+    g = torch.Generator(device="cpu").manual_seed(2)
+    wave = 0.1 * torch.randn(S, win + 6 * hop, generator=g)
+
+    def run(fast):
+        old = config.STREAM_FAST_CHUNK
+        config.STREAM_FAST_CHUNK = fast
+        try:
+            dec = BatchedStreamDecoder(m, flags, S, dither=dither)
+            out = []
+            for c in range(6):
+                if c == 3 and S > 1:
+                    mask = torch.zeros(S, dtype=torch.bool)
+                    mask[1::3] = True
+                    dec.reset(mask)
+                if c == 5:
+                    with torch.no_grad():           # a parameter changes under the decoder: the plan must notice
+                        m.joint.joint[2].bias[5] += 0.25
+                toks = dec.decode(wave[:, c * hop:c * hop + win].cuda().contiguous())
+                out.append((toks.cpu(), dec.enc_h.clone().cpu(), dec.enc_c.clone().cpu(), dec.state.h.clone().cpu(),
+                            dec.state.dec_out.float().cpu()))
+            with torch.no_grad():
+                m.joint.joint[2].bias[5] -= 0.25
+            used = getattr(dec, "_plan", None) is not None and dec._plan.ok
+            return out, used
+        finally:
+            config.STREAM_FAST_CHUNK = old
+    fast, used = run(True)
+    slow, used_slow = run(False)
+    assert used and not used_slow
+    for a, b in zip(fast, slow):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
