@@ -20,6 +20,6 @@ done
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE -d /tmp/prof_$TAG/MFMA -o p -- $CMD > $OUT/${TAG}_pmc_MFMA.log 2>&1
 cd $ROOT
 DB=$(find /tmp/prof_$TAG/trace -name "*results.db" | head -1)
-python profiles/summarize.py $DB $OUT/${TAG}_kernel_stats.md "$TAG: bench.py --steps 3 --warmup 1 (E6D2, bf16, B=64, 15 s): 4 training steps + the 2 stamped steps of the roofline measurement"
+python profiles/summarize.py $DB $OUT/${TAG}_kernel_stats.md "$TAG: bench.py --steps 3 --warmup 1 (E6D2, bf16, B=64, 15 s): every training step of the run: warm-up, timed, the 2 stamped steps of the roofline measurement, the 3 steps of host_unthrottled_ms"
 python profiles/pmc_summary.py $OUT/${TAG}_pmc.json $(find /tmp/prof_$TAG/FETCH_SIZE -name "*results.db" | head -1) $(find /tmp/prof_$TAG/WRITE_SIZE -name "*results.db" | head -1) $(find /tmp/prof_$TAG/MFMA -name "*results.db" | head -1)
 cp $DB $OUT/${TAG}_results.db

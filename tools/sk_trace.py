@@ -9,7 +9,7 @@ import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["EDGEDICT_STACK_BWD_SK"] = "1"
-os.environ["EDGEDICT_SK_STEPS"] = sys.argv[1] if len(sys.argv) > 1 else "6"
+os.environ["EDGEDICT_SK_STEPS"] = sys.argv[1] if len(sys.argv) > 1 else "16"
 import torch  # noqa: E402
 
 from edgedict_amd import _lib  # noqa: E402
