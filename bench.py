@@ -567,6 +567,7 @@ def main():
                 "bound": "hbm", "achieved": per_launch / (kernel_us * 1e-6) / 1e9,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": per_launch / (kernel_us * 1e-6) / 1e9 / HBM_PEAK_GBS, "traffic": tr,
+                "traffic_source": "profiles/pmc_latest.json - per-launch HBM bytes of this kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same bench command (profiles/collect.sh, committed with the build); NOT re-measured in this run",
                 "algorithmic_bytes": per_launch, "kernel_us": kernel_us, "launch_period_us": period_us,
                 "launches_timed": kern["bwd"][1] if "bwd" in kern else n_b.value,
                 "fwd_kernel_us": kern["fwd"][0] if "fwd" in kern else None,
@@ -636,6 +637,7 @@ def main():
                           "%d dense cells)" % (rows, V, J, rows, args.batch * Tp * U1),
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": traffic,
+                "traffic_source": "profiles/pmc_latest.json - per-launch HBM bytes of this kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same bench command (profiles/collect.sh, committed with the build); NOT re-measured in this run",
                 "algorithmic_bytes": 2.0 * rows * (J + V) + 2.0 * V * J,
                 "launch_ms": ms, "launches_timed": n, "mfma_util_pmc": mfma_util,
             },

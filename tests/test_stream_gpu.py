@@ -183,7 +183,8 @@ def test_256_streams_in_lock_step_equal_single_stream_decoders_and_reference_gol
     assert same >= 0.98 * total
 
 
-@pytest.mark.parametrize("B,T,H,L,red", [(1, 1, 64, 3, [1]), (37, 2, 64, 3, [1]), (70, 3, 128, 4, [0, 2]), (5, 5, 64, 2, [])])
+@pytest.mark.parametrize("B,T,H,L,red", [(1, 1, 64, 3, [1]), (37, 2, 64, 3, [1]), (70, 3, 128, 4, [0, 2]), (5, 5, 64, 2, []),
+                                           (300, 1, 96, 2, []), (17, 2, 160, 2, [0])])
 def test_fused_stream_encoder_step_matches_the_per_layer_path_and_is_row_independent(hip_lib, B, T, H, L, red):
     """edgedict_stream_encoder_step (csrc/decode_fused.hip: the streaming decoder's encoder call, rnnt/stream.py:93-100 ->
     Encoder.forward rnnt/models.py:131-136, as ONE native call with a fused launch per layer-frame) against the
