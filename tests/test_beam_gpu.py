@@ -168,3 +168,35 @@ def test_greedy_fused_frame_fp32_matches_oracle_and_bf16_runs(hip_lib):
     with torch.no_grad():
         tb, sb = mb.greedy_decode(xs.cuda(), xlen.cuda())
     assert all(((t >= 0) & (t < CFG32["vocab_size"])).all() for t in tb) and torch.isfinite(sb).all()
+
+
+# ragged against the kernels' tiles: V = 100 (two 64-column slices, the second one 36 wide), J = P2 = 96 (one and a half
+# 64-column blocks), H = 96 (six unit blocks, three k-steps), E = 64
+CFG_RAGGED = dict(vocab_embed_size=64, vocab_size=100, input_size=24, enc_hidden_size=32, enc_layers=2,
+                  enc_proj_size=32, dec_hidden_size=96, dec_layers=2, dec_proj_size=96, joint_size=96)
+
+
+@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
+def test_fused_frame_on_dimensions_that_do_not_fill_the_tiles(hip_lib, dtype):
+    from edgedict_amd.models import Transducer
+    sd = M.make_state_dict(CFG_RAGGED, 21)
+    xs, ys, xlen, ylen = M.make_batch(CFG_RAGGED, 22, 21, 13, 4)
+    m = Transducer(enc_dropout=0.0, dec_dropout=0.0, output_loss=False, **CFG_RAGGED)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().eval()
+    m.compute_dtype = dtype
+    with torch.no_grad():
+        tokens, score = m.greedy_decode(xs.cuda(), xlen.cuda())
+        seqs, bscore = m.beam_search(xs.cuda(), xlen, W=2, max_expansions=400)
+    if dtype == "fp32":
+        rt, rs = M.greedy_decode(sd, xs, xlen)
+        for b, t in enumerate(tokens):
+            assert np.array_equal(t, np.asarray(rt[b])[:len(t)]), b
+        np.testing.assert_allclose(score.cpu().numpy(), np.asarray(rs), rtol=1e-4, atol=1e-4)
+        bs, bsc, _ = beam_ref.beam_search(sd, xs, xlen, W=2)
+        for a, b in zip(seqs, bs):
+            assert np.array_equal(a, b)
+        np.testing.assert_allclose(bscore.numpy(), bsc, rtol=2e-4, atol=2e-4)
+    else:
+        assert all(((t >= 0) & (t < 100)).all() for t in tokens) and torch.isfinite(score).all()
+        assert all(((s > 0) & (s < 100)).all() for s in seqs) and torch.isfinite(bscore).all()

@@ -59,7 +59,7 @@ def _close(got, ref, tol):
 
 
 @pytest.mark.parametrize("B,T,I,H", [(3, 5, 24, 32), (16, 7, 64, 64), (64, 4, 256, 256),
-                                     (20, 3, 48, 96)])
+                                     (20, 3, 48, 96), (9, 3, 64, 1024), (70, 2, 32, 320)])
 def test_fp32_generic_path(hip_lib, B, T, I, H):
     got, ref = _run(torch.float32, B, T, I, H, True)
     for a, b in zip(got, ref):
