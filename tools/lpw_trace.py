@@ -18,7 +18,7 @@ os.environ["EDGEDICT_LPW_STEPS"] = steps
 torch.manual_seed(0)
 enc = Encoder(240, 1024, 6, 0.0, 640).cuda()
 enc.compute_dtype = torch.bfloat16
-xs = torch.randn(64, 401, 240, device="cuda")
+xs = torch.randn(int(os.environ.get("EDGEDICT_TRACE_B", "64")), 401, 240, device="cuda")      # EDGEDICT_TRACE_B: rows of the batch
 with torch.no_grad():
     for _ in range(3):
         enc(xs)

@@ -19,7 +19,7 @@ lib = _lib.load()
 torch.manual_seed(0)
 enc = Encoder(240, 1024, 6, 0.0, 640).cuda()
 enc.compute_dtype = torch.bfloat16
-xs = torch.randn(64, 401, 240, device="cuda")
+xs = torch.randn(int(os.environ.get("EDGEDICT_TRACE_B", "64")), 401, 240, device="cuda")      # EDGEDICT_TRACE_B: rows of the batch
 for p in enc.parameters():
     p.grad = torch.zeros_like(p)
 buf = torch.zeros(8192, dtype=torch.int64, device="cuda")
