@@ -113,32 +113,65 @@ __global__ __launch_bounds__(256) void rnnt_lse_from_parts(
     const int32_t* __restrict__ label_lens, int Tm, int U1, int V, int blank,
     float* __restrict__ denom, float* __restrict__ lpb, float* __restrict__ lpl,
     const long long* __restrict__ pk_off) {
-    // ONE LANE per lattice row: the row's `slots` pairs are 8 * slots contiguous bytes (16-byte loads, every
-    // line is used up over the loop), no cross-lane reduction, 64 independent rows in flight per wave, and the
-    // three outputs of 64 consecutive rows leave as coalesced stores.  Measured 0.14 ms for 543 526 rows, the
-    // same as half a wave per row with shuffles: the bound is the 1.09 M scattered 2-byte reads of the blank
-    // and label logits (one 64-byte sector each, rows 4 KB apart), not the pairs.
+    // ONE LANE per lattice row (no cross-lane reduction, the three outputs of consecutive rows leave as coalesced
+    // stores), but the row's `slots` pairs (8 * slots contiguous bytes) reach the lane through LDS: a wave copies the
+    // pairs of its next 64 (32) rows - one contiguous block of the packed lattice - with coalesced 16-byte loads and each
+    // lane then reads its own row.  Read straight from global memory, lane by lane, the 64 lanes of a load touch 64
+    // different lines of which 16 bytes are used; the line is gone from the CU's cache before the loop comes back for
+    // the next 16: the PMC counters showed 1.08 GB fetched for 139 MB of pairs (0.20 ms at the HBM roof).
+    // The arithmetic per row - pairs merged two at a time in slot order - is unchanged.
+    constexpr int WAVE_F4 = 64 * 17;                       // float4 per wave: 64 rows x (16 + 1) or 32 rows x (33 + 1)
+    __shared__ float4 stage[4][WAVE_F4];
     const int b = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int Tb = max(0, min(act_lens[b], Tm)), Ub = max(0, min(label_lens[b], U1 - 1));   // as rnnt_alpha_beta
     const int Wb = Ub + 1, nvalid = Tb * Wb;
-    for (int r = blockIdx.x * 256 + threadIdx.x; r < nvalid; r += gridDim.x * 256) {
+    const int q4 = slots >> 1;                             // 16-byte pieces per row (slots even on this path)
+    const int RP = (slots & 1) ? 0 : (q4 <= 16 ? 64 : (q4 <= 33 ? 32 : 0));   // rows per wave and pass (0: direct loads)
+    const int stride = q4 + 1;
+    float4* sp = stage[wave];
+    const int step = RP ? RP : 64;
+    for (int r0 = (blockIdx.x * 4 + wave) * step; r0 < nvalid; r0 += gridDim.x * 4 * step) {
+        const int nrows = min(step, nvalid - r0);
+        const long long arow0 = pk_off[b] + r0;
+        if (RP) {
+            const float4* p4 = reinterpret_cast<const float4*>(parts + arow0 * slots);       // slots even: 16-byte aligned
+            __builtin_amdgcn_wave_barrier();               // (the previous pass's reads of the stage are done)
+            for (int i = lane; i < nrows * q4; i += 64) {
+                const int rr = i / q4;
+                sp[rr * stride + (i - rr * q4)] = p4[i];
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (lane >= nrows) continue;
+        const int r = r0 + lane;
         const int t = r / Wb, u = r - t * Wb;
         const long long row = ((long long)b * Tm + t) * U1 + u;
-        const long long arow = pk_off[b] + r;
-        const float4* p4 = reinterpret_cast<const float4*>(parts + arow * slots);   // slots even: 16-byte aligned
+        const long long arow = arow0 + lane;
         float m = -INFINITY, sm = 0.f;
         int k = 0;
-        for (; (slots & 1) == 0 && k + 1 < slots; k += 2) {
-            const float4 p = p4[k >> 1];           // (max, sum) of slots k and k + 1
-            const float nm = fmaxf(m, fmaxf(p.x, p.z));
-            if (nm != -INFINITY) sm = sm * __expf(m - nm) + p.y * __expf(p.x - nm) + p.w * __expf(p.z - nm);
-            m = nm;
-        }
-        for (; k < slots; ++k) {                   // odd slot counts: 8-byte loads
-            const float2 p = parts[arow * slots + k];
-            const float nm = fmaxf(m, p.x);
-            if (nm != -INFINITY) sm = sm * __expf(m - nm) + p.y * __expf(p.x - nm);
-            m = nm;
+        if (RP) {
+            for (; k + 1 < slots; k += 2) {
+                const float4 p = sp[lane * stride + (k >> 1)];      // (max, sum) of slots k and k + 1
+                const float nm = fmaxf(m, fmaxf(p.x, p.z));
+                if (nm != -INFINITY) sm = sm * __expf(m - nm) + p.y * __expf(p.x - nm) + p.w * __expf(p.z - nm);
+                m = nm;
+            }
+        } else {
+            const float4* p4 = reinterpret_cast<const float4*>(parts + arow * slots);
+            for (; (slots & 1) == 0 && k + 1 < slots; k += 2) {
+                const float4 p = p4[k >> 1];
+                const float nm = fmaxf(m, fmaxf(p.x, p.z));
+                if (nm != -INFINITY) sm = sm * __expf(m - nm) + p.y * __expf(p.x - nm) + p.w * __expf(p.z - nm);
+                m = nm;
+            }
+            for (; k < slots; ++k) {                   // odd slot counts: 8-byte loads
+                const float2 p = parts[arow * slots + k];
+                const float nm = fmaxf(m, p.x);
+                if (nm != -INFINITY) sm = sm * __expf(m - nm) + p.y * __expf(p.x - nm);
+                m = nm;
+            }
         }
         const float lse = m + logf(sm);
         const bf16_t* z = acts + arow * (long long)V;
