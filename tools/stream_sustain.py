@@ -1,5 +1,6 @@
-"""cProfile of the Python host path of one streaming chunk step (BatchedStreamDecoder.decode, S streams, E6D2, bf16,
-75 ms chunks): where the wall time of a chunk step goes beyond its ~190 us of kernels.  usage: python tools/stream_host_profile.py [S]"""
+"""Does the streaming chunk step hold its rate over long runs?  ms per chunk step for n = 20 .. 800 consecutive chunk steps
+(S streams, E6D2, bf16, 75 ms chunks), with and without a device synchronisation every 20 steps.
+usage: python tools/stream_sustain.py [S]"""
 import os
 import sys
 import time
@@ -22,21 +23,17 @@ chunk = 0.1 * torch.randn(S, win, device="cuda")
 for _ in range(5):
     dec.decode(chunk)
 torch.cuda.synchronize()
-n = 200
+for n in (20, 50, 100, 200, 400, 800, 20):
+    t = time.time()
+    for _ in range(n):
+        dec.decode(chunk)
+    th = time.time() - t
+    torch.cuda.synchronize()
+    ta = time.time() - t
+    print("n = %4d: host %.3f ms per step, device done %.3f ms per step" % (n, th / n * 1e3, ta / n * 1e3))
 t = time.time()
-for _ in range(n):
+for i in range(400):
     dec.decode(chunk)
-t_host = (time.time() - t) / n
-torch.cuda.synchronize()
-t_all = (time.time() - t) / n
-print("S = %d: host returns after %.3f ms per chunk step, device done after %.3f ms per chunk step" % (S, t_host * 1e3, t_all * 1e3))
-import cProfile  # noqa: E402
-import pstats  # noqa: E402
-pr = cProfile.Profile()
-pr.enable()
-for _ in range(n):
-    dec.decode(chunk)
-pr.disable()
-torch.cuda.synchronize()
-st = pstats.Stats(pr)
-st.sort_stats("cumulative").print_stats(40)
+    if i % 20 == 19:
+        torch.cuda.synchronize()
+print("n =  400 with a synchronize every 20 steps: %.3f ms per step" % ((time.time() - t) / 400 * 1e3))
