@@ -91,7 +91,9 @@ class _ChunkPlan:
             return t
         # ---- A. dither + log-mel + stacking (features.FilterbankFeatures._run / StackedLogFbank.forward)
         self.fb = fb
-        self.xs = hold(torch.empty(S, T0, I0, dtype=torch.float32, device=dev))
+        # (bf16 straight from the log-mel kernel: the module path writes fp32 and the encoder step casts it - the same rounding,
+        # one launch more)
+        self.xs = hold(torch.empty(S, T0, I0, dtype=cd, device=dev))
         lo, hi = fb._win_support
         self.dither_args = [None, ll(frames.stride(0)), ci(S), ci(N), vp(0), ctypes.c_float(float(fb.dither)), None]
         self.fbank_args = [None, ll(frames.stride(0)), ci(S), ci(N), vp(0), P(fb._window_full), P(fb._twiddle), P(fb.fb),
