@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256, ED_FWD_OCC) void stack_fwd_kernel(EdFwdLaunch 
 //   * the only per-step global traffic on the dependency chain is the h fragment image: written with
 //     write-through (sc1) stores, every writing wave drains, ONE lane bumps the layer's arrival counter;
 //     readers poll that counter (one lane, relaxed) and read the image with L2-served (sc1) loads - the
-//     recipe of cdna_hip_programming.md G16 / wsr_kernels.hip,
+//     recipe of cdna_hip_programming.md G16,
 //   * everything a LATER kernel reads (gates for the backward pass, h rows for the LayerNorm, c rows) leaves
 //     after the publish, off the chain, with plain stores.
 // The arithmetic - MFMA order per wave, order of the cross-wave sum, cell math - is that of fwd_step_role,

@@ -42,7 +42,7 @@ for k in sorted(set(cnt[:n.value])):
     print("  %d layer-steps: %3d launches, mean duration %.1f us, mean gap before %.1f us" % (k, m.sum(), d[m].mean(), g[m].mean()))
 big = np.argsort(-g)[:10]
 print("largest gaps:", [(int(i), round(float(g[i]), 1)) for i in sorted(big)])
-if os.environ.get("EDGEDICT_STACK_LPW_BWD") == "1" or os.environ.get("EDGEDICT_STACK_BWD_SK") == "1":
+if os.environ.get("EDGEDICT_STACK_BWD_SK", "1") == "1":
     per = [[0] * 6 for _ in range(nl)]
     for l in range(6):
         for t, w in enumerate(steps[l]):
