@@ -760,26 +760,39 @@ extern "C" int edgedict_beam_search(
     std::vector<double> logp_h;
     std::vector<int2> nodes_h;
     std::vector<float> qout;
+    // the token tree is APPEND-ONLY (beam_expand writes node n_nodes[b]++ and nothing else): the host keeps a mirror and
+    // fetches, per frame, only the node columns that are new since its last fetch - one strided copy of
+    // [B] x [min_b mirrored[b], max_b n_nodes[b]) instead of the whole B x NODES tree (O(T^2 EM B) bytes per utterance
+    // batch)
+    std::vector<int32_t> mirrored;
+    struct Pair { int b, j, i, q0, nq; };
+    std::vector<Pair> pairs;
+    std::vector<std::vector<int>> paths;                          // per list entry: its nodes, last token first
+    if (prefix) { nodes_h.resize((size_t)B * NODES); mirrored.assign(B, 0); paths.resize(W); }
     void* node_pred = prefix ? (void*)(p + w.node_pred) : nullptr;
     auto prefix_merge = [&](int t, const char* e1t) -> int {
         nbp_h.resize(B); node_h.resize((size_t)B * W); logp_h.resize((size_t)B * W); nn_h.resize(B);
         ED_CHECK_HIP(hipMemcpyAsync(nbp_h.data(), q.n_bp, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+        ED_CHECK_HIP(hipMemcpyAsync(nn_h.data(), q.n_nodes, (size_t)B * 4, hipMemcpyDeviceToHost, s));
         ED_CHECK_HIP(hipStreamSynchronize(s));
         bool any = false;
         for (int b = 0; b < B; ++b) any = any || (t < lens_host[b] && nbp_h[b] > 1);
         if (!any) return ED_OK;
-        nodes_h.resize((size_t)B * NODES);
+        int lo = NODES, hi = 0;
+        for (int b = 0; b < B; ++b) {
+            if (nn_h[b] > mirrored[b]) { lo = std::min(lo, mirrored[b]); hi = std::max(hi, nn_h[b]); }
+        }
         ED_CHECK_HIP(hipMemcpyAsync(node_h.data(), q.bp_node, node_h.size() * 4, hipMemcpyDeviceToHost, s));
         ED_CHECK_HIP(hipMemcpyAsync(logp_h.data(), q.bp_logp, logp_h.size() * 8, hipMemcpyDeviceToHost, s));
-        ED_CHECK_HIP(hipMemcpyAsync(nn_h.data(), q.n_nodes, (size_t)B * 4, hipMemcpyDeviceToHost, s));
-        ED_CHECK_HIP(hipMemcpyAsync(nodes_h.data(), q.nodes, nodes_h.size() * 8, hipMemcpyDeviceToHost, s));
+        if (hi > lo)
+            ED_CHECK_HIP(hipMemcpy2DAsync(nodes_h.data() + lo, (size_t)NODES * 8, q.nodes + lo, (size_t)NODES * 8,
+                                          (size_t)(hi - lo) * 8, (size_t)B, hipMemcpyDeviceToHost, s));
         ED_CHECK_HIP(hipStreamSynchronize(s));
+        for (int b = 0; b < B; ++b) mirrored[b] = std::max(mirrored[b], nn_h[b]);
         // every (j, i > j) with A[i] a proper prefix of A[j]: the tokens of A[j] behind A[i], each with the prediction
         // stored at the node before it on A[j]'s path (g; the first one is the prediction of A[i]'s sequence)
-        struct Pair { int b, j, i, q0, nq; };
-        std::vector<Pair> pairs;
+        pairs.clear();
         qrow.clear(); qnode.clear(); qtok.clear();
-        std::vector<std::vector<int>> paths(W);                   // per list entry: its nodes, last token first
         for (int b = 0; b < B; ++b) {
             if (t >= lens_host[b]) continue;
             const int n = nbp_h[b];

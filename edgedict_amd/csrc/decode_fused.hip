@@ -246,6 +246,7 @@ struct LstmStepArgs {
     float* h_out; float* c_out;            // [B, H] fp32 candidates
     ET* y_out;                             // [B, H] copy of h_out in the mode's type (next layer / projection operand)
     int B, H, Kx;
+    int V;                                 // rows of the embedding table: every symbol that indexes it is clamped to [0, V)
 };
 template <typename ET>
 __global__ __launch_bounds__(256) void dec_lstm_step(LstmStepArgs<ET> A, int first) {
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(256) void dec_lstm_step(LstmStepArgs<ET> A, int fir
         for (int c = 0; c < CH; ++c) xx[c] = Md::ldx(xp + min(c * Md::KS, A.Kx - Md::KS));
     } else {
         if (first == 2) {                          // beam search: the symbol is the popped hypothesis' last token
-            if (threadIdx.x < 16) s_pred[threadIdx.x] = A.pred[min(row0 + (int)threadIdx.x, A.B - 1)];
+            if (threadIdx.x < 16) s_pred[threadIdx.x] = min(max(A.pred[min(row0 + (int)threadIdx.x, A.B - 1)], 0), A.V - 1);
         } else {
             // thread <-> (row tid >> 4, slice share tid & 15)
             const int pr = threadIdx.x >> 4, ps = threadIdx.x & 15;
@@ -302,6 +303,10 @@ __global__ __launch_bounds__(256) void dec_lstm_step(LstmStepArgs<ET> A, int fir
             int pick = a;
             // rnnt/stream.py:105-108: an arg-max that is <unk> has its logit set to 0 and the arg-max is retaken
             if (A.unk >= 0 && a == A.unk) pick = (0.f > mx || (0.f == mx && A.unk < ax)) ? A.unk : ax;
+            // a row without ONE comparable logit (all NaN, or all -inf: `v > m` never held) leaves the sentinel: such a
+            // stream emits blank - its prediction network does not advance, nothing is read outside the embedding table,
+            // and the other rows of the batch are untouched (the composed path clamped in edgedict_embedding_fwd)
+            if ((unsigned)pick >= (unsigned)A.V) pick = min(max(A.blank, 0), A.V - 1);
             if (ps == 0) s_pred[pr] = pick;
             if (blockIdx.y == 0 && row0 + pr < A.B) {
                 if (ps == 0) {
@@ -705,10 +710,11 @@ void launch_lstm_steps(int first_mode, const PickPart* parts, int NS, int unk, i
                        long long tok_stride, int t, float* score, const void* emb, int emb_dtype, int E, int L,
                        const void* const* w_ih, const void* const* w_hh, const float* const* b_ih,
                        const float* const* b_hh, int H, const float* h_state, const float* c_state, float* h_new,
-                       float* c_new, void* const* Y, int B, hipStream_t s) {
+                       float* c_new, void* const* Y, int B, int V, hipStream_t s) {
     const int RB = (B + 15) / 16;
     for (int k = 0; k < L; ++k) {
         LstmStepArgs<ET> A;
+        A.V = V;
         A.parts = parts; A.nslices = NS; A.unk = unk; A.blank = blank;
         A.pred = pred; A.tokens = tokens; A.tok_stride = tok_stride; A.t = t; A.score = score;
         A.emb = emb; A.emb_f32 = emb_dtype == ED_F32 ? 1 : 0; A.E = E;
@@ -731,7 +737,7 @@ int beam_step_t(const void* E1t, long long e_row_stride, int B, int J, const voi
     const int RB = (B + 15) / 16;
     void* Y[2] = {Y0, Y1};
     launch_lstm_steps<ET>(2, nullptr, 0, -1, -1, const_cast<int32_t*>(pred), nullptr, 0, 0, nullptr, emb, emb_dtype, E, L,
-                          w_ih, w_hh, b_ih, b_hh, H, h_state, c_state, h_new, c_new, Y, B, s);
+                          w_ih, w_hh, b_ih, b_hh, H, h_state, c_state, h_new, c_new, Y, B, V, s);
     hipLaunchKernelGGL(dec_proj_commit<ET>, dim3(RB, (P2 + 63) / 64), dim3(256), 0, s, (const ET*)Y[(L - 1) & 1], H,
                        (const ET*)Wp, bp, P2, (const int32_t*)nullptr, 0, (ET*)dec_new, (float*)nullptr,
                        (const float*)nullptr, (float*)nullptr, (const float*)nullptr, L, B);
@@ -756,7 +762,7 @@ int frame_t(const void* E1t, long long e_row_stride, int B, int J, const void* W
                        unk, score ? 1 : 0, (PickPart*)parts, (float*)nullptr, B);
     void* Y[2] = {Y0, Y1};
     launch_lstm_steps<ET>(1, (const PickPart*)parts, NS, unk, blank, pred, tokens_out, tok_stride, t, score, emb, emb_dtype,
-                          E, L, w_ih, w_hh, b_ih, b_hh, H, h_state, c_state, h_new, c_new, Y, B, s);
+                          E, L, w_ih, w_hh, b_ih, b_hh, H, h_state, c_state, h_new, c_new, Y, B, V, s);
     hipLaunchKernelGGL(dec_proj_commit<ET>, dim3(RB, (P2 + 63) / 64), dim3(256), 0, s, (const ET*)Y[(L - 1) & 1], H,
                        (const ET*)Wp, bp, P2, pred, blank, (ET*)dec_out, h_state, h_new, c_state, c_new, L, B);
     return ED_OK;

@@ -191,7 +191,13 @@ __device__ __forceinline__ double log_add64(double a, double b) {
     const double m = fmax(a, b);
     if (m == -(double)INFINITY) return m;
     const float d = (float)(fmin(a, b) - m);  // <= 0, may be -inf
-    return m + (double)__logf(1.f + __expf(d));
+    // 1 + x rounds to 1 below x ~ 6e-8 and loses x's low bits long before: for small x the series x - x^2 / 2
+    // (error < x^3 / 3 = 3e-13 at the switch) keeps the term that `__logf(1.f + x)` drops - over a chain of T + U
+    // log-adds the dropped terms were a one-sided bias (bounded by tests/test_rnnt_loss_gpu.py on a
+    // 1000 x 201 lattice)
+    const float x = __expf(d);
+    const float c = x < 1e-4f ? x - 0.5f * x * x : __logf(1.f + x);
+    return m + (double)c;
 }
 
 // ------------------------------------------------------------------ kernel 2
@@ -203,7 +209,8 @@ __device__ __forceinline__ double log_add64(double a, double b) {
 // needs from the row above is the lane's own value of the step before.  No LDS, no barrier: T + ceil(U1/C) - 1 steps
 // of C dependent log-adds each (E6D2: 233 steps of 2, against 265 diagonals with a workgroup barrier and an LDS round
 // trip each: 0.17 -> 0.03 ms).  Per cell the arithmetic and its operand order are those of the barrier kernel it
-// replaces (fp64 carry, fp32 correction term): alphas, betas and the likelihoods are bit-identical.
+// replaces (fp64 carry, fp32 correction term of log_add64 above): alphas, betas and the likelihoods are bit-identical
+// to that kernel built with the same log_add64 (the correction term itself changed in rounds 4 and 5).
 template <int C>
 __global__ __launch_bounds__(64) void rnnt_alpha_beta(const float* __restrict__ lpb, const float* __restrict__ lpl,
                                                       const int32_t* __restrict__ act_lens,

@@ -745,7 +745,7 @@ class Encoder(nn.Module):
             xs, h, c = encoder_stack.EncoderStackFn.apply(
                 xs, self.norm.weight, self.norm.bias, h0, c0, tuple(lstm.reductions), None, *params)
             hiddens = (h, c)
-        elif (isinstance(lstm, ResLayerNormLSTM) and xs.dim() == 3 and cd == torch.bfloat16
+        elif (isinstance(lstm, ResLayerNormLSTM) and xs.dim() == 3 and cd == torch.bfloat16 and not drop
               and not torch.is_grad_enabled() and 0 < xs.shape[1] < config.STACK_MIN_FRAMES
               and xs.shape[0] <= (config.STREAM_STEP_MAX_ROWS_SHORT if xs.shape[1] <= 2 else config.STREAM_STEP_MAX_ROWS)
               and lstm.hidden_size % 32 == 0 and xs.shape[2] % 8 == 0 and config.STREAM_ENCODER_STEP):

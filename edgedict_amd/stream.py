@@ -68,7 +68,12 @@ class _ChunkPlan:
         S, N = frames.shape
         self.ok = False
         self.key = (S, N, frames.stride(0))
-        self.params = list(m.parameters())
+        # (module._parameters dict, name, Parameter) of every parameter: a REPLACED Parameter object (load_state_dict(assign=True),
+        # `module.weight = ...`, module._apply swapping tensors) fails the identity check, `p.data = ...` the data_ptr check, an
+        # in-place update the version check - the plan holds the old tensors alive, so it must never outlive them silently
+        self.slots = [(mod._parameters, name, p) for mod in m.modules() for name, p in mod._parameters.items() if p is not None]
+        self.params = [p for _, _, p in self.slots]
+        self.dec = dec
         self.sig = self._signature()
         k, M = tr.n_frame, fb.n_filt
         T0 = tr.output_frames(N)
@@ -77,7 +82,8 @@ class _ChunkPlan:
                 and _compute_dtype(enc) == cd and _compute_dtype(m.decoder) == cd and _compute_dtype(m.joint) == cd
                 and 0 < T0 < config.STACK_MIN_FRAMES and tr.out_dtype == torch.float32
                 and S <= (config.STREAM_STEP_MAX_ROWS_SHORT if T0 <= 2 else config.STREAM_STEP_MAX_ROWS)
-                and lstm.hidden_size % 32 == 0 and I0 % 8 == 0 and getattr(lstm, "dropout", 0) == 0):
+                and lstm.hidden_size % 32 == 0 and I0 % 8 == 0
+                and (getattr(lstm, "dropout", 0) == 0 or not m.training)):    # (train mode + dropout: the module path applies it)
             return
         dev = frames.device
         lib = _lib.load()
@@ -160,7 +166,13 @@ class _ChunkPlan:
         self.ok = True
 
     def _signature(self):
-        return (config.param_epoch(), sum(p._version for p in self.params), self.params[0].data_ptr(), len(self.params))
+        # everything a bound argument list was derived from: parameter identity / storage / version, the engine's parameter
+        # epoch, train / eval mode, and the scalars baked into the calls (dither amplitude, <unk> id, blank id)
+        dec, fb = self.dec, self.dec.transform.fbank
+        return (config.param_epoch(), sum(p._version for p in self.params),
+                hash(tuple(p.data_ptr() for p in self.params)),
+                all(d.get(n) is p for d, n, p in self.slots), dec.model.training,
+                float(fb.dither), int(dec.unk_id), int(dec.model.blank))
 
     def valid(self, frames):
         return (self.key == (frames.shape[0], frames.shape[1], frames.stride(0)) and frames.dtype == torch.float32
@@ -294,7 +306,9 @@ class PytorchStreamDecoder(StreamTransducerDecoder):
     def reset(self):
         self._batched.reset()
 
-    # state attributes the reference exposes (rnnt/stream.py:80-91)
+    # state attributes the reference exposes (rnnt/stream.py:80-91).  NOTE (differs from the reference, which rebinds
+    # fresh tensors every chunk, rnnt/stream.py:97-98): on the bound-argument fast path (_ChunkPlan) the encoder state is
+    # updated IN PLACE - a caller that wants a rollback point must keep `dec.enc_h.clone()`, not the tensor itself.
     @property
     def enc_h(self):
         return self._batched.enc_h

@@ -254,3 +254,21 @@ def test_backward_in_utterance_ranges_equals_one_pass(hip_lib):
     with pytest.raises(RuntimeError):
         _lib.call("rnnt_loss_backward_packed_range", logits, code, parts, labels, act_d, lab_d, off_d, B, T, U1, V, 0, ws,
                   1.0 / B, None, 0, 3, 3)
+
+
+@pytest.mark.gpu
+def test_long_lattice_drift_is_bounded(hip_lib):
+    """a chain of T + U ~ 1200 log-adds (T = 1000, U = 200; peaked logits, so most log-adds see a tiny
+    second term - the regime in which a correction term evaluated as log(1 + x) drops x altogether).  Cost and the
+    whole gradient against the float64 restatement: the cost within 2e-6 relative (north-star bound: 1e-3), the
+    gradient within 2e-5 absolute (the bound of the short-lattice cases)."""
+    rng = np.random.default_rng(123)
+    B, T, U1, V = 1, 1000, 201, 16
+    acts = (4.0 * rng.normal(size=(B, T, U1, V))).astype(np.float32)
+    labels = rng.integers(1, V, size=(B, U1 - 1)).astype(np.int32)
+    al = np.array([T], np.int32)
+    ll = np.array([U1 - 1], np.int32)
+    costs, grads = R.rnnt_loss(acts.astype(np.float64), labels, al, ll)
+    loss, g = _run_hip(acts, labels, al, ll, reduction="none")
+    assert abs(loss[0] - costs[0]) <= 2e-6 * abs(costs[0]), (loss[0], costs[0])
+    assert np.abs(g - grads).max() <= 2e-5, np.abs(g - grads).max()

