@@ -109,3 +109,17 @@ def test_bruteforce_reproduces_the_upstream_known_answer():
     c, g = BF.rnnt_loss(ka["acts"], ka["labels"], ka["act_lens"], ka["label_lens"])
     assert abs(c[0] - ka["cost"]) < 2e-6
     np.testing.assert_allclose(g, ka["grads"], atol=5e-7)
+
+
+def test_batch_known_answer_b2_costs_and_gradient():
+    """The B = 2 vector of upstream's unit tests (provenance and its limits: oracle/rnnt_loss_ref.py, KNOWN_ANSWER_B2):
+    72 logits, 2 published costs and 72 published gradient entries must agree through the float64 recursion AND
+    through the enumeration of every alignment - a digit wrong in any of them breaks one of the 148 comparisons."""
+    from oracle import rnnt_loss_bruteforce as BF
+    ka = R.KNOWN_ANSWER_B2
+    costs, grads = R.rnnt_loss(ka["acts"], ka["labels"], ka["act_lens"], ka["label_lens"])
+    np.testing.assert_allclose(costs, ka["costs"], rtol=0, atol=5e-7)
+    np.testing.assert_allclose(grads, ka["grads"], rtol=0, atol=1e-6)
+    c, g = BF.rnnt_loss(ka["acts"], ka["labels"], ka["act_lens"], ka["label_lens"])
+    np.testing.assert_allclose(c, ka["costs"], rtol=0, atol=5e-7)
+    np.testing.assert_allclose(g, ka["grads"], rtol=0, atol=1e-6)

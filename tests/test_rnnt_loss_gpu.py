@@ -43,6 +43,19 @@ def test_known_answer(hip_lib):
     np.testing.assert_allclose(grads, ka["grads"], atol=2e-6)
 
 
+def test_batch_known_answer_b2(hip_lib):
+    """Upstream's B = 2 unit-test vector (oracle/rnnt_loss_ref.py, KNOWN_ANSWER_B2): both costs and all 72 gradient
+    entries, reduction 'none' / 'sum' (gradient of the sum) and 'mean' (x 1/B)."""
+    ka = R.KNOWN_ANSWER_B2
+    loss, grads = _run_hip(ka["acts"].astype(np.float32), ka["labels"], ka["act_lens"], ka["label_lens"],
+                           reduction="none")
+    np.testing.assert_allclose(loss, ka["costs"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(grads, ka["grads"], rtol=0, atol=2e-6)
+    loss_m, grads_m = _run_hip(ka["acts"].astype(np.float32), ka["labels"], ka["act_lens"], ka["label_lens"])
+    assert abs(loss_m[0] - ka["costs"].mean()) < 2e-6
+    np.testing.assert_allclose(grads_m, ka["grads"] / 2, rtol=0, atol=2e-6)
+
+
 @pytest.mark.parametrize("B,T,U1,V,ragged", [
     (1, 1, 1, 7, False),       # single cell, empty label sequence
     (2, 5, 1, 16, True),       # U = 0 for every utterance
