@@ -32,3 +32,25 @@ def test_stream_oracle_reproduces_reference_texts(name):
             ids = [t for t in oracles[s].decode(wave[s:s + 1, c * HOP:c * HOP + WIN].clone()) if t != 0]
             assert ids == ids_of(str(texts[s, c])), (c, s)
             assert "".join(vocab.id_to_token(t).replace("</w>", " ") for t in ids) == str(texts[s, c])
+
+
+def test_compiled_reference_loops_match_the_reference_checkout():
+    """oracle/_ref/*.bin (oracle/ref_lift.py) is what tests/test_reference_loops_gpu.py executes on the GPU box, where
+    /root/reference does not exist: here, where it does, the manifest must name the current reference files (a stale
+    build would test yesterday's loops) and every piece must load into code that defines the names it promises."""
+    import hashlib
+    import json
+    import os
+    import pytest
+    from oracle import ref_lift
+    if not os.path.isdir(ref_lift.REF):
+        pytest.skip("no reference checkout here")
+    if not ref_lift.available():
+        ref_lift.build(verbose=False)
+    man = json.load(open(os.path.join(ref_lift.OUT, "manifest.json")))
+    for name, (rel, cls, names) in ref_lift.PIECES.items():
+        entry = man["pieces"][name]
+        digest = hashlib.sha256(open(os.path.join(ref_lift.REF, rel), "rb").read()).hexdigest()
+        assert entry["sha256_of_reference_file"] == digest, name
+        ns = ref_lift.load(name, {"torch": __import__("torch")})
+        assert all(n in ns for n in names), name
