@@ -6,3 +6,6 @@ import os as _os
 # enables this itself; set it for hosts that initialise HIP through this package first.  Must happen
 # before the HIP runtime initialises, i.e. before the first device call of the process.
 _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
+# EDGEDICT_POISON=1 (debug): uninitialised allocations are filled with NaN / 0xA5 (see _poison.py)
+from . import _poison as _poison  # noqa: E402,F401

@@ -461,6 +461,37 @@ extern "C" void* edgedict_aux_stream(int which) {
     return which == 0 ? (void*)r->R : which == 1 ? (void*)r->S[0] : (void*)r->W;
 }
 
+// Which of the library's internal streams of the current device still have work enqueued (hipStreamQuery): bit 0 the
+// recurrence stream, bit 1 the chunk-GEMM stream, bit 2 the auxiliary (weight-gradient) stream, bits 3.. the lazily
+// created per-layer side streams.  Every entry point joins the streams it used into the caller's stream before it
+// returns and every host-side borrower of the auxiliary stream joins it too (side.py), so once the CALLER's stream is
+// idle a set bit is work that nothing orders behind - the caching allocator may hand its buffers to somebody else.
+// Never creates the streams (0 if the runtime of this device does not exist yet).
+extern "C" int edgedict_streams_busy(unsigned* mask) {
+    ED_CHECK_ARG(mask != nullptr, "streams_busy: null mask");
+    *mask = 0;
+    int dev = 0;
+    ED_CHECK_HIP(hipGetDevice(&dev));
+    Runtime* r = nullptr;
+    {
+        std::lock_guard<std::mutex> registry(g_rt_mu);
+        if ((int)g_rt.size() > dev) r = g_rt[dev];
+    }
+    if (!r) return ED_OK;
+    auto busy = [&](hipStream_t s, int bit) -> int {
+        if (!s) return ED_OK;
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipErrorNotReady) { *mask |= 1u << bit; (void)hipGetLastError(); return ED_OK; }
+        ED_CHECK_HIP(e);
+        return ED_OK;
+    };
+    ED_TRY(busy(r->R, 0));
+    ED_TRY(busy(r->S[0], 1));
+    ED_TRY(busy(r->W, 2));
+    for (int i = 1; i < ED_STACK_MAX_SLOTS; ++i) ED_TRY(busy(r->S[i], 2 + i));
+    return ED_OK;
+}
+
 extern "C" size_t edgedict_stack_struct_bytes(int which) {
     return which == 0 ? sizeof(edgedict_stack_layer_t) : sizeof(edgedict_stack_desc_t);
 }

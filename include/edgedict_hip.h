@@ -312,6 +312,12 @@ size_t edgedict_stack_struct_bytes(int which);
  * borrow stream 2 instead of creating more streams: beyond the 4 hardware queues HIP multiplexes
  * streams and every cross-stream dependency gets slower. */
 void* edgedict_aux_stream(int which);
+/* Debug / test aid: which internal streams of the current device still have work enqueued (hipStreamQuery; bit 0
+ * recurrence, bit 1 chunk GEMMs, bit 2 auxiliary, bits 3.. lazily created per-layer side streams).  Every entry
+ * point joins the streams it used into the caller's stream before it returns, so with the CALLER's stream idle a
+ * set bit is work nothing is ordered behind (tests/conftest.py asserts mask == 0 after every GPU test).  Creates
+ * nothing. */
+int edgedict_streams_busy(unsigned* mask);
 size_t edgedict_stack_workspace_bytes(const edgedict_stack_desc_t* desc);
 int edgedict_stack_pack_weights(const float* w_ih, const float* w_hh, const float* b_ih,
                                 const float* b_hh, int H, int I, void* wih_p, void* wih_t,
