@@ -1229,7 +1229,13 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     // the products are spread under the whole recurrence instead of piling up behind the last
     // layers (the BPTT launches next to a busy W stream take 27 us instead of 16).
     auto weight_grads = [&](int l, int t0, int t1, bool first, bool last_of_all) -> int {
-        if (g_trace) return ED_OK;
+        if (g_trace) {
+            // dry run: no product, but the host callback fires at the same point of the schedule - a data-parallel
+            // host can be tested for WHEN each layer's bucket may leave (tests/test_dp_gloo.py: ranks whose batches
+            // differ in length run different launch counts and must still issue the same collectives in the same order)
+            if (t0 == 0 && d->grads_final) d->grads_final(l, d->grads_final_user);
+            return ED_OK;
+        }
         const edgedict_stack_layer_t& y = d->layers[l];
         const int M = (t1 - t0) * B;
         const long long r0 = (long long)t0 * B;

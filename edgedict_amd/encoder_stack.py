@@ -360,11 +360,13 @@ class EncoderStackFn(torch.autograd.Function):
         return tuple(out)
 
 
-def schedule(T0, I0, H, reductions, B=64, chunk=None, backward=False, lag=0, flags=0):
+def schedule(T0, I0, H, reductions, B=64, chunk=None, backward=False, lag=0, flags=0, grads_final=None):
     """Dry run of the native scheduler (no device): returns ``(step_launch, chunk_enqueued,
     n_launches, max_slots)`` where ``step_launch[l][t]`` is the launch index that carries step t of
     layer l and ``chunk_enqueued[l][k]`` the number of launches issued when chunk k's side-stream
-    product was enqueued (-1 = available from the start).  Used by tests/test_stack_schedule.py."""
+    product was enqueued (-1 = available from the start).  Used by tests/test_stack_schedule.py.
+    ``grads_final(layer)`` (backward only) is called where the real pass reports a layer's weight gradients final
+    (``edgedict_stack_desc_t.grads_final``): tests/test_dp_gloo.py drives the gradient exchange with it."""
     import numpy as np
     lib = _lib.load()
     L = len(reductions)
@@ -391,6 +393,10 @@ def schedule(T0, I0, H, reductions, B=64, chunk=None, backward=False, lag=0, fla
     d.h0 = d.c0 = None
     d.out = d.dout = d.ws = dummy
     d.ws_bytes = 1 << 62
+    cb = None
+    if grads_final is not None:
+        cb = GRADS_FINAL_CB(lambda layer, _user: grads_final(layer))
+        d.grads_final = ctypes.cast(cb, ctypes.c_void_p).value
     f0 = 1
     for r in reductions:
         f0 *= r

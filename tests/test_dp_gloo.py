@@ -227,3 +227,81 @@ def test_issue_order_is_rank_invariant():
     # rank 0 completes 0, 1 (late: held), 2 -> [0], [0], [0, 2, 1];  rank 1 completes 2 (held behind 0), 1, 0
     assert out[0][3] == [[0], [0], [0, 2, 1]]
     assert out[1][3] == [[], [], [0, 2, 1]]
+
+
+def _worker_ragged(rank, world, port, q):
+    """Per-rank ragged T: every rank slices its shard to ITS longest utterance (rnnt/models.py:229-230), so the encoder
+    stack of rank 0 (T0 = 401) and of rank 1 (T0 = 283) run different launch schedules and report their layers'
+    weight gradients final (edgedict_stack_desc_t.grads_final -> BucketedAllReduce.ready) at different launches.  The
+    NATIVE scheduler is driven in its dry-run mode (no device) with the real callback wiring; the joint's bucket is
+    reported first, the remaining parameters complete through hooks at the end, as in a training step."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from edgedict_amd import encoder_stack as es
+    from edgedict_amd.dp import BucketedAllReduce
+    from edgedict_amd.optim import FlatParams
+    L = 6
+    torch.manual_seed(0)
+    model = torch.nn.Module()
+    model.layers = torch.nn.ModuleList([torch.nn.ParameterList(          # w_ih, w_hh, b_ih, b_hh of a layer, in this order
+        [torch.nn.Parameter(torch.zeros(n)) for n in (40, 48, 8, 8)]) for _ in range(L)])
+    model.joint = torch.nn.Linear(9, 11)
+    model.rest = torch.nn.Linear(5, 3)
+    flat = FlatParams(model)
+    layer_params = [list(m) for m in model.layers]
+    red = BucketedAllReduce(flat, bucket_bytes=1 << 30, min_bytes=4,
+                            boundaries=[lp[0] for lp in layer_params] + [model.joint.weight, model.rest.weight],
+                            late=list(model.rest.parameters()))
+    assert len(red.bounds) == L + 2 and red.issue_order == list(range(1, L + 2)) + [0]
+    issued = []
+    orig = red._issue
+
+    def spy(b):
+        issued.append(b)
+        orig(b)
+    red._issue = spy
+    g = torch.Generator().manual_seed(77 + rank)
+    flat.zero_grad()
+    for p in flat.params:
+        p.grad.copy_(torch.randn(p.shape, generator=g))
+    mine = flat.grad.clone()
+    T0 = (401, 283)[rank]
+    red.ready(list(model.joint.parameters()))                  # the joint's backward node reports first
+    reported = []
+
+    def on_final(layer):
+        reported.append(layer)
+        red.ready(layer_params[layer])
+    _, _, n_launches, _ = es.schedule(T0, 240, 1024, [1, 2, 1, 1, 1, 1], backward=True, grads_final=on_final)
+    early = list(issued)
+    scale = red.finish()
+    q.put((rank, mine.numpy(), flat.grad.clone().numpy(), issued, early, reported, n_launches, scale))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_ranks_with_different_launch_counts_issue_the_same_collectives():
+    world, port = 2, 35500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_ragged, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = {}
+    for _ in range(world):
+        r = q.get(timeout=90)
+        out[r[0]] = r[1:]
+    for p in procs:
+        p.join(timeout=30)
+        assert p.exitcode == 0
+    import numpy as np
+    total = out[0][0] + out[1][0]
+    for r in range(world):
+        np.testing.assert_allclose(out[r][1], total, rtol=1e-6, atol=1e-6)
+        assert out[r][4] == [5, 4, 3, 2, 1, 0]            # layers become final top-down on every rank
+    assert out[0][5] != out[1][5] and out[0][5] == 37       # different launch counts (tests/test_stack_schedule.py pins 37)
+    assert out[0][2] == out[1][2]                           # ... the same collectives in the same order
+    assert out[0][3] == out[1][3] and len(out[0][3]) == 7   # joint + six layers left before finish(), `rest` from it
