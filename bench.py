@@ -453,7 +453,15 @@ def main():
     from edgedict_amd import encoder_stack as _es
     _es.check_wsr_error()        # no bounded in-kernel wait gave up during the timed steps (host word, after the sync)
     tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+    # per-rank figures of the timed region, so that the first real multi-GPU run is diagnosable from ONE line: each
+    # rank's own wall time per step (the reported time is their maximum), its host enqueue time and how many of its
+    # buckets left from inside the backward pass
+    per_rank = None
     if world > 1:
+        mine = torch.zeros(world, 3, dtype=torch.float64, device=device)
+        mine[rank, 0], mine[rank, 1], mine[rank, 2] = 1e3 * dt / args.steps, 1e3 * host_s / args.steps, float(left_early)
+        dist.all_reduce(mine)
+        per_rank = mine.tolist()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
     loss_val = float(loss.item())
@@ -607,6 +615,11 @@ def main():
                              1e3 * dt_first / args.steps,
                          ("ms_per_step_after_backward" if engine.reducer.overlap else "ms_per_step_overlap"):
                              1e3 * dt_other / args.steps,
+                         "rank_ms_per_step": [round(r[0], 4) for r in per_rank] if per_rank else None,
+                         "rank_ms_per_step_spread": (round(max(r[0] for r in per_rank) - min(r[0] for r in per_rank), 4)
+                                                     if per_rank else None),
+                         "rank_host_enqueue_ms_per_step": [round(r[1], 4) for r in per_rank] if per_rank else None,
+                         "rank_left_during_backward": [int(r[2]) for r in per_rank] if per_rank else None,
                          "semantics": "sum over ranks, x 1/N inside the Adam kernel (cli/lightning.py:325-331: "
                                       "DDP mean)"} if world > 1 else None,
             "rank_devices": devices,

@@ -83,6 +83,11 @@ def test_world2_body_of_bench_runs_on_one_gpu_over_gloo():
     # the joint's and the encoder layers' buckets left from inside the backward pass (grads_final path)
     assert ex["left_during_backward"] >= 7, ex
     assert ex["ms_per_step_overlap"] > 0 and ex["ms_per_step_after_backward"] > 0
+    # per-rank figures (the first real multi-GPU run must be diagnosable from this one line): the reported time is
+    # the slowest rank's, every rank sent the same buckets early
+    assert len(ex["rank_ms_per_step"]) == 2 and abs(max(ex["rank_ms_per_step"]) - out["ms_per_step"]) < 1e-3
+    assert ex["rank_ms_per_step_spread"] >= 0 and len(ex["rank_host_enqueue_ms_per_step"]) == 2
+    assert ex["rank_left_during_backward"] == [ex["left_during_backward"]] * 2
     # `value` is the DEFAULT exchange mode (what TrainEngine ships: overlapped), never the faster of the two
     assert ex["overlap_default"] is True and ex["mode_reported"] == "overlap"
     assert abs(out["ms_per_step"] - ex["ms_per_step_overlap"]) < 1e-6
