@@ -55,7 +55,7 @@ __global__ void add_tanh_rows(const T* __restrict__ E1, long long e_stride,
 __global__ __launch_bounds__(256) void pick_kernel(const float* __restrict__ logits, int B, int V,
                                                    int unk, int32_t* __restrict__ pred,
                                                    int32_t* __restrict__ tokens, int tok_stride,
-                                                   int t, float* __restrict__ score) {
+                                                   int t, float* __restrict__ score, int blank) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -93,6 +93,10 @@ __global__ __launch_bounds__(256) void pick_kernel(const float* __restrict__ log
         s = wave_sum(s);
         if (lane == 0) score[b] += logf(s);  // -(max log p) = log sum exp(z - max)
     }
+    // a row without one comparable logit (all NaN / all -inf: `x > best` never held) leaves the sentinel: it emits blank,
+    // as the fused frame does (decode_fused.hip dec_lstm_step) - the prediction network of that row does not advance and
+    // no out-of-range id reaches `pred`, `tokens` or the embedding gather
+    if ((unsigned)arg >= (unsigned)V) arg = min(max(blank, 0), V - 1);
     if (lane == 0) {
         pred[b] = arg;
         if (tokens) tokens[(long long)b * tok_stride + t] = arg;
@@ -220,7 +224,7 @@ extern "C" int edgedict_greedy_decode(
                                 0, 1, s)))
             return rc;
         hipLaunchKernelGGL(pick_kernel, dim3((B + 3) / 4), dim3(256), 0, s, logits, B, V, unk, pred,
-                           tokens_out, tok_stride, t, score);
+                           tokens_out, tok_stride, t, score, blank);
         // prediction network step on the picked symbols (for every row, committed where != blank)
         if ((rc = edgedict_embedding_fwd(dtype, emb_dtype, pred, 1, emb, x, B, 1, E, V, 0, 0, s)))
             return rc;

@@ -116,6 +116,10 @@ class FilterbankFeatures(nn.Module):
         return 1 + n_samples // self.hop_length
 
     def _run(self, x, lengths, out, o_b, o_group, o_k, o_m, stack, frames_out):
+        if x.is_cuda and self.fb.device != x.device:
+            # the window / twiddle / filter tables follow the waveform's device: a caller written for the CPU reference
+            # (rnnt/stream.py:38-44 builds the transform and never moves it) only has to hand over device tensors
+            self.to(x.device)
         require_cuda(x, self.fb)
         if x.dim() != 2 or x.dtype != torch.float32 or x.stride(1) != 1:
             raise ValueError("waveform must be a float32 [B, N] tensor with unit sample stride")
