@@ -68,29 +68,6 @@ STREAM_STEP_MAX_ROWS = int(os.environ.get("EDGEDICT_STREAM_STEP_MAX_ROWS", "16")
 # inputs shorter than this many frames use the per-layer path even in bf16 (see Encoder.forward)
 STACK_MIN_FRAMES = int(os.environ.get("EDGEDICT_STACK_MIN_FRAMES", "24"))
 
-# Joint network + loss backward in TIME WINDOWS, last frames first (models._JointLossWinFn): the encoder's BPTT starts
-# when the last window's gradient exists and the earlier windows run on the auxiliary stream under the BPTT's ramp
-# (where only the top layers are runnable and most of the chip idles).  Comma-separated fractions of the encoder
-# frames, counted from the END, at which a window is cut (rounded down to a multiple of the stack's chunk);
-# "" or "0" = one pass (models._JointLossFn).
-JOINT_BWD_WINDOWS = os.environ.get("EDGEDICT_JOINT_WINDOWS", "0.12,0.4,0.7")
-# ... only for lattices of at least this many encoder frames
-JOINT_BWD_WINDOWS_MIN_FRAMES = int(os.environ.get("EDGEDICT_JOINT_WINDOWS_MIN_FRAMES", "96"))
-
-
-def joint_window_bounds(T, chunk):
-    """Ascending frame boundaries [0, ..., T] of the joint backward's time windows for a lattice of T encoder frames."""
-    spec = JOINT_BWD_WINDOWS.strip()
-    if not spec or spec == "0" or T < JOINT_BWD_WINDOWS_MIN_FRAMES:
-        return [0, T]
-    cuts = set()
-    for f in spec.split(","):
-        t = int(T * (1.0 - float(f))) // chunk * chunk
-        if 0 < t < T:
-            cuts.add(t)
-    return [0] + sorted(cuts) + [T]
-
-
 _state = {"dtype": _parse(os.environ.get("EDGEDICT_DTYPE", "fp32")), "epoch": 0}
 
 

@@ -167,24 +167,20 @@ __global__ __launch_bounds__(256) void joint_hidden_fwd(const T* __restrict__ E1
                                                         T* __restrict__ hid, int B, int Tn, int U1,
                                                         int J, const int32_t* __restrict__ act_lens,
                                                         const int32_t* __restrict__ label_lens,
-                                                        const long long* __restrict__ pk_off, int t_lo, int t_hi) {
+                                                        const long long* __restrict__ pk_off) {
     constexpr int VEC = ElemIO<T>::VEC;
     const int chunks = J / VEC;  // J % VEC == 0 checked on the host
     const int ulanes = max(1, 256 / chunks);          // u values handled side by side
     const int c = threadIdx.x % chunks, ul = threadIdx.x / chunks;
     if (ul >= ulanes) return;
-    // frames [t_lo, t_hi) (a time window of a window-major packed lattice: pk_off[b] = row of cell (b, t_lo, 0); the
-    // whole lattice is [0, Tn))
-    const int nt = t_hi - t_lo;
-    for (int i = blockIdx.x; i < B * nt; i += gridDim.x) {
-        const int b = i / nt, t = t_lo + (i - b * nt);
-        const int bt = b * Tn + t;
+    for (int bt = blockIdx.x; bt < B * Tn; bt += gridDim.x) {
+        const int b = bt / Tn, t = bt - b * Tn;
         int Ub = U1 - 1;
         long long row0 = (long long)bt * U1;       // dense: row = (b*T + t)*U1 + u
         if (pk_off) {   // packed lattice: only cells inside the utterance's (T_b, U_b + 1) box exist
             Ub = label_lens[b];
             if (t >= act_lens[b]) continue;
-            row0 = pk_off[b] + (long long)(t - t_lo) * (Ub + 1);
+            row0 = pk_off[b] + (long long)t * (Ub + 1);
         }
         float e[VEC];
         ElemIO<T>::load_vec(E1 + (long long)bt * J + c * VEC, e);
@@ -232,22 +228,18 @@ __global__ __launch_bounds__(256) void joint_hidden_bwd(const T* __restrict__ dh
                                                         int U1, int J, int t_per_block,
                                                         const int32_t* __restrict__ act_lens,
                                                         const int32_t* __restrict__ label_lens,
-                                                        const long long* __restrict__ pk_off, int t_lo, int t_hi,
-                                                        bf16_t* __restrict__ dE1c_tm) {
+                                                        const long long* __restrict__ pk_off) {
     __shared__ float4 red[2][JB_NU][2][64];   // lane-wise hand-off of partial label sums (36 KB)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int jv = lane & 7, ug = lane >> 3;
     const int j0 = blockIdx.x * 64 + jv * 8;
     const int b = blockIdx.y;
-    // frames [t_lo, t_hi) (a time window of a window-major packed lattice, pk_off[b] = row of cell (b, t_lo, 0); the
-    // whole lattice is [0, Tn)); dE1c_tm (optional): the same dE1 rows once more, bf16, TIME-major [Tn, B, J] - a window's
-    // rows are then one contiguous GEMM operand for the products that follow it on the critical path
-    const int t0 = t_lo + blockIdx.z * t_per_block, t1 = min(t_hi, t0 + t_per_block);
+    const int t0 = blockIdx.z * t_per_block, t1 = min(Tn, t0 + t_per_block);
     const bool jlive = j0 < J;   // J % 8 == 0 checked on the host
-    // packed lattice: utterance b owns rows pk_off[b] + (t - t_lo)*(U_b+1) + u, t < T_b, u <= U_b
+    // packed lattice: utterance b owns rows pk_off[b] + t*(U_b+1) + u, t < T_b, u <= U_b
     const int Tb = pk_off ? act_lens[b] : Tn;
     const int Ulim = pk_off ? label_lens[b] + 1 : U1;
-    const long long rbase = (pk_off ? pk_off[b] : (long long)b * Tn * U1) - (long long)t_lo * Ulim;
+    const long long rbase = pk_off ? pk_off[b] : (long long)b * Tn * U1;
     for (int uc = 0; uc < U1; uc += JB_UCHUNK) {
         float usum[JB_NU][8];
 #pragma unroll
@@ -285,18 +277,7 @@ __global__ __launch_bounds__(256) void joint_hidden_bwd(const T* __restrict__ dh
                     *reinterpret_cast<float4*>(de + 4) = make_float4(tsum[4], tsum[5], tsum[6], tsum[7]);
                 } else {
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        de[e] += tsum[e];
-                        tsum[e] = de[e];
-                    }
-                }
-                if (dE1c_tm && uc + JB_UCHUNK >= U1) {          // (the last label chunk holds the complete sums)
-                    uint4 pk;
-                    pk.x = (unsigned)f32_to_bf16(tsum[0]) | ((unsigned)f32_to_bf16(tsum[1]) << 16);
-                    pk.y = (unsigned)f32_to_bf16(tsum[2]) | ((unsigned)f32_to_bf16(tsum[3]) << 16);
-                    pk.z = (unsigned)f32_to_bf16(tsum[4]) | ((unsigned)f32_to_bf16(tsum[5]) << 16);
-                    pk.w = (unsigned)f32_to_bf16(tsum[6]) | ((unsigned)f32_to_bf16(tsum[7]) << 16);
-                    *reinterpret_cast<uint4*>(dE1c_tm + ((long long)t * B + b) * J + j0) = pk;
+                    for (int e = 0; e < 8; ++e) de[e] += tsum[e];
                 }
             }
         }
@@ -549,10 +530,7 @@ extern "C" int edgedict_spec_mask(float* x, int B, int T, int F, const int32_t* 
 
 static int joint_hidden_fwd_impl(int dtype, const void* E1, const void* D1, void* hid, int B, int T,
                                  int U1, int J, const int32_t* act_lens, const int32_t* label_lens,
-                                 const long long* pk_off, void* stream_, int t_lo = 0, int t_hi = -1) {
-    if (t_hi < 0) t_hi = T;
-    ED_CHECK_ARG(0 <= t_lo && t_lo < t_hi && t_hi <= T && (pk_off || (t_lo == 0 && t_hi == T)),
-                 "joint_hidden_fwd: bad frame window [%d, %d) of %d (windows need the packed lattice)", t_lo, t_hi, T);
+                                 const long long* pk_off, void* stream_) {
     ED_CHECK_ARG(dtype == ED_F32 || dtype == ED_BF16, "joint_hidden_fwd: bad dtype");
     ED_CHECK_ARG(B > 0 && T > 0 && U1 > 0 && J > 0, "joint_hidden_fwd: bad shape");
     const int vec = dtype == ED_F32 ? 4 : 8;
@@ -560,11 +538,11 @@ static int joint_hidden_fwd_impl(int dtype, const void* E1, const void* D1, void
     ED_CHECK_ARG(E1 && D1 && hid, "joint_hidden_fwd: null pointer");
     hipStream_t s = (hipStream_t)stream_;
     ED_CHECK_ARG(J / vec <= 256, "joint_hidden_fwd: joint size %d too large", J);
-    const int grid = ed_grid_for((long long)B * (t_hi - t_lo), 1, 256 * 64);
+    const int grid = ed_grid_for((long long)B * T, 1, 256 * 64);
     if (dtype == ED_F32)
-        hipLaunchKernelGGL(joint_hidden_fwd<float>, dim3(grid), dim3(256), 0, s, (const float*)E1, (const float*)D1, (float*)hid, B, T, U1, J, act_lens, label_lens, pk_off, t_lo, t_hi);
+        hipLaunchKernelGGL(joint_hidden_fwd<float>, dim3(grid), dim3(256), 0, s, (const float*)E1, (const float*)D1, (float*)hid, B, T, U1, J, act_lens, label_lens, pk_off);
     else
-        hipLaunchKernelGGL(joint_hidden_fwd<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)E1, (const bf16_t*)D1, (bf16_t*)hid, B, T, U1, J, act_lens, label_lens, pk_off, t_lo, t_hi);
+        hipLaunchKernelGGL(joint_hidden_fwd<bf16_t>, dim3(grid), dim3(256), 0, s, (const bf16_t*)E1, (const bf16_t*)D1, (bf16_t*)hid, B, T, U1, J, act_lens, label_lens, pk_off);
     ED_CHECK_LAUNCH("joint_hidden_fwd");
     return ED_OK;
 }
@@ -584,27 +562,18 @@ extern "C" int edgedict_joint_hidden_fwd_packed(int dtype, const void* E1, const
 
 static int joint_hidden_bwd_impl(int dtype, const void* dhid, const void* hid, float* dE1, float* dD1,
                                  int B, int T, int U1, int J, const int32_t* act_lens,
-                                 const int32_t* label_lens, const long long* pk_off, void* stream_,
-                                 int t_lo = 0, int t_hi = -1, void* dE1c_tm = nullptr, int zero_dD1 = 1) {
-    if (t_hi < 0) t_hi = T;
-    ED_CHECK_ARG(0 <= t_lo && t_lo < t_hi && t_hi <= T && (pk_off || (t_lo == 0 && t_hi == T)),
-                 "joint_hidden_bwd: bad frame window [%d, %d) of %d (windows need the packed lattice)", t_lo, t_hi, T);
+                                 const int32_t* label_lens, const long long* pk_off, void* stream_) {
     ED_CHECK_ARG(dtype == ED_F32 || dtype == ED_BF16, "joint_hidden_bwd: bad dtype");
     ED_CHECK_ARG(B > 0 && T > 0 && U1 > 0 && J > 0, "joint_hidden_bwd: bad shape");
     ED_CHECK_ARG(dhid && hid && dE1 && dD1, "joint_hidden_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream_;
-    // dD1 is accumulated with atomics across t slabs (and, window by window, across calls: the caller zeroes it once
-    // and passes zero_dD1 = 0): zero it first
-    if (zero_dD1) {
-        hipError_t e = hipMemsetAsync(dD1, 0, (size_t)B * U1 * J * sizeof(float), s);
-        if (e != hipSuccess) {
-            ed_set_error("joint_hidden_bwd: memset failed: %s", hipGetErrorString(e));
-            return ED_ERR_LAUNCH;
-        }
+    // dD1 is accumulated with atomics across t slabs: zero it first
+    hipError_t e = hipMemsetAsync(dD1, 0, (size_t)B * U1 * J * sizeof(float), s);
+    if (e != hipSuccess) {
+        ed_set_error("joint_hidden_bwd: memset failed: %s", hipGetErrorString(e));
+        return ED_ERR_LAUNCH;
     }
     ED_CHECK_ARG(J % 8 == 0, "joint_hidden_bwd: joint size %d must be a multiple of 8", J);
-    const int T_all = T;
-    T = t_hi - t_lo;            // the slab partition below is over the window's frames
     const int jblocks = (J + 63) / 64;
     static const int wg_target = [] { const char* e = getenv("EDGEDICT_JHB_WGS"); return e && atoi(e) > 0 ? atoi(e) : 1280; }();
     // t slabs per (utterance, 64-column block): every slab ends with U1 x 64 atomics into dD1, so more workgroups are
@@ -616,9 +585,9 @@ static int joint_hidden_bwd_impl(int dtype, const void* dhid, const void* hid, f
     tslabs = (T + tpb - 1) / tpb;
     dim3 grid(jblocks, B, tslabs);
     if (dtype == ED_F32)
-        hipLaunchKernelGGL(joint_hidden_bwd<float>, grid, dim3(256), 0, s, (const float*)dhid, (const float*)hid, dE1, dD1, B, T_all, U1, J, tpb, act_lens, label_lens, pk_off, t_lo, t_hi, (bf16_t*)dE1c_tm);
+        hipLaunchKernelGGL(joint_hidden_bwd<float>, grid, dim3(256), 0, s, (const float*)dhid, (const float*)hid, dE1, dD1, B, T, U1, J, tpb, act_lens, label_lens, pk_off);
     else
-        hipLaunchKernelGGL(joint_hidden_bwd<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dhid, (const bf16_t*)hid, dE1, dD1, B, T_all, U1, J, tpb, act_lens, label_lens, pk_off, t_lo, t_hi, (bf16_t*)dE1c_tm);
+        hipLaunchKernelGGL(joint_hidden_bwd<bf16_t>, grid, dim3(256), 0, s, (const bf16_t*)dhid, (const bf16_t*)hid, dE1, dD1, B, T, U1, J, tpb, act_lens, label_lens, pk_off);
     ED_CHECK_LAUNCH("joint_hidden_bwd");
     return ED_OK;
 }
@@ -635,29 +604,6 @@ extern "C" int edgedict_joint_hidden_bwd_packed(int dtype, const void* dhid, con
                                                 int J, void* stream_) {
     ED_CHECK_ARG(act_lens && label_lens && row_offsets, "joint_hidden_bwd_packed: null lengths/offsets");
     return joint_hidden_bwd_impl(dtype, dhid, hid, dE1, dD1, B, T, U1, J, act_lens, label_lens, row_offsets, stream_);
-}
-
-// One time window of a WINDOW-MAJOR packed lattice (frames [t_lo, t_hi) of every utterance; window_offsets[b] = packed row
-// of cell (b, t_lo, 0) in the full hid / dhid matrices).  Same kernels, same per-cell arithmetic as the whole-lattice
-// entry points (which are the window [0, T)).
-extern "C" int edgedict_joint_hidden_fwd_packed_win(int dtype, const void* E1, const void* D1, void* hid,
-                                                    const int32_t* act_lens, const int32_t* label_lens,
-                                                    const long long* window_offsets, int B, int T, int U1, int J,
-                                                    int t_lo, int t_hi, void* stream_) {
-    ED_CHECK_ARG(act_lens && label_lens && window_offsets, "joint_hidden_fwd_packed_win: null lengths/offsets");
-    return joint_hidden_fwd_impl(dtype, E1, D1, hid, B, T, U1, J, act_lens, label_lens, window_offsets, stream_, t_lo, t_hi);
-}
-// ... backward: dE1 rows [b, t_lo..t_hi) are written (f32 [B, T, J]) and, when dE1c_tm is given, once more as bf16 in
-// TIME-major order ([T, B, J]: the window is then one contiguous operand); dD1 is ACCUMULATED (zero_dD1 = 0: the caller
-// zeroed it before the first window)
-extern "C" int edgedict_joint_hidden_bwd_packed_win(int dtype, const void* dhid, const void* hid, float* dE1,
-                                                    float* dD1, void* dE1c_tm, const int32_t* act_lens,
-                                                    const int32_t* label_lens, const long long* window_offsets,
-                                                    int B, int T, int U1, int J, int t_lo, int t_hi, int zero_dD1,
-                                                    void* stream_) {
-    ED_CHECK_ARG(act_lens && label_lens && window_offsets, "joint_hidden_bwd_packed_win: null lengths/offsets");
-    return joint_hidden_bwd_impl(dtype, dhid, hid, dE1, dD1, B, T, U1, J, act_lens, label_lens, window_offsets, stream_,
-                                 t_lo, t_hi, dE1c_tm, zero_dD1);
 }
 
 extern "C" int edgedict_adam_step_guarded(float* p, const float* g, float* m, float* v, long long n,

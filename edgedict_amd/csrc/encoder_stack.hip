@@ -1211,29 +1211,9 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     {
         const edgedict_stack_layer_t& y = d->layers[L - 1];
         hipStream_t S = st.S[L - 1];
-        // dout window by window (edgedict_stack_desc_t.n_dout_windows): the side stream waits for a window's event in
-        // front of the first chunk that reads one of its frames; chunks AND windows are walked last frames first
-        const long long do_st = d->dout_t_stride ? d->dout_t_stride : (long long)H;
-        const long long do_sb = d->dout_b_stride ? d->dout_b_stride : (long long)T_out * H;
-        int waited_lo = d->n_dout_windows;      // windows [waited_lo, n) have been waited for
-        if (d->n_dout_windows > 0) {
-            ED_CHECK_ARG(d->dout_window_t0 && d->dout_window_events && d->dout_window_t0[0] == 0 &&
-                             d->dout_window_t0[d->n_dout_windows] == T_out,
-                         "encoder_stack: dout windows must cover output frames [0, %d)", T_out);
-            for (int w = 0; w < d->n_dout_windows; ++w)
-                ED_CHECK_ARG(d->dout_window_t0[w] < d->dout_window_t0[w + 1], "encoder_stack: dout window %d is empty", w);
-        }
         for (int k = g[L - 1].nchunks - 1; k >= 0; --k) {
             const int t0 = k * g[L - 1].cf, t1 = min(y.T, t0 + g[L - 1].cf);
-            if (d->n_dout_windows > 0 && !g_trace) {
-                const int o0 = t0 / max(1, y.reduce);               // lowest output frame this chunk reads
-                while (waited_lo > 0 && d->dout_window_t0[waited_lo] > o0) {
-                    --waited_lo;
-                    if (d->dout_window_events[waited_lo])
-                        ED_CHECK_HIP(hipStreamWaitEvent(S, (hipEvent_t)d->dout_window_events[waited_lo], 0));
-                }
-            }
-            ED_DEV(ed_stack_ln_bwd(bptr(d->dout), do_st, do_sb, bptr(y.Yx) + BH,
+            ED_DEV(ed_stack_ln_bwd(bptr(d->dout), H, (long long)T_out * H, bptr(y.Yx) + BH,
                                    y.residual ? bptr(y.X) : nullptr, y.ln_gamma, y.mean, y.rstd, bptr(y.dZ),
                                    (float*)(ws + wl.lnpart[L - 1]) + (size_t)k * LNB_GRID * 2 * H, LNB_GRID, B, H,
                                    t0, t1, y.reduce, S));

@@ -112,9 +112,7 @@ __global__ __launch_bounds__(256) void rnnt_lse_from_parts(
     const int32_t* __restrict__ labels, const int32_t* __restrict__ act_lens,
     const int32_t* __restrict__ label_lens, int Tm, int U1, int V, int blank,
     float* __restrict__ denom, float* __restrict__ lpb, float* __restrict__ lpl,
-    const long long* __restrict__ pk_off, int t_lo, int t_hi) {
-    // frames [t_lo, t_hi) only (a time window of the lattice; the whole lattice is [0, Tm)): pk_off[b] is then the packed
-    // row of cell (b, t_lo, 0) and the utterance's rows of the window follow it contiguously, t-major
+    const long long* __restrict__ pk_off) {
     // ONE LANE per lattice row (no cross-lane reduction, the three outputs of consecutive rows leave as coalesced
     // stores), but the row's `slots` pairs (8 * slots contiguous bytes) reach the lane through LDS: a wave copies the
     // pairs of its next 64 (32) rows - one contiguous block of the packed lattice - with coalesced 16-byte loads and each
@@ -127,7 +125,7 @@ __global__ __launch_bounds__(256) void rnnt_lse_from_parts(
     const int b = blockIdx.y;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int Tb = max(0, min(act_lens[b], Tm)), Ub = max(0, min(label_lens[b], U1 - 1));   // as rnnt_alpha_beta
-    const int Wb = Ub + 1, nvalid = max(0, min(Tb, t_hi) - t_lo) * Wb;
+    const int Wb = Ub + 1, nvalid = Tb * Wb;
     const int q4 = slots >> 1;                             // 16-byte pieces per row (slots even on this path)
     const int RP = (slots & 1) ? 0 : (q4 <= 16 ? 64 : (q4 <= 33 ? 32 : 0));   // rows per wave and pass (0: direct loads)
     const int stride = q4 + 1;
@@ -148,7 +146,7 @@ __global__ __launch_bounds__(256) void rnnt_lse_from_parts(
         }
         if (lane >= nrows) continue;
         const int r = r0 + lane;
-        const int tw = r / Wb, u = r - tw * Wb, t = t_lo + tw;
+        const int t = r / Wb, u = r - t * Wb;
         const long long row = ((long long)b * Tm + t) * U1 + u;
         const long long arow = arow0 + lane;
         float m = -INFINITY, sm = 0.f;
@@ -343,7 +341,7 @@ __global__ __launch_bounds__(256, ED_GRAD_OCC) void rnnt_grad(
     int U1, int V, int blank, const float* __restrict__ denom, const double* __restrict__ alphas,
     const double* __restrict__ betas, const double* __restrict__ ll, float scale_host,
     const float* __restrict__ scale_dev, int scale_stride, int vec_ok,
-    const long long* __restrict__ pk_off, int b0, int t_lo, int t_hi) {
+    const long long* __restrict__ pk_off, int b0) {
     constexpr int VEC = ElemIO<T>::VEC;
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -352,12 +350,9 @@ __global__ __launch_bounds__(256, ED_GRAD_OCC) void rnnt_grad(
     const int b = b0 + blockIdx.y;      // utterances [b0, b0 + gridDim.y) of the batch
     const int Tb = min(act_lens[b], Tm), Ub = min(label_lens[b], U1 - 1);
     const float scale = scale_host * (scale_dev ? scale_dev[(long long)b * scale_stride] : 1.f);
-    // packed: frames [t_lo, t_hi) of the utterance's box (pk_off[b] = packed row of cell (b, t_lo, 0); the whole box is
-    // [0, Tm)); dense: always the whole slab
-    const int Wb = pk_off ? Ub + 1 : U1, ncells = pk_off ? max(0, min(Tb, t_hi) - t_lo) * Wb : Tm * U1;
-    const int tbase = pk_off ? t_lo : 0;
+    const int Wb = pk_off ? Ub + 1 : U1, ncells = pk_off ? Tb * Wb : Tm * U1;
     for (int r = blockIdx.x * 4 + wave; r < ncells; r += gridDim.x * 4) {
-        const int tw = r / Wb, u = r - tw * Wb, t = tbase + tw;
+        const int t = r / Wb, u = r - t * Wb;
         const long long row = ((long long)b * Tm + t) * U1 + u;
         const bool inside = (t < Tb && u <= Ub);
         const long long arow = pk_off ? pk_off[b] + r : row;
@@ -465,8 +460,7 @@ static int loss_forward(const void* acts, int acts_dtype, const int32_t* labels,
                         const int32_t* act_lens, const int32_t* label_lens, int B, int T, int U1,
                         int V, int blank, float* costs, float* reduced, float reduce_scale,
                         void* workspace, const long long* pk_off, void* stream_,
-                        const float* lse_parts = nullptr, int lse_slots = 0,
-                        const int* win_t0 = nullptr, int n_win = 0) {
+                        const float* lse_parts = nullptr, int lse_slots = 0) {
     if (int rc = check_common(B, T, U1, V, blank, acts_dtype)) return rc;
     ED_CHECK_ARG(acts && (labels || U1 == 1) && act_lens && label_lens && costs && workspace,
                  "rnnt_loss_forward: null pointer argument");
@@ -488,23 +482,10 @@ static int loss_forward(const void* acts, int acts_dtype, const int32_t* labels,
         ED_CHECK_ARG(((uintptr_t)lse_parts & 15) == 0, "rnnt_loss_forward: lse_parts must be 16-byte aligned");
         ED_CHECK_ARG(acts_dtype == ED_BF16 && pk_off && lse_slots > 0,
                      "rnnt_loss_forward: log-sum-exp partials need bf16 logits on the packed lattice");
-        if (n_win > 0) {
-            // WINDOW-MAJOR packed lattice: pk_off is [n_win][B], window w holds frames [win_t0[w], win_t0[w + 1])
-            ED_CHECK_ARG(win_t0[0] == 0 && win_t0[n_win] == T, "rnnt_loss_forward: the windows must cover [0, %d)", T);
-            for (int w = 0; w < n_win; ++w) {
-                const int t_lo = win_t0[w], t_hi = win_t0[w + 1];
-                ED_CHECK_ARG(0 <= t_lo && t_lo < t_hi && t_hi <= T, "rnnt_loss_forward: bad window [%d, %d) of %d frames", t_lo, t_hi, T);
-                const dim3 gridw(ed_grid_for((long long)(t_hi - t_lo) * U1, 256, max(1, 256 * 16 / B)), B);
-                hipLaunchKernelGGL(rnnt_lse_from_parts, gridw, dim3(256), 0, stream, (const bf16_t*)acts,
-                                   (const float2*)lse_parts, lse_slots, labels, act_lens, label_lens, T, U1, V,
-                                   blank, denom, lpb, lpl, pk_off + (size_t)w * B, t_lo, t_hi);
-            }
-        } else {
-            const dim3 gridp(ed_grid_for((long long)T * U1, 256, max(1, 256 * 16 / B)), B);
-            hipLaunchKernelGGL(rnnt_lse_from_parts, gridp, dim3(256), 0, stream, (const bf16_t*)acts,
-                               (const float2*)lse_parts, lse_slots, labels, act_lens, label_lens, T, U1, V,
-                               blank, denom, lpb, lpl, pk_off, 0, T);
-        }
+        const dim3 gridp(ed_grid_for((long long)T * U1, 256, max(1, 256 * 16 / B)), B);
+        hipLaunchKernelGGL(rnnt_lse_from_parts, gridp, dim3(256), 0, stream, (const bf16_t*)acts,
+                           (const float2*)lse_parts, lse_slots, labels, act_lens, label_lens, T, U1, V,
+                           blank, denom, lpb, lpl, pk_off);
     } else if (acts_dtype == ED_F32)
         hipLaunchKernelGGL(rnnt_lse_gather<float>, grid1, dim3(256), 0, stream,
                            (const float*)acts, labels, act_lens, label_lens, B, T, U1, V, blank,
@@ -568,26 +549,11 @@ extern "C" int edgedict_rnnt_loss_forward_packed_parts(const void* acts, const i
                         reduced, reduce_scale, workspace, row_offsets, stream_, lse_parts, lse_slots);
 }
 
-extern "C" int edgedict_rnnt_loss_forward_packed_parts_win(const void* acts, const int32_t* labels,
-                                                           const int32_t* act_lens, const int32_t* label_lens,
-                                                           const long long* win_offsets, const int* win_t0,
-                                                           int n_win, int B, int T, int U1, int V, int blank,
-                                                           float* costs, float* reduced, float reduce_scale,
-                                                           void* workspace, const float* lse_parts, int lse_slots,
-                                                           void* stream_) {
-    ED_CHECK_ARG(win_offsets && win_t0 && lse_parts && n_win >= 1 && n_win <= 64,
-                 "rnnt_loss_forward_packed_parts_win: bad window arguments");
-    ED_CHECK_ARG(lse_slots == (V + 63) / 64, "rnnt_loss_forward_packed_parts_win: lse_slots must be ceil(V / 64)");
-    return loss_forward(acts, ED_BF16, labels, act_lens, label_lens, B, T, U1, V, blank, costs,
-                        reduced, reduce_scale, workspace, win_offsets, stream_, lse_parts, lse_slots, win_t0, n_win);
-}
-
 static int loss_backward(const void* acts, int acts_dtype, void* grads, const int32_t* labels,
                          const int32_t* act_lens, const int32_t* label_lens, int B, int T, int U1,
                          int V, int blank, const void* workspace, float grad_scale_host,
                          const float* grad_scale_dev, int grad_scale_stride,
-                         const long long* pk_off, void* stream_, int b0 = 0, int nb = -1,
-                         int t_lo = 0, int t_hi = -1) {
+                         const long long* pk_off, void* stream_, int b0 = 0, int nb = -1) {
     if (int rc = check_common(B, T, U1, V, blank, acts_dtype)) return rc;
     if (nb < 0) nb = B - b0;
     ED_CHECK_ARG(b0 >= 0 && nb >= 0 && b0 + nb <= B, "rnnt_loss_backward: utterance range [%d, %d) outside the batch of %d", b0, b0 + nb, B);
@@ -604,20 +570,17 @@ static int loss_backward(const void* acts, int acts_dtype, void* grads, const in
     const size_t esz = acts_dtype == ED_F32 ? 4 : 2;
     const int vec_ok = ((V * esz) % 16 == 0) && (((uintptr_t)acts & 15) == 0) &&
                        (((uintptr_t)grads & 15) == 0);
-    if (t_hi < 0) t_hi = T;
-    ED_CHECK_ARG(0 <= t_lo && t_lo < t_hi && t_hi <= T && (pk_off || (t_lo == 0 && t_hi == T)),
-                 "rnnt_loss_backward: bad frame window [%d, %d) of %d (windows need the packed lattice)", t_lo, t_hi, T);
-    const dim3 grid(ed_grid_for((long long)(t_hi - t_lo) * U1, 4, max(1, 256 * 16 / B)), nb);
+    const dim3 grid(ed_grid_for((long long)T * U1, 4, max(1, 256 * 16 / B)), nb);
     if (acts_dtype == ED_F32)
         hipLaunchKernelGGL(rnnt_grad<float>, grid, dim3(256), 0, stream, (const float*)acts,
                            (float*)grads, labels, act_lens, label_lens, B, T, U1, V, blank, denom,
                            alphas, betas, ll, grad_scale_host, grad_scale_dev, grad_scale_stride,
-                           vec_ok, pk_off, b0, t_lo, t_hi);
+                           vec_ok, pk_off, b0);
     else
         hipLaunchKernelGGL(rnnt_grad<bf16_t>, grid, dim3(256), 0, stream,
                            (const bf16_t*)acts, (bf16_t*)grads, labels, act_lens, label_lens, B, T,
                            U1, V, blank, denom, alphas, betas, ll, grad_scale_host, grad_scale_dev,
-                           grad_scale_stride, vec_ok, pk_off, b0, t_lo, t_hi);
+                           grad_scale_stride, vec_ok, pk_off, b0);
     ED_CHECK_LAUNCH("rnnt_grad");
     return ED_OK;
 }
@@ -656,20 +619,4 @@ extern "C" int edgedict_rnnt_loss_backward_packed_range(const void* acts, int ac
     return loss_backward(acts, acts_dtype, grads, labels, act_lens, label_lens, B, T, U1, V, blank,
                          workspace, grad_scale_host, grad_scale_dev, grad_scale_stride, row_offsets,
                          stream_, b0, nb);
-}
-
-// The gradient of ONE time window of a window-major packed lattice: frames [t_lo, t_hi) of every utterance,
-// `window_offsets[b]` = packed row of cell (b, t_lo, 0).  Same kernel and per-cell arithmetic as the one-pass entry
-// points; lets the host run the joint network's backward pass window by window, last frames first, so that the
-// encoder's BPTT starts when the FIRST window's gradient exists (models._JointLossWinFn).
-extern "C" int edgedict_rnnt_loss_backward_packed_win(const void* acts, int acts_dtype, void* grads,
-                                                      const int32_t* labels, const int32_t* act_lens,
-                                                      const int32_t* label_lens, const long long* window_offsets,
-                                                      int B, int T, int U1, int V, int blank, const void* workspace,
-                                                      float grad_scale_host, const float* grad_scale_dev,
-                                                      int grad_scale_stride, int t_lo, int t_hi, void* stream_) {
-    ED_CHECK_ARG(window_offsets, "rnnt_loss_backward_packed_win: null window_offsets");
-    return loss_backward(acts, acts_dtype, grads, labels, act_lens, label_lens, B, T, U1, V, blank,
-                         workspace, grad_scale_host, grad_scale_dev, grad_scale_stride, window_offsets,
-                         stream_, 0, -1, t_lo, t_hi);
 }

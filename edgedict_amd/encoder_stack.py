@@ -40,10 +40,7 @@ class StackDesc(ctypes.Structure):
                 ("in_gamma", _fp), ("in_beta", _fp), ("in_mean", _fp), ("in_rstd", _fp),
                 ("h0", _fp), ("c0", _fp), ("out", _vp), ("dout", _vp),
                 ("d_in_gamma", _fp), ("d_in_beta", _fp), ("ws", _vp), ("ws_bytes", ctypes.c_size_t),
-                ("grads_final", _vp), ("grads_final_user", _vp),
-                ("dout_t_stride", ctypes.c_longlong), ("dout_b_stride", ctypes.c_longlong),
-                ("n_dout_windows", ctypes.c_int), ("dout_window_t0", ctypes.POINTER(ctypes.c_int)),
-                ("dout_window_events", ctypes.POINTER(ctypes.c_void_p))]
+                ("grads_final", _vp), ("grads_final_user", _vp)]
 
 
 GRADS_FINAL_CB = ctypes.CFUNCTYPE(None, ctypes.c_int, ctypes.c_void_p)
@@ -68,18 +65,6 @@ BWD_SK = os.environ.get("EDGEDICT_STACK_BWD_SK_PACK", "1") != "0"
 
 def _p(t):
     return None if t is None else t.data_ptr()
-
-
-# Gradients of the stack's output that become valid WINDOW BY WINDOW (models._JointLossWinFn): data_ptr of the gradient
-# tensor -> (ascending frame boundaries [0..T'], one torch.cuda.Event or None per window).  The producer registers the
-# entry right before it returns the tensor to autograd; _Plan.backward pops it and passes the (already recorded) events
-# to the native scheduler (edgedict_stack_desc_t.dout_window_*).
-DOUT_WINDOWS = {}
-
-
-def register_dout_windows(dout, bounds, events):
-    DOUT_WINDOWS.clear()          # at most one backward pass in flight per process
-    DOUT_WINDOWS[dout.data_ptr()] = (list(bounds), list(events))
 
 
 def side_stream(device):
@@ -299,31 +284,7 @@ class _Plan:
             dig = zeros[2 * H * self.L:2 * H * self.L + self.I0]
             dib = zeros[2 * H * self.L + self.I0:]
             d.flags &= ~ACCUM_GRADS
-        win = DOUT_WINDOWS.pop(dout.data_ptr(), None)
-        T_out = dout.shape[1]
-        if dout.dim() == 3 and dout.stride() == (H, B * H, 1) and B > 1:
-            # a [B, T', H] VIEW of a time-major [T', B, H] gradient: read in place through the strides
-            d.dout_t_stride, d.dout_b_stride = B * H, H
-        else:
-            if win is not None:
-                raise RuntimeError("edgedict_amd: a windowed gradient must reach the encoder stack as the tensor it "
-                                   "was registered with")
-            dout = dout.contiguous()
-            d.dout_t_stride = d.dout_b_stride = 0
-        keep_win = None
-        if win is not None:
-            bounds, events = win
-            assert bounds[0] == 0 and bounds[-1] == T_out and len(events) == len(bounds) - 1
-            t0s = (ctypes.c_int * len(bounds))(*bounds)
-            evs = (ctypes.c_void_p * len(events))(*[None if e is None else e.cuda_event for e in events])
-            d.n_dout_windows = len(events)
-            d.dout_window_t0 = ctypes.cast(t0s, ctypes.POINTER(ctypes.c_int))
-            d.dout_window_events = ctypes.cast(evs, ctypes.POINTER(ctypes.c_void_p))
-            keep_win = (t0s, evs, events)
-        else:
-            d.n_dout_windows = 0
-            d.dout_window_t0 = None
-            d.dout_window_events = None
+        dout = dout.contiguous()
         d.dout, d.d_in_gamma, d.d_in_beta = _p(dout), _p(dig), _p(dib)
         # data parallelism: tell the gradient exchange when a layer's weight gradients are final on the
         # auxiliary stream, so its bucket leaves while the layers below are still in their BPTT
@@ -349,8 +310,6 @@ class _Plan:
         with ops.host_timed("stack_backward_call"):
             check(lib.edgedict_stack_backward(ctypes.byref(d), stream_ptr()), "stack_backward")
         d.grads_final = None
-        d.n_dout_windows, d.dout_window_t0, d.dout_window_events = 0, None, None
-        del keep_win
         if cb is not None and errors:
             raise errors[0]
         ops.mark("stack_bwd:exit")
@@ -389,7 +348,7 @@ class EncoderStackFn(torch.autograd.Function):
                                "by a previous backward (retain_graph is not supported)")
         ctx.plan = None
         if dout.dtype != BF16:
-            dout = dout.to(BF16)          # (never the case for a windowed gradient: _JointLossWinFn produces bf16)
+            dout = dout.to(BF16)
         with ops.timed("enc_stack_bwd_T%d_L%d" % (plan.T0, plan.L)):
             res = plan.backward(dout, ctx.params, ctx.in_norm)
         if res is None:        # accumulated in place

@@ -550,185 +550,6 @@ class _JointLossFn(torch.autograd.Function):
         return denc, ddec, dw1, db1, dw2, db2, None, None, None, None, None
 
 
-class _JointLossWinFn(torch.autograd.Function):
-    """Encoder output projection + joint network + RNN-T loss on a WINDOW-MAJOR packed lattice, backward pass in TIME
-    WINDOWS (rnnt/models.py:135 ``encoder.proj``, 169-179 ``Joint.forward``, 221,238 the loss call).
-
-    The BPTT of the encoder is a chain of dependent launches that starts at the LAST frame and whose first ~11 launches
-    carry only the top layers (the wavefront's ramp): most of the chip idles there, and before it the whole joint
-    backward pass (loss gradient -> dhid product -> tanh backward -> two small products: 2.9 ms of an E6D2 step) runs with
-    nothing beside it.  Here the lattice rows are ordered (window, utterance, frame, label) - ``config.joint_window_bounds``
-    cuts the encoder frames into a few windows - so that a time window is ONE contiguous row range of hid / logits /
-    their gradients, and the backward pass runs window by window, last frames first:
-
-      * the LAST window on the caller's stream: the encoder stack's backward call starts behind it;
-      * the earlier windows on the auxiliary stream, each followed by an event; the stack's top-layer LayerNorm backward
-        waits for a window's event in front of the first chunk that reads it (``edgedict_stack_desc_t.dout_window_*``);
-      * the gradient w.r.t. the STACK's output (the projection is folded in: its backward is two small products per
-        window) is written time-major, so a window is contiguous there too; the stack reads it through strides;
-      * everything that needs all windows - the prediction network's gradient (a sum over time), every weight
-        gradient - follows on the auxiliary stream.
-
-    Per-cell arithmetic is that of ``_JointLossFn``: the loss is bit-identical, the activation gradients are those of
-    the one-pass node up to the K-order of the products (tests/test_joint_windows_gpu.py)."""
-
-    @staticmethod
-    def forward(ctx, hstack, pw, pb, dec, w1, b1, w2, b2, labels, act_lens, label_lens, blank, cd, bounds):
-        import ctypes
-        from ._staging import to_device
-        B, T, H = hstack.shape
-        U1, P2 = dec.shape[1], dec.shape[2]
-        J, V, P = w1.shape[0], w2.shape[0], pw.shape[0]
-        dev = hstack.device
-        al = act_lens.to(torch.int64).cpu()
-        ll = label_lens.to(torch.int64).cpu()
-        if int(al.max()) != T or int(ll.max()) != U1 - 1 or int(al.min()) < 1 or int(ll.min()) < 0:
-            raise ValueError("Input length mismatch")     # wording of warprnnt_pytorch's checks
-        nw = len(bounds) - 1
-        lo = torch.tensor(bounds[:-1], dtype=torch.int64)[:, None]
-        hi = torch.tensor(bounds[1:], dtype=torch.int64)[:, None]
-        rows = (torch.minimum(al[None, :], hi) - lo).clamp_(min=0) * (ll[None, :] + 1)       # [nw, B]
-        flat = rows.reshape(-1)
-        off = torch.zeros(nw * B, dtype=torch.int64)
-        off[1:] = torch.cumsum(flat, 0)[:-1]
-        M = int(flat.sum())
-        wrow = [int(v) for v in off.view(nw, B)[:, 0]] + [M]                                    # first row of each window
-        off_d = to_device(off, dev).view(nw, B)
-        al_d = to_device(al.to(torch.int32), dev)
-        ll_d = to_device(ll.to(torch.int32), dev)
-        pwc = WEIGHTS.get(pw, cd)
-        w1c = WEIGHTS.get(w1, cd)
-        w2c = WEIGHTS.get(w2, cd)
-        hs2 = hstack.reshape(B * T, H)
-        dec2 = dec.reshape(B * U1, P2)
-        enc2 = ops.gemm(hs2, pwc, bias=pb.detach() if pb is not None else None)
-        E1 = ops.gemm(enc2, w1c[:, :P])
-        D1 = ops.gemm(dec2, w1c[:, P:], bias=b1.detach())
-        hid = torch.empty(M, J, dtype=cd, device=dev)
-        code = _lib.dtype_code(cd)
-        with ops.timed("joint_hidden_fwd"):
-            for w in range(nw):
-                _lib.call("joint_hidden_fwd_packed_win", code, E1, D1, hid, al_d, ll_d, off_d[w], B, T, U1, J,
-                          bounds[w], bounds[w + 1])
-        ops.LAST["joint_rows"] = M
-        lib = _lib.load()
-        ws = torch.empty(lib.edgedict_rnnt_workspace_bytes(B, T, U1), dtype=torch.uint8, device=dev)
-        costs = torch.empty(B, dtype=F32, device=dev)
-        reduced = torch.empty(1, dtype=F32, device=dev)
-        slots = (V + 63) // 64
-        parts = torch.empty(M, slots, 2, dtype=F32, device=dev)
-        logits = torch.empty(M, V, dtype=cd, device=dev)
-        with ops.timed("joint_logits_gemm"):
-            _lib.call("gemm_nt_lse", hid, ops._ll(J), w2c, ops._ll(J), logits, ops._ll(V), M, V, J,
-                      b2.detach(), parts)
-        t0s = (ctypes.c_int * (nw + 1))(*bounds)
-        with ops.timed("rnnt_loss_fwd"):
-            _lib.call("rnnt_loss_forward_packed_parts_win", logits, labels, al_d, ll_d, off_d, t0s, nw, B, T, U1, V,
-                      int(blank), costs, reduced, 1.0 / B, ws, parts, slots)
-        ops.LAST["joint_costs"] = costs
-        ops.LAST["joint_windows"] = list(bounds)
-        ctx.save_for_backward(hs2, enc2, dec2, pw, w1, w2, hid, logits, labels, al_d, ll_d, off_d, ws)
-        ctx.pb, ctx.b1, ctx.b2 = pb, b1, b2
-        ctx.cfg = (cd, B, T, U1, H, P, P2, J, V, M, int(blank), list(bounds), wrow)
-        return reduced
-
-    @staticmethod
-    def backward(ctx, gout):
-        ops.mark("joint_bwd:enter")
-        hs2, enc2, dec2, pw, w1, w2, hid, logits, labels, al_d, ll_d, off_d, ws = ctx.saved_tensors
-        cd, B, T, U1, H, P, P2, J, V, M, blank, bounds, wrow = ctx.cfg
-        pb, b1, b2 = ctx.pb, ctx.b1, ctx.b2
-        dev = logits.device
-        nw = len(bounds) - 1
-        code = _lib.dtype_code(cd)
-        main = torch.cuda.current_stream(dev)
-        aux = side.stream(dev)
-        gscale = gout.contiguous().float()
-        w1c = WEIGHTS.get(w1, cd)
-        w2t = WEIGHTS.get(w2, cd, transposed=True)
-        pwc = WEIGHTS.get(pw, cd)
-        wparams = [p for p in (pw, pb, w1, b1, w2, b2) if p is not None]
-        defer = config.DEFER_WEIGHT_GRADS and all(
-            p.grad is not None and p.grad.dtype == F32 and p.grad.is_contiguous() for p in wparams)
-        # every buffer is allocated on the caller's stream and handed to the auxiliary stream explicitly
-        dl = torch.empty_like(logits)
-        dhid = torch.empty(M, J, dtype=cd, device=dev)
-        dE1 = torch.empty(B, T, J, dtype=F32, device=dev)
-        dD1 = torch.zeros(B, U1, J, dtype=F32, device=dev)            # accumulated window by window (atomics)
-        dE1c = torch.empty(T, B, J, dtype=cd, device=dev)             # TIME-major: a window is a contiguous operand
-        denc = torch.empty(T * B, P, dtype=cd, device=dev)
-        dout = torch.empty(T, B, H, dtype=cd, device=dev)
-        dout2 = dout.view(T * B, H)
-        shared = (dl, dhid, dE1, dD1, dE1c, denc, dout, hs2, enc2, dec2, hid, logits, labels, al_d, ll_d, off_d, ws,
-                  gscale, w1c, w2t, pwc)
-
-        def window(w):
-            t0, t1 = bounds[w], bounds[w + 1]
-            r0, r1 = wrow[w], wrow[w + 1]
-            with ops.timed("rnnt_grad_win"):
-                _lib.call("rnnt_loss_backward_packed_win", logits, code, dl, labels, al_d, ll_d, off_d[w],
-                          B, T, U1, V, blank, ws, 1.0 / B, gscale, 0, t0, t1)
-            with ops.timed("joint_dhid_gemm_win"):
-                ops.gemm(dl[r0:r1], w2t, out=dhid[r0:r1])
-            with ops.timed("joint_hidden_bwd_win"):
-                _lib.call("joint_hidden_bwd_packed_win", code, dhid, hid, dE1, dD1, dE1c, al_d, ll_d, off_d[w],
-                          B, T, U1, J, t0, t1, 0)
-            a, b = t0 * B, t1 * B
-            ops.gemm(dE1c.view(T * B, J)[a:b], w1c[:, :P].t(), out=denc[a:b])
-            ops.gemm(denc[a:b], pwc.t(), out=dout2[a:b])
-
-        # ---- windows 0 .. nw-2 on the auxiliary stream (enqueued first: they start beside the last window)
-        events = [None] * nw
-        aux.wait_stream(main)
-        for t in shared:
-            t.record_stream(aux)
-        with torch.cuda.stream(aux):
-            for w in range(nw - 2, -1, -1):
-                window(w)
-                events[w] = torch.cuda.Event()
-                events[w].record(aux)
-        # ---- the LAST window on the caller's stream: the encoder stack's backward call is enqueued behind it
-        window(nw - 1)
-        dpw = dpb = dw1 = db1 = dw2 = db2 = None
-        dE1_2 = dE1.view(B * T, J)
-        if defer:
-            with side.deferred(dev, *shared):
-                # (the auxiliary stream now waits for the last window too: dD1 is complete behind this point)
-                dD1c = ops.cast(dD1, cd).view(B * U1, J)
-                ddec = ops.gemm(dD1c, w1c[:, P:].t()).view(B, U1, P2)
-                ops.gemm(dl.t(), hid.t(), out=w2.grad, accumulate=True, split_k=8, max_wg_per_cu=2)
-                ops.colsum(dl, out=b2.grad)
-                dE1b = ops.cast(dE1_2, cd)                             # batch-first rows, as enc2 / hs2 are
-                dencb = ops.gemm(dE1b, w1c[:, :P].t())
-                g1 = w1.grad
-                ops.gemm(dE1b.t(), enc2.t(), out=g1[:, :P], accumulate=True, split_k=ops.pick_split_k(J, P, B * T))
-                ops.gemm(dD1c.t(), dec2.t(), out=g1[:, P:], accumulate=True, split_k=ops.pick_split_k(J, P2, B * U1))
-                ops.colsum(dD1.view(B * U1, J), out=b1.grad)
-                ops.gemm(dencb.t(), hs2.t(), out=pw.grad, accumulate=True, split_k=ops.pick_split_k(P, H, B * T))
-                if pb is not None:
-                    ops.colsum(dencb, out=pb.grad)
-            _grads_ready(tuple(wparams), dev)
-        else:
-            main.wait_stream(aux)
-            dD1c = ops.cast(dD1, cd).view(B * U1, J)
-            ddec = ops.gemm(dD1c, w1c[:, P:].t()).view(B, U1, P2)
-            dw2 = ops.gemm(dl.t(), hid.t(), out_dtype=F32, split_k=ops.pick_split_k(V, J, M))
-            db2 = ops.colsum(dl)
-            dE1b = ops.cast(dE1_2, cd)
-            dencb = ops.gemm(dE1b, w1c[:, :P].t())
-            dw1 = torch.empty(J, P + P2, dtype=F32, device=dev)
-            ops.gemm(dE1b.t(), enc2.t(), out=dw1[:, :P], split_k=ops.pick_split_k(J, P, B * T))
-            ops.gemm(dD1c.t(), dec2.t(), out=dw1[:, P:], split_k=ops.pick_split_k(J, P2, B * U1))
-            db1 = ops.colsum(dD1.view(B * U1, J))
-            dpw = ops.gemm(dencb.t(), hs2.t(), out_dtype=F32, split_k=ops.pick_split_k(P, H, B * T))
-            dpb = ops.colsum(dencb) if pb is not None else None
-            events = [None] * nw              # everything is ordered by the caller's stream now
-        dstack = dout.transpose(0, 1)         # [B, T, H] view of the time-major gradient
-        encoder_stack.register_dout_windows(dstack, bounds, events)
-        ops.mark("joint_bwd:exit")
-        return dstack, dpw, dpb, ddec, dw1, db1, dw2, db2, None, None, None, None, None, None
-
-
 # ----------------------------------------------------------------------------------------
 # parameter containers with the reference's names, shapes and default initialisation
 class TimeReduction(nn.Module):
@@ -902,39 +723,28 @@ class Encoder(nn.Module):
         if has_proj:
             self.proj = _LinearParams(hidden_size, proj_size)
 
-    def _stack_applies(self, xs):
-        cd = getattr(self, "compute_dtype", None) or config.get_compute_dtype()
-        lstm = self.lstm
-        drop = getattr(lstm, "dropout", 0) > 0 and self.training    # per-layer path applies it
-        # short inputs (streaming chunks of a few frames) stay on the per-layer kernels: the
-        # wavefront needs ~5 lags of launches to fill, more than 6 x T per-layer steps for small T
-        return (isinstance(lstm, ResLayerNormLSTM) and xs.dim() == 3 and not drop
-                and xs.shape[1] >= config.STACK_MIN_FRAMES
-                and encoder_stack.supported(cd, lstm.hidden_size, xs.shape[2], len(lstm.lstms),
-                                            lstm.reductions))
-
-    def _stack(self, xs, hiddens=None):
-        """Input LayerNorm + all layers as one layer-pipelined native call per direction (bf16), WITHOUT the output
-        projection: ([B, T', H] bf16, (h, c))."""
-        lstm = self.lstm
-        h0 = c0 = None
-        if hiddens is not None:
-            h0 = _state(hiddens[0]).contiguous()
-            c0 = _state(hiddens[1]).contiguous()
-        params = []
-        for m, proj in zip(lstm.lstms, lstm.projs):
-            params += list(m.layer(0)) + [proj[0].weight, proj[0].bias]
-        xs, h, c = encoder_stack.EncoderStackFn.apply(
-            xs, self.norm.weight, self.norm.bias, h0, c0, tuple(lstm.reductions), None, *params)
-        return xs, (h, c)
-
     def forward(self, xs, hiddens=None):
         require_cuda(xs)
         cd = getattr(self, "compute_dtype", None) or config.get_compute_dtype()
         lstm = self.lstm
         drop = getattr(lstm, "dropout", 0) > 0 and self.training    # per-layer path applies it
-        if self._stack_applies(xs):
-            xs, hiddens = self._stack(xs, hiddens)
+        # short inputs (streaming chunks of a few frames) stay on the per-layer kernels: the
+        # wavefront needs ~5 lags of launches to fill, more than 6 x T per-layer steps for small T
+        if (isinstance(lstm, ResLayerNormLSTM) and xs.dim() == 3 and not drop
+                and xs.shape[1] >= config.STACK_MIN_FRAMES
+                and encoder_stack.supported(cd, lstm.hidden_size, xs.shape[2], len(lstm.lstms),
+                                            lstm.reductions)):
+            # bf16: input LayerNorm + all layers as one layer-pipelined native call per direction
+            h0 = c0 = None
+            if hiddens is not None:
+                h0 = _state(hiddens[0]).contiguous()
+                c0 = _state(hiddens[1]).contiguous()
+            params = []
+            for m, proj in zip(lstm.lstms, lstm.projs):
+                params += list(m.layer(0)) + [proj[0].weight, proj[0].bias]
+            xs, h, c = encoder_stack.EncoderStackFn.apply(
+                xs, self.norm.weight, self.norm.bias, h0, c0, tuple(lstm.reductions), None, *params)
+            hiddens = (h, c)
         elif (isinstance(lstm, ResLayerNormLSTM) and xs.dim() == 3 and cd == torch.bfloat16 and not drop
               and not torch.is_grad_enabled() and 0 < xs.shape[1] < config.STACK_MIN_FRAMES
               and xs.shape[0] <= (config.STREAM_STEP_MAX_ROWS_SHORT if xs.shape[1] <= 2 else config.STREAM_STEP_MAX_ROWS)
@@ -1105,29 +915,6 @@ class Transducer(nn.Module):
             # a host-side label batch (seq_collate output with only xs uploaded): one upload here,
             # the prediction network and the loss kernels both read the device copy
             ys = ys.to(xs.device, non_blocking=True)
-        # the joint's backward pass in time windows (_JointLossWinFn): the encoder hands over its STACK's output, the
-        # projection moves into the joint node
-        enc = self.encoder
-        cd = self.compute_dtype
-        wbounds = None
-        if (self.output_loss and config.PACKED_LATTICE and config.FUSED_LSE and config.DECODER_ON_AUX_STREAM
-                and xs.is_cuda and not xlen.is_cuda and not ylen.is_cuda and torch.is_grad_enabled()
-                and cd == torch.bfloat16 and getattr(enc, "has_proj", False) and enc._stack_applies(xs)
-                and not config.DECODER_ENQUEUE_FIRST):
-            T_out = xs.shape[1]
-            for r in enc.lstm.reductions:
-                T_out = (T_out + r - 1) // r
-            l1, l2 = self.joint.joint[0], self.joint.joint[2]
-            J, V = l1.weight.shape[0], l2.weight.shape[0]
-            if J >= 128 and J % 64 == 0 and V % 8 == 0:
-                wbounds = config.joint_window_bounds(T_out, encoder_stack.CHUNK)
-                if len(wbounds) < 3:
-                    wbounds = None
-
-        def run_encoder():
-            if wbounds is not None:
-                return enc._stack(xs)[0]
-            return enc(xs)[0]
         if config.DECODER_ON_AUX_STREAM and xs.is_cuda:
             # the prediction network does not depend on the encoder: it runs on the auxiliary
             # stream under the encoder's recurrences.  Autograd replays each node on its forward
@@ -1142,7 +929,7 @@ class Transducer(nn.Module):
                     h_dec, _ = self.decoder(ys)
                 h_enc, _ = self.encoder(xs)
             else:
-                h_enc = run_encoder()                # enqueued first: it is the long pole
+                h_enc, _ = self.encoder(xs)          # enqueued first: it is the long pole
                 aux.wait_event(ready)
                 ys.record_stream(aux)
                 with torch.cuda.stream(aux):
@@ -1153,17 +940,6 @@ class Transducer(nn.Module):
             h_enc, _ = self.encoder(xs)
             h_dec, _ = self.decoder(ys)
         ops.mark("joint:enter")
-        if wbounds is not None:
-            l1, l2 = self.joint.joint[0], self.joint.joint[2]
-            T_out = h_enc.shape[1]
-            scale = (xlen.max().float() / T_out).ceil()           # scale_length on the stack's frame count (= proj's)
-            act = (xlen / scale).ceil().int()
-            labels = ys.to(device=h_enc.device, dtype=torch.int32).contiguous()
-            loss = _JointLossWinFn.apply(_to_cd(h_enc, cd), enc.proj.weight, enc.proj.bias, _to_cd(h_dec, cd),
-                                         l1.weight, l1.bias, l2.weight, l2.bias, labels, act, ylen, self.blank, cd,
-                                         tuple(wbounds))
-            ops.mark("joint:exit")
-            return loss
         if (self.output_loss and config.PACKED_LATTICE and not xlen.is_cuda and not ylen.is_cuda
                 and h_enc.dim() == 3 and h_enc.is_cuda):
             # lengths on the host: joint + loss on the packed lattice (no padding rows anywhere)

@@ -107,21 +107,6 @@ int edgedict_rnnt_loss_backward_packed(const void* acts, int acts_dtype, void* g
 /* the same for utterances [b0, b0 + nb) of the batch only (all array arguments are still the whole batch's):
  * lets the host pipeline the gradient of one group of utterances (HBM-bound) against the joint's dhid product
  * of the previous group (matrix-pipe-bound) on a second stream. */
-/* WINDOW-MAJOR packed lattice (models._JointLossWinFn): the lattice rows are ordered (window, utterance, frame, label),
- * window w = encoder frames [win_t0[w], win_t0[w+1]); win_offsets is a DEVICE array [n_win][B] of the packed row of cell
- * (b, win_t0[w], 0), win_t0 a HOST array of n_win + 1 frame indices from 0 to T.  Per-cell arithmetic, alpha / beta and
- * the costs are those of edgedict_rnnt_loss_forward_packed_parts (only the order of the rows in memory differs). */
-int edgedict_rnnt_loss_forward_packed_parts_win(const void* acts, const int32_t* labels, const int32_t* act_lens,
-                                                const int32_t* label_lens, const long long* win_offsets,
-                                                const int* win_t0, int n_win, int B, int T, int U1, int V, int blank,
-                                                float* costs, float* reduced, float reduce_scale, void* workspace,
-                                                const float* lse_parts, int lse_slots, void* stream);
-/* ... and the gradient of ONE window (frames [t_lo, t_hi); window_offsets = that window's row of win_offsets) */
-int edgedict_rnnt_loss_backward_packed_win(const void* acts, int acts_dtype, void* grads, const int32_t* labels,
-                                           const int32_t* act_lens, const int32_t* label_lens,
-                                           const long long* window_offsets, int B, int T, int U1, int V, int blank,
-                                           const void* workspace, float grad_scale_host, const float* grad_scale_dev,
-                                           int grad_scale_stride, int t_lo, int t_hi, void* stream);
 int edgedict_rnnt_loss_backward_packed_range(const void* acts, int acts_dtype, void* grads,
                                              const int32_t* labels, const int32_t* act_lens,
                                              const int32_t* label_lens, const long long* row_offsets,
@@ -316,21 +301,6 @@ typedef struct edgedict_stack_desc {
        The callback must not call back into this library. */
     void (*grads_final)(int layer, void* user);
     void* grads_final_user;
-    /* backward, optional - dout handed over WINDOW BY WINDOW (all zero / NULL: dout is batch-first [B, T', H] and
-       complete on the caller's stream when the call is made).
-       dout_t_stride / dout_b_stride: element strides of dout between frames / utterances (both 0 = H and T'*H);
-       a time-major [T', B, H] gradient is (B*H, H).
-       n_dout_windows > 0: output frames [dout_window_t0[w], dout_window_t0[w+1]) of dout (host array of n + 1
-       ascending frame indices, 0 .. T') are valid once dout_window_events[w] (host array of hipEvent_t, each ALREADY
-       RECORDED on some stream of this device when the call is made; NULL = ordered by the caller's stream like
-       everything else) has completed.  The top layer's LayerNorm backward walks the frames last chunk first and waits
-       for a window's event in front of the first chunk that reads it - the BPTT starts as soon as the LAST window
-       exists, while the producer (the joint network's backward pass, models._JointLossWinFn) is still working on the
-       earlier frames (rnnt/models.py:169-179,131-136 backward). */
-    long long dout_t_stride, dout_b_stride;
-    int n_dout_windows;
-    const int* dout_window_t0;
-    void* const* dout_window_events;
 } edgedict_stack_desc_t;
 
 /* sizeof(edgedict_stack_layer_t) (which = 0) / sizeof(edgedict_stack_desc_t) (which = 1): lets a
@@ -446,17 +416,6 @@ int edgedict_joint_hidden_fwd_packed(int dtype, const void* E1, const void* D1, 
                                      const int32_t* act_lens, const int32_t* label_lens,
                                      const long long* row_offsets, int B, int T, int U1, int J,
                                      void* stream);
-/* One time window [t_lo, t_hi) of a window-major packed lattice (see edgedict_rnnt_loss_forward_packed_parts_win):
- * forward writes the window's hid rows; backward writes dE1[b, t_lo..t_hi) (f32 [B, T, J]) and - dE1c_tm non-NULL - the
- * same rows as bf16 in TIME-major order [T, B, J], and ACCUMULATES dD1 (zero_dD1 = 1 zeroes it first). */
-int edgedict_joint_hidden_fwd_packed_win(int dtype, const void* E1, const void* D1, void* hid,
-                                         const int32_t* act_lens, const int32_t* label_lens,
-                                         const long long* window_offsets, int B, int T, int U1, int J,
-                                         int t_lo, int t_hi, void* stream);
-int edgedict_joint_hidden_bwd_packed_win(int dtype, const void* dhid, const void* hid, float* dE1, float* dD1,
-                                         void* dE1c_tm, const int32_t* act_lens, const int32_t* label_lens,
-                                         const long long* window_offsets, int B, int T, int U1, int J,
-                                         int t_lo, int t_hi, int zero_dD1, void* stream);
 int edgedict_joint_hidden_bwd_packed(int dtype, const void* dhid, const void* hid, float* dE1,
                                      float* dD1, const int32_t* act_lens, const int32_t* label_lens,
                                      const long long* row_offsets, int B, int T, int U1, int J,

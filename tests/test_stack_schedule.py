@@ -209,21 +209,3 @@ def test_split_k_bptt_schedule_invariants_on_random_geometries(T0, reductions, c
         reductions = [1 if i > 1 else r for i, r in enumerate(reductions)]
     n, longest = _check_sk(T0, reductions, chunk, nsub)
     assert longest <= nsub
-
-
-def test_joint_window_bounds_are_chunk_aligned_cuts_from_the_end():
-    """config.joint_window_bounds: the time windows of the joint's backward pass (models._JointLossWinFn) are cut at
-    multiples of the stack's chunk - the top layer's LayerNorm backward walks whole chunks - counted from the end."""
-    from edgedict_amd import config
-    old = config.JOINT_BWD_WINDOWS
-    try:
-        config.JOINT_BWD_WINDOWS = "0.12,0.4,0.7"
-        assert config.joint_window_bounds(201, 16) == [0, 48, 112, 176, 201]
-        assert config.joint_window_bounds(126, 16) == [0, 32, 64, 96, 126]
-        assert config.joint_window_bounds(95, 16) == [0, 95]          # below JOINT_BWD_WINDOWS_MIN_FRAMES
-        config.JOINT_BWD_WINDOWS = ""
-        assert config.joint_window_bounds(201, 16) == [0, 201]
-        config.JOINT_BWD_WINDOWS = "0.5"
-        assert config.joint_window_bounds(201, 16) == [0, 96, 201]
-    finally:
-        config.JOINT_BWD_WINDOWS = old
