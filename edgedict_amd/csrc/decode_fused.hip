@@ -507,19 +507,13 @@ __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
-template <int NS>
-__global__ __launch_bounds__(256, (NS <= 4 ? 2 : 1)) void enc_lstm_tile(const bf16_t* __restrict__ x, long long ldx, int Kx,
+__global__ __launch_bounds__(256, 2) void enc_lstm_tile(const bf16_t* __restrict__ x, long long ldx, int Kx,
                                                         const bf16_t* __restrict__ w_ih, const bf16_t* __restrict__ w_hh,
                                                         const float* __restrict__ b_ih, const float* __restrict__ b_hh,
                                                         const bf16_t* __restrict__ hb, long long ldh, const float* c_in,
                                                         float* __restrict__ h_out, float* c_out, bf16_t* __restrict__ y,
                                                         long long ldy, int B, int H) {
-    // NS ring stages of 16 KB: NS - 1 stages are in flight while one is consumed.  A workgroup has a CU to itself at
-    // S <= 256 streams (grid = S / 64 x H / 16 = 256 at E6D2) and what bounds its 32-stage K loop is bytes in flight over
-    // the L2 round trip, not LDS or MFMA: three stages (round 4) keep 32 KB in flight = 20 us per layer-frame against a
-    // floor of 10.4 us (512 KB per CU at 49 GB/s)
-    constexpr int BKK = 64, A_BYTES = 64 * BKK * 2, BUF_BYTES = 2 * A_BYTES;      // 16 KB per stage
-    constexpr int AHEAD = NS - 1;
+    constexpr int BKK = 64, NS = 3, A_BYTES = 64 * BKK * 2, BUF_BYTES = 2 * A_BYTES;      // 16 KB per stage
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * BUF_BYTES];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -560,17 +554,10 @@ __global__ __launch_bounds__(256, (NS <= 4 ? 2 : 1)) void enc_lstm_tile(const bf
 #pragma unroll
         for (int j = 0; j < 2; ++j) accx[i][j] = acch[i][j] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
     auto stage = [&](int q, f32x4_t (&acc)[2][2]) {
-        // stages q + 1 .. q + AHEAD - 1 may still be in flight (4 DMA ops per wave and stage); towards the end fewer are
-        const int behind = min(AHEAD - 1, KT - 1 - q);
-        if (behind >= 6) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else if (behind == 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-        else if (behind == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else if (behind == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-        else if (behind == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (behind == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (q + 1 < KT) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_barrier" ::: "memory");          // stage q landed everywhere; stage q - 1 is read out
-        if (q + AHEAD < KT) issue(q + AHEAD);
+        if (q + 2 < KT) issue(q + 2);
         const unsigned char* sA = smem + (q % NS) * BUF_BYTES;
         const unsigned char* sB = sA + A_BYTES;
 #pragma unroll
@@ -590,9 +577,8 @@ __global__ __launch_bounds__(256, (NS <= 4 ? 2 : 1)) void enc_lstm_tile(const bf
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
         }
     };
-#pragma unroll
-    for (int q = 0; q < AHEAD; ++q)
-        if (q < KT) issue(q);
+    issue(0);
+    if (KT > 1) issue(1);
     for (int q = 0; q < KT0; ++q) stage(q, accx);
     for (int q = KT0; q < KT; ++q) stage(q, acch);
     __syncthreads();
@@ -686,17 +672,10 @@ extern "C" int edgedict_stream_encoder_step(const void* xs, int x_dtype, int B, 
                 hipLaunchKernelGGL(enc_lstm_step<1>, grid1, dim3(512), 0, s, X + (size_t)t * K, (long long)Tl * K, K,
                                    (const bf16_t*)w_ih[l], (const bf16_t*)w_hh[l], b_ih[l], b_hh[l], hb, ldh, cl, hl, cl,
                                    Y + (size_t)t * H, (long long)Tl * H, B, H);
-            else {
-                static const int ns = [] { const char* e = getenv("EDGEDICT_ENC_TILE_NS"); return e ? atoi(e) : 6; }();
-#define ED_TILE(NSV) hipLaunchKernelGGL(enc_lstm_tile<NSV>, grid4, dim3(256), 0, s, X + (size_t)t * K, (long long)Tl * K, K, \
-                                   (const bf16_t*)w_ih[l], (const bf16_t*)w_hh[l], b_ih[l], b_hh[l], hb, ldh, cl, hl, cl,    \
-                                   Y + (size_t)t * H, (long long)Tl * H, B, H)
-                if (ns <= 3) ED_TILE(3);
-                else if (ns == 4) ED_TILE(4);
-                else if (ns <= 6) ED_TILE(6);
-                else ED_TILE(8);
-#undef ED_TILE
-            }
+            else
+                hipLaunchKernelGGL(enc_lstm_tile, grid4, dim3(256), 0, s, X + (size_t)t * K, (long long)Tl * K, K,
+                                   (const bf16_t*)w_ih[l], (const bf16_t*)w_hh[l], b_ih[l], b_hh[l], hb, ldh, cl, hl, cl,
+                                   Y + (size_t)t * H, (long long)Tl * H, B, H);
         }
         const int Tn = (Tl + reduce[l] - 1) / reduce[l];
         void* dst = (l == L - 1) ? out : (void*)Xn;
