@@ -133,6 +133,17 @@ __device__ __forceinline__ float log_add(float a, float b) {
     return m + log1pf(expf(-fabsf(a - b)));
 }
 
+// Counter-based dropout mask (elementwise.hip dropout_kernel, the encoder stack's norm role and LayerNorm backward):
+// element i of the tensor is KEPT iff hash(seed, i) >= p * 2^32; stateless, so the backward pass regenerates it.
+__device__ __forceinline__ unsigned ed_drop_hash(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ bool ed_drop_keep(unsigned seed, long long i, unsigned thresh) {
+    return ed_drop_hash(seed ^ ed_drop_hash((unsigned)i * 0x9e3779b9U + (unsigned)(i >> 32))) >= thresh;
+}
+__host__ __device__ static inline unsigned ed_drop_thresh(float p) { return (unsigned)((double)p * 4294967296.0); }
+
 static inline int ed_grid_for(long long work_items, int per_block, int max_blocks = 256 * 8) {
     long long g = (work_items + per_block - 1) / per_block;
     if (g < 1) g = 1;

@@ -105,19 +105,14 @@ __global__ void embedding_bwd(const int32_t* __restrict__ tokens, int tok_stride
 // tensor): the backward pass regenerates it from the same (seed, index), so dy -> dx is the SAME
 // kernel.  nn.Dropout / nn.LSTM(dropout=p) semantics (rnnt/models.py:47-53,145-147): scaling by
 // 1/(1-p) in training, identity in eval (the host simply does not call it).
-__device__ __forceinline__ unsigned drop_hash(unsigned x) {
-    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-    return x;
-}
 template <typename T>
 __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, long long n, float p,
                                unsigned seed) {
-    const unsigned thresh = (unsigned)(p * 4294967296.0);   // keep iff hash >= p * 2^32
+    const unsigned thresh = ed_drop_thresh(p);              // keep iff hash >= p * 2^32 (common.hpp)
     const float scale = 1.f / (1.f - p);
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
          i += (long long)gridDim.x * blockDim.x) {
-        const unsigned h = drop_hash(seed ^ drop_hash((unsigned)i * 0x9e3779b9U + (unsigned)(i >> 32)));
-        ElemIO<T>::store(y + i, h >= thresh ? ElemIO<T>::load(x + i) * scale : 0.f);
+        ElemIO<T>::store(y + i, ed_drop_keep(seed, i, thresh) ? ElemIO<T>::load(x + i) * scale : 0.f);
     }
 }
 

@@ -295,6 +295,7 @@ int validate(const edgedict_stack_desc_t* d, std::vector<Geom>& g, bool backward
         const edgedict_stack_layer_t& y = d->layers[l];
         ED_CHECK_ARG(y.T == T && y.I == I, "encoder_stack: layer %d geometry (T=%d I=%d) does not follow from the layers above (T=%d I=%d)", l, y.T, y.I, T, I);
         ED_CHECK_ARG(!y.residual || y.I == d->H, "encoder_stack: layer %d: residual needs I == H", l);
+        ED_CHECK_ARG(y.drop_p >= 0.f && y.drop_p < 1.f, "encoder_stack: layer %d: dropout probability must be in [0, 1)", l);
         ED_CHECK_ARG(y.wih_p && y.bias_p && y.whh_f && y.ln_gamma && y.ln_beta && y.X && y.G && y.Yx && y.Cx && y.mean && y.rstd, "encoder_stack: layer %d: null pointer", l);
         if (backward)
             ED_CHECK_ARG(y.whh_b && y.dZ && (l == 0 || y.dX) && y.dW_ih && y.dW_hh && y.db && y.dgamma && y.dbeta, "encoder_stack: layer %d: null backward pointer", l);
@@ -435,6 +436,17 @@ int open_streams(const edgedict_stack_desc_t* d, void* stream_, Streams& st) {
     }
     st.W = st.rt->W;
     return ED_OK;
+}
+
+// dropout behind layer y's LayerNorm (+ TimeReduction): mask threshold (0 = off), scale, frames of the layer's output
+struct DropCfg { unsigned thresh, seed; float scale; int T_out; };
+inline DropCfg drop_of(const edgedict_stack_layer_t& y) {
+    DropCfg c;
+    c.thresh = y.drop_p > 0.f ? ed_drop_thresh(y.drop_p) : 0u;
+    c.seed = y.drop_seed;
+    c.scale = y.drop_p > 0.f ? 1.f / (1.f - y.drop_p) : 1.f;
+    c.T_out = (y.T + y.reduce - 1) / y.reduce;
+    return c;
 }
 
 inline bf16_t* bptr(void* p) { return reinterpret_cast<bf16_t*>(p); }
@@ -708,6 +720,8 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
                 e.t0 = ran[i].t0;
                 e.t1 = ran[i].t1;
                 e.reduce = y.reduce;
+                const DropCfg dc = drop_of(y);
+                e.drop_thresh = dc.thresh; e.drop_seed = dc.seed; e.drop_scale = dc.scale; e.drop_T = dc.T_out;
                 idx[ni++] = i;
             }
             if (ni == 0) continue;
@@ -931,6 +945,9 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
                     n.mean1 = tb >= 0 ? y.mean + (long long)tb * B : nullptr;
                     n.rstd1 = tb >= 0 ? y.rstd + (long long)tb * B : nullptr;
                     n.scale = y.reduce == 1 ? 1.f : 0.5f;
+                    const DropCfg dc = drop_of(y);
+                    n.drop_thresh = dc.thresh; n.drop_seed = dc.seed; n.drop_scale = dc.scale; n.drop_T = dc.T_out;
+                    n.tau = tau;
                 }
                 // last frame of a chunk: the next layer's input rows of this chunk are complete
                 const int k = t / g[l].cf;
@@ -1211,12 +1228,13 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     {
         const edgedict_stack_layer_t& y = d->layers[L - 1];
         hipStream_t S = st.S[L - 1];
+        const DropCfg dcT = drop_of(y);
         for (int k = g[L - 1].nchunks - 1; k >= 0; --k) {
             const int t0 = k * g[L - 1].cf, t1 = min(y.T, t0 + g[L - 1].cf);
             ED_DEV(ed_stack_ln_bwd(bptr(d->dout), H, (long long)T_out * H, bptr(y.Yx) + BH,
                                    y.residual ? bptr(y.X) : nullptr, y.ln_gamma, y.mean, y.rstd, bptr(y.dZ),
                                    (float*)(ws + wl.lnpart[L - 1]) + (size_t)k * LNB_GRID * 2 * H, LNB_GRID, B, H,
-                                   t0, t1, y.reduce, S));
+                                   t0, t1, y.reduce, S, dcT.thresh, dcT.seed, dcT.scale, dcT.T_out));
             if (soft) ED_DEV(ed_stack_set_flag(bflag + (L - 1) * 512 + k, S));
             else ED_TRY(st.record(Eb[L - 1][k], S));
         }
@@ -1300,7 +1318,8 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                 ED_DEV(ed_stack_ln_bwd(bptr(y.dX), (long long)B * y.I, y.I, bptr(z.Yx) + BH,
                                        z.residual ? bptr(z.X) : nullptr, z.ln_gamma, z.mean, z.rstd,
                                        bptr(z.dZ), (float*)(ws + wl.lnpart[l - 1]) + (size_t)k * LNB_GRID * 2 * H,
-                                       LNB_GRID, B, H, u0, u1, z.reduce, S));
+                                       LNB_GRID, B, H, u0, u1, z.reduce, S, drop_of(z).thresh, drop_of(z).seed,
+                                       drop_of(z).scale, drop_of(z).T_out));
                 if (soft) ED_DEV(ed_stack_set_flag(bflag + (l - 1) * 512 + k, S));
                 else ED_TRY(st.record(Eb[l - 1][k], S));
                 queued[l - 1][k] = 1;

@@ -337,6 +337,13 @@ __device__ __forceinline__ void fwd_norm_role(const EdFwdNorm& p, int rb, int B,
         }
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] *= p.scale;
+        if (p.drop_thresh) {
+            // the reference's Dropout sees the LayerNorm's output as a tensor: round first, then mask and scale
+            const long long i0 = ((long long)b * p.drop_T + p.tau) * H + c;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                o[i] = ed_drop_keep(p.drop_seed, i0 + i, p.drop_thresh) ? bf16_to_f32(f32_to_bf16(o[i])) * p.drop_scale : 0.f;
+        }
         ElemIO<bf16_t>::store_vec(out + c, o);
     }
 }
@@ -752,6 +759,9 @@ struct ChunkNormArgs {
     float* rstd;
     int B, H, T, t0, reduce;
     float eps;
+    unsigned drop_thresh, drop_seed;
+    float drop_scale;
+    int drop_T;
 };
 __device__ __forceinline__ void chunk_norm_body(const ChunkNormArgs& a, int bid) {
     const int RB = (a.B + 3) >> 2;
@@ -778,6 +788,8 @@ __device__ __forceinline__ void chunk_norm_body(const ChunkNormArgs& a, int bid)
     p.mean1 = tb >= 0 ? a.mean + (long long)tb * a.B : nullptr;
     p.rstd1 = tb >= 0 ? a.rstd + (long long)tb * a.B : nullptr;
     p.scale = a.reduce == 1 ? 1.f : 0.5f;
+    p.drop_thresh = a.drop_thresh; p.drop_seed = a.drop_seed; p.drop_scale = a.drop_scale; p.drop_T = a.drop_T;
+    p.tau = tau;
     fwd_norm_role(p, rb, a.B, a.H, a.eps);
 }
 
@@ -1394,7 +1406,8 @@ __global__ __launch_bounds__(256) void stack_ln_bwd_kernel(
     const bf16_t* __restrict__ dout, long long dout_st, long long dout_sb,
     const bf16_t* __restrict__ y, const bf16_t* __restrict__ res, const float* __restrict__ gamma,
     const float* __restrict__ mean_in, const float* __restrict__ rstd_in, bf16_t* __restrict__ dz,
-    float* __restrict__ part, int B, int H, int t0, int t1, int reduce) {
+    float* __restrict__ part, int B, int H, int t0, int t1, int reduce, unsigned drop_thresh, unsigned drop_seed,
+    float drop_scale, int drop_T) {
     __shared__ float red[2][3][LNB_NB * 8][64];   // waves 1..3 -> wave 0, 48 KB
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float scale = 1.f / (float)reduce;
@@ -1431,6 +1444,13 @@ __global__ __launch_bounds__(256) void stack_ln_bwd_kernel(
                     ElemIO<bf16_t>::load_vec(rsr + c, r2);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) z[e] += r2[e];
+                }
+                if (drop_thresh) {
+                    // the gradient arrives at the layer's output BEHIND its Dropout (drop_T output frames, batch-first
+                    // element index as in the forward norm role): the same mask and scale, regenerated
+                    const long long i0 = ((long long)b * drop_T + t / reduce) * H + c;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) dy[i][e] = ed_drop_keep(drop_seed, i0 + e, drop_thresh) ? dy[i][e] * drop_scale : 0.f;
                 }
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
@@ -1612,6 +1632,7 @@ int ed_stack_multi_norm(const EdChunkNorm* items, int n, int B, int H, float eps
         a.Yx1 = e.Yx1; a.X = e.X; a.gamma = e.gamma; a.beta = e.beta; a.out = e.out; a.out_st = e.out_st;
         a.out_sb = e.out_sb; a.mean = e.mean; a.rstd = e.rstd; a.B = B; a.H = H; a.T = e.T; a.t0 = e.t0;
         a.reduce = e.reduce; a.eps = eps;
+        a.drop_thresh = e.drop_thresh; a.drop_seed = e.drop_seed; a.drop_scale = e.drop_scale; a.drop_T = e.drop_T;
         M.first[M.n] = grid;
         const int frames_out = e.reduce == 1 ? e.t1 - e.t0 : (e.t1 - e.t0 + 1) / 2;
         grid += frames_out * ((B + 3) >> 2);
@@ -1692,10 +1713,11 @@ int ed_stack_launch_bwd(const EdBwdLaunch& L, hipStream_t s) {
 int ed_stack_ln_bwd(const bf16_t* dout, long long dout_st, long long dout_sb, const bf16_t* y,
                     const bf16_t* res, const float* gamma, const float* mean, const float* rstd,
                     bf16_t* dz, float* part, int grid, int B, int H, int t0, int t1, int reduce,
-                    hipStream_t s) {
+                    hipStream_t s, unsigned drop_thresh, unsigned drop_seed, float drop_scale, int drop_T) {
     // fixed grid: every workgroup writes its partial row (zeros when it owns no rows)
     hipLaunchKernelGGL(stack_ln_bwd_kernel, dim3(grid), dim3(256), 0, s, dout, dout_st, dout_sb, y,
-                       res, gamma, mean, rstd, dz, part, B, H, t0, max(t0, t1), reduce);
+                       res, gamma, mean, rstd, dz, part, B, H, t0, max(t0, t1), reduce, drop_thresh, drop_seed,
+                       drop_scale, drop_T);
     ED_CHECK_LAUNCH("stack_ln_bwd_kernel");
     return ED_OK;
 }

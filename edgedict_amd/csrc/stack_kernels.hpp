@@ -34,6 +34,12 @@ struct EdFwdNorm {             // LayerNorm(y + r) of one frame, or the pair mea
     float* mean0; float* rstd0;   // [B] saved statistics of frame 0 / frame 1
     float* mean1; float* rstd1;
     float scale;               // 1 (no reduction) or 0.5 (pair mean; a missing partner counts as 0)
+    // nn.Dropout behind the LayerNorm (+ TimeReduction) of the layer (rnnt/models.py:47-53,70), training only: element
+    // (b, tau, j) of the layer's [B, drop_T, H] output is kept iff ed_drop_keep(drop_seed, (b drop_T + tau) H + j,
+    // drop_thresh) and scaled by drop_scale = 1 / (1 - p); drop_thresh = 0: no dropout
+    unsigned drop_thresh, drop_seed;
+    float drop_scale;
+    int drop_T, tau;
 };
 
 struct EdFwdLaunch {
@@ -118,6 +124,9 @@ struct EdChunkNorm {
     float* mean;
     float* rstd;
     int T, t0, t1, reduce;
+    unsigned drop_thresh, drop_seed;   // as EdFwdNorm (drop_thresh = 0: no dropout); the layer's output has
+    float drop_scale;                  // drop_T = ceil(T / reduce) frames
+    int drop_T;
 };
 // one lane spins on stream s until counters[i] >= targets[i] for every i (bounded: give-up code 800 + i)
 int ed_stack_wait_counters(const unsigned* const* counters, const unsigned* targets, int n, unsigned* err, hipStream_t s);
@@ -171,7 +180,8 @@ int ed_stack_launch_bwd(const EdBwdLaunch& L, hipStream_t s);
 int ed_stack_ln_bwd(const bf16_t* dout, long long dout_st, long long dout_sb, const bf16_t* y,
                     const bf16_t* res, const float* gamma, const float* mean, const float* rstd,
                     bf16_t* dz, float* part, int grid, int B, int H, int t0, int t1, int reduce,
-                    hipStream_t s);
+                    hipStream_t s, unsigned drop_thresh = 0, unsigned drop_seed = 0, float drop_scale = 1.f,
+                    int drop_T = 0);
 int ed_stack_sum_parts(const float* part, int rows, int H, float* dgamma, float* dbeta, hipStream_t s);
 int ed_stack_input_norm(int x_dtype, const void* x, const float* gamma, const float* beta,
                         bf16_t* out, float* mean, float* rstd, int B, int T, int D, float eps,

@@ -28,7 +28,8 @@ class StackLayer(ctypes.Structure):
                 ("ln_gamma", _fp), ("ln_beta", _fp),
                 ("X", _vp), ("G", _vp), ("Yx", _vp), ("Cx", _fp), ("mean", _fp), ("rstd", _fp),
                 ("dZ", _vp), ("dX", _vp), ("dW_ih", _fp), ("dW_hh", _fp), ("db", _fp), ("db_hh", _fp),
-                ("dgamma", _fp), ("dbeta", _fp), ("whh_s", _vp)]
+                ("dgamma", _fp), ("dbeta", _fp), ("whh_s", _vp),
+                ("drop_p", ctypes.c_float), ("drop_seed", ctypes.c_uint)]
 
 
 class StackDesc(ctypes.Structure):
@@ -176,8 +177,10 @@ def prepack(encoder, stream):
 class _Plan:
     """Buffers + descriptors of one forward/backward pair."""
 
-    def __init__(self, x, in_norm, layers, reductions, h0, c0, flags):
+    def __init__(self, x, in_norm, layers, reductions, h0, c0, flags, drop=None):
         self.keep = []          # tensors referenced by raw pointer from the descriptors
+        # drop: None, or (p, [seed of layer 0, ...]): nn.Dropout behind every layer's LayerNorm (+ TimeReduction),
+        # rnnt/models.py:47-53,70, applied inside the norm role / the LayerNorm backward (training mode only)
         if _PREPACK_EVENT[0] is not None:      # images were rebuilt on another stream (prepack)
             torch.cuda.current_stream(x.device).wait_event(_PREPACK_EVENT[0])
             _PREPACK_EVENT[0] = None
@@ -207,6 +210,7 @@ class _Plan:
             y.wih_p, y.wih_t, y.bias_p, y.whh_f, y.whh_b = map(
                 _p, (pk.wih_p, pk.wih_t, pk.bias_p, pk.whh_f, pk.whh_b))
             y.whh_s = _p(pk.whh_s)
+            y.drop_p, y.drop_seed = (float(drop[0]), int(drop[1][l]) & 0xFFFFFFFF) if drop else (0.0, 0)
             g, b = ln_w.detach(), ln_b.detach()
             y.ln_gamma, y.ln_beta = _p(g), _p(b)
             self.keep += [pk.wih_p, pk.wih_t, pk.bias_p, pk.whh_f, pk.whh_b, pk.whh_s, g, b]
@@ -317,11 +321,11 @@ class _Plan:
 
 
 class EncoderStackFn(torch.autograd.Function):
-    """(xs [B,T0,I0], in_gamma, in_beta, 6 tensors per layer..., h0, c0, reductions, flags)
-    -> (out [B,T',H] bf16, hN [L,B,H] f32, cN [L,B,H] f32)"""
+    """(xs [B,T0,I0], in_gamma, in_beta, h0, c0, reductions, flags, drop, 6 tensors per layer...)
+    -> (out [B,T',H] bf16, hN [L,B,H] f32, cN [L,B,H] f32);  drop = None or (p, per-layer seeds)"""
 
     @staticmethod
-    def forward(ctx, xs, in_g, in_b, h0, c0, reductions, flags, *params):
+    def forward(ctx, xs, in_g, in_b, h0, c0, reductions, flags, drop, *params):
         assert len(params) % 6 == 0
         layers = [params[i:i + 6] for i in range(0, len(params), 6)]
         x = xs.contiguous()
@@ -329,7 +333,7 @@ class EncoderStackFn(torch.autograd.Function):
             x = x.float()
         needs_bwd = any(ctx.needs_input_grad)        # (grad mode is off inside forward(); this is what autograd knows)
         plan = _Plan(x, (in_g, in_b), layers, list(reductions), h0, c0,
-                     (FLAGS if flags is None else flags) | (0 if needs_bwd else INFERENCE))
+                     (FLAGS if flags is None else flags) | (0 if needs_bwd else INFERENCE), drop)
         with ops.timed("enc_stack_fwd_T%d_L%d" % (x.shape[1], len(layers))):
             plan.forward()
         hN, cN = plan.final_states()
@@ -352,9 +356,9 @@ class EncoderStackFn(torch.autograd.Function):
         with ops.timed("enc_stack_bwd_T%d_L%d" % (plan.T0, plan.L)):
             res = plan.backward(dout, ctx.params, ctx.in_norm)
         if res is None:        # accumulated in place
-            return (None,) * (7 + len(ctx.params))
+            return (None,) * (8 + len(ctx.params))
         dig, dib, grads = res
-        out = [None, dig, dib, None, None, None, None]
+        out = [None, dig, dib, None, None, None, None, None]
         for gb in grads:
             out += [gb["dW_ih"], gb["dW_hh"], gb["db"], gb["db"].clone(), gb["dgamma"], gb["dbeta"]]
         return tuple(out)
@@ -380,7 +384,9 @@ def schedule(T0, I0, H, reductions, B=64, chunk=None, backward=False, lag=0, fla
         y = layers[l]
         y.T, y.I, y.reduce, y.residual = T, I, reductions[l], 1 if l > 0 else 0
         for name, typ in StackLayer._fields_[4:]:
-            setattr(y, name, fdummy if typ is _fp else dummy)
+            if typ in (_vp, _fp):
+                setattr(y, name, fdummy if typ is _fp else dummy)
+        y.drop_p, y.drop_seed = 0.0, 0
         Ts.append(T)
         T = (T + reductions[l] - 1) // reductions[l]
         I = H

@@ -293,12 +293,15 @@ class _DropoutFn(torch.autograd.Function):
 _dropout_calls = [0]
 
 
-def _dropout(x, p):
+def _next_dropout_seed():
     """A fresh mask per call: seed = torch's RNG stream (so torch.manual_seed governs it) mixed with
     a call counter."""
     _dropout_calls[0] += 1
-    seed = (torch.initial_seed() * 0x9E3779B1 + _dropout_calls[0] * 0x85EBCA6B) & 0xFFFFFFFF
-    return _DropoutFn.apply(x, p, seed)
+    return (torch.initial_seed() * 0x9E3779B1 + _dropout_calls[0] * 0x85EBCA6B) & 0xFFFFFFFF
+
+
+def _dropout(x, p):
+    return _DropoutFn.apply(x, p, _next_dropout_seed())
 
 
 class _LinearFn(torch.autograd.Function):
@@ -727,10 +730,10 @@ class Encoder(nn.Module):
         require_cuda(xs)
         cd = getattr(self, "compute_dtype", None) or config.get_compute_dtype()
         lstm = self.lstm
-        drop = getattr(lstm, "dropout", 0) > 0 and self.training    # per-layer path applies it
+        drop = getattr(lstm, "dropout", 0) > 0 and self.training    # applied inside the stack / by the per-layer path
         # short inputs (streaming chunks of a few frames) stay on the per-layer kernels: the
         # wavefront needs ~5 lags of launches to fill, more than 6 x T per-layer steps for small T
-        if (isinstance(lstm, ResLayerNormLSTM) and xs.dim() == 3 and not drop
+        if (isinstance(lstm, ResLayerNormLSTM) and xs.dim() == 3
                 and xs.shape[1] >= config.STACK_MIN_FRAMES
                 and encoder_stack.supported(cd, lstm.hidden_size, xs.shape[2], len(lstm.lstms),
                                             lstm.reductions)):
@@ -742,8 +745,11 @@ class Encoder(nn.Module):
             params = []
             for m, proj in zip(lstm.lstms, lstm.projs):
                 params += list(m.layer(0)) + [proj[0].weight, proj[0].bias]
+            # nn.Dropout behind every layer's LayerNorm (+ TimeReduction), rnnt/models.py:47-53,70: inside the stack's
+            # norm role, one seed per layer drawn in the order the per-layer path draws them
+            dcfg = (float(lstm.dropout), tuple(_next_dropout_seed() for _ in lstm.lstms)) if drop else None
             xs, h, c = encoder_stack.EncoderStackFn.apply(
-                xs, self.norm.weight, self.norm.bias, h0, c0, tuple(lstm.reductions), None, *params)
+                xs, self.norm.weight, self.norm.bias, h0, c0, tuple(lstm.reductions), None, dcfg, *params)
             hiddens = (h, c)
         elif (isinstance(lstm, ResLayerNormLSTM) and xs.dim() == 3 and cd == torch.bfloat16 and not drop
               and not torch.is_grad_enabled() and 0 < xs.shape[1] < config.STACK_MIN_FRAMES

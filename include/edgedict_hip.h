@@ -260,6 +260,12 @@ typedef struct edgedict_stack_layer {
     const void* whh_s;     /* bf16 split-K fragment image of W_hh (edgedict_stack_pack_sk), nullable: with it (and B <= 64,
                               H % 64 == 0, H <= 1024, EDGEDICT_STACK_BWD_SK != 0) the BPTT runs on the split-K
                               weights-stationary kernel, several steps per launch; without it one launch per step */
+    /* nn.Dropout behind this layer's LayerNorm (+ TimeReduction), rnnt/models.py:47-53,70 - training mode only, the
+       caller passes 0 in eval mode: element (b, tau, j) of the layer's [B, ceil(T / reduce), H] output is zeroed with
+       probability drop_p and scaled by 1 / (1 - drop_p) otherwise; the mask is the counter-based one of
+       edgedict_dropout (same hash, same batch-first element index, drop_seed), regenerated in the backward pass */
+    float drop_p;
+    unsigned drop_seed;
 } edgedict_stack_layer_t;
 
 #define EDGEDICT_STACK_SERIAL 1     /* run everything on the caller's stream (debug / bit-exact check) */
