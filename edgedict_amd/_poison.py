@@ -37,6 +37,10 @@ def install():
     empty, empty_like, new_empty = torch.empty, torch.empty_like, torch.Tensor.new_empty
 
     def p_empty(*a, **k):
+        # torch.set_default_device works through a function mode that recognises the ORIGINAL factory functions: behind
+        # this wrapper it would no longer see `torch.empty`, so the default device is passed on explicitly
+        if "device" not in k:
+            k["device"] = torch.get_default_device()
         return _fill(empty(*a, **k))
 
     def p_empty_like(*a, **k):
