@@ -119,6 +119,41 @@ def run_train_steps(piece, namespace, trainer, batches):
     return [float(step(b)) for b in batches]
 
 
+class StubTextTokenizer:
+    """Stand-in for rnnt.tokenizer's decode_plus (rnnt/tokenizer.py: ids <= 3 dropped, the rest joined): the text IS the
+    id list, so WER compares token ids."""
+
+    def decode_plus(self, seqs):
+        return [" ".join("t%d" % int(t) for t in seq if int(t) > 3) for seq in seqs]
+
+
+def stub_jiwer():
+    """jiwer.wer(truth, hypothesis) on lists of strings: word-level edit distance / reference words (jiwer's default)."""
+    def wer(truth, hyp):
+        errs = words = 0
+        for t, h in zip(truth, hyp):
+            a, b = t.split(), h.split()
+            d = list(range(len(b) + 1))
+            for i in range(1, len(a) + 1):
+                prev, d[0] = d[0], i
+                for j in range(1, len(b) + 1):
+                    cur = min(d[j] + 1, d[j - 1] + 1, prev + (a[i - 1] != b[j - 1]))
+                    prev, d[j] = d[j], cur
+            errs += d[len(b)]
+            words += len(a)
+        return errs / max(1, words)
+    return types.SimpleNamespace(wer=wer)
+
+
+def run_evaluate_step(namespace, trainer, batch):
+    """cli/baseline.py's Trainer.evaluate_step (loss in eval mode, greedy_decode, decode_plus, jiwer.wer) bound to
+    ``trainer``; returns (loss, wer, pred_seq, true_seq)."""
+    ns = ref_lift.load("baseline_eval", namespace)
+    trainer.model.eval()
+    with torch.no_grad():
+        return types.MethodType(ns["evaluate_step"], trainer)(batch)
+
+
 def run_mic(namespace, decoder, blocks):
     """stream.py's callback over ``blocks``; returns what it printed."""
     namespace.update(buffer=[], blank_counter=0, stream_decoder=decoder, np=np, torch=torch)
@@ -174,6 +209,16 @@ def main():
     out["baseline_losses"] = np.array(run_train_steps("baseline_train_step", ns, tr, [train_batch(c)] * c["steps"]))
     out["baseline_checksum"] = checksum(model.parameters())
     print("cli/baseline.py train_step losses:", out["baseline_losses"])
+
+    # ---- cli/baseline.py evaluate_step on the seeded weights (a fresh model: independent of the optimiser path)
+    model = ref.Transducer(enc_dropout=0.0, dec_dropout=0.0, output_loss=True, **c["cfg"])
+    model.load_state_dict(M.make_state_dict(c["cfg"], c["wseed"]), strict=True)
+    tr = types.SimpleNamespace(model=model, tokenizer=StubTextTokenizer())
+    ns = dict(FLAGS=train_flags(c), device=torch.device("cpu"), torch=torch, np=np, jiwer=stub_jiwer())
+    loss, wer, pred, true = run_evaluate_step(ns, tr, train_batch(c))
+    out["eval_loss"], out["eval_wer"] = np.float64(loss), np.float64(wer)
+    out["eval_pred"], out["eval_true"] = np.array(pred), np.array(true)
+    print("cli/baseline.py evaluate_step: loss %.5f wer %.4f pred[0] %r" % (loss, wer, pred[0]))
 
     # ---- cli/train.py train_step (FrontEnd)
     c = FRONT

@@ -8,6 +8,7 @@ into this repository, and /root/reference is never read at test time):
   piece                  reference lines                               what runs it
   ---------------------  --------------------------------------------  -----------------------------------------
   baseline_train_step    cli/baseline.py  Trainer.train_step           tests/test_reference_loops_gpu.py (engine),
+  baseline_eval          cli/baseline.py  Trainer.evaluate_step/save/load  (same two runners)
   frontend_train_step    cli/train.py     Trainer.train_step             oracle/make_golden_ref_loops.py (reference
   stream_decode          cli/openvino_wav_inference.py stream_decode     modules on the CPU -> tests/golden/
   stream_classes         rnnt/stream.py   StreamTransducerDecoder,       ref_loops.npz)
@@ -36,6 +37,7 @@ OUT = os.path.join(ROOT, "oracle", "_ref")
 PIECES = {
     "baseline_train_step": ("cli/baseline.py", "Trainer", ["train_step"]),
     "frontend_train_step": ("cli/train.py", "Trainer", ["train_step"]),
+    "baseline_eval": ("cli/baseline.py", "Trainer", ["evaluate_step", "save", "load"]),
     "stream_decode": ("cli/openvino_wav_inference.py", None, ["stream_decode"]),
     "stream_classes": ("rnnt/stream.py", None, ["StreamTransducerDecoder", "PytorchStreamDecoder"]),
     "mic_callback": ("stream.py", None, ["callback"]),
