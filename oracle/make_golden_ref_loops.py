@@ -154,6 +154,47 @@ def run_evaluate_step(namespace, trainer, batch):
         return types.MethodType(ns["evaluate_step"], trainer)(batch)
 
 
+LIGHTNING = dict(cfg=TRAIN_CFG, wseed=51, xseed=52, B=3, T0=33, U=5, steps=3, lr=2e-3, clip=10.0, warmup_step=2)
+
+
+def lightning_module(model, loss_fn, optimizer, tokenizer):
+    """What ParallelTraining.__init__ (cli/lightning.py:29-70) and Lightning's trainer leave on the module, without
+    pytorch_lightning: the attributes its training_step / validation_step read."""
+    log = types.SimpleNamespace(experiment=types.SimpleNamespace(add_scalar=lambda *a, **k: None,
+                                                                 add_text=lambda *a, **k: None))
+    return types.SimpleNamespace(model=model, loss_fn=loss_fn, optimizer=optimizer, tokenizer=tokenizer, logger=log,
+                                 steps=0, epoch=0)
+
+
+def run_lightning(namespace, module, batch, steps, clip):
+    """cli/lightning.py's training_step `steps` times, each followed by what Lightning's trainer does around it
+    (cli/lightning.py:325-331: backward, gradient_clip_val=10, optimizer step, zero_grad), then one validation_step.
+    Returns (losses, validation dict)."""
+    ns = ref_lift.load("lightning_steps", namespace)
+    module.warmup_optimizer_step = types.MethodType(ns["warmup_optimizer_step"], module)
+    train = types.MethodType(ns["training_step"], module)
+    val = types.MethodType(ns["validation_step"], module)
+    losses = []
+    for i in range(steps):
+        module.model.train()
+        out = train(batch, i)
+        out["loss"].sum().backward()
+        torch.nn.utils.clip_grad_norm_(module.model.parameters(), clip)
+        module.optimizer.step()
+        module.optimizer.zero_grad()
+        losses.append(float(out["log"]["loss"]))
+    module.model.eval()
+    with torch.no_grad():
+        v = val(batch, 0)
+    return losses, v
+
+
+def stub_jiwer_measures():
+    j = stub_jiwer()
+    j.compute_measures = lambda truth, hyp: {"wer": j.wer(truth, hyp)}
+    return j
+
+
 def run_mic(namespace, decoder, blocks):
     """stream.py's callback over ``blocks``; returns what it printed."""
     namespace.update(buffer=[], blank_counter=0, stream_decoder=decoder, np=np, torch=torch)
@@ -219,6 +260,21 @@ def main():
     out["eval_loss"], out["eval_wer"] = np.float64(loss), np.float64(wer)
     out["eval_pred"], out["eval_true"] = np.array(pred), np.array(true)
     print("cli/baseline.py evaluate_step: loss %.5f wer %.4f pred[0] %r" % (loss, wer, pred[0]))
+
+    # ---- cli/lightning.py training_step / validation_step: the EXTERNAL loss call (Transducer(output_loss=False))
+    c = LIGHTNING
+    model = ref.Transducer(enc_dropout=0.0, dec_dropout=0.0, output_loss=False, **c["cfg"])
+    model.load_state_dict(M.make_state_dict(c["cfg"], c["wseed"]), strict=True)
+    mod = lightning_module(model, _OracleRNNTLoss(blank=M.NUL), torch.optim.Adam(model.parameters(), lr=c["lr"]),
+                           StubTextTokenizer())
+    ns = dict(FLAGS=types.SimpleNamespace(warmup_step=c["warmup_step"], lr=c["lr"]), torch=torch, np=np,
+              jiwer=stub_jiwer_measures())
+    batch = M.make_batch(c["cfg"], c["xseed"], c["B"], c["T0"], c["U"])
+    losses, v = run_lightning(ns, mod, batch, c["steps"], c["clip"])
+    out["lightning_losses"] = np.array(losses)
+    out["lightning_val_loss"], out["lightning_wer"] = np.float64(v["val_loss"]), np.float64(v["wer"])
+    out["lightning_hypothesis"] = np.array(v["hypothesis"])
+    print("cli/lightning.py training_step losses:", losses, "validation:", v["val_loss"], v["wer"], repr(v["hypothesis"])[:60])
 
     # ---- cli/train.py train_step (FrontEnd)
     c = FRONT

@@ -9,6 +9,9 @@ into this repository, and /root/reference is never read at test time):
   ---------------------  --------------------------------------------  -----------------------------------------
   baseline_train_step    cli/baseline.py  Trainer.train_step           tests/test_reference_loops_gpu.py (engine),
   baseline_eval          cli/baseline.py  Trainer.evaluate_step/save/load  (same two runners)
+  lightning_steps        cli/lightning.py ParallelTraining.training_step / validation_step / warmup_optimizer_step
+                                          (the EXTERNAL loss call: Transducer(output_loss=False) -> scale_length ->
+                                          warprnnt_pytorch.RNNTLoss, cli/lightning.py:40,85-91)
   frontend_train_step    cli/train.py     Trainer.train_step             oracle/make_golden_ref_loops.py (reference
   stream_decode          cli/openvino_wav_inference.py stream_decode     modules on the CPU -> tests/golden/
   stream_classes         rnnt/stream.py   StreamTransducerDecoder,       ref_loops.npz)
@@ -38,6 +41,7 @@ PIECES = {
     "baseline_train_step": ("cli/baseline.py", "Trainer", ["train_step"]),
     "frontend_train_step": ("cli/train.py", "Trainer", ["train_step"]),
     "baseline_eval": ("cli/baseline.py", "Trainer", ["evaluate_step", "save", "load"]),
+    "lightning_steps": ("cli/lightning.py", "ParallelTraining", ["warmup_optimizer_step", "training_step", "validation_step"]),
     "stream_decode": ("cli/openvino_wav_inference.py", None, ["stream_decode"]),
     "stream_classes": ("rnnt/stream.py", None, ["StreamTransducerDecoder", "PytorchStreamDecoder"]),
     "mic_callback": ("stream.py", None, ["callback"]),

@@ -207,3 +207,29 @@ def test_baseline_trainer_evaluate_step_and_checkpoints_run_on_the_engine(hip_li
         assert torch.equal(v, want[k]), k
     loss2, wer2, pred2, _ = G.run_evaluate_step(ns, tr, G.train_batch(c))
     assert loss2 == loss and list(pred2) == list(pred) and wer2 == wer
+
+
+def test_lightning_module_steps_run_on_the_engine_with_the_external_loss_call(hip_lib):
+    """cli/lightning.py's ``ParallelTraining.training_step`` (:85-107: ``Transducer(output_loss=False)`` -> logits ->
+    ``model.scale_length`` -> the EXTERNAL ``warprnnt_pytorch.RNNTLoss(blank=NUL)(acts, ys.int(), xlen, ylen)`` call,
+    :40,91), its warm-up hook and ``validation_step`` (:109-117: ``greedy_decode`` -> ``decode_plus`` -> jiwer), verbatim,
+    with ``warprnnt_pytorch`` resolved through the root shim and what Lightning's trainer does around a step (backward,
+    gradient_clip_val = 10, optimiser step: :325-331) restated by oracle/make_golden_ref_loops.run_lightning on both sides."""
+    models, _, _, tok = _shims()
+    import warprnnt_pytorch
+    assert warprnnt_pytorch.RNNTLoss.__module__.startswith("edgedict_amd.")
+    c = G.LIGHTNING
+    model = models.Transducer(enc_dropout=0.0, dec_dropout=0.0, output_loss=False, **c["cfg"])
+    model.load_state_dict(M.make_state_dict(c["cfg"], c["wseed"]), strict=True)
+    model = model.to(DEV)
+    mod = G.lightning_module(model, warprnnt_pytorch.RNNTLoss(blank=tok.NUL),
+                             torch.optim.Adam(model.parameters(), lr=c["lr"]), G.StubTextTokenizer())
+    ns = dict(FLAGS=types.SimpleNamespace(warmup_step=c["warmup_step"], lr=c["lr"]), torch=torch, np=np,
+              jiwer=G.stub_jiwer_measures())
+    batch = [t.to(DEV) for t in M.make_batch(c["cfg"], c["xseed"], c["B"], c["T0"], c["U"])]   # Lightning moves the batch
+    losses, v = G.run_lightning(ns, mod, batch, c["steps"], c["clip"])
+    _close(losses, GOLD["lightning_losses"], 2e-5)
+    assert losses[2] < losses[1] < losses[0]
+    assert mod.steps == c["steps"]
+    _close([v["val_loss"]], [float(GOLD["lightning_val_loss"])], 1e-4)
+    assert v["wer"] == float(GOLD["lightning_wer"]) and v["hypothesis"] == str(GOLD["lightning_hypothesis"])
