@@ -6,6 +6,8 @@ outputs that travel with the snapshot; /root/reference is not read here).  They 
 maintainer gets with this repository in front of the reference checkout on PYTHONPATH:
 
   * cli/baseline.py:214-248  Trainer.train_step   3 optimiser steps, torch.optim.Adam, clip_grad_norm_, 2 sub-batches
+  * cli/baseline.py:273-323  Trainer.evaluate_step / save / load   loss + greedy_decode + decode_plus + WER; checkpoints
+  * cli/lightning.py:72-117  ParallelTraining.training_step / validation_step   the EXTERNAL warprnnt_pytorch.RNNTLoss call
   * cli/train.py:223-271     Trainer.train_step   the FrontEnd trainer (conv front-end + length rescaling)
   * cli/openvino_wav_inference.py:29-46 stream_decode   the chunk loop, over ``PytorchStreamDecoder(FLAGS)`` built as
                                                   stream.py:122 builds it (checkpoint + BPE vocabulary from disk)
