@@ -55,3 +55,16 @@ def test_encoder_stack_validates_before_launching(hip_lib):
     rc = hip_lib.edgedict_stack_pack_weights(None, None, None, None, 64, 16, None, None, None,
                                              None, None, None)
     assert rc == -1
+
+
+def test_streams_busy_probe_is_safe_without_a_device_and_rejects_null(hip_lib):
+    """edgedict_streams_busy (the isolation fixture's probe): a null mask is an argument error, and on a box without a
+    device it returns a status (nothing has been created, so nothing can be busy) instead of touching HIP state."""
+    assert hip_lib.edgedict_streams_busy(None) == -1
+    mask = ctypes.c_uint(123)
+    rc = hip_lib.edgedict_streams_busy(ctypes.byref(mask))
+    import torch
+    if torch.cuda.is_available():
+        assert rc == 0
+    else:
+        assert mask.value == 0        # cleared before anything else happens; rc may report the missing device
