@@ -39,7 +39,7 @@ def install():
     def p_empty(*a, **k):
         # torch.set_default_device works through a function mode that recognises the ORIGINAL factory functions: behind
         # this wrapper it would no longer see `torch.empty`, so the default device is passed on explicitly
-        if "device" not in k:
+        if k.get("device") is None:          # (nn.Embedding & co. pass device=None explicitly)
             k["device"] = torch.get_default_device()
         return _fill(empty(*a, **k))
 
