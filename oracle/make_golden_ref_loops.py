@@ -169,11 +169,14 @@ def lightning_module(model, loss_fn, optimizer, tokenizer):
 def run_lightning(namespace, module, batch, steps, clip):
     """cli/lightning.py's training_step `steps` times, each followed by what Lightning's trainer does around it
     (cli/lightning.py:325-331: backward, gradient_clip_val=10, optimizer step, zero_grad), then one validation_step.
-    Returns (losses, validation dict)."""
+    Returns (losses, validation dict before the steps, validation dict after them)."""
     ns = ref_lift.load("lightning_steps", namespace)
     module.warmup_optimizer_step = types.MethodType(ns["warmup_optimizer_step"], module)
     train = types.MethodType(ns["training_step"], module)
     val = types.MethodType(ns["validation_step"], module)
+    module.model.eval()
+    with torch.no_grad():
+        v0 = val(batch, 0)            # on the seeded weights: token-exact on both sides
     losses = []
     for i in range(steps):
         module.model.train()
@@ -185,8 +188,8 @@ def run_lightning(namespace, module, batch, steps, clip):
         losses.append(float(out["log"]["loss"]))
     module.model.eval()
     with torch.no_grad():
-        v = val(batch, 0)
-    return losses, v
+        v = val(batch, 0)             # after the optimiser steps: weights equal to rounding only
+    return losses, v0, v
 
 
 def stub_jiwer_measures():
@@ -270,11 +273,13 @@ def main():
     ns = dict(FLAGS=types.SimpleNamespace(warmup_step=c["warmup_step"], lr=c["lr"]), torch=torch, np=np,
               jiwer=stub_jiwer_measures())
     batch = M.make_batch(c["cfg"], c["xseed"], c["B"], c["T0"], c["U"])
-    losses, v = run_lightning(ns, mod, batch, c["steps"], c["clip"])
+    losses, v0, v = run_lightning(ns, mod, batch, c["steps"], c["clip"])
     out["lightning_losses"] = np.array(losses)
-    out["lightning_val_loss"], out["lightning_wer"] = np.float64(v["val_loss"]), np.float64(v["wer"])
-    out["lightning_hypothesis"] = np.array(v["hypothesis"])
-    print("cli/lightning.py training_step losses:", losses, "validation:", v["val_loss"], v["wer"], repr(v["hypothesis"])[:60])
+    out["lightning_val0_loss"], out["lightning_val0_wer"] = np.float64(v0["val_loss"]), np.float64(v0["wer"])
+    out["lightning_val0_hypothesis"] = np.array(v0["hypothesis"])
+    out["lightning_val_loss"] = np.float64(v["val_loss"])
+    print("cli/lightning.py training_step losses:", losses, "validation before:", v0["val_loss"], v0["wer"],
+          repr(v0["hypothesis"])[:70], "after:", v["val_loss"])
 
     # ---- cli/train.py train_step (FrontEnd)
     c = FRONT

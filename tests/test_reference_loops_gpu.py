@@ -229,9 +229,12 @@ def test_lightning_module_steps_run_on_the_engine_with_the_external_loss_call(hi
     ns = dict(FLAGS=types.SimpleNamespace(warmup_step=c["warmup_step"], lr=c["lr"]), torch=torch, np=np,
               jiwer=G.stub_jiwer_measures())
     batch = [t.to(DEV) for t in M.make_batch(c["cfg"], c["xseed"], c["B"], c["T0"], c["U"])]   # Lightning moves the batch
-    losses, v = G.run_lightning(ns, mod, batch, c["steps"], c["clip"])
+    losses, v0, v = G.run_lightning(ns, mod, batch, c["steps"], c["clip"])
+    # validation on the seeded weights: greedy tokens are bit-exact, so the decoded text and the WER are identical
+    _close([v0["val_loss"]], [float(GOLD["lightning_val0_loss"])], 1e-5)
+    assert v0["wer"] == float(GOLD["lightning_val0_wer"]) and v0["hypothesis"] == str(GOLD["lightning_val0_hypothesis"])
     _close(losses, GOLD["lightning_losses"], 2e-5)
     assert losses[2] < losses[1] < losses[0]
     assert mod.steps == c["steps"]
+    # ... after three optimiser steps the weights agree to rounding only: the score, not the text, is compared
     _close([v["val_loss"]], [float(GOLD["lightning_val_loss"])], 1e-4)
-    assert v["wer"] == float(GOLD["lightning_wer"]) and v["hypothesis"] == str(GOLD["lightning_hypothesis"])
