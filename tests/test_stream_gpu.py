@@ -292,3 +292,48 @@ def test_non_finite_stream_does_not_fault_and_leaves_the_other_streams_alone(hip
         assert got[keep].tolist() == want[keep].tolist(), c
         assert (got[bad] == 0).all(), (c, got[bad].tolist())     # blank (NUL = 0), never the 0x7fffffff sentinel
     assert any(t != 0 for t in want.flatten().tolist()) or True
+
+
+def test_chunk_plan_notices_replaced_parameters_and_changed_scalars(hip_lib):
+    """the pre-bound chunk plan holds the tensors it was built from alive, so it must not outlive them
+    silently.  A REPLACED Parameter object (what `load_state_dict(assign=True)` or `module.weight = ...` do), a swapped
+    `.data`, a changed dither amplitude and train mode each rebuild the plan: the tokens are those of a fresh decoder on
+    the changed model."""
+    from edgedict_amd.stream import BatchedStreamDecoder, chunk_geometry
+    flags, sd, m = _setup()
+    m.compute_dtype = "bf16"
+    win, hop = chunk_geometry(flags, 2)
+    S = 4
+    g = torch.Generator(device="cpu").manual_seed(7)
+    wave = (0.1 * torch.randn(S, win + 4 * hop, generator=g)).cuda()
+    chunk = lambda c: wave[:, c * hop:c * hop + win].contiguous()      # noqa: E731
+    dec = BatchedStreamDecoder(m, flags, S, dither=0)
+    dec.decode(chunk(0))
+    plan0 = dec._plan
+    assert plan0 is not None and plan0.ok
+    dec.decode(chunk(1))
+    assert dec._plan is plan0                                   # nothing changed: the plan is reused
+    # (1) a replaced Parameter: everything but blank becomes impossible
+    out = m.joint.joint[2]
+    bias = out.bias.detach().clone()
+    bias[0] += 100.0
+    out.bias = torch.nn.Parameter(bias)
+    toks = dec.decode(chunk(2))
+    assert dec._plan is not plan0 and (toks == 0).all()
+    plan1 = dec._plan
+    # (2) `.data` swapped behind the same Parameter object: blank becomes impossible again
+    bias2 = bias.clone()
+    bias2[0] -= 200.0
+    out.bias.data = bias2
+    toks = dec.decode(chunk(3))
+    assert dec._plan is not plan1 and (toks != 0).all()
+    # (3) scalars baked into the bound calls
+    plan2 = dec._plan
+    dec.transform.fbank.dither = 1e-5
+    dec.decode(chunk(3).clone())
+    assert dec._plan is not plan2
+    plan3 = dec._plan
+    m.train()
+    dec.decode(chunk(3).clone())
+    assert dec._plan is not plan3
+    m.eval()
