@@ -15,6 +15,10 @@ bool ed_gemm_nt256_shape_ok(int M, int N, int K);
 int ed_gemm_nt256_launch(const void* A, long long lda, const void* B, long long ldb, void* C,
                          long long ldc, int M, int N, int K, const float* bias1, const float* bias2,
                          hipStream_t s, float* lse_part = nullptr);
+// persistent ring variant of the same product (gemm_nt256r.hip, round 6; EDGEDICT_GEMM_NT256R=0 switches it off)
+bool ed_gemm_nt256r_ok(int M, int N, int K, bool has_bias, int* grid_out = nullptr);
+int ed_gemm_nt256r_launch(const void* A, long long lda, const void* B, long long ldb, void* C, long long ldc, int M,
+                          int N, int K, const float* bias1, const float* bias2, hipStream_t s, float* lse_part);
 // 256 x 128-tile TN kernel for weight gradients (gemm_tn256.hip): P[s][M,N] = sum_{k in slice s} A[k,m] B[k,n],
 // fp32 K-slice partials written once each ("quiet"); the caller sums the `slices` slices
 bool ed_gemm_tn256_ok(const void* A, long long lda, const void* B, long long ldb, int M, int N, int K);

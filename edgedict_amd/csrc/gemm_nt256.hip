@@ -271,6 +271,8 @@ bool ed_gemm_nt256_ok(int M, int N, int K, int accumulate) {
 int ed_gemm_nt256_launch(const void* A, long long lda, const void* B, long long ldb, void* C,
                          long long ldc, int M, int N, int K, const float* bias1, const float* bias2,
                          hipStream_t s, float* lse_part) {
+    if (ed_gemm_nt256r_ok(M, N, K, bias1 || bias2))
+        return ed_gemm_nt256r_launch(A, lda, B, ldb, C, ldc, M, N, K, bias1, bias2, s, lse_part);
     Nt256Args g;
     g.A = (const bf16_t*)A; g.B = (const bf16_t*)B; g.C = (bf16_t*)C;
     g.bias1 = bias1; g.bias2 = bias2;

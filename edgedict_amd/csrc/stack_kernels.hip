@@ -1194,8 +1194,14 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
                     // (vmcnt(0) right after the next slot's issue); the counted waits below are the real rule
                     const unsigned m0v = __builtin_amdgcn_readfirstlane(
                         (unsigned)(size_t)(__attribute__((address_space(3))) void*)(dst + j * 4096));
-                    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2"
-                                     ::"v"(avoff), "s"(m0v), "s"(img + (long long)ks * MT * 1024) : "memory", "m0");
+                    // m0 is saved and restored INSIDE the statement: naming a reserved register as a clobber is undefined
+                    // behaviour for the register allocator (the instruction reads m0 at issue, so the restore may follow
+                    // it at once)
+                    unsigned m0_keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\t"
+                                 "s_mov_b32 m0, %0"
+                                 : "=&s"(m0_keep)
+                                 : "v"(avoff), "s"(m0v), "s"(img + (long long)ks * MT * 1024) : "memory");
                 }
             };
             // (older loads of this wave - the cell operands - only make the counted waits below conservative)

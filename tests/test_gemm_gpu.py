@@ -131,6 +131,71 @@ def test_gemm_nt256_macro_tile_path(hip_lib, M, N, K):
     assert torch.isfinite(out.float()).all()
 
 
+@pytest.mark.parametrize("M,N,K,lse,bias", [
+    (256 * 40, 2048, 640, True, True),          # 320 tiles: some workgroups walk two tiles, all full
+    (256 * 70 + 37, 2048, 640, True, True),     # the logits shape, ragged last row panel, 3 tiles per workgroup
+    (256 * 100 + 5, 640, 2048, False, False),   # the dhid shape: 3 column tiles, the last one ragged (N = 640)
+    (256 * 36, 4096, 128, False, True),         # K = 128: two K tiles per tile, the ring wraps every tile
+    (256 * 80 + 100, 1000, 192, True, True),    # odd number of K tiles (slot parity flips between tiles), ragged N
+    (300, 520, 256, False, True),               # fewer tiles than CUs: one tile per workgroup
+])
+def test_gemm_nt256_ring_kernel_full_output(hip_lib, M, N, K, lse, bias):
+    """The persistent ring kernel (gemm_nt256r.hip): EVERY element of C - and every log-sum-exp partial - against
+    the one-tile-per-workgroup kernel of round 2-5 on the same operands (bit-identical: same MFMA order over K) and
+    against an fp32 product; twice in a row (a stale ring slot or a race would not repeat)."""
+    import os
+    from edgedict_amd import _lib
+    from edgedict_amd.ops import _ll
+    a = _mk((M, K), torch.bfloat16, 41)
+    b = _mk((N, K), torch.bfloat16, 42)
+    bv = torch.randn(N, generator=torch.Generator().manual_seed(6)).cuda() if bias else None
+    slots = (N + 63) // 64
+
+    def run():
+        c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        parts = torch.full((M, slots, 2), float("nan"), device="cuda") if lse else None
+        if lse:
+            _lib.call("gemm_nt_lse", a, _ll(K), b, _ll(K), c, _ll(N), M, N, K, bv, parts)
+        else:
+            # the macro-tile entry behind edgedict_gemm needs >= 512 tiles; the lse entry with a scratch buffer does not
+            scratch = torch.empty(M, slots, 2, device="cuda")
+            _lib.call("gemm_nt_lse", a, _ll(K), b, _ll(K), c, _ll(N), M, N, K, bv, scratch)
+        torch.cuda.synchronize()
+        return c, parts
+
+    old_env = os.environ.get("EDGEDICT_GEMM_NT256R")
+    try:
+        os.environ["EDGEDICT_GEMM_NT256R"] = "1"
+        c1, p1 = run()
+        c2, p2 = run()
+        os.environ["EDGEDICT_GEMM_NT256R"] = "0"
+        c0, p0 = run()
+    finally:
+        if old_env is None:
+            os.environ.pop("EDGEDICT_GEMM_NT256R", None)
+        else:
+            os.environ["EDGEDICT_GEMM_NT256R"] = old_env
+    assert torch.isfinite(c1.float()).all()
+    assert torch.equal(c1.view(torch.int16), c2.view(torch.int16))
+    assert torch.equal(c1.view(torch.int16), c0.view(torch.int16))
+    if lse:
+        assert torch.isfinite(p1).all()
+        assert torch.equal(p1, p2)
+        # same values, same reduction tree; the exponentials go through the same instructions
+        assert torch.allclose(p1, p0, rtol=1e-6, atol=0)
+        mx, sm = p1[..., 0].double(), p1[..., 1].double()
+        got = (mx.max(dim=1).values + torch.log((sm * torch.exp(mx - mx.max(dim=1, keepdim=True).values)).sum(1)))
+        pad = slots * 64 - N
+        cf = c1.double()
+        ref_lse = torch.logsumexp(cf, dim=1)
+        assert (got - ref_lse).abs().max().item() < 1e-4, pad
+    ref = a.float() @ b.float().t()
+    if bias:
+        ref = ref + bv
+    err = (c1.float() - ref).abs()
+    assert (err <= 2.0 ** -7 * ref.abs() + 1e-3 * (K ** 0.5)).all()
+
+
 @pytest.mark.parametrize("M,N,K,split", [(512, 256, 4096, 2), (1024, 240, 5003, 4), (264, 648, 1111, 1),
                                          (2048, 640, 9000, 4)])
 def test_gemm_tn256_weight_gradient_path(hip_lib, M, N, K, split):

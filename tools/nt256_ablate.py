@@ -15,6 +15,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     hid = torch.randn(M, J, device="cuda").bfloat16()
     w2 = (0.05 * torch.randn(V, J, device="cuda")).bfloat16()
     b2 = torch.zeros(V, device="cuda")
+    if os.environ.get("ABLATE_ZERO"):       # zero operands: the data-dependent part of the power draw is gone
+        hid.zero_(); w2.zero_()
     logits = torch.empty(M, V, device="cuda", dtype=torch.bfloat16)
     parts = torch.empty(M, V // 64, 2, device="cuda")
     for K in (J, 2048):
@@ -31,9 +33,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         torch.cuda.synchronize()
         ms = s.elapsed_time(e) / 5
         tiles = ((m + 255) // 256) * (V // 256)
-        print("  dbg %2s  M=%6d K=%4d: %7.3f ms  %6.1f TFLOP/s  %5.1f us per tile-slot (tiles/256 CUs)"
+        mhz = ""
+        if int(os.environ.get("EDGEDICT_NT256_DEBUG", "0")) & 64:
+            st = parts.view(-1)[:1024].view(torch.int64).cpu().view(256, 2).double()
+            mhz = "  shader clock %6.0f MHz (workgroup cycles / 100 MHz ticks)" % (st[:, 0].sum() / st[:, 1].sum() * 100).item()
+        print("  dbg %2s  M=%6d K=%4d: %7.3f ms  %6.1f TFLOP/s  %5.1f us per tile-slot (tiles/256 CUs)%s"
               % (os.environ.get("EDGEDICT_NT256_DEBUG", "0"), m, K, ms, 2.0 * m * V * K / ms / 1e9,
-                 ms * 1e3 / (tiles / 256.0)), flush=True)
+                 ms * 1e3 / (tiles / 256.0), mhz), flush=True)
 else:
     for dbg in sys.argv[1:] or ["0", "1", "2", "3", "11", "4", "15"]:
         env = dict(os.environ, EDGEDICT_NT256_DEBUG=dbg)
