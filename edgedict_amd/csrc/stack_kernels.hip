@@ -1036,6 +1036,9 @@ __global__ __launch_bounds__(256, ED_BWD_OCC) void stack_bwd_kernel(EdBwdLaunch 
 #ifndef ED_SK_ABLATE
 #define ED_SK_ABLATE 0      // timing experiments only (results wrong): 1 no dG stream, 2 no LDS reads / MFMA
 #endif
+#ifndef ED_SK_TAIL
+#define ED_SK_TAIL 0        // timing experiments only (results wrong): 1 no row-form dG stores, 2 the cell operands of the
+#endif                      // first step for every step (no re-request).  profiles/r6_sk_tail.txt: BOTH make the pass slower
 constexpr int SK_GK = ED_SK_GK;             // k-steps per ring slot
 constexpr int SK_SLOT = SK_GK * 4 * 1024;   // 16 KB: 4 k-steps x 4 row tiles x 1 KB
 constexpr int SK_MAXG = 32 / SK_GK;         // ring slots per step at H = 1024
@@ -1360,12 +1363,12 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
         SK_STAMP(4);
         // ---- (7) off the chain: the dG rows the dX / weight-gradient products read (later kernels, ordered by an event
         // behind this launch), the same two chunks; then the next frame's cell operands
-        if (live) {
+        if (live && !(ED_SK_TAIL & 1)) {
             bf16_t* G_t = S.G - (long long)s * B * H4 + (long long)crow * H4 + kc0;
 #pragma unroll
             for (int i = 0; i < 2; ++i) *reinterpret_cast<u32x4_t*>(G_t + i * 16) = v16[i];
         }
-        if (s + 1 < S.nsteps) request_operands(s + 1);
+        if (s + 1 < S.nsteps && !(ED_SK_TAIL & 2)) request_operands(s + 1);
         SK_STAMP(5);
     }
 #undef SK_STAMP
