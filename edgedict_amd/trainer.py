@@ -96,6 +96,50 @@ class TrainEngine:
                                            factor=getattr(flags, "sched_factor", 0.5),
                                            min_lr=getattr(flags, "sched_min_lr", 1e-6))
         self.step_count = 0
+        self._pref = None        # (key, xs, xlen, event): the front-end of the NEXT batch, computed during this step
+
+    # ---- front-end (dither -> log-mel -> frame stacking -> SpecAugment) and its prefetch.  The reference computes the
+    # features of batch n + 1 in DataLoader workers while the GPU trains on batch n (rnnt/dataset.py:102-103, num_workers
+    # in cli/train.py:119-137); here the front-end is a GPU kernel chain of ~0.6 ms at the head of the step, in front of a
+    # recurrence that leaves most of the chip idle for its first launches.  train_step(..., next_batch=(wave, wave_len))
+    # runs the next batch's front-end on the auxiliary stream under this step's encoder forward; the next call finds it.
+    # Every batch's features are computed exactly once, in batch order (same dither seeds, same mask draws as without
+    # the prefetch).
+    def _front_end(self, wave, wave_len):
+        xs, xlen = self.features(wave, wave_len)
+        if self.spec_augment is not None:
+            xs = self.spec_augment(xs, xlen)
+        return xs, xlen
+
+    @staticmethod
+    def _batch_key(wave, wave_len):
+        return (wave.data_ptr(), tuple(wave.shape), wave._version,
+                None if wave_len is None else (wave_len.data_ptr(), wave_len._version))
+
+    def _prefetch(self, wave, wave_len):
+        from . import side
+        cur = torch.cuda.current_stream(self.device)
+        aux = side.stream(self.device)
+        aux.wait_stream(cur)                 # the waveform may have been produced on the current stream
+        with torch.cuda.stream(aux):
+            xs, xlen = self._front_end(wave, wave_len)
+            ev = aux.record_event()
+        wave.record_stream(aux)
+        if wave_len is not None and wave_len.is_cuda:
+            wave_len.record_stream(aux)
+        self._pref = (self._batch_key(wave, wave_len), xs, xlen, ev)
+
+    def _take_prefetched(self, wave, wave_len):
+        pref, self._pref = self._pref, None
+        if pref is None or pref[0] != self._batch_key(wave, wave_len):
+            return None
+        _, xs, xlen, ev = pref
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)
+        xs.record_stream(cur)
+        if torch.is_tensor(xlen) and xlen.is_cuda:
+            xlen.record_stream(cur)
+        return xs, xlen
 
     # ---- checkpoints in the reference's layout (cli/train.py:321-351): {'optim', 'model', 'sched'}
     def save(self, path):
@@ -138,8 +182,10 @@ class TrainEngine:
         if self.sched is not None:
             self.sched.step(val_loss)
 
-    def train_step(self, wave, wave_len, ys, ylen):
+    def train_step(self, wave, wave_len, ys, ylen, next_batch=None):
         """wave f32[B,N] (device), wave_len i32[B] samples (or None), ys i32[B,U], ylen i32[B].
+        next_batch: optional (wave, wave_len) of the batch the NEXT call will be given - its front-end then runs on the
+        auxiliary stream during this step (one slice per step only; a different batch at the next call just discards it).
         Returns the mean loss of the local batch as a device tensor (no host sync)."""
         from . import ops
         ops.mark("step:enter")
@@ -154,9 +200,12 @@ class TrainEngine:
         for s in starts:
             e = min(B, s + sub)
             self.reducer.armed = (s == starts[-1])   # exchange once, after the last accumulation
-            xs, xlen = self.features(wave[s:e], None if wave_len is None else wave_len[s:e])
-            if self.spec_augment is not None:
-                xs = self.spec_augment(xs, xlen)
+            got = self._take_prefetched(wave, wave_len) if len(starts) == 1 else None
+            if got is None:
+                got = self._front_end(wave[s:e], None if wave_len is None else wave_len[s:e])
+            xs, xlen = got
+            if next_batch is not None and len(starts) == 1:
+                self._prefetch(next_batch[0], next_batch[1])
             loss = self.model(xs, ys[s:e], xlen, ylen[s:e])
             loss = loss / len(starts)
             ops.mark("backward:enter")

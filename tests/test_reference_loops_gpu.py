@@ -5,7 +5,8 @@ outputs that travel with the snapshot; /root/reference is not read here).  They 
 ``rnnt.stream`` / ``rnnt.transforms`` / ``rnnt.tokenizer`` imported THROUGH THE ROOT SHIMS, i.e. exactly what a
 maintainer gets with this repository in front of the reference checkout on PYTHONPATH:
 
-  * cli/baseline.py:214-248  Trainer.train_step   3 optimiser steps, torch.optim.Adam, clip_grad_norm_, 2 sub-batches
+  * cli/baseline.py:214-248  Trainer.train_step   3 optimiser steps, torch.optim.Adam, clip_grad_norm_, 2 sub-batches;
+                                                  and 2 steps over the BENCHED path: E6D2 at full size, bf16, wavefront stack
   * cli/baseline.py:273-323  Trainer.evaluate_step / save / load   loss + greedy_decode + decode_plus + WER; checkpoints
   * cli/lightning.py:72-117  ParallelTraining.training_step / validation_step   the EXTERNAL warprnnt_pytorch.RNNTLoss call
   * cli/train.py:223-271     Trainer.train_step   the FrontEnd trainer (conv front-end + length rescaling)
@@ -77,6 +78,40 @@ def test_baseline_trainer_train_step_runs_on_the_engine(hip_lib):
     got, want = G.checksum(model.parameters()), GOLD["baseline_checksum"]
     assert got.shape == want.shape
     assert np.abs(got[:, 0] - want[:, 0]).max() <= 2e-3 * np.abs(want[:, 0]).max()
+
+
+def test_baseline_trainer_drives_the_benched_bf16_path_at_e6d2_size(hip_lib):
+    """the same verbatim cli/baseline.py Trainer.train_step, but over the path bench.py times - the
+    E6D2 architecture at full width and depth (6 x 1024 + 2 x 256, T0 = 401, U = 64; the committed reference golden's
+    weights and batch), bf16, so the call goes through the wavefront encoder stack (launch-persistent forward, split-K
+    BPTT: asserted through last_mode), the packed lattice with the fused log-sum-exp partials and the in-place
+    gradient accumulation that bypasses autograd - with torch.optim.Adam stepping the module's own parameters.
+    Step 1's loss is the reference's (golden, 1e-3 relative: the north-star bound; bf16 sits at ~1e-4), step 2's is
+    lower, every parameter received a finite gradient and moved."""
+    from oracle.make_golden import CASES
+    from edgedict_amd import encoder_stack
+    models, _, _, _ = _shims()
+    cfg, B, T0, U, seed = CASES["E6D2"]
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "transducer_E6D2.npz"))
+    model = models.Transducer(enc_dropout=0.0, dec_dropout=0.0, output_loss=True, **cfg)
+    model.load_state_dict(M.make_state_dict(cfg, seed), strict=True)
+    model = model.to(DEV).train()
+    model.compute_dtype = "bf16"
+    before = [p.detach().clone() for p in model.parameters()]
+    tr = types.SimpleNamespace(model=model, optim=torch.optim.Adam(model.parameters(), lr=1e-4))
+    flags = types.SimpleNamespace(batch_size=B, sub_batch_size=B, multi_gpu=False, apex=False, gradclip=None)
+    ns = dict(FLAGS=flags, device=torch.device(DEV), torch=torch, amp=None)
+    batch = M.make_batch(cfg, seed + 1, B, T0, U)
+    losses = G.run_train_steps("baseline_train_step", ns, tr, [batch, batch])
+    torch.cuda.synchronize()
+    encoder_stack.check_wsr_error()
+    assert encoder_stack.last_mode(False) == (1, encoder_stack.CHUNK)        # launch-persistent forward
+    assert encoder_stack.last_mode(True) == (2, encoder_stack.CHUNK)         # split-K weights-stationary BPTT
+    _close(losses[:1], [float(gold["loss_mean"])], 1e-3)
+    assert losses[1] < losses[0]
+    for (n, p), p0 in zip(model.named_parameters(), before):
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+        assert not torch.equal(p.detach(), p0), n
 
 
 def test_frontend_trainer_train_step_runs_on_the_engine(hip_lib):

@@ -114,3 +114,53 @@ def test_checkpoint_round_trip_in_the_reference_layout(hip_lib, tmp_path):
     assert la.item() == lb.item()
     assert (a.flat.data - b.flat.data).abs().max().item() <= 1e-7
     assert abs(a.optim.param_groups[0]["lr"] - fl.lr * 3 / 4) < 1e-12   # warm-up: step 3 of 4
+
+
+def test_front_end_prefetch_gives_the_same_loss_sequence(hip_lib):
+    """train_step(..., next_batch=...) computes the next batch's front-end (dither -> log-mel -> stacking -> SpecAugment) on
+    the auxiliary stream under this step's encoder forward (the reference's DataLoader workers do the same on the CPU,
+    rnnt/dataset.py:102-103): the losses of 4 steps over 3 different batches - dither and SpecAugment ON, so the features
+    depend on the per-call seeds and mask draws - are bit-identical to the serial order; a next_batch that is NOT the
+    batch of the next call is discarded, and the parameters after the steps agree."""
+    from edgedict_amd.trainer import TrainEngine
+
+    def run(prefetch):
+        fl = _flags()
+        fl.dither = 1e-3
+        fl.T_mask, fl.T_num_mask, fl.F_mask, fl.F_num_mask = 5, 2, 6, 2
+        torch.manual_seed(3)
+        eng = TrainEngine(fl, vocab_size=40, device="cuda", compute_dtype="bf16")
+        g = torch.Generator(device="cpu").manual_seed(11)
+        batches = []
+        for i in range(3):
+            wave = (0.1 * torch.randn(5, 16000, generator=g)).cuda()
+            wlen = torch.tensor([16000, 15000 - 500 * i, 12000, 16000, 9000 + 300 * i], dtype=torch.int32)
+            ys = torch.randint(4, 40, (5, 7), generator=g, dtype=torch.int32).cuda()
+            ylen = torch.tensor([7, 5, 6, 3, 7], dtype=torch.int32)
+            batches.append((wave, wlen, ys, ylen))
+        order = [0, 1, 2, 1]
+        losses = []
+        import random
+        random.seed(5)
+        torch.manual_seed(17)          # the SpecAugment draws
+        for i, b in enumerate(order):
+            nxt = None
+            if prefetch and i + 1 < len(order):
+                # the third call announces the WRONG batch: its prefetched features must be thrown away
+                nb = batches[order[i + 1]] if i != 2 else batches[0]
+                nxt = (nb[0], nb[1])
+            losses.append(eng.train_step(*batches[b], next_batch=nxt))
+        torch.cuda.synchronize()
+        eng.check()
+        out = [x.item() for x in losses], eng.flat.data.clone()
+        eng.close()
+        return out
+
+    serial, p_serial = run(False)
+    pre, p_pre = run(True)
+    assert all(x == x and x > 0 for x in serial)
+    # steps 0-2: every batch's front-end ran once, in batch order -> identical features -> identical losses
+    assert pre[:3] == serial[:3], (pre, serial)
+    # step 3: the discarded prefetch consumed one dither seed / one mask draw more - same batch, another augmentation
+    assert abs(pre[3] - serial[3]) / serial[3] < 0.2
+    assert torch.isfinite(p_pre).all()

@@ -34,19 +34,20 @@ def child(variant):
     dev = torch.device("cuda", 0)
     eng = TrainEngine(flags, device=dev, compute_dtype="bf16")
     batch = bench.synth_batch(flags, 64, 15.0, 64, 1000, dev)
+    nxt = None if variant == "serial front-end" else (batch[0], batch[1])      # bench.py prefetches the next front-end
     for _ in range(4):
-        eng.train_step(*batch)
+        eng.train_step(*batch, next_batch=nxt)
     torch.cuda.synchronize()
     import time
     t0 = time.perf_counter()
     for _ in range(10):
-        eng.train_step(*batch)
+        eng.train_step(*batch, next_batch=nxt)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 100
     lib.edgedict_stack_time_launches(1)
     ops.MARKS = []
     for _ in range(2):
-        eng.train_step(*batch)
+        eng.train_step(*batch, next_batch=nxt)
     torch.cuda.synchronize()
     marks, ops.MARKS = ops.MARKS, None
     print("== %s: %.2f ms per step (10 un-stamped steps)" % (variant, ms))
@@ -77,7 +78,7 @@ if __name__ == "__main__":
         child(sys.argv[1])
     else:
         print(__doc__.split("usage:")[0])
-        for variant, env in (("default", {}), ("stack weight grads at end", {"EDGEDICT_STACK_FLAGS": "2"}),
+        for variant, env in (("default", {}), ("serial front-end", {}), ("stack weight grads at end", {"EDGEDICT_STACK_FLAGS": "2"}),
                              ("nodefer", {}), ("forward hand-off through arrival counters (EDGEDICT_LPW_POLL=0)", {"EDGEDICT_LPW_POLL": "0"}),
                              ("forward one launch per step (EDGEDICT_STACK_LPW=0)", {"EDGEDICT_STACK_LPW": "0"})):
             e = dict(os.environ)
