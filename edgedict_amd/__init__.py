@@ -7,5 +7,7 @@ import os as _os
 # before the HIP runtime initialises, i.e. before the first device call of the process.
 _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
-# EDGEDICT_POISON=1 (debug): uninitialised allocations are filled with NaN / 0xA5 (see _poison.py)
-from . import _poison as _poison  # noqa: E402,F401
+# EDGEDICT_POISON=1 (debug): uninitialised allocations are filled with NaN / 0xA5 (see _poison.py); the module is only
+# imported - and torch's factory functions only wrapped - when the switch is on
+if _os.environ.get("EDGEDICT_POISON", "0") == "1":
+    from . import _poison as _poison  # noqa: E402,F401

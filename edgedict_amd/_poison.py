@@ -39,7 +39,10 @@ def install():
     def p_empty(*a, **k):
         # torch.set_default_device works through a function mode that recognises the ORIGINAL factory functions: behind
         # this wrapper it would no longer see `torch.empty`, so the default device is passed on explicitly
-        if k.get("device") is None:          # (nn.Embedding & co. pass device=None explicitly)
+        # (only where nothing else already fixes the placement: `out=` carries its own device, pinned staging buffers
+        # are host memory by definition; torch < 2.3 has no get_default_device)
+        if (k.get("device") is None and k.get("out") is None and not k.get("pin_memory")
+                and hasattr(torch, "get_default_device")):          # (nn.Embedding & co. pass device=None explicitly)
             k["device"] = torch.get_default_device()
         return _fill(empty(*a, **k))
 

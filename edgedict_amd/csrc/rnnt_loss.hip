@@ -191,12 +191,13 @@ __device__ __forceinline__ double log_add64(double a, double b) {
     const double m = fmax(a, b);
     if (m == -(double)INFINITY) return m;
     const float d = (float)(fmin(a, b) - m);  // <= 0, may be -inf
-    // 1 + x rounds to 1 below x ~ 6e-8 and loses x's low bits long before: for small x the series x - x^2 / 2
-    // (error < x^3 / 3 = 3e-13 at the switch) keeps the term that `__logf(1.f + x)` drops - over a chain of T + U
-    // log-adds the dropped terms were a one-sided bias (bounded by tests/test_rnnt_loss_gpu.py on a
-    // 1000 x 201 lattice)
+    // 1 + x rounds to 1 below x ~ 6e-8 and carries 6e-8 of absolute rounding error wherever it is formed: a relative
+    // error of 6e-4 in the correction term at x = 1e-4, 6e-6 at 1e-2.  Below 1e-2 the series x - x^2 / 2 + x^3 / 3
+    // (truncation < x^4 / 4 = 2.5e-9 at the switch, where 1.f + x is already off by 6e-8) keeps what
+    // `__logf(1.f + x)` drops - over a chain of T + U log-adds the dropped terms were a one-sided bias (ADVICE r4 / r5;
+    // bounded by tests/test_rnnt_loss_gpu.py on a 1000 x 201 lattice)
     const float x = __expf(d);
-    const float c = x < 1e-4f ? x - 0.5f * x * x : __logf(1.f + x);
+    const float c = x < 1e-2f ? x * (1.f - x * (0.5f - x * (1.f / 3.f))) : __logf(1.f + x);
     return m + (double)c;
 }
 

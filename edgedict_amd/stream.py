@@ -83,7 +83,9 @@ class _ChunkPlan:
                 and 0 < T0 < config.STACK_MIN_FRAMES and tr.out_dtype == torch.float32
                 and S <= (config.STREAM_STEP_MAX_ROWS_SHORT if T0 <= 2 else config.STREAM_STEP_MAX_ROWS)
                 and lstm.hidden_size % 32 == 0 and I0 % 8 == 0
-                and (getattr(lstm, "dropout", 0) == 0 or not m.training)):    # (train mode + dropout: the module path applies it)
+                # (train mode + dropout: the module path applies it.  Encoder.forward decides from the ENCODER's own flags,
+                # which differ from the Transducer's after m.eval(); m.encoder.train() or with frozen sub-modules)
+                and (getattr(lstm, "dropout", 0) == 0 or not (m.training or enc.training or lstm.training))):
             return
         dev = frames.device
         lib = _lib.load()
@@ -171,7 +173,8 @@ class _ChunkPlan:
         dec, fb = self.dec, self.dec.transform.fbank
         return (config.param_epoch(), sum(p._version for p in self.params),
                 hash(tuple(p.data_ptr() for p in self.params)),
-                all(d.get(n) is p for d, n, p in self.slots), dec.model.training,
+                all(d.get(n) is p for d, n, p in self.slots),
+                (dec.model.training, dec.model.encoder.training, dec.model.encoder.lstm.training),
                 float(fb.dither), int(dec.unk_id), int(dec.model.blank))
 
     def valid(self, frames):
@@ -254,6 +257,22 @@ class BatchedStreamDecoder(StreamTransducerDecoder):
         self.state.dec_out[m] = fresh.dec_out[m]
         self.state.h[:, m] = fresh.h[:, m]
         self.state.c[:, m] = fresh.c[:, m]
+
+    @torch.no_grad()
+    def nonfinite_streams(self):
+        """bool [S] (device): streams whose carried state - encoder (h, c), prediction network (h, c), its projected
+        output - holds a NaN or Inf.  The search frames never emit an out-of-range id: a row of logits without one
+        comparable value emits blank, and a row with SOME NaNs picks its best finite logit (torch.argmax, which the
+        reference's loop uses - rnnt/stream.py:100-103 -, would return the first NaN's index instead).  A stream that has
+        gone non-finite therefore keeps producing plausible-looking tokens from poisoned state; this is the caller's
+        signal - one reduction over the states, no host synchronisation until the result is read - e.g. every few
+        hundred chunks: ``bad = dec.nonfinite_streams(); dec.reset(bad)``."""
+        bad = ~torch.isfinite(self.enc_h).all(dim=2).all(dim=0)
+        bad |= ~torch.isfinite(self.enc_c).all(dim=2).all(dim=0)
+        bad |= ~torch.isfinite(self.state.h).all(dim=2).all(dim=0)
+        bad |= ~torch.isfinite(self.state.c).all(dim=2).all(dim=0)
+        bad |= ~torch.isfinite(self.state.dec_out.float()).all(dim=-1).reshape(self.S, -1).all(dim=1)
+        return bad
 
     @torch.no_grad()
     def decode(self, frames):

@@ -68,11 +68,13 @@ def build(verbose=True):
     for name, (rel, cls, names) in PIECES.items():
         path = os.path.join(REF, rel)
         code, lines = _lift(path, cls, names)
+        blob = marshal.dumps(code)
         with open(os.path.join(OUT, name + ".bin"), "wb") as f:
-            marshal.dump(code, f)
+            f.write(blob)
         manifest["pieces"][name] = {
             "file": rel, "class": cls, "names": names, "lines": list(lines),
-            "sha256_of_reference_file": hashlib.sha256(open(path, "rb").read()).hexdigest()}
+            "sha256_of_reference_file": hashlib.sha256(open(path, "rb").read()).hexdigest(),
+            "sha256_of_bin": hashlib.sha256(blob).hexdigest()}
     with open(os.path.join(OUT, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1)
     if verbose:
@@ -87,15 +89,23 @@ def available():
     except OSError:
         return False
     return (man.get("python") == list(sys.version_info[:3])
-            and all(os.path.exists(os.path.join(OUT, n + ".bin")) for n in PIECES))
+            and all(os.path.exists(os.path.join(OUT, n + ".bin")) and "sha256_of_bin" in man.get("pieces", {}).get(n, {})
+                    for n in PIECES))
 
 
 def load(name, namespace):
     """Execute piece ``name`` in ``namespace`` (a dict that already holds what the reference module would have
     imported) and return the namespace: the lifted functions / classes are then its entries."""
     with open(os.path.join(OUT, name + ".bin"), "rb") as f:
-        code = marshal.load(f)
-    exec(code, namespace)
+        blob = f.read()
+    # the blobs are untracked build outputs: only what THIS build wrote (manifest digest) is unmarshalled and executed
+    man = json.load(open(os.path.join(OUT, "manifest.json")))
+    want = man["pieces"][name]["sha256_of_bin"]
+    got = hashlib.sha256(blob).hexdigest()
+    if got != want:
+        raise RuntimeError("oracle/_ref/%s.bin does not match its manifest digest (%s != %s): rebuild with "
+                           "python oracle/ref_lift.py" % (name, got[:12], want[:12]))
+    exec(marshal.loads(blob), namespace)
     return namespace
 
 

@@ -40,6 +40,8 @@ DEV = "cuda:0"
 @pytest.fixture(autouse=True)
 def _need_compiled_loops():
     if not ref_lift.available():
+        # EDGEDICT_REQUIRE_REF_LOOPS=1 (set it on a GPU box that is supposed to carry oracle/_ref) turns the skip into a failure
+        assert os.environ.get("EDGEDICT_REQUIRE_REF_LOOPS", "0") != "1", "oracle/_ref is missing or stale on this box"
         pytest.skip("oracle/_ref is not built (python oracle/ref_lift.py where /root/reference exists; "
                     "__graft_entry__.build() does it)")
 

@@ -292,6 +292,11 @@ def test_non_finite_stream_does_not_fault_and_leaves_the_other_streams_alone(hip
         assert got[keep].tolist() == want[keep].tolist(), c
         assert (got[bad] == 0).all(), (c, got[bad].tolist())     # blank (NUL = 0), never the 0x7fffffff sentinel
     assert any(t != 0 for t in want.flatten().tolist()) or True
+    # the caller's signal - the poisoned stream (and only it) is reported, and a reset of those streams clears it
+    assert dirty.nonfinite_streams().cpu().tolist() == [s == bad for s in range(S)]
+    assert not clean.nonfinite_streams().any()
+    dirty.reset(dirty.nonfinite_streams())
+    assert not dirty.nonfinite_streams().any()
 
 
 def test_chunk_plan_notices_replaced_parameters_and_changed_scalars(hip_lib):
