@@ -653,7 +653,9 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
                 ED_CHECK_ARG(queued[l][k], "encoder_stack: schedule violated (layer %d chunk %d)", l, k);
                 if (!soft) ED_TRY(st.wait(st.R, Eg[l][k]));
             }
-            const int t1 = min(t + nsub, min(g[l].T, (k + 1) * g[l].cf));    // never across a chunk boundary
+            // (never across a chunk boundary.  Letting a single left-over frame - T = 401 = 25 x 16 + 1 - ride along, as the
+            // BPTT does, moves the parity of the drain and costs a launch here: 36 instead of 35 at E6D2, dry run)
+            const int t1 = min(t + nsub, min(g[l].T, (k + 1) * g[l].cf));
             EdLpwSlot& sl = Lc.slot[Lc.nslot];
             sl.G = bptr(y.G) + (long long)t * B * 4 * H;
             sl.img = bptr(ws + wl.himg[l]);
@@ -1400,7 +1402,10 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                     if (next_t[j] > 0 && next_t[j] < g[j].T) m_min = min(m_min, g[j].m);
                 if (!Pace::allows(w, l, g[l].m, m_min)) continue;
                 if (opens && !soft) ED_TRY(st.wait(st.R, Eb[l][k]));
-                const int t_end = max(k * g[l].cf, t - sk_ns + 1);      // last (lowest) frame of this macro-step
+                int t_end = max(k * g[l].cf, t - sk_ns + 1);            // last (lowest) frame of this macro-step
+                // a single left-over frame (T = 401 = 25 x 16 + 1 at E6D2) rides along: as a launch of its own it cost the
+                // layer - and layer 0 below it, the critical path - a whole launch of the wavefront (37 -> 36 launches)
+                if (t_end - k * g[l].cf == 1) t_end = k * g[l].cf;
                 EdSkSlot& ss = Ls.slot[Ls.nslot++];
                 ss.G = bptr(y.G) + (long long)t * B * 4 * H;
                 ss.img = bptr(ws + wl.gimg[l]);

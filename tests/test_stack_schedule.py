@@ -196,9 +196,14 @@ def test_launch_persistent_schedule_invariants_on_random_geometries(T0, reductio
 def test_e6d2_split_k_bptt_schedule():
     # 64 x H=1024: 64 workgroups per layer (16 unit blocks x 4 K quarters), at most 4 layers per launch
     n, longest = _check_sk(401, [1, 2, 1, 1, 1, 1], 12, 12, H=1024, B=64)
-    assert longest == 12 and n <= 50
+    assert longest in (12, 13) and n <= 50
     n6, longest6 = _check_sk(401, [1, 2, 1, 1, 1, 1], 12, 6, H=1024, B=64)
-    assert longest6 == 6 and n6 <= 90
+    assert longest6 in (6, 7) and n6 <= 90
+    # the benched default: chunks of 16 output frames, a chunk per launch.  Layers 0 and 1 have 401 = 25 x 16 + 1 frames:
+    # the left-over frame rides along with the first launch of its chunk (17 steps) instead of costing the layer - and the
+    # critical path below it - a launch of its own (37 launches before round 6)
+    n16, longest16 = _check_sk(401, [1, 2, 1, 1, 1, 1], 16, 16, H=1024, B=64)
+    assert longest16 == 17 and n16 == 36
 
 
 @settings(max_examples=60, deadline=None, derandomize=True)
@@ -208,4 +213,4 @@ def test_split_k_bptt_schedule_invariants_on_random_geometries(T0, reductions, c
     if int(np.prod(reductions)) > 4:
         reductions = [1 if i > 1 else r for i, r in enumerate(reductions)]
     n, longest = _check_sk(T0, reductions, chunk, nsub)
-    assert longest <= nsub
+    assert longest <= nsub + 1          # (+ 1: a single left-over frame of a chunk rides along with the launch before)
