@@ -536,8 +536,12 @@ def main():
             tiles = ((rows + 127) // 128) * ((V + 127) // 128)
             # the summaries label GEMM launches by grid threads / 256; this kernel has 512-thread workgroups
             tiles256 = 2 * ((rows + 255) // 256) * ((V + 255) // 256)
-            ent = next((v for k, v in pmc.items()
-                        if k.startswith("gemm_nt256_kernel") and k.endswith("[tiles=%d]" % tiles256)), None)
+            # round 6: the persistent ring kernel (gemm_nt256r.hip; <true> = with the fused log-sum-exp partials, i.e. the
+            # logits product; its grid is the CU count, not the tile count)
+            ent = next((v for k, v in pmc.items() if k.startswith("gemm_nt256r_kernel<true>")), None)
+            if ent is None:
+                ent = next((v for k, v in pmc.items()
+                            if k.startswith("gemm_nt256_kernel") and k.endswith("[tiles=%d]" % tiles256)), None)
             if ent is None:
                 ent = next((v for k, v in pmc.items() if k.startswith("gemm_nt256_kernel")), None)
             if ent:
@@ -661,9 +665,9 @@ def main():
             },
             "roofline": None,        # filled below: the dominant kernel
             "roofline_mfma": {
-                "kernel": "gemm_nt256_kernel (own: bf16 NT, 256x256 tiles, half-tile DMA pipeline, log-sum-exp "
-                          "partials fused in the epilogue) joint logits [%d x %d x %d] (packed lattice: %d of "
-                          "%d dense cells)" % (rows, V, J, rows, args.batch * Tp * U1),
+                "kernel": "gemm_nt256r_kernel (own: bf16 NT, persistent 256x256 tiles, 8-slot LDS-DMA operand ring, "
+                          "log-sum-exp partials + C stores straight from the accumulators) joint logits [%d x %d x %d] "
+                          "(packed lattice: %d of %d dense cells)" % (rows, V, J, rows, args.batch * Tp * U1),
                 "bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                 "frac": achieved / peak, "traffic": traffic,
                 "traffic_source": "profiles/pmc_latest.json - per-launch HBM bytes of this kernel from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over the same bench command (profiles/collect.sh, committed with the build); NOT re-measured in this run",
