@@ -24,6 +24,8 @@
 //   (K = 4H, one gate per wave, operand W_hh^T), then the cell backward, writing the
 //   pre-activation gradients in place over G[:, t] and carrying dc in a [B,H] fp32 buffer.
 // After the sweep G holds dG for every t, and dX / dW_ih / dW_hh / db are plain GEMMs / column sums.
+#include <stdlib.h>
+
 #include "common.hpp"
 #include "lstm_fast.hpp"
 
@@ -186,6 +188,170 @@ __global__ __launch_bounds__(256) void lstm_step_fwd(
     }
 }
 
+// =====================================================================================
+// fp32, launch-persistent (round 6): ALL T steps of one layer in ONE launch.
+//
+// The exact-f32 mode is the token-exact mode (greedy / stream / beam tokens equal to the reference's), and its encoder
+// is a chain of T launches of lstm_step_fwd<float> per layer: 20.6 us per layer-step at E6D2, of which ~3 us are the
+// dependent launch boundary and ~6 us the re-fetch of the workgroup's 64 KB W_hh slice, in front of a gather of the
+// 256 KB of fp32 h_{t-1} that every workgroup needs anyway.  Here a workgroup owns its (4 units x 4 gates, 64 rows)
+// for the whole sequence - the structure of the bf16 stack's stack_fwd_lpw_kernel without the wavefront around it:
+//   * its W_hh slice (16 rows x H fp32) stays in NCH float4 registers per lane (wave w: k quarter w);
+//   * c_t of a thread's (row, unit) stays in a register;
+//   * h_t goes to Hprev[:, t + 1] with write-through 4-byte stores; readers gather Hprev[:, t] with L2-coherent loads
+//     and recognise what is not written yet by the fill pattern (all ones: a NaN no h = o * tanh(c) can be) - the
+//     host fills Hprev before the launch; every dword is checked (the four units of a row's 16 bytes come from four
+//     threads), a wave that came too early sleeps and gathers again (bounded: give-up word of the encoder stack);
+//   * the arithmetic is lstm_step_fwd<float>'s, instruction for instruction: the same K quarters per wave, the same
+//     chunk order inside f32_product16, the same order of the four partial sums, the same cell math - outputs, saved
+//     gates and states are BIT-IDENTICAL to the per-step kernels (tests/test_lstm_gpu.py), so the token-exactness
+//     pinned on the reference's goldens carries over.
+// Needs every workgroup resident at once ((H / 4) x ceil(B / 64) <= CUs) and H in {256, 512, 1024}; else the per-step
+// kernels run.  EDGEDICT_LSTM_F32_LPW=0 switches it off.
+// =====================================================================================
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4_lstm_t;
+
+template <int NCH>        // 16-k chunks per wave quarter: H = 64 NCH
+__global__ __launch_bounds__(256, 1) void lstm_fwd_lpw_f32(
+    float* __restrict__ G, float* __restrict__ Hprev, float* __restrict__ Y, float* __restrict__ Cst,
+    const float* __restrict__ Whh, const float* __restrict__ c0, float* __restrict__ hN, float* __restrict__ cN,
+    int B, int Tn, unsigned* err) {
+    constexpr int H = 64 * NCH;
+    constexpr int CHK = NCH < 8 ? NCH : 8;          // chunks requested together (f32_product16<4>: 8)
+    __shared__ float red[4][64][17];
+    __shared__ unsigned bail_s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j0 = blockIdx.x * UNITS;
+    const int b0 = blockIdx.y * 64;
+    const int kbeg = wave * (H / 4);
+    const int n = lane & 15, ko = (lane >> 4) * 4;
+    if (tid == 0) bail_s = 0u;
+
+    // ---- stationary weights: W_hh row gate*H + j0 + unit, this wave's K quarter
+    float4 wq[NCH];
+    {
+        const float* wptr = Whh + (long long)((n / UNITS) * H + j0 + (n % UNITS)) * H + kbeg + ko;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) wq[c] = *reinterpret_cast<const float4*>(wptr + 16 * c);
+    }
+    // ---- this lane's rows of h (fragment rows 16 m + n), as byte offsets into Hprev at frame 0
+    // (readfirstlane returns a SIGNED int: through unsigned temporaries, or a low word with bit 31 set sign-extends
+    // into the high word of the base)
+    const unsigned long long hp = (unsigned long long)Hprev;
+    const unsigned hp_lo = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)hp);
+    const unsigned hp_hi = (unsigned)__builtin_amdgcn_readfirstlane((unsigned)(hp >> 32));
+    const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(((unsigned long long)hp_hi << 32) | (unsigned long long)hp_lo), 0,
+        (int)((unsigned)B * (unsigned)Tn * (unsigned)H * 4u), 0x00020000);
+    unsigned aoff[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+        aoff[m] = (unsigned)(((long long)min(b0 + 16 * m + n, B - 1) * Tn * H + kbeg + ko) * 4);
+
+    // ---- this thread's cell: row bl, unit u
+    const int bl = tid / UNITS, u = tid % UNITS;
+    const bool live = b0 + bl < B;
+    // (rows past the batch compute on a clamped row and store nothing: every address a load could be speculated to
+    // stays inside the tensors)
+    const int b = min(b0 + bl, B - 1), j = j0 + u;
+    float cprev = c0 ? c0[(long long)b * H + j] : 0.f;
+    float pre_g[4];
+    {
+        const float* grow = G + ((long long)b * Tn) * 4 * H;
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate) pre_g[gate] = grow[gate * H + j];
+    }
+    __syncthreads();
+
+    for (int t = 0; t < Tn; ++t) {
+        f32x4_t acc[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        const unsigned toff = (unsigned)t * (unsigned)(H * 4);
+        // CHK chunks are requested together, looked at (all ones = a peer has not written it yet: sleep, request again),
+        // then multiplied - f32_product16's batches and MFMA order.  (Requesting all NCH chunks at once and validating
+        // chunk by chunk in front of its MFMAs - 256 more registers, which one wave per SIMD has - was measured SLOWER:
+        // encoder 30.1 vs 28.2 ms; the gather runs at the per-CU fetch rate either way.)
+#pragma unroll
+        for (int c0i = 0; c0i < NCH; c0i += CHK) {
+            float4 aq[CHK][4];
+            unsigned tries = 0;
+            for (;;) {
+                unsigned worst = 0u;
+#pragma unroll
+                for (int c = 0; c < CHK; ++c)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const u32x4_lstm_t v = __builtin_amdgcn_raw_buffer_load_b128(
+                            rh, aoff[m] + (unsigned)((c0i + c) * 64), toff, 16);
+                        aq[c][m] = *reinterpret_cast<const float4*>(&v);
+                        worst = max(worst, max(max(v[0], v[1]), max(v[2], v[3])));
+                    }
+                if (t == 0 || !__any(worst == 0xffffffffu)) break;     // (frame 0 was written before the launch)
+                __builtin_amdgcn_s_sleep(2);
+                if (++tries > (1u << 20)) {                            // a peer never became resident
+                    if (err) atomicCAS(err, 0u, 710u);
+                    bail_s = 1u;
+                    break;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CHK; ++c) {
+                const float bv[4] = {wq[c0i + c].x, wq[c0i + c].y, wq[c0i + c].z, wq[c0i + c].w};
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) {
+                        const float av[4] = {aq[c][m].x, aq[c][m].y, aq[c][m].z, aq[c][m].w};
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj], bv[jj], acc[m], 0, 0, 0);
+                    }
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][m * 16 + (lane >> 4) * 4 + r][lane & 15] = acc[m][r];
+        __syncthreads();
+        if (bail_s) break;
+        {
+            float pre[4];
+#pragma unroll
+            for (int gate = 0; gate < 4; ++gate) {
+                const int col = gate * UNITS + u;
+                pre[gate] = red[0][bl][col] + red[1][bl][col] + red[2][bl][col] + red[3][bl][col] + pre_g[gate];
+            }
+            const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
+            // (the contraction lstm_step_fwd<float> compiles `fg * cprev + ig * gg` to - fg * cprev rounded, then one
+            // fma - spelled out: left to the compiler this kernel got the other pairing, one ulp apart)
+            const float fc = fg * cprev;
+            const float c = __builtin_fmaf(ig, gg, fc);
+            const float h = og * tanhf(c);
+            cprev = c;
+            const long long row = (long long)b * Tn + t;
+            // publish first: h_t is what the peers wait for
+            if (live && t + 1 < Tn)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h), rh, (unsigned)(((row + 1) * H + j) * 4), 0, 16);
+            float* grow = G + row * 4 * H;
+            if (live) {
+                grow[0 * H + j] = ig;
+                grow[1 * H + j] = fg;
+                grow[2 * H + j] = gg;
+                grow[3 * H + j] = og;
+                Cst[row * H + j] = c;
+                Y[row * H + j] = h;
+            }
+            if (t + 1 < Tn) {
+#pragma unroll
+                for (int gate = 0; gate < 4; ++gate) pre_g[gate] = grow[4 * H + gate * H + j];      // next frame's pre-activations
+            } else if (live) {
+                if (hN) hN[(long long)b * H + j] = h;
+                if (cN) cN[(long long)b * H + j] = c;
+            }
+        }
+        __syncthreads();          // red is rewritten by the next step
+    }
+}
+
 // Hprev[:, 0, :] <- h0 (or zeros)
 template <typename T>
 __global__ void lstm_init_hprev(T* __restrict__ Hprev, const float* __restrict__ h0, int B, int Tn,
@@ -280,9 +446,48 @@ __global__ void fill_f32(float* p, long long n, float v) {
         p[i] = v;
 }
 
+// the launch-persistent fp32 forward covers this geometry (see lstm_fwd_lpw_f32)
+bool f32_lpw_ok(int B, int Tn, int H) {
+    const char* e = getenv("EDGEDICT_LSTM_F32_LPW");        // read per call: tests compare both paths in one process
+    if (e && atoi(e) == 0) return false;
+    if (!(H == 256 || H == 512 || H == 1024) || Tn < 2) return false;
+    if ((unsigned long long)B * Tn * H * 4ull >= (1ull << 32)) return false;      // one 32-bit buffer descriptor
+    static const int n_cu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
+        return n;
+    }();
+    return (long long)(H / UNITS) * ((B + 63) / 64) <= n_cu;      // every workgroup resident at once
+}
+
+extern "C" void* edgedict_stack_error_words(int host);      // encoder_stack.hip: the give-up words of the bounded waits
+
 template <typename T>
 int run_fwd(void* G, void* Hprev, void* Y, float* Cst, const void* Whh, const float* h0,
             const float* c0, float* hN, float* cN, int B, int Tn, int H, hipStream_t s) {
+    if constexpr (sizeof(T) == 4) {
+        if (f32_lpw_ok(B, Tn, H)) {
+            // frames 1 .. T-1 of Hprev: "not written yet" (all ones); frame 0: h0
+            ED_CHECK_HIP(hipMemsetAsync(Hprev, 0xff, (size_t)B * Tn * H * sizeof(float), s));
+            hipLaunchKernelGGL(lstm_init_hprev<float>, dim3(ed_grid_for((long long)B * H, 256)), dim3(256), 0, s,
+                               (float*)Hprev, h0, B, Tn, H);
+            ED_CHECK_LAUNCH("lstm_init_hprev");
+            unsigned* err = reinterpret_cast<unsigned*>(edgedict_stack_error_words(0));
+            if (err) err += 2;                 // the step kernels' word (encoder_stack.py reports code 7xx as a forward wait)
+            const dim3 grid(H / UNITS, (B + 63) / 64);
+            if (H == 1024)
+                hipLaunchKernelGGL(lstm_fwd_lpw_f32<16>, grid, dim3(256), 0, s, (float*)G, (float*)Hprev, (float*)Y, Cst,
+                                   (const float*)Whh, c0, hN, cN, B, Tn, err);
+            else if (H == 512)
+                hipLaunchKernelGGL(lstm_fwd_lpw_f32<8>, grid, dim3(256), 0, s, (float*)G, (float*)Hprev, (float*)Y, Cst,
+                                   (const float*)Whh, c0, hN, cN, B, Tn, err);
+            else
+                hipLaunchKernelGGL(lstm_fwd_lpw_f32<4>, grid, dim3(256), 0, s, (float*)G, (float*)Hprev, (float*)Y, Cst,
+                                   (const float*)Whh, c0, hN, cN, B, Tn, err);
+            ED_CHECK_LAUNCH("lstm_fwd_lpw_f32");
+            return ED_OK;
+        }
+    }
     hipLaunchKernelGGL(lstm_init_hprev<T>, dim3(ed_grid_for((long long)B * H, 256)), dim3(256), 0,
                        s, (T*)Hprev, h0, B, Tn, H);
     ED_CHECK_LAUNCH("lstm_init_hprev");

@@ -81,3 +81,43 @@ def test_bf16_fast_equals_generic_closely(hip_lib):
     gen, _ = _run(torch.bfloat16, 64, 9, 256, 512, True, seed=3)
     for a, b in zip(fast, gen):
         _close(a, b, 1.5e-2)      # same arithmetic, different accumulation split
+
+
+@pytest.mark.parametrize("B,T,H,with_state", [(64, 9, 1024, True), (37, 12, 256, False), (5, 3, 512, True),
+                                              (64, 40, 256, True), (16, 33, 1024, False)])
+def test_fp32_launch_persistent_forward_is_bit_identical_to_the_step_kernels(hip_lib, B, T, H, with_state):
+    """The exact-f32 recurrence as ONE launch per layer (lstm_fwd_lpw_f32: W_hh slice in registers, c in a register, h
+    exchanged through write-through stores and validated gathers) against the launch-per-step kernel it replaces: the
+    same MFMA order, the same order of the partial sums, the same cell math - every output (h rows, the h_{t-1} image,
+    cell states, final states, the saved gates) must be bit-identical, twice in a row (a stale or torn read would not
+    repeat).  This is what carries the token-exactness pinned on the reference's goldens over to the faster path."""
+    import os
+    from edgedict_amd import encoder_stack, ops
+    g = torch.Generator(device="cpu").manual_seed(B + T + H)
+    k = 1.0 / H ** 0.5
+    w_hh = ((torch.rand(4 * H, H, generator=g) * 2 - 1) * k).cuda()
+    G0 = torch.randn(B, T, 4 * H, generator=g).cuda()
+    h0 = (0.5 * torch.randn(B, H, generator=g)).cuda() if with_state else None
+    c0 = (0.5 * torch.randn(B, H, generator=g)).cuda() if with_state else None
+
+    def run(lpw):
+        old = os.environ.get("EDGEDICT_LSTM_F32_LPW")
+        os.environ["EDGEDICT_LSTM_F32_LPW"] = "1" if lpw else "0"
+        try:
+            G = G0.clone()
+            out = ops.lstm_forward(G, w_hh, h0, c0)
+            torch.cuda.synchronize()
+            return (G,) + tuple(out)
+        finally:
+            if old is None:
+                os.environ.pop("EDGEDICT_LSTM_F32_LPW", None)
+            else:
+                os.environ["EDGEDICT_LSTM_F32_LPW"] = old
+
+    ref = run(False)
+    for _ in range(2):
+        got = run(True)
+        encoder_stack.check_wsr_error()
+        for name, a, b in zip(("gates", "Y", "Hprev", "Cst", "hN", "cN"), got, ref):
+            assert torch.isfinite(a).all(), name
+            assert torch.equal(a, b), (name, (a - b).abs().max().item())
