@@ -26,6 +26,8 @@
 // After the sweep G holds dG for every t, and dX / dW_ih / dW_hh / db are plain GEMMs / column sums.
 #include <stdlib.h>
 
+#include <mutex>
+
 #include "common.hpp"
 #include "lstm_fast.hpp"
 
@@ -462,6 +464,40 @@ bool f32_lpw_ok(int B, int Tn, int H) {
 
 extern "C" void* edgedict_stack_error_words(int host);      // encoder_stack.hip: the give-up words of the bounded waits
 
+// Two launch-persistent kernels must never share the chip: each spins until ALL of its workgroups are resident, and two
+// half-resident ones (the encoder's on the caller's stream, the prediction network's on the auxiliary stream: fp32 mode
+// runs both through here) would wait for each other's CUs until the bounded spins give up.  Launches of this kernel on
+// one device are therefore chained: a launch on another stream than the last one waits for that one's event.
+struct LpwChain {
+    std::mutex mu;
+    hipEvent_t ev[16] = {};
+    hipStream_t last[16] = {};
+    bool valid[16] = {};
+};
+LpwChain g_lpw_chain;
+
+int lpw_chain_before(hipStream_t s, int* dev_out) {
+    int dev = 0;
+    ED_CHECK_HIP(hipGetDevice(&dev));
+    ED_CHECK_ARG(dev >= 0 && dev < 16, "lstm: device ordinal %d out of range", dev);
+    *dev_out = dev;
+    std::lock_guard<std::mutex> lock(g_lpw_chain.mu);
+    if (!g_lpw_chain.ev[dev]) ED_CHECK_HIP(hipEventCreateWithFlags(&g_lpw_chain.ev[dev], hipEventDisableTiming));
+    // (EDGEDICT_LSTM_LPW_NOCHAIN=1: test aid - tests/test_lstm_gpu.py shows the hazard is real)
+    const char* e_nc = getenv("EDGEDICT_LSTM_LPW_NOCHAIN");
+    if (g_lpw_chain.valid[dev] && g_lpw_chain.last[dev] != s && !(e_nc && atoi(e_nc)))
+        ED_CHECK_HIP(hipStreamWaitEvent(s, g_lpw_chain.ev[dev], 0));
+    return ED_OK;
+}
+
+int lpw_chain_after(hipStream_t s, int dev) {
+    std::lock_guard<std::mutex> lock(g_lpw_chain.mu);
+    ED_CHECK_HIP(hipEventRecord(g_lpw_chain.ev[dev], s));
+    g_lpw_chain.last[dev] = s;
+    g_lpw_chain.valid[dev] = true;
+    return ED_OK;
+}
+
 template <typename T>
 int run_fwd(void* G, void* Hprev, void* Y, float* Cst, const void* Whh, const float* h0,
             const float* c0, float* hN, float* cN, int B, int Tn, int H, hipStream_t s) {
@@ -474,6 +510,11 @@ int run_fwd(void* G, void* Hprev, void* Y, float* Cst, const void* Whh, const fl
             ED_CHECK_LAUNCH("lstm_init_hprev");
             unsigned* err = reinterpret_cast<unsigned*>(edgedict_stack_error_words(0));
             if (err) err += 2;                 // the step kernels' word (encoder_stack.py reports code 7xx as a forward wait)
+            int dev = 0;
+            {
+                const int rc = lpw_chain_before(s, &dev);
+                if (rc != ED_OK) return rc;
+            }
             const dim3 grid(H / UNITS, (B + 63) / 64);
             if (H == 1024)
                 hipLaunchKernelGGL(lstm_fwd_lpw_f32<16>, grid, dim3(256), 0, s, (float*)G, (float*)Hprev, (float*)Y, Cst,
@@ -485,7 +526,7 @@ int run_fwd(void* G, void* Hprev, void* Y, float* Cst, const void* Whh, const fl
                 hipLaunchKernelGGL(lstm_fwd_lpw_f32<4>, grid, dim3(256), 0, s, (float*)G, (float*)Hprev, (float*)Y, Cst,
                                    (const float*)Whh, c0, hN, cN, B, Tn, err);
             ED_CHECK_LAUNCH("lstm_fwd_lpw_f32");
-            return ED_OK;
+            return lpw_chain_after(s, dev);
         }
     }
     hipLaunchKernelGGL(lstm_init_hprev<T>, dim3(ed_grid_for((long long)B * H, 256)), dim3(256), 0,

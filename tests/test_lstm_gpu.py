@@ -121,3 +121,44 @@ def test_fp32_launch_persistent_forward_is_bit_identical_to_the_step_kernels(hip
         for name, a, b in zip(("gates", "Y", "Hprev", "Cst", "hN", "cN"), got, ref):
             assert torch.isfinite(a).all(), name
             assert torch.equal(a, b), (name, (a - b).abs().max().item())
+
+
+def test_fp32_launch_persistent_forward_on_two_streams_at_once(hip_lib):
+    """fp32 mode runs the encoder on the caller's stream and the prediction network on the auxiliary stream, both through
+    the launch-persistent kernel, whose workgroups spin until ALL of them are resident: two such launches that each got
+    part of the chip wait for each other's CUs until the bounded spins give up (found by the whole suite: E6D2_LARGE in
+    fp32, 1 run in ~3; EDGEDICT_LSTM_LPW_NOCHAIN=1 brings it back).  The library chains them - a launch on another stream
+    waits for the previous one's event.  Here an encoder-sized and a prediction-network-sized call are queued behind a
+    sleeping kernel on two streams, so that both become runnable in the same instant, eight times: results equal to the
+    same calls issued alone."""
+    from edgedict_amd import encoder_stack, ops, side
+    g = torch.Generator(device="cpu").manual_seed(9)
+    dev = torch.device("cuda", 0)
+    aux = side.stream(dev)
+    cur = torch.cuda.current_stream(dev)
+
+    def make(B, T, H):
+        w = ((torch.rand(4 * H, H, generator=g) * 2 - 1) / H ** 0.5).cuda()
+        return w, torch.randn(B, T, 4 * H, generator=g).cuda()
+    wa, Ga = make(64, 40, 1024)          # 256 workgroups: the whole chip
+    wb, Gb = make(64, 65, 512)           # 128 workgroups
+    ra = ops.lstm_forward(Ga.clone(), wa)[0].clone()
+    rb = ops.lstm_forward(Gb.clone(), wb)[0].clone()
+    torch.cuda.synchronize()
+    for i in range(8):
+        ga, gb = Ga.clone(), Gb.clone()
+        torch.cuda.synchronize()
+        torch.cuda._sleep(40_000_000)            # ~20 ms: the host enqueues both calls meanwhile
+        aux.wait_stream(cur)
+        order = ("a", "b") if i % 2 == 0 else ("b", "a")
+        out = {}
+        for which in order:
+            if which == "a":
+                out["a"] = ops.lstm_forward(ga, wa)[0]
+            else:
+                with torch.cuda.stream(aux):
+                    out["b"] = ops.lstm_forward(gb, wb)[0]
+        cur.wait_stream(aux)
+        torch.cuda.synchronize()
+        encoder_stack.check_wsr_error()
+        assert torch.equal(out["a"], ra) and torch.equal(out["b"], rb), i
