@@ -213,30 +213,37 @@ __global__ __launch_bounds__(256) void lstm_step_fwd(
 // =====================================================================================
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4_lstm_t;
 
+// Tiling: a workgroup owns 16 ROWS x 16 UNITS (x 4 gates), not the step kernel's 64 rows x 4 units: what a workgroup must
+// gather per step is the h of ITS rows - 16 x H fp32 = 64 KB instead of 256 KB, and the per-CU fetch rate is what bounds a
+// step (first version, 64 x 4: 13 us per layer-step; this one: see DESIGN 4.33) - while its W_hh slice grows to 64 rows x H =
+// 256 KB, i.e. 4 x NCH float4 registers per lane, which one wave per SIMD has (512).  Per output element nothing changes:
+// the same K quarter per wave, the same chunk order, one v_mfma_f32_16x16x4_f32 chain per (row, gate column).
 template <int NCH>        // 16-k chunks per wave quarter: H = 64 NCH
 __global__ __launch_bounds__(256, 1) void lstm_fwd_lpw_f32(
     float* __restrict__ G, float* __restrict__ Hprev, float* __restrict__ Y, float* __restrict__ Cst,
     const float* __restrict__ Whh, const float* __restrict__ c0, float* __restrict__ hN, float* __restrict__ cN,
     int B, int Tn, unsigned* err) {
     constexpr int H = 64 * NCH;
-    constexpr int CHK = NCH < 8 ? NCH : 8;          // chunks requested together (f32_product16<4>: 8)
-    __shared__ float red[4][64][17];
+    constexpr int CHK = NCH < 8 ? NCH : 8;          // chunks requested together (f32_product16: 8)
+    constexpr int WU = 16;                          // units per workgroup
+    __shared__ float red[4][16][4 * WU + 1];
     __shared__ unsigned bail_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int j0 = blockIdx.x * UNITS;
-    const int b0 = blockIdx.y * 64;
+    const int j0 = blockIdx.x * WU;
+    const int b0 = blockIdx.y * 16;
     const int kbeg = wave * (H / 4);
     const int n = lane & 15, ko = (lane >> 4) * 4;
     if (tid == 0) bail_s = 0u;
 
-    // ---- stationary weights: W_hh row gate*H + j0 + unit, this wave's K quarter
-    float4 wq[NCH];
-    {
-        const float* wptr = Whh + (long long)((n / UNITS) * H + j0 + (n % UNITS)) * H + kbeg + ko;
+    // ---- stationary weights: gate g's row g*H + j0 + n, this wave's K quarter
+    float4 wq[4][NCH];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) wq[c] = *reinterpret_cast<const float4*>(wptr + 16 * c);
+    for (int g = 0; g < 4; ++g) {
+        const float* wptr = Whh + (long long)(g * H + j0 + n) * H + kbeg + ko;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) wq[g][c] = *reinterpret_cast<const float4*>(wptr + 16 * c);
     }
-    // ---- this lane's rows of h (fragment rows 16 m + n), as byte offsets into Hprev at frame 0
+    // ---- this lane's row of h (fragment row n), as a byte offset into Hprev at frame 0
     // (readfirstlane returns a SIGNED int: through unsigned temporaries, or a low word with bit 31 set sign-extends
     // into the high word of the base)
     const unsigned long long hp = (unsigned long long)Hprev;
@@ -245,13 +252,10 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_lpw_f32(
     const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(
         (void*)(((unsigned long long)hp_hi << 32) | (unsigned long long)hp_lo), 0,
         (int)((unsigned)B * (unsigned)Tn * (unsigned)H * 4u), 0x00020000);
-    unsigned aoff[4];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-        aoff[m] = (unsigned)(((long long)min(b0 + 16 * m + n, B - 1) * Tn * H + kbeg + ko) * 4);
+    const unsigned aoff = (unsigned)(((long long)min(b0 + n, B - 1) * Tn * H + kbeg + ko) * 4);
 
     // ---- this thread's cell: row bl, unit u
-    const int bl = tid / UNITS, u = tid % UNITS;
+    const int bl = tid / WU, u = tid % WU;
     const bool live = b0 + bl < B;
     // (rows past the batch compute on a clamped row and store nothing: every address a load could be speculated to
     // stays inside the tensors)
@@ -268,27 +272,22 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_lpw_f32(
     for (int t = 0; t < Tn; ++t) {
         f32x4_t acc[4];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) acc[m] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < 4; ++g) acc[g] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
         const unsigned toff = (unsigned)t * (unsigned)(H * 4);
         // CHK chunks are requested together, looked at (all ones = a peer has not written it yet: sleep, request again),
-        // then multiplied - f32_product16's batches and MFMA order.  (Requesting all NCH chunks at once and validating
-        // chunk by chunk in front of its MFMAs - 256 more registers, which one wave per SIMD has - was measured SLOWER:
-        // encoder 30.1 vs 28.2 ms; the gather runs at the per-CU fetch rate either way.)
+        // then multiplied - f32_product16's batches and chunk order
 #pragma unroll
         for (int c0i = 0; c0i < NCH; c0i += CHK) {
-            float4 aq[CHK][4];
+            float4 aq[CHK];
             unsigned tries = 0;
             for (;;) {
                 unsigned worst = 0u;
 #pragma unroll
-                for (int c = 0; c < CHK; ++c)
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        const u32x4_lstm_t v = __builtin_amdgcn_raw_buffer_load_b128(
-                            rh, aoff[m] + (unsigned)((c0i + c) * 64), toff, 16);
-                        aq[c][m] = *reinterpret_cast<const float4*>(&v);
-                        worst = max(worst, max(max(v[0], v[1]), max(v[2], v[3])));
-                    }
+                for (int c = 0; c < CHK; ++c) {
+                    const u32x4_lstm_t v = __builtin_amdgcn_raw_buffer_load_b128(rh, aoff + (unsigned)((c0i + c) * 64), toff, 16);
+                    aq[c] = *reinterpret_cast<const float4*>(&v);
+                    worst = max(worst, max(max(v[0], v[1]), max(v[2], v[3])));
+                }
                 if (t == 0 || !__any(worst == 0xffffffffu)) break;     // (frame 0 was written before the launch)
                 __builtin_amdgcn_s_sleep(2);
                 if (++tries > (1u << 20)) {                            // a peer never became resident
@@ -299,27 +298,29 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_lpw_f32(
             }
 #pragma unroll
             for (int c = 0; c < CHK; ++c) {
-                const float bv[4] = {wq[c0i + c].x, wq[c0i + c].y, wq[c0i + c].z, wq[c0i + c].w};
+                const float av[4] = {aq[c].x, aq[c].y, aq[c].z, aq[c].w};
 #pragma unroll
                 for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                    for (int m = 0; m < 4; ++m) {
-                        const float av[4] = {aq[c][m].x, aq[c][m].y, aq[c][m].z, aq[c][m].w};
-                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj], bv[jj], acc[m], 0, 0, 0);
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 wv = wq[g][c0i + c];
+                        const float bv[4] = {wv.x, wv.y, wv.z, wv.w};
+                        acc[g] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[jj], bv[jj], acc[g], 0, 0, 0);
                     }
             }
         }
+        // partial tile of this wave: rows (lane >> 4) * 4 + r, gate g's column n
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) red[wave][m * 16 + (lane >> 4) * 4 + r][lane & 15] = acc[m][r];
+            for (int r = 0; r < 4; ++r) red[wave][(lane >> 4) * 4 + r][g * WU + n] = acc[g][r];
         __syncthreads();
         if (bail_s) break;
         {
             float pre[4];
 #pragma unroll
             for (int gate = 0; gate < 4; ++gate) {
-                const int col = gate * UNITS + u;
+                const int col = gate * WU + u;
                 pre[gate] = red[0][bl][col] + red[1][bl][col] + red[2][bl][col] + red[3][bl][col] + pre_g[gate];
             }
             const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
@@ -330,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void lstm_fwd_lpw_f32(
             const float h = og * tanhf(c);
             cprev = c;
             const long long row = (long long)b * Tn + t;
-            // publish first: h_t is what the peers wait for
+            // publish first: h_t is what the peers wait for (16 consecutive units of a row: 64 bytes per row)
             if (live && t + 1 < Tn)
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(h), rh, (unsigned)(((row + 1) * H + j) * 4), 0, 16);
             float* grow = G + row * 4 * H;
@@ -459,7 +460,7 @@ bool f32_lpw_ok(int B, int Tn, int H) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
         return n;
     }();
-    return (long long)(H / UNITS) * ((B + 63) / 64) <= n_cu;      // every workgroup resident at once
+    return (long long)(H / 16) * ((B + 15) / 16) <= n_cu;      // every workgroup (16 rows x 16 units) resident at once
 }
 
 extern "C" void* edgedict_stack_error_words(int host);      // encoder_stack.hip: the give-up words of the bounded waits
@@ -515,7 +516,7 @@ int run_fwd(void* G, void* Hprev, void* Y, float* Cst, const void* Whh, const fl
                 const int rc = lpw_chain_before(s, &dev);
                 if (rc != ED_OK) return rc;
             }
-            const dim3 grid(H / UNITS, (B + 63) / 64);
+            const dim3 grid(H / 16, (B + 15) / 16);
             if (H == 1024)
                 hipLaunchKernelGGL(lstm_fwd_lpw_f32<16>, grid, dim3(256), 0, s, (float*)G, (float*)Hprev, (float*)Y, Cst,
                                    (const float*)Whh, c0, hN, cN, B, Tn, err);
