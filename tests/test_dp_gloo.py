@@ -302,6 +302,6 @@ def test_ranks_with_different_launch_counts_issue_the_same_collectives():
     for r in range(world):
         np.testing.assert_allclose(out[r][1], total, rtol=1e-6, atol=1e-6)
         assert out[r][4] == [5, 4, 3, 2, 1, 0]            # layers become final top-down on every rank
-    assert out[0][5] != out[1][5] and out[0][5] == 37       # different launch counts (tests/test_stack_schedule.py pins 37)
+    assert out[0][5] != out[1][5] and out[0][5] == 36       # different launch counts (tests/test_stack_schedule.py pins 36)
     assert out[0][2] == out[1][2]                           # ... the same collectives in the same order
     assert out[0][3] == out[1][3] and len(out[0][3]) == 7   # joint + six layers left before finish(), `rest` from it
