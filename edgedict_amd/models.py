@@ -168,6 +168,7 @@ class _LSTMBlockFn(torch.autograd.Function):
         else:
             out, mean, rstd = Y, None, None
         ctx.save_for_backward(x, w_ih, w_hh, ln_w, c0)
+        ctx.biases = (b_ih, b_hh)
         ctx.inter = (G, Y, Hprev, Cst, mean, rstd)
         ctx.cfg = (residual, reduce, cd, ln_w is not None)
         ctx.mark_non_differentiable(hN, cN)
@@ -198,10 +199,7 @@ class _LSTMBlockFn(torch.autograd.Function):
         dG = G.view(B * T, 4 * H)
         x2 = x.view(B * T, I)
         M = B * T
-        dw_ih = ops.gemm(dG.t(), x2.t(), out_dtype=F32, split_k=ops.pick_split_k(4 * H, I, M))
-        dw_hh = ops.gemm(dG.t(), Hprev.view(M, H).t(), out_dtype=F32,
-                         split_k=ops.pick_split_k(4 * H, H, M))
-        db = ops.colsum(dG)
+        # the layer below waits for dx only: it goes first; the weight gradients feed nothing downstream
         dx = None
         if ctx.needs_input_grad[0]:
             wih = WEIGHTS.get(w_ih, cd)
@@ -210,6 +208,23 @@ class _LSTMBlockFn(torch.autograd.Function):
                 ops.gemm(dG, wih.t(), out=ds.view(M, I), accumulate=True)
             else:
                 dx = ops.gemm(dG, wih.t()).view(B, T, I)
+        b_ih, b_hh = ctx.biases
+        if config.DEFER_WEIGHT_GRADS and config.DEFER_LSTM_WEIGHT_GRADS and all(
+                p.grad is not None and p.grad.dtype == F32 and p.grad.is_contiguous()
+                for p in (w_ih, w_hh, b_ih, b_hh)):
+            # ... so they accumulate straight into the .grad buffers on the auxiliary stream, under the next
+            # layer's BPTT (as the joint's dW2 does, side.py)
+            with side.deferred(dG.device, G, x, Hprev):
+                ops.gemm(dG.t(), x2.t(), out=w_ih.grad, accumulate=True, split_k=ops.pick_split_k(4 * H, I, M))
+                ops.gemm(dG.t(), Hprev.view(M, H).t(), out=w_hh.grad, accumulate=True,
+                         split_k=ops.pick_split_k(4 * H, H, M))
+                ops.colsum(dG, out=b_ih.grad)
+                ops.colsum(dG, out=b_hh.grad)
+            return (dx, None, None, None, None, dgamma, dbeta, None, None, None, None, None)
+        dw_ih = ops.gemm(dG.t(), x2.t(), out_dtype=F32, split_k=ops.pick_split_k(4 * H, I, M))
+        dw_hh = ops.gemm(dG.t(), Hprev.view(M, H).t(), out_dtype=F32,
+                         split_k=ops.pick_split_k(4 * H, H, M))
+        db = ops.colsum(dG)
         return (dx, dw_ih, dw_hh, db, db.clone(), dgamma, dbeta, None, None, None, None, None)
 
 
