@@ -232,8 +232,13 @@ WsLayout ws_layout(const edgedict_stack_desc_t* d) {
         const size_t fb = align256(B16 * 4 * d->H * sizeof(bf16_t));
         w.frag0.push_back(off); off += fb;
         w.frag1.push_back(off); off += fb;
-        w.dC.push_back(off); off += align256((size_t)d->B * d->H * sizeof(float));
         if ((size_t)d->layers[l].I > maxK) maxK = d->layers[l].I;
+    }
+    // running dL/dc of every layer, contiguous: the backward pass zeroes them with ONE memset (nine memsets of 2-3 us,
+    // ~6 us apart, sat in front of the BPTT's first launch)
+    for (int l = 0; l < d->L; ++l) {
+        w.dC.push_back(off);
+        off += align256((size_t)d->B * d->H * sizeof(float));
     }
     // LayerNorm-backward partial sums: LNB_GRID rows per chunk call + LNB_GRID_TOP for the top layer
     {
@@ -576,10 +581,7 @@ int forward_lpw(const edgedict_stack_desc_t* d, const std::vector<Geom>& g, Stre
     unsigned* cnt = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + SYNC_FCNT;      // [8] arrival counter lines
     unsigned* gerr = (st.rt && st.rt->wsr_err_dev) ? st.rt->wsr_err_dev + 2 : nullptr;
     for (int l = 0; l < L; ++l) ED_CHECK_ARG(g[l].nchunks <= 512, "encoder_stack: too many chunks for the flag table");
-    ED_DEV(ed_stack_zero(fflag, (size_t)8 * 512 * sizeof(unsigned), st.C));
-    ED_DEV(ed_stack_zero(cnt, (size_t)8 * LPW_CNT_STRIDE * sizeof(unsigned), st.C));
-    ED_TRY(st.chain(st.C, st.R));
-    for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.C, st.S[l]));
+    // (flags and counters were zeroed by the caller before the streams forked)
     // TWO side streams: what follows a full-rate layer (its LayerNorm, the next layer's product) runs on the
     // chunk-GEMM stream, what follows a layer behind the time reduction on the CALLER's stream - idle until the
     // join and already one of the four hardware queues.  One side stream was the bottleneck: per recurrence
@@ -846,18 +848,33 @@ extern "C" int edgedict_stack_forward(const edgedict_stack_desc_t* d, void* stre
     // a read that overtakes its producer would go unnoticed; with the poison it turns every result into NaN
     // ... and it is how the data-polling forward kernel works at all (stack_fwd_lpw_kernel<DP>): readers recognise a
     // chunk that has not been written yet by this pattern (205 MB for E6D2 at 15 s: ~50 us of memset)
+    // (the layers' images are contiguous in the workspace: one memset)
     if (lpw_ns && (poison_on() || lpw_data_poll()))
-        for (int l = 0; l < L; ++l)
-            ED_DEV(ed_stack_fill(ws + wl.himg[l], 0xff, (size_t)(d->layers[l].T + 1) * wl.himg_stride, st.C));
+        ED_DEV(ed_stack_fill(ws + wl.himg[0], 0xff,
+                             wl.himg[L - 1] + (size_t)(d->layers[L - 1].T + 1) * wl.himg_stride - wl.himg[0], st.C));
     if (st.rt) {
         st.rt->tkind[0] = lpw_ns ? 1 : 0;
         st.rt->tsteps[0] = lpw_ns;
     }
-    for (int l = 0; l < L; ++l) {
-        const edgedict_stack_layer_t& y = d->layers[l];
-        ED_DEV(ed_stack_init_state(d->h0 ? d->h0 + l * BH : nullptr, d->c0 ? d->c0 + l * BH : nullptr,
-                                   bptr(y.Yx), y.Cx, bptr(ws + (lpw_ns ? wl.himg[l] : wl.frag0[l])), B, H, st.C));
+    for (int l0 = 0; l0 < L; l0 += 8) {     // initial states, eight layers per launch
+        EdInitStates A;
+        A.n = min(8, L - l0);
+        A.B = B;
+        A.H = H;
+        for (int j = 0; j < A.n; ++j) {
+            const int l = l0 + j;
+            const edgedict_stack_layer_t& y = d->layers[l];
+            A.h0[j] = d->h0 ? d->h0 + l * BH : nullptr;
+            A.c0[j] = d->c0 ? d->c0 + l * BH : nullptr;
+            A.Yx0[j] = bptr(y.Yx);
+            A.Cx0[j] = y.Cx;
+            A.hfrag[j] = bptr(ws + (lpw_ns ? wl.himg[l] : wl.frag0[l]));
+        }
+        ED_DEV(ed_stack_init_states(A, st.C));
     }
+    // chunk flags and arrival counters of the launch-persistent pass: one memset over the head of the sync region (it
+    // covers the backward pass's flags too, which that pass zeroes again), before the streams fork
+    if (lpw_ns) ED_DEV(ed_stack_zero(ws + wl.wsr_sync, SYNC_BCNT * sizeof(unsigned), st.C));
     ED_TRY(st.chain(st.C, st.R));
     if (st.R2 != st.R) ED_TRY(st.chain(st.C, st.R2));
     for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.C, st.S[l]));
@@ -1189,10 +1206,8 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
     const bool soft = soft_env && !st.serial && L <= 8;       // flag waits, as in the forward pass
     unsigned* bflag = reinterpret_cast<unsigned*>(ws + wl.wsr_sync) + SYNC_BFLAG;   // [8][512], after the forward's
     unsigned* gerr = (st.rt && st.rt->wsr_err_dev) ? st.rt->wsr_err_dev + 2 : nullptr;
-    if (soft) {
+    if (soft)
         for (int l = 0; l < L; ++l) ED_CHECK_ARG(g[l].nchunks <= 512, "encoder_stack: too many chunks for the flag table");
-        ED_DEV(ed_stack_zero(bflag, (size_t)8 * 512 * sizeof(unsigned), st.C));
-    }
     // split-K weights-stationary BPTT (stack_bwd_sk_kernel): steps per launch (0 = one launch per step) and the
     // layers' arrival counters, behind the forward pass's in the sync region
     const int sk_ns = sk_bwd_steps(d);
@@ -1208,11 +1223,12 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
                 ED_DEV(ed_stack_fill(ws + wl.gimg[l], 0xff, (size_t)(d->layers[l].T + 1) * wl.gimg_stride, st.C));
                 ED_DEV(ed_stack_fill(ws + wl.skpart[l], 0xff, (size_t)2 * (H / 64) * 4 * 64 * 64 * sizeof(float), st.C));
             }
-        ED_DEV(ed_stack_zero(cntb, (size_t)8 * LPW_CNT_STRIDE * sizeof(unsigned), st.C));
-        ED_DEV(ed_stack_zero(gcnt, (size_t)8 * SK_CNT_LINES * 64 * sizeof(unsigned), st.C));
     }
-    // ---- prologue: running dL/dc = 0
-    for (int l = 0; l < L; ++l) ED_DEV(ed_stack_zero(ws + wl.dC[l], (size_t)BH * sizeof(float), st.C));
+    // ---- prologue: chunk flags + arrival counters (everything in the sync region behind the forward pass's flags,
+    // one memset), running dL/dc = 0 (contiguous, one memset)
+    if (soft || sk_ns)
+        ED_DEV(ed_stack_zero(ws + wl.wsr_sync + SYNC_BFLAG * sizeof(unsigned), WSR_SYNC_BYTES - SYNC_BFLAG * sizeof(unsigned), st.C));
+    ED_DEV(ed_stack_zero(ws + wl.dC[0], wl.dC[L - 1] + (size_t)BH * sizeof(float) - wl.dC[0], st.C));
     ED_TRY(st.chain(st.C, st.R));
     if (st.R2 != st.R) ED_TRY(st.chain(st.C, st.R2));
     for (int l = 0; l < L; ++l) ED_TRY(st.chain(st.C, st.S[l]));

@@ -1617,6 +1617,31 @@ __global__ void stack_init_state_kernel(const float* __restrict__ h0, const floa
     }
 }
 
+// the same for up to 8 layers in one launch (blockIdx.y = layer): six launches of ~5 us each sat in front of the forward
+// pass's first recurrence launch
+__global__ void stack_init_states_kernel(EdInitStates A) {
+    const int l = blockIdx.y;
+    const float* __restrict__ h0 = A.h0[l];
+    const float* __restrict__ c0 = A.c0[l];
+    bf16_t* __restrict__ Yx0 = A.Yx0[l];
+    float* __restrict__ Cx0 = A.Cx0[l];
+    bf16_t* __restrict__ hfrag = A.hfrag[l];
+    const int B = A.B, H = A.H;
+    const int B16 = (B + 15) / 16 * 16;
+    const long long n = (long long)B16 * H;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (long long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / H), j = (int)(i % H);
+        const bool live = b < B;
+        const bf16_t hv = f32_to_bf16((live && h0) ? h0[i] : 0.f);
+        if (live) {
+            Yx0[i] = hv;
+            Cx0[i] = c0 ? c0[i] : 0.f;
+        }
+        hfrag[((((long long)(j >> 5) * (B16 >> 4) + (b >> 4)) * 64) + ((j & 31) >> 3) * 16 + (b & 15)) * 8 + (j & 7)] = hv;
+    }
+}
+
 }  // namespace
 
 int ed_stack_launch_fwd(const EdFwdLaunch& L, hipStream_t s) {
@@ -1777,6 +1802,15 @@ int ed_stack_init_state(const float* h0, const float* c0, bf16_t* Yx0, float* Cx
     hipLaunchKernelGGL(stack_init_state_kernel, dim3(ed_grid_for(n, 256)), dim3(256), 0, s, h0, c0,
                        Yx0, Cx0, hfrag, B, H);
     ED_CHECK_LAUNCH("stack_init_state_kernel");
+    return ED_OK;
+}
+
+int ed_stack_init_states(const EdInitStates& A, hipStream_t s) {
+    if (A.n <= 0) return ED_OK;
+    ED_CHECK_ARG(A.n <= 8, "stack_init_states: too many layers in one call");
+    const long long n = (long long)((A.B + 15) / 16 * 16) * A.H;
+    hipLaunchKernelGGL(stack_init_states_kernel, dim3(ed_grid_for(n, 256), A.n), dim3(256), 0, s, A);
+    ED_CHECK_LAUNCH("stack_init_states_kernel");
     return ED_OK;
 }
 

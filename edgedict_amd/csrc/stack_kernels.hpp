@@ -189,6 +189,15 @@ int ed_stack_input_norm(int x_dtype, const void* x, const float* gamma, const fl
 int ed_stack_input_norm_bwd(int x_dtype, const void* x, const bf16_t* dX, const float* mean,
                             const float* rstd, float* dgamma, float* dbeta, int B, int T, int D,
                             hipStream_t s);
+struct EdInitStates {      // initial states of up to 8 layers, one launch
+    int n, B, H;
+    const float* h0[8];
+    const float* c0[8];
+    bf16_t* Yx0[8];
+    float* Cx0[8];
+    bf16_t* hfrag[8];
+};
+int ed_stack_init_states(const EdInitStates& A, hipStream_t s);
 int ed_stack_init_state(const float* h0, const float* c0, bf16_t* Yx0, float* Cx0, bf16_t* hfrag,
                         int B, int H, hipStream_t s);
 int ed_stack_zero(void* p, size_t bytes, hipStream_t s);

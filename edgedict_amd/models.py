@@ -329,6 +329,7 @@ class _LinearFn(torch.autograd.Function):
         wc = WEIGHTS.get(w, cd)
         y = ops.gemm(x2, wc, bias=b.detach() if b is not None else None)
         ctx.save_for_backward(x2, w)
+        ctx.bias = b
         ctx.cfg = (cd, shp, b is not None)
         return y.view(*shp[:-1], w.shape[0])
 
@@ -336,16 +337,27 @@ class _LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x2, w = ctx.saved_tensors
         cd, shp, has_b = ctx.cfg
+        b = ctx.bias
         dy2 = dy.reshape(-1, w.shape[0])
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         M = x2.shape[0]
-        dw = ops.gemm(dy2.t(), x2.t(), out_dtype=F32,
-                      split_k=ops.pick_split_k(w.shape[0], w.shape[1], M))
-        db = ops.colsum(dy2) if has_b else None
+        # dx first: it is what the rest of the backward pass waits for (the encoder's projection sits between the joint
+        # and the stack's BPTT); dW / db go to the auxiliary stream when they can accumulate in place (side.py)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = ops.gemm(dy2, WEIGHTS.get(w, cd).t()).view(*shp)
+        if config.DEFER_WEIGHT_GRADS and config.DEFER_LSTM_WEIGHT_GRADS and all(
+                p is None or (p.grad is not None and p.grad.dtype == F32 and p.grad.is_contiguous()) for p in (w, b)):
+            with side.deferred(dy2.device, dy2, x2):
+                ops.gemm(dy2.t(), x2.t(), out=w.grad, accumulate=True,
+                         split_k=ops.pick_split_k(w.shape[0], w.shape[1], M))
+                if has_b:
+                    ops.colsum(dy2, out=b.grad)
+            return dx, None, None, None
+        dw = ops.gemm(dy2.t(), x2.t(), out_dtype=F32,
+                      split_k=ops.pick_split_k(w.shape[0], w.shape[1], M))
+        db = ops.colsum(dy2) if has_b else None
         return dx, dw, db, None
 
 
