@@ -35,7 +35,21 @@ int ed_gemm_quiet_partials(int dtype_in, const void* A, long long lda, int a_kma
 namespace {
 
 // ---------------------------------------------------------------- weight images
-// wih_p[kappa(g,j)][k] = W_ih[g*H + j][k] (bf16);  bias_p[kappa] = b_ih + b_hh (fp32)
+// (Re-built after every optimiser step, in front of the next step's encoder: one 16-byte store per thread.  The
+// element-per-thread versions took 10 us per W_hh image and 35 us for W_ih + its transpose - 0.39 ms per step for
+// six layers, most of what separated the optimiser step from the first recurrence launch.)
+__device__ __forceinline__ uint4 pack8(const float* v) {
+    uint4 o;
+    o.x = (unsigned)f32_to_bf16(v[0]) | ((unsigned)f32_to_bf16(v[1]) << 16);
+    o.y = (unsigned)f32_to_bf16(v[2]) | ((unsigned)f32_to_bf16(v[3]) << 16);
+    o.z = (unsigned)f32_to_bf16(v[4]) | ((unsigned)f32_to_bf16(v[5]) << 16);
+    o.w = (unsigned)f32_to_bf16(v[6]) | ((unsigned)f32_to_bf16(v[7]) << 16);
+    return o;
+}
+// W_ih row of interleaved gate column kap (stack_kernels.hpp ed_gate_col)
+__device__ __forceinline__ int row_of_kap(int kap, int H) { return ((kap >> 4) & 3) * H + (kap >> 6) * 16 + (kap & 15); }
+
+// wih_p[kappa(g,j)][k] = W_ih[g*H + j][k] (bf16);  bias_p[kappa] = b_ih + b_hh (fp32).  Any I (scalar).
 __global__ void pack_wih_kernel(const float* __restrict__ W, const float* __restrict__ b_ih,
                                 const float* __restrict__ b_hh, bf16_t* __restrict__ Wp,
                                 bf16_t* __restrict__ Wt, float* __restrict__ bp, int H, int I) {
@@ -51,38 +65,90 @@ __global__ void pack_wih_kernel(const float* __restrict__ W, const float* __rest
         if (k == 0) bp[kap] = b_ih[row] + b_hh[row];
     }
 }
+// the same for I % 8 == 0: thread = (kap, 8 consecutive k)
+__global__ void pack_wih8_kernel(const float* __restrict__ W, const float* __restrict__ b_ih,
+                                 const float* __restrict__ b_hh, bf16_t* __restrict__ Wp, float* __restrict__ bp, int H,
+                                 int I) {
+    const int I8 = I >> 3;
+    const long long n8 = 4ll * H * I8;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < n8; c += (long long)gridDim.x * blockDim.x) {
+        const int kap = (int)(c / I8), k8 = (int)(c % I8);
+        const int row = row_of_kap(kap, H);
+        float v[8];
+        const float4 a = *reinterpret_cast<const float4*>(W + (long long)row * I + k8 * 8);
+        const float4 b = *reinterpret_cast<const float4*>(W + (long long)row * I + k8 * 8 + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        *reinterpret_cast<uint4*>(Wp + (long long)kap * I + k8 * 8) = pack8(v);
+        if (k8 == 0) bp[kap] = b_ih[row] + b_hh[row];
+    }
+}
+// wih_t[k][kappa] = W_ih[row(kappa)][k]: 64 x 64 tiles through LDS (rows of W in, rows of the transpose out)
+__global__ __launch_bounds__(256) void pack_wih_t_kernel(const float* __restrict__ W, bf16_t* __restrict__ Wt, int H,
+                                                         int I) {
+    __shared__ __attribute__((aligned(16))) bf16_t tile[64][64 + 8];                      // [k][kap], 144-byte rows: 16-byte aligned chunks
+    const int kt = (I + 63) >> 6;
+    const int kap0 = (blockIdx.x / kt) * 64, k0 = (blockIdx.x % kt) * 64;
+    const int tid = threadIdx.x;
+    for (int q = tid; q < 64 * 16; q += 256) {               // 64 rows x 16 float4
+        const int r = q >> 4, c4 = (q & 15) * 4;
+        const int row = row_of_kap(kap0 + r, H);
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if ((I & 3) == 0 && k0 + c4 + 3 < I) {
+            const float4 a = *reinterpret_cast<const float4*>(W + (long long)row * I + k0 + c4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
+        } else {
+            for (int e = 0; e < 4; ++e)
+                if (k0 + c4 + e < I) v[e] = W[(long long)row * I + k0 + c4 + e];
+        }
+        for (int e = 0; e < 4; ++e) tile[c4 + e][r] = f32_to_bf16(v[e]);
+    }
+    __syncthreads();
+    for (int q = tid; q < 64 * 8; q += 256) {                // 64 k x 8 chunks of 8 kap
+        const int k = q >> 3, c8 = (q & 7) * 8;
+        if (k0 + k < I)
+            *reinterpret_cast<uint4*>(Wt + (long long)(k0 + k) * 4 * H + kap0 + c8) = *reinterpret_cast<const uint4*>(&tile[k][c8]);
+    }
+}
 // Fragment images of W_hh.  A wave's loads walk each image front to back (k-step major, the
 // operands of one k-step adjacent), so a workgroup's slice is ONE sequential stream instead of
 // several streams a power-of-two apart (which would camp on the same L2 channel).
 // forward: frag[ub][ks][gate][lane][8]: n = lane & 15 -> W_hh row gate*H + ub*16 + n,
 //          k = ks*32 + (lane >> 4)*8 + e
+// thread = one 16-byte chunk (8 consecutive k of one row)
 __global__ void pack_whh_fwd_kernel(const float* __restrict__ W, bf16_t* __restrict__ out, int H) {
-    const long long n = 4ll * H * H;
+    const long long n8 = 4ll * H * H / 8;
     const int KS = H >> 5;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
-        const long long blk = i >> 9;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < n8; c += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(c & 63);
+        const long long blk = c >> 6;
         const int g = (int)(blk & 3), ks = (int)((blk >> 2) % KS), ub = (int)((blk >> 2) / KS);
         const int row = g * H + ub * 16 + (lane & 15);
-        const int k = ks * 32 + (lane >> 4) * 8 + e;
-        out[i] = f32_to_bf16(W[(long long)row * H + k]);
+        const int k = ks * 32 + (lane >> 4) * 8;
+        float v[8];
+        const float4 a = *reinterpret_cast<const float4*>(W + (long long)row * H + k);
+        const float4 b = *reinterpret_cast<const float4*>(W + (long long)row * H + k + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        *reinterpret_cast<uint4*>(out + c * 8) = pack8(v);
     }
 }
 // backward: frag[nb32][ks][n2][lane][8]: n = lane & 15 -> hidden unit (nb32*2 + n2)*16 + n,
 //           k = interleaved gate column ks*32 + (lane >> 4)*8 + e
+// thread = one chunk: 8 consecutive gate columns = 8 consecutive W rows at one unit (16 lanes read 64 contiguous bytes
+// of each)
 __global__ void pack_whh_bwd_kernel(const float* __restrict__ W, bf16_t* __restrict__ out, int H) {
-    const long long n = 4ll * H * H;
+    const long long n8 = 4ll * H * H / 8;
     const int KS = H >> 3;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63);
-        const long long blk = i >> 9;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < n8; c += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(c & 63);
+        const long long blk = c >> 6;
         const int n2 = (int)(blk & 1), ks = (int)((blk >> 1) % KS), nb = (int)((blk >> 1) / KS);
         const int unit = (nb * 2 + n2) * 16 + (lane & 15);
-        const int kap = ks * 32 + (lane >> 4) * 8 + e;
-        const int ub = kap >> 6, g = (kap >> 4) & 3, u = kap & 15;
-        out[i] = f32_to_bf16(W[((long long)g * H + ub * 16 + u) * H + unit]);
+        const int kap = ks * 32 + (lane >> 4) * 8;
+        const float* src = W + (long long)row_of_kap(kap, H) * H + unit;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = src[(long long)e * H];
+        *reinterpret_cast<uint4*>(out + c * 8) = pack8(v);
     }
 }
 // dst[g*H + j][k] (+)= sum_s src[s][kappa(g,j)][k]   (slices of a quiet split-K product; dst2 gets
@@ -522,16 +588,38 @@ extern "C" int edgedict_stack_pack_weights(const float* w_ih, const float* w_hh,
                                            const float* b_hh, int H, int I, void* wih_p, void* wih_t,
                                            float* bias_p, void* whh_f, void* whh_b, void* stream_) {
     ED_CHECK_ARG(H >= 32 && H % 32 == 0 && I >= 1, "stack_pack_weights: need H %% 32 == 0 (H=%d I=%d)", H, I);
-    ED_CHECK_ARG(w_ih && w_hh && b_ih && b_hh && wih_p && bias_p && whh_f, "stack_pack_weights: null pointer");
+    ED_CHECK_ARG(w_ih && w_hh, "stack_pack_weights: null weight pointer");
+    ED_CHECK_ARG(wih_p || wih_t || whh_f || whh_b, "stack_pack_weights: no output image requested");
+    ED_CHECK_ARG(!wih_p || (b_ih && b_hh && bias_p), "stack_pack_weights: wih_p comes with the packed bias (b_ih, b_hh, bias_p)");
+    ED_CHECK_ARG((uintptr_t)w_hh % 16 == 0 && (uintptr_t)whh_f % 16 == 0 && (uintptr_t)whh_b % 16 == 0 &&
+                     (uintptr_t)wih_t % 16 == 0,
+                 "stack_pack_weights: W_hh and the images must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream_;
-    hipLaunchKernelGGL(pack_wih_kernel, dim3(ed_grid_for(4ll * H * I, 256, 4096)), dim3(256), 0, s,
-                       w_ih, b_ih, b_hh, (bf16_t*)wih_p, (bf16_t*)wih_t, bias_p, H, I);
-    ED_CHECK_LAUNCH("pack_wih_kernel");
-    hipLaunchKernelGGL(pack_whh_fwd_kernel, dim3(ed_grid_for(4ll * H * H, 256, 4096)), dim3(256), 0,
-                       s, w_hh, (bf16_t*)whh_f, H);
-    ED_CHECK_LAUNCH("pack_whh_fwd_kernel");
+    // every output is optional: the images of the forward pass (wih_p + bias_p, whh_f) can be rebuilt in front of it and
+    // those only the backward pass reads (wih_t, whh_b; edgedict_stack_pack_sk) behind it, off the critical path
+    if (wih_p) {
+        if (I % 8 == 0 && (uintptr_t)w_ih % 16 == 0 && (uintptr_t)wih_p % 16 == 0) {
+            hipLaunchKernelGGL(pack_wih8_kernel, dim3(ed_grid_for(4ll * H * I / 8, 256, 4096)), dim3(256), 0, s,
+                               w_ih, b_ih, b_hh, (bf16_t*)wih_p, bias_p, H, I);
+            ED_CHECK_LAUNCH("pack_wih8_kernel");
+        } else {
+            hipLaunchKernelGGL(pack_wih_kernel, dim3(ed_grid_for(4ll * H * I, 256, 4096)), dim3(256), 0, s,
+                               w_ih, b_ih, b_hh, (bf16_t*)wih_p, (bf16_t*)nullptr, bias_p, H, I);
+            ED_CHECK_LAUNCH("pack_wih_kernel");
+        }
+    }
+    if (wih_t) {
+        hipLaunchKernelGGL(pack_wih_t_kernel, dim3((4 * H / 64) * ((I + 63) / 64)), dim3(256), 0, s, w_ih,
+                           (bf16_t*)wih_t, H, I);
+        ED_CHECK_LAUNCH("pack_wih_t_kernel");
+    }
+    if (whh_f) {
+        hipLaunchKernelGGL(pack_whh_fwd_kernel, dim3(ed_grid_for(4ll * H * H / 8, 256, 4096)), dim3(256), 0,
+                           s, w_hh, (bf16_t*)whh_f, H);
+        ED_CHECK_LAUNCH("pack_whh_fwd_kernel");
+    }
     if (whh_b) {
-        hipLaunchKernelGGL(pack_whh_bwd_kernel, dim3(ed_grid_for(4ll * H * H, 256, 4096)), dim3(256),
+        hipLaunchKernelGGL(pack_whh_bwd_kernel, dim3(ed_grid_for(4ll * H * H / 8, 256, 4096)), dim3(256),
                            0, s, w_hh, (bf16_t*)whh_b, H);
         ED_CHECK_LAUNCH("pack_whh_bwd_kernel");
     }

@@ -1387,18 +1387,24 @@ __global__ __launch_bounds__(256, 2) void stack_bwd_sk_kernel(EdSkLaunch L) {
 
 // split-K fragment image of W_hh: frag[ub H/64][kq 4][ksl H/32][n 4][lane 64][8], W as the FIRST MFMA operand:
 // row index lane & 15 -> unit ub*64 + n*16 + (lane & 15); k = interleaved gate column kq*H + ksl*32 + (lane >> 4)*8 + e
+// thread = one 16-byte chunk: 8 consecutive gate columns = 8 consecutive W rows at one unit; the four waves of a block
+// cover 64 consecutive units (256 contiguous bytes of each row)
 __global__ void pack_whh_sk_kernel(const float* __restrict__ W, bf16_t* __restrict__ out, int H) {
-    const long long n = 4ll * H * H;
+    const long long n8 = 4ll * H * H / 8;
     const int KSq = H >> 5;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (long long)gridDim.x * blockDim.x) {
-        const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), nn = (int)((i >> 9) & 3);
-        const long long blk = i >> 11;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < n8; c += (long long)gridDim.x * blockDim.x) {
+        const int lane = (int)(c & 63), nn = (int)((c >> 6) & 3);
+        const long long blk = c >> 8;
         const int ksl = (int)(blk % KSq), kq = (int)((blk / KSq) & 3), ub = (int)(blk / KSq / 4);
         const int unit = ub * 64 + nn * 16 + (lane & 15);
-        const int kcol = kq * H + ksl * 32 + (lane >> 4) * 8 + e;
+        const int kcol = kq * H + ksl * 32 + (lane >> 4) * 8;
         const int ubk = kcol >> 6, g = (kcol >> 4) & 3, u = kcol & 15;
-        out[i] = f32_to_bf16(W[((long long)g * H + ubk * 16 + u) * H + unit]);
+        const float* src = W + ((long long)g * H + ubk * 16 + u) * H + unit;
+        unsigned o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            o[e] = (unsigned)f32_to_bf16(src[(long long)(2 * e) * H]) | ((unsigned)f32_to_bf16(src[(long long)(2 * e + 1) * H]) << 16);
+        *reinterpret_cast<uint4*>(out + c * 8) = make_uint4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -1697,7 +1703,7 @@ int ed_stack_wait_counters(const unsigned* const* counters, const unsigned* targ
 int ed_stack_sk_supported(int B, int H) { return (B >= 1 && B <= 64 && H % 64 == 0 && H >= 64 && H <= 1024) ? 1 : 0; }
 
 int ed_stack_pack_sk(const float* w_hh, bf16_t* out, int H, hipStream_t s) {
-    hipLaunchKernelGGL(pack_whh_sk_kernel, dim3(ed_grid_for(4ll * H * H, 256, 4096)), dim3(256), 0, s, w_hh, out, H);
+    hipLaunchKernelGGL(pack_whh_sk_kernel, dim3(ed_grid_for(4ll * H * H / 8, 256, 4096)), dim3(256), 0, s, w_hh, out, H);
     ED_CHECK_LAUNCH("pack_whh_sk_kernel");
     return ED_OK;
 }

@@ -79,29 +79,42 @@ def supported(cd, H, I0, L, reductions):
 
 
 class _PackedLayer:
-    """bf16 weight images of one LSTM layer, rebuilt when the fp32 masters change."""
-    __slots__ = ("key", "ref", "wih_p", "wih_t", "bias_p", "whh_f", "whh_b", "whh_s")
+    """bf16 weight images of one LSTM layer, rebuilt when the fp32 masters change: the forward pass's images (wih_p,
+    bias_p, whh_f) under ``key``, the ones only the backward pass reads (wih_t, whh_b, whh_s) under ``bwd_key``."""
+    __slots__ = ("key", "bwd_key", "ref", "wih_p", "wih_t", "bias_p", "whh_f", "whh_b", "whh_s")
 
     def __init__(self, owner):
-        self.key = None
+        self.key = self.bwd_key = None
         self.ref = weakref.ref(owner)
 
 
 _PACKED = {}
 
 
-def packed_weights(w_ih, w_hh, b_ih, b_hh):
+def _sources(*ts):
+    srcs = [t.detach().contiguous() for t in ts]
+    for t in srcs:
+        if t.dtype != F32:
+            raise TypeError("encoder stack: master weights must be fp32")
+    return srcs
+
+
+def packed_weights(w_ih, w_hh, b_ih, b_hh, backward_images=True):
+    """The layer's images, (re)built on the current stream when the masters changed (a NEW entry then: descriptors that
+    hold pointers into the old one keep reading consistent images).  ``backward_images=False`` leaves wih_t / whh_b /
+    whh_s allocated but not built - their pointers can go into a descriptor, and ``fill_backward_images`` builds them
+    before the backward pass reads them (``_Plan.backward``; ``prepack`` does it behind the forward images)."""
     ent = _PACKED.get(id(w_hh))
-    if ent is None or ent.ref() is not w_hh:     # ids are recycled: the entry must be this tensor's
+    key = (w_ih.data_ptr(), w_hh.data_ptr(), w_ih._version, w_hh._version, b_ih._version,
+           b_hh._version, config.param_epoch(), BWD_SK)
+    if ent is None or ent.ref() is not w_hh or ent.key != key:     # (ids are recycled: the entry must be this tensor's)
         for k in [k for k, v in _PACKED.items() if v.ref() is None]:
             del _PACKED[k]                       # images of parameters that no longer exist
         ent = _PACKED[id(w_hh)] = _PackedLayer(w_hh)
-    key = (w_ih.data_ptr(), w_hh.data_ptr(), w_ih._version, w_hh._version, b_ih._version,
-           b_hh._version, config.param_epoch(), BWD_SK)
-    if ent.key != key:
         H4, I = w_ih.shape
         H = H4 // 4
         dev = w_ih.device
+        srcs = _sources(w_ih, w_hh, b_ih, b_hh)
         ent.wih_p = torch.empty(H4, I, dtype=BF16, device=dev)
         ent.wih_t = torch.empty(I, H4, dtype=BF16, device=dev)
         ent.bias_p = torch.empty(H4, dtype=F32, device=dev)
@@ -109,18 +122,28 @@ def packed_weights(w_ih, w_hh, b_ih, b_hh):
         ent.whh_b = torch.empty(H4 * H, dtype=BF16, device=dev)
         # split-K image of the weights-stationary BPTT kernel (csrc/stack_kernels.hip stack_bwd_sk_kernel)
         ent.whh_s = torch.empty(H4 * H, dtype=BF16, device=dev) if (BWD_SK and H % 64 == 0 and 64 <= H <= 1024) else None
-        srcs = [t.detach().contiguous() for t in (w_ih, w_hh, b_ih, b_hh)]
-        for t in srcs:
-            if t.dtype != F32:
-                raise TypeError("encoder stack: master weights must be fp32")
-        lib = _lib.load()
-        check(lib.edgedict_stack_pack_weights(ptr(srcs[0]), ptr(srcs[1]), ptr(srcs[2]), ptr(srcs[3]),
-                                              H, I, ptr(ent.wih_p), ptr(ent.wih_t), ptr(ent.bias_p), ptr(ent.whh_f),
-                                              ptr(ent.whh_b), stream_ptr()), "stack_pack_weights")
-        if ent.whh_s is not None:
-            check(lib.edgedict_stack_pack_sk(ptr(srcs[1]), H, ptr(ent.whh_s), stream_ptr()), "stack_pack_sk")
+        check(_lib.load().edgedict_stack_pack_weights(ptr(srcs[0]), ptr(srcs[1]), ptr(srcs[2]), ptr(srcs[3]),
+                                                      H, I, ptr(ent.wih_p), None, ptr(ent.bias_p), ptr(ent.whh_f),
+                                                      None, stream_ptr()), "stack_pack_weights")
         ent.key = key
+    if backward_images:
+        fill_backward_images(ent, w_ih, w_hh)
     return ent
+
+
+def fill_backward_images(ent, w_ih, w_hh):
+    """Build wih_t / whh_b / whh_s of ``ent`` on the current stream unless they are there already."""
+    if ent.bwd_key == ent.key:
+        return
+    H4, I = w_ih.shape
+    H = H4 // 4
+    srcs = _sources(w_ih, w_hh)
+    lib = _lib.load()
+    check(lib.edgedict_stack_pack_weights(ptr(srcs[0]), ptr(srcs[1]), None, None, H, I, None, ptr(ent.wih_t), None,
+                                          None, ptr(ent.whh_b), stream_ptr()), "stack_pack_weights (backward images)")
+    if ent.whh_s is not None:
+        check(lib.edgedict_stack_pack_sk(ptr(srcs[1]), H, ptr(ent.whh_s), stream_ptr()), "stack_pack_sk")
+    ent.bwd_key = ent.key
 
 
 def clear_cache():
@@ -157,21 +180,27 @@ def last_mode(backward):
     return kind.value, steps.value
 
 
-_PREPACK_EVENT = [None]
+_PREPACK_EVENT = [None, None]     # images of the forward pass / of the backward pass rebuilt on another stream
 
 
 def prepack(encoder, stream):
     """Rebuild the weight images of ``encoder`` (an ``Encoder`` whose ``lstm`` is a
     ``ResLayerNormLSTM``) on ``stream`` - the trainer calls this on the auxiliary stream right after
-    the optimiser step, so the 0.3 ms of packing kernels run beside the next step's front-end
-    instead of in front of its encoder.  The first plan built afterwards waits for the event."""
+    the optimiser step.  The next forward pass cannot start before its images exist, so those come first
+    (~60 us; the first plan built afterwards waits for their event) and the backward pass's images behind
+    them (its first call waits for the second event, long complete by then).  Round 6: 0.39 -> ~0.06 ms
+    between the optimiser step and the encoder (profiles/r6_pack.txt)."""
     lstm = encoder.lstm
     if not hasattr(lstm, "lstms"):
         return
     with torch.cuda.stream(stream):
-        for m in lstm.lstms:
-            packed_weights(*m.layer(0))
+        # what the forward pass reads first (the wait in front of the encoder is this part's: ~60 of the ~150 us), then
+        # what only the backward pass reads
+        ents = [(packed_weights(*m.layer(0), backward_images=False), m.layer(0)) for m in lstm.lstms]
         _PREPACK_EVENT[0] = stream.record_event()
+        for ent, lay in ents:
+            fill_backward_images(ent, lay[0], lay[1])
+        _PREPACK_EVENT[1] = stream.record_event()
 
 
 class _Plan:
@@ -194,9 +223,11 @@ class _Plan:
         self.in_rstd = torch.empty(B * T0, dtype=F32, device=dev)
         self.larr = (StackLayer * L)()
         self.layer_bufs = []
+        self.packs = []         # (weight images, masters) per layer: the backward pass's images may still have to be built
         T, I = T0, I0
         for l, (w_ih, w_hh, b_ih, b_hh, ln_w, ln_b) in enumerate(layers):
-            pk = packed_weights(w_ih, w_hh, b_ih, b_hh)
+            pk = packed_weights(w_ih, w_hh, b_ih, b_hh, backward_images=False)
+            self.packs.append((pk, w_ih, w_hh))
             bufs = dict(
                 X=torch.empty(T, B, I, dtype=BF16, device=dev),
                 G=torch.empty(T, B, 4 * H, dtype=BF16, device=dev),
@@ -258,6 +289,11 @@ class _Plan:
         B, H = self.B, self.H
         grads = []
         d = self.desc
+        if _PREPACK_EVENT[1] is not None:      # the backward pass's weight images were rebuilt on another stream (prepack)
+            torch.cuda.current_stream(dev).wait_event(_PREPACK_EVENT[1])
+            _PREPACK_EVENT[1] = None
+        for pk, w_ih, w_hh in self.packs:      # ... or not at all yet (no prepack: first step, plain autograd use)
+            fill_backward_images(pk, w_ih, w_hh)
         everyone = list(params) + list(in_norm)
         direct = config.DEFER_WEIGHT_GRADS and all(
             p.grad is not None and p.grad.dtype == F32 and p.grad.is_contiguous() for p in everyone)

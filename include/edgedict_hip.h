@@ -325,6 +325,10 @@ void* edgedict_aux_stream(int which);
  * nothing. */
 int edgedict_streams_busy(unsigned* mask);
 size_t edgedict_stack_workspace_bytes(const edgedict_stack_desc_t* desc);
+/* fp32 master weights of one layer (nn.LSTM's weight_ih_l0 [4H, I], weight_hh_l0 [4H, H], biases [4H]) -> the bf16
+ * images edgedict_stack_layer_t points at.  Every output is optional (null = skip): wih_p (+ bias_p, needs b_ih / b_hh)
+ * and whh_f are what the forward pass reads; wih_t, whh_b (and edgedict_stack_pack_sk's image) only the backward pass -
+ * a trainer rebuilds the first group in front of the next forward pass and the second behind it. */
 int edgedict_stack_pack_weights(const float* w_ih, const float* w_hh, const float* b_ih,
                                 const float* b_hh, int H, int I, void* wih_p, void* wih_t,
                                 float* bias_p, void* whh_f, void* whh_b, void* stream);

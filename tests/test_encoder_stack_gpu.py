@@ -257,3 +257,46 @@ def test_stack_dropout_mask_is_the_elementwise_kernels_mask(hip_lib):
     assert out.shape == (B, 20, H)
     assert torch.equal(out != 0, mask), ((out != 0) != mask).sum().item()
     assert 0.5 < mask.float().mean().item() < 0.7
+
+
+@pytest.mark.parametrize("H,I", [(64, 24), (64, 20), (128, 80), (1024, 240), (256, 256)])
+def test_weight_images_match_their_documented_layouts(hip_lib, H, I):
+    """The weight images the stack's kernels read (edgedict_stack_pack_weights / _pack_sk; rebuilt after every optimiser
+    step) against the layouts written out here, index by index - the vectorised pack kernels (16-byte stores, an LDS
+    transpose for W_ih^T) and the scalar fall-back (I % 8 != 0) must produce the same bytes."""
+    import numpy as np
+    from edgedict_amd import encoder_stack as es
+    es.clear_cache()
+    g = torch.Generator().manual_seed(H + I)
+    w_ih = torch.randn(4 * H, I, generator=g).cuda()
+    w_hh = torch.randn(4 * H, H, generator=g).cuda()
+    b_ih = torch.randn(4 * H, generator=g).cuda()
+    b_hh = torch.randn(4 * H, generator=g).cuda()
+    pk = es.packed_weights(w_ih, w_hh, b_ih, b_hh)
+    torch.cuda.synchronize()
+    wi = w_ih.bfloat16().cpu().view(torch.int16).numpy()
+    wh = w_hh.bfloat16().cpu().view(torch.int16).numpy()
+
+    def row_of(kap):                                    # W row of interleaved gate column kap (ed_gate_col inverted)
+        return ((kap >> 4) & 3) * H + (kap >> 6) * 16 + (kap & 15)
+
+    kap = np.arange(4 * H)
+    got = pk.wih_p.cpu().view(torch.int16).numpy()
+    assert np.array_equal(got, wi[row_of(kap)])
+    assert np.array_equal(pk.wih_t.cpu().view(torch.int16).numpy(), wi[row_of(kap)].T)
+    assert torch.equal(pk.bias_p.cpu(), (b_ih + b_hh).cpu()[torch.from_numpy(row_of(kap))])
+    i = np.arange(4 * H * H)
+    e, lane = i & 7, (i >> 3) & 63
+    blk = i >> 9                                        # forward: frag[ub][ks][gate][lane][8]
+    gate, ks, ub = blk & 3, (blk >> 2) % (H // 32), (blk >> 2) // (H // 32)
+    assert np.array_equal(pk.whh_f.cpu().view(torch.int16).numpy(),
+                          wh[gate * H + ub * 16 + (lane & 15), ks * 32 + (lane >> 4) * 8 + e])
+    n2, ks, nb = blk & 1, (blk >> 1) % (H // 8), (blk >> 1) // (H // 8)      # backward: frag[nb32][ks][n2][lane][8]
+    assert np.array_equal(pk.whh_b.cpu().view(torch.int16).numpy(),
+                          wh[row_of(ks * 32 + (lane >> 4) * 8 + e), (nb * 2 + n2) * 16 + (lane & 15)])
+    if pk.whh_s is not None:                            # split-K: frag[ub][kq][ksl][n][lane][8]
+        nn, blk = (i >> 9) & 3, i >> 11
+        ksl, kq, ub = blk % (H // 32), (blk // (H // 32)) & 3, blk // (H // 32) // 4
+        assert np.array_equal(pk.whh_s.cpu().view(torch.int16).numpy(),
+                              wh[row_of(kq * H + ksl * 32 + (lane >> 4) * 8 + e), ub * 64 + nn * 16 + (lane & 15)])
+    es.clear_cache()
