@@ -37,6 +37,10 @@ USE_ENCODER_STACK = os.environ.get("EDGEDICT_ENCODER_STACK", "1") != "0"
 # weight gradients that feed nothing downstream are accumulated straight into existing .grad
 # buffers on the auxiliary stream, concurrently with the rest of the backward pass (side.py)
 DEFER_WEIGHT_GRADS = os.environ.get("EDGEDICT_DEFER_DW", "1") != "0"
+# the joint's output-bias gradient as partial column sums out of the loss-gradient kernel (csrc/rnnt_loss.hip rnnt_grad<T, true>)
+# instead of a pass over the gradient matrix on the auxiliary stream
+FUSED_DB2 = os.environ.get("EDGEDICT_FUSED_DB2", "1") != "0"
+
 # the same for the per-layer LSTM blocks (fp32 mode, prediction network, small encoders): dW_ih / dW_hh / db of a layer
 # run on the auxiliary stream under the BPTT of the layer below
 DEFER_LSTM_WEIGHT_GRADS = os.environ.get("EDGEDICT_DEFER_LSTM_DW", "1") != "0"

@@ -437,6 +437,8 @@ extern "C" int edgedict_colsum(int dtype, const void* x, long long ld, float* ou
     if (M == 0 || N == 0) return ED_OK;
     ED_CHECK_ARG(x && out, "colsum: null pointer");
     hipStream_t s = (hipStream_t)stream_;
+    // (a 16-byte-per-thread variant of this kernel was measured in round 6: beside the encoder's BPTT it cost the step
+    // 0.45 ms - profiles/r6_colsum.txt - and was removed; the one big column sum of the step is fused into rnnt_grad)
     const int colblocks = (N + 255) / 256;
     long long want_rowblocks = (2048 + colblocks - 1) / colblocks;  // ~2k workgroups in total
     long long rpb = (M + want_rowblocks - 1) / want_rowblocks;

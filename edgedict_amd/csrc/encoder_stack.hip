@@ -168,6 +168,48 @@ __global__ void unpermute_rows_kernel(const float* __restrict__ src, long long s
     }
 }
 
+// the same, four columns per thread (K % 4 == 0, 16-byte aligned buffers): same sums in the same order
+__global__ void unpermute_rows4_kernel(const float* __restrict__ src, long long slice_stride, int S,
+                                       float* __restrict__ dst, float* __restrict__ dst2, int H, int K,
+                                       int accumulate) {
+    const int K4 = K >> 2;
+    const long long n4 = 4ll * H * K4;
+    for (long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x; c < n4; c += (long long)gridDim.x * blockDim.x) {
+        const int row = (int)(c / K4), k = (int)(c % K4) * 4;
+        const long long o = (long long)ed_gate_col(row / H, row % H) * K + k;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sl = 0; sl < S; ++sl) {
+            const float4 p = *reinterpret_cast<const float4*>(src + sl * slice_stride + o);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        const long long i = (long long)row * K + k;
+        if (accumulate) {
+            const float4 d = *reinterpret_cast<const float4*>(dst + i);
+            *reinterpret_cast<float4*>(dst + i) = make_float4(d.x + v.x, d.y + v.y, d.z + v.z, d.w + v.w);
+            if (dst2) {
+                const float4 e = *reinterpret_cast<const float4*>(dst2 + i);
+                *reinterpret_cast<float4*>(dst2 + i) = make_float4(e.x + v.x, e.y + v.y, e.z + v.z, e.w + v.w);
+            }
+        } else {
+            *reinterpret_cast<float4*>(dst + i) = v;
+            if (dst2) *reinterpret_cast<float4*>(dst2 + i) = v;
+        }
+    }
+}
+int unpermute_rows(const float* src, long long slice_stride, int S, float* dst, float* dst2, int H, int K, int accumulate,
+                   hipStream_t s) {
+    const bool vec = K % 4 == 0 && slice_stride % 4 == 0 && (uintptr_t)src % 16 == 0 && (uintptr_t)dst % 16 == 0 &&
+                     (uintptr_t)dst2 % 16 == 0;
+    if (vec)
+        hipLaunchKernelGGL(unpermute_rows4_kernel, dim3(ed_grid_for(4ll * H * K / 4, 256, 4096)), dim3(256), 0, s, src,
+                           slice_stride, S, dst, dst2, H, K, accumulate);
+    else
+        hipLaunchKernelGGL(unpermute_rows_kernel, dim3(ed_grid_for(4ll * H * K, 256, 4096)), dim3(256), 0, s, src,
+                           slice_stride, S, dst, dst2, H, K, accumulate);
+    ED_CHECK_LAUNCH("unpermute_rows_kernel");
+    return ED_OK;
+}
+
 // ---------------------------------------------------------------- per-device runtime
 struct Runtime {
     // ONE call at a time per device (the event pool, the timing record and the stamp buffers belong to a call);
@@ -1375,12 +1417,10 @@ extern "C" int edgedict_stack_backward(const edgedict_stack_desc_t* d, void* str
         // and are summed + un-permuted in one pass
         ED_TRY(ed_gemm_quiet_partials(ED_BF16, bptr(y.G) + r0 * 4 * H, 4ll * H, 0, bptr(y.X) + r0 * y.I, y.I, 0,
                                       4 * H, y.I, M, sk, cap, tmpW, &S, st.W));
-        hipLaunchKernelGGL(unpermute_rows_kernel, dim3(ed_grid_for(4ll * H * y.I, 256, 4096)),
-                           dim3(256), 0, st.W, tmpW, 4ll * H * y.I, S, y.dW_ih, nullptr, H, y.I, acc);
+        ED_TRY(unpermute_rows(tmpW, 4ll * H * y.I, S, y.dW_ih, nullptr, H, y.I, acc, st.W));
         ED_TRY(ed_gemm_quiet_partials(ED_BF16, bptr(y.G) + r0 * 4 * H, 4ll * H, 0, bptr(y.Yx) + r0 * H, H, 0,
                                       4 * H, H, M, sk, cap, tmpW, &S, st.W));
-        hipLaunchKernelGGL(unpermute_rows_kernel, dim3(ed_grid_for(4ll * H * H, 256, 4096)),
-                           dim3(256), 0, st.W, tmpW, 4ll * H * H, S, y.dW_hh, nullptr, H, H, acc);
+        ED_TRY(unpermute_rows(tmpW, 4ll * H * H, S, y.dW_hh, nullptr, H, H, acc, st.W));
         ED_TRY(ed_stack_zero(tmpB, (size_t)4 * H * sizeof(float), st.W));
         ED_TRY(edgedict_colsum(ED_BF16, bptr(y.G) + r0 * 4 * H, 4ll * H, tmpB, M, 4 * H, st.W));
         hipLaunchKernelGGL(unpermute_rows_kernel, dim3(ed_grid_for(4ll * H, 256, 4096)), dim3(256),

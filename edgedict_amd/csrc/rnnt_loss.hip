@@ -427,6 +427,82 @@ __global__ __launch_bounds__(256, ED_GRAD_OCC) void rnnt_grad(
     }
 }
 
+// rnnt_grad for the PACKED lattice that also leaves the column sums of the gradient matrix (fp32 values in front of the
+// store's rounding) as one partial row per workgroup in colsum_parts[blockIdx.y * gridDim.x + blockIdx.x][V]: the joint's
+// output-bias gradient is the column sum of this matrix, and a separate pass over its 2.2 GB (E6D2 bench batch) on the
+// auxiliary stream beside the encoder's BPTT cost the step 0.4 ms (profiles/r6_colsum.txt).
+// Work split: the workgroup's rows are those of rnnt_grad (groups of 4: r = 4 (blockIdx.x + k gridDim.x) + q), but wave w
+// owns COLUMN SLICE w (64 * VEC columns: one 16-byte vector per lane) of all four rows of a group instead of one whole
+// row - VEC accumulators per lane with static indices, four loads in flight as before.  (Tried first: one row per wave
+// with 4 x VEC register accumulators, 1.09 instead of 0.88 ms; LDS ds_add_f32 accumulators, 5.8 ms.)
+// Needs 16-byte aligned rows and V <= 4 * 64 * VEC (2048 in bf16, 1024 in f32); arithmetic per cell as in rnnt_grad.
+template <typename T>
+__global__ __launch_bounds__(256, ED_GRAD_OCC) void rnnt_grad_cs(
+    const T* __restrict__ acts, T* __restrict__ grads, const int32_t* __restrict__ labels,
+    const int32_t* __restrict__ act_lens, const int32_t* __restrict__ label_lens, int B, int Tm,
+    int U1, int V, int blank, const float* __restrict__ denom, const double* __restrict__ alphas,
+    const double* __restrict__ betas, const double* __restrict__ ll, float scale_host,
+    const float* __restrict__ scale_dev, int scale_stride, const long long* __restrict__ pk_off,
+    float* __restrict__ colsum_parts) {
+    constexpr int VEC = ElemIO<T>::VEC;
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int b = blockIdx.y;
+    const int Tb = min(act_lens[b], Tm), Ub = min(label_lens[b], U1 - 1);
+    const float scale = scale_host * (scale_dev ? scale_dev[(long long)b * scale_stride] : 1.f);
+    const int Wb = Ub + 1, ncells = Tb * Wb;
+    const int v = (wave * 64 + lane) * VEC;          // this lane's columns v .. v + VEC - 1 of every row
+    const bool col_live = v < V;
+    const double L = ll[2 * b];
+    float cs[VEC];
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) cs[i] = 0.f;
+    for (int r0 = blockIdx.x * 4; r0 < ncells; r0 += gridDim.x * 4) {
+        uint4 raw[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (col_live && r0 + q < ncells) raw[q] = *reinterpret_cast<const uint4*>(acts + (pk_off[b] + r0 + q) * (long long)V + v);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int r = r0 + q;
+            if (r >= ncells) break;
+            const int t = r / Wb, u = r - t * Wb;
+            const long long row = ((long long)b * Tm + t) * U1 + u;
+            const double a = alphas[row], bt_ = betas[row];
+            const float lse = denom[row];
+            const float c_all = (float)(a + bt_ - L) - lse;
+            float c_blank = -INFINITY, c_label = -INFINITY;
+            int y = -1;
+            if (t < Tb - 1)
+                c_blank = (float)(a + betas[row + U1] - L) - lse;
+            else if (u == Ub)
+                c_blank = (float)(a - L) - lse;
+            if (u < Ub) {
+                y = labels[(long long)b * (U1 - 1) + u];
+                c_label = (float)(a + betas[row + 1] - L) - lse;
+            }
+            if (col_live) {
+                float x[VEC], o[VEC];
+                ElemIO<T>::cvt_vec(raw[q], x);
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    float gv = __expf(x[i] + c_all);
+                    if (v + i == blank) gv -= __expf(x[i] + c_blank);
+                    if (v + i == y) gv -= __expf(x[i] + c_label);
+                    o[i] = gv * scale;
+                    cs[i] += o[i];
+                }
+                ElemIO<T>::store_vec(grads + (pk_off[b] + r) * (long long)V + v, o);
+            }
+        }
+    }
+    if (col_live) {
+        float* out = colsum_parts + ((long long)blockIdx.y * gridDim.x + blockIdx.x) * V + v;
+#pragma unroll
+        for (int i = 0; i < VEC; ++i) out[i] = cs[i];
+    }
+}
+
 inline int check_common(int B, int T, int U1, int V, int blank, int dtype) {
     ED_CHECK_ARG(B > 0 && T > 0 && U1 > 0 && V > 0, "rnnt_loss: B,T,U1,V must be positive (got %d,%d,%d,%d)", B, T, U1, V);
     ED_CHECK_ARG(U1 <= 1024, "rnnt_loss: U+1 = %d exceeds the supported maximum of 1024", U1);
@@ -550,11 +626,15 @@ extern "C" int edgedict_rnnt_loss_forward_packed_parts(const void* acts, const i
                         reduced, reduce_scale, workspace, row_offsets, stream_, lse_parts, lse_slots);
 }
 
+// workgroups per utterance of rnnt_grad (grid.x; grid.y = utterances)
+static int grad_grid_x(int B, int T, int U1) { return ed_grid_for((long long)T * U1, 4, max(1, 256 * 16 / B)); }
+
 static int loss_backward(const void* acts, int acts_dtype, void* grads, const int32_t* labels,
                          const int32_t* act_lens, const int32_t* label_lens, int B, int T, int U1,
                          int V, int blank, const void* workspace, float grad_scale_host,
                          const float* grad_scale_dev, int grad_scale_stride,
-                         const long long* pk_off, void* stream_, int b0 = 0, int nb = -1) {
+                         const long long* pk_off, void* stream_, int b0 = 0, int nb = -1,
+                         float* colsum_parts = nullptr) {
     if (int rc = check_common(B, T, U1, V, blank, acts_dtype)) return rc;
     if (nb < 0) nb = B - b0;
     ED_CHECK_ARG(b0 >= 0 && nb >= 0 && b0 + nb <= B, "rnnt_loss_backward: utterance range [%d, %d) outside the batch of %d", b0, b0 + nb, B);
@@ -571,7 +651,23 @@ static int loss_backward(const void* acts, int acts_dtype, void* grads, const in
     const size_t esz = acts_dtype == ED_F32 ? 4 : 2;
     const int vec_ok = ((V * esz) % 16 == 0) && (((uintptr_t)acts & 15) == 0) &&
                        (((uintptr_t)grads & 15) == 0);
-    const dim3 grid(ed_grid_for((long long)T * U1, 4, max(1, 256 * 16 / B)), nb);
+    const dim3 grid(grad_grid_x(B, T, U1), nb);
+    if (colsum_parts) {
+        const int cs_width = 4 * 64 * (acts_dtype == ED_F32 ? 4 : 8);      // four column slices of 64 lanes x 16 bytes
+        ED_CHECK_ARG(vec_ok && V <= cs_width && pk_off && b0 == 0 && nb == B,
+                     "rnnt_loss_backward: fused column sums need the packed lattice, 16-byte aligned rows and V <= %d (got V = %d)",
+                     cs_width, V);
+        if (acts_dtype == ED_F32)
+            hipLaunchKernelGGL(rnnt_grad_cs<float>, grid, dim3(256), 0, stream, (const float*)acts, (float*)grads, labels,
+                               act_lens, label_lens, B, T, U1, V, blank, denom, alphas, betas, ll, grad_scale_host,
+                               grad_scale_dev, grad_scale_stride, pk_off, colsum_parts);
+        else
+            hipLaunchKernelGGL(rnnt_grad_cs<bf16_t>, grid, dim3(256), 0, stream, (const bf16_t*)acts, (bf16_t*)grads,
+                               labels, act_lens, label_lens, B, T, U1, V, blank, denom, alphas, betas, ll,
+                               grad_scale_host, grad_scale_dev, grad_scale_stride, pk_off, colsum_parts);
+        ED_CHECK_LAUNCH("rnnt_grad_cs");
+        return ED_OK;
+    }
     if (acts_dtype == ED_F32)
         hipLaunchKernelGGL(rnnt_grad<float>, grid, dim3(256), 0, stream, (const float*)acts,
                            (float*)grads, labels, act_lens, label_lens, B, T, U1, V, blank, denom,
@@ -607,6 +703,26 @@ extern "C" int edgedict_rnnt_loss_backward_packed(const void* acts, int acts_dty
     return loss_backward(acts, acts_dtype, grads, labels, act_lens, label_lens, B, T, U1, V, blank,
                          workspace, grad_scale_host, grad_scale_dev, grad_scale_stride, row_offsets,
                          stream_);
+}
+
+extern "C" int edgedict_rnnt_grad_colsum_rows(int acts_dtype, int B, int T, int U1, int V) {
+    if (B <= 0 || T <= 0 || U1 <= 0 || V <= 0 || (acts_dtype != ED_F32 && acts_dtype != ED_BF16)) return 0;
+    const int esz = acts_dtype == ED_F32 ? 4 : 2;
+    if ((V * esz) % 16 != 0 || V > 4 * 64 * (16 / esz)) return 0;
+    return grad_grid_x(B, T, U1) * B;
+}
+
+extern "C" int edgedict_rnnt_loss_backward_packed_colsum(const void* acts, int acts_dtype, void* grads,
+                                                         const int32_t* labels, const int32_t* act_lens,
+                                                         const int32_t* label_lens,
+                                                         const long long* row_offsets, int B, int T, int U1,
+                                                         int V, int blank, const void* workspace,
+                                                         float grad_scale_host, const float* grad_scale_dev,
+                                                         int grad_scale_stride, float* colsum_parts, void* stream_) {
+    ED_CHECK_ARG(row_offsets && colsum_parts, "rnnt_loss_backward_packed_colsum: null pointer");
+    return loss_backward(acts, acts_dtype, grads, labels, act_lens, label_lens, B, T, U1, V, blank,
+                         workspace, grad_scale_host, grad_scale_dev, grad_scale_stride, row_offsets,
+                         stream_, 0, -1, colsum_parts);
 }
 
 extern "C" int edgedict_rnnt_loss_backward_packed_range(const void* acts, int acts_dtype, void* grads,

@@ -543,9 +543,17 @@ class _JointLossFn(torch.autograd.Function):
         dD1 = torch.empty(B, U1, J, dtype=F32, device=dl.device)
         # (pipelining the loss gradient against the dhid product by utterance groups on two streams was measured:
         # 21.70 ms per step in one pass, 21.74 / 22.26 / 23.18 with 2 / 4 / 8 groups - both sit on the L2/HBM path)
+        # the output bias's gradient is the column sum of dl: the loss-gradient kernel leaves it as per-workgroup
+        # partial rows (a few MB) instead of a second pass over dl beside the encoder's BPTT (0.4 ms per step)
+        cs_rows = _lib.load().edgedict_rnnt_grad_colsum_rows(_lib.dtype_code(cd), B, T, U1, V) if config.FUSED_DB2 else 0
+        db2_parts = torch.empty(cs_rows, V, dtype=F32, device=dl.device) if cs_rows > 0 else None
         with ops.timed("rnnt_grad"):
-            _lib.call("rnnt_loss_backward_packed", logits, _lib.dtype_code(cd), dl, labels, al_d, ll_d,
-                      off_d, B, T, U1, V, blank, ws, 1.0 / B, gscale, 0)
+            if db2_parts is not None:
+                _lib.call("rnnt_loss_backward_packed_colsum", logits, _lib.dtype_code(cd), dl, labels, al_d, ll_d,
+                          off_d, B, T, U1, V, blank, ws, 1.0 / B, gscale, 0, db2_parts)
+            else:
+                _lib.call("rnnt_loss_backward_packed", logits, _lib.dtype_code(cd), dl, labels, al_d, ll_d,
+                          off_d, B, T, U1, V, blank, ws, 1.0 / B, gscale, 0)
         del logits
         with ops.timed("joint_dhid_gemm"):
             dhid = ops.gemm(dl, w2t)
@@ -554,16 +562,16 @@ class _JointLossFn(torch.autograd.Function):
                       off_d, B, T, U1, J)
         if not defer:
             dw2 = ops.gemm(dl.t(), hid.t(), out_dtype=F32, split_k=ops.pick_split_k(V, J, M))
-            db2 = ops.colsum(dl)
+            db2 = ops.colsum(dl if db2_parts is None else db2_parts)
         del dhid
         dE1c = ops.cast(dE1, cd).view(B * T, J)
         dD1c = ops.cast(dD1, cd).view(B * U1, J)
         denc = ops.gemm(dE1c, w1c[:, :P].t()).view(B, T, P)
         ddec = ops.gemm(dD1c, w1c[:, P:].t()).view(B, U1, P2)
         if defer:
-            with side.deferred(dl.device, dl, hid, dE1c, dD1c, dD1, enc2, dec2):
+            with side.deferred(dl.device, dl, hid, dE1c, dD1c, dD1, enc2, dec2, db2_parts):
                 ops.gemm(dl.t(), hid.t(), out=w2.grad, accumulate=True, split_k=8, max_wg_per_cu=2)
-                ops.colsum(dl, out=ctx.b2.grad)
+                ops.colsum(dl if db2_parts is None else db2_parts, out=ctx.b2.grad)
                 g1 = w1.grad
                 ops.gemm(dE1c.t(), enc2.t(), out=g1[:, :P], accumulate=True,
                          split_k=ops.pick_split_k(J, P, B * T))

@@ -104,6 +104,18 @@ int edgedict_rnnt_loss_backward_packed(const void* acts, int acts_dtype, void* g
                                        int B, int T, int U1, int V, int blank, const void* workspace,
                                        float grad_scale_host, const float* grad_scale_dev,
                                        int grad_scale_stride, void* stream);
+/* edgedict_rnnt_loss_backward_packed that also leaves the COLUMN SUMS of the gradient matrix it writes (of the fp32 values
+ * before they are rounded to the gradient's dtype) as `edgedict_rnnt_grad_colsum_rows(...)` partial rows of V floats in
+ * colsum_parts: their sum over rows is the joint's output-bias gradient (rnnt/models.py:165-167 through autograd), which
+ * otherwise takes a second pass over the matrix (2.2 GB at the E6D2 bench batch).  _rows returns 0 when the fused form
+ * is not available (V * sizeof(element) not a multiple of 16, or V > 2048 for bf16 / 1024 for f32). */
+int edgedict_rnnt_grad_colsum_rows(int acts_dtype, int B, int T, int U1, int V);
+int edgedict_rnnt_loss_backward_packed_colsum(const void* acts, int acts_dtype, void* grads,
+                                              const int32_t* labels, const int32_t* act_lens,
+                                              const int32_t* label_lens, const long long* row_offsets,
+                                              int B, int T, int U1, int V, int blank, const void* workspace,
+                                              float grad_scale_host, const float* grad_scale_dev,
+                                              int grad_scale_stride, float* colsum_parts, void* stream);
 /* the same for utterances [b0, b0 + nb) of the batch only (all array arguments are still the whole batch's):
  * lets the host pipeline the gradient of one group of utterances (HBM-bound) against the joint's dhid product
  * of the previous group (matrix-pipe-bound) on a second stream. */

@@ -270,6 +270,53 @@ def test_backward_in_utterance_ranges_equals_one_pass(hip_lib):
 
 
 @pytest.mark.gpu
+def test_fused_column_sums_of_the_gradient(hip_lib):
+    """edgedict_rnnt_loss_backward_packed_colsum: the gradient matrix is the plain entry point's bit for bit, and the partial
+    rows it leaves add up to the column sums of that matrix (of the fp32 values in front of the store: in bf16 they differ
+    from the sums of the stored values by the rounding, 2^-9 per element) - the joint's output-bias gradient without a
+    second pass over the matrix.  V at the limit (2048 bf16 / 1024 f32), ragged boxes, an empty one."""
+    from edgedict_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device="cpu").manual_seed(13)
+    B, T, U1 = 5, 23, 7
+    act = torch.tensor([23, 20, 9, 23, 4], dtype=torch.int32)
+    lab = torch.tensor([6, 2, 6, 0, 5], dtype=torch.int32)
+    rows = act.long() * (lab.long() + 1)
+    off = torch.zeros(B, dtype=torch.int64)
+    off[1:] = torch.cumsum(rows, 0)[:-1]
+    M = int(rows.sum())
+    for dt, code, V in ((torch.float32, 0, 1024), (torch.bfloat16, 1, 2048), (torch.bfloat16, 1, 264)):
+        logits = torch.randn(M, V, generator=g).to(dt).cuda()
+        labels = torch.randint(1, V, (B, U1 - 1), generator=g, dtype=torch.int32).cuda()
+        act_d, lab_d, off_d = act.cuda(), lab.cuda(), off.cuda()
+        ws = torch.zeros(lib.edgedict_rnnt_workspace_bytes(B, T, U1), dtype=torch.uint8, device="cuda")
+        costs, red = torch.empty(B, device="cuda"), torch.empty(1, device="cuda")
+        _lib.call("rnnt_loss_forward_packed", logits, code, labels, act_d, lab_d, off_d, B, T, U1, V, 0, costs, red,
+                  1.0 / B, ws)
+        plain = torch.zeros_like(logits)
+        _lib.call("rnnt_loss_backward_packed", logits, code, plain, labels, act_d, lab_d, off_d, B, T, U1, V, 0, ws,
+                  1.0 / B, None, 0)
+        n = lib.edgedict_rnnt_grad_colsum_rows(code, B, T, U1, V)
+        assert n > 0
+        parts = torch.full((n, V), float("nan"), device="cuda")
+        fused = torch.zeros_like(logits)
+        _lib.call("rnnt_loss_backward_packed_colsum", logits, code, fused, labels, act_d, lab_d, off_d, B, T, U1, V, 0,
+                  ws, 1.0 / B, None, 0, parts)
+        torch.cuda.synchronize()
+        assert torch.equal(plain, fused)
+        want = plain.double().sum(0)
+        got = parts.double().sum(0)
+        assert torch.isfinite(got).all()
+        tol = 1e-5 if dt == torch.float32 else 2.0 ** -8
+        assert ((got - want).abs() <= tol * plain.double().abs().sum(0) + 1e-12).all()
+    assert lib.edgedict_rnnt_grad_colsum_rows(1, B, T, U1, 2056) == 0          # more than four vector passes of a wave
+    assert lib.edgedict_rnnt_grad_colsum_rows(1, B, T, U1, 100) == 0           # rows not 16-byte multiples
+    with pytest.raises(RuntimeError):
+        _lib.call("rnnt_loss_backward_packed_colsum", logits, code, fused, labels, act_d, lab_d, off_d, B, T, U1, V, 0, ws,
+                  1.0 / B, None, 0, None)
+
+
+@pytest.mark.gpu
 def test_long_lattice_drift_is_bounded(hip_lib):
     """a chain of T + U ~ 1200 log-adds (T = 1000, U = 200; peaked logits, so most log-adds see a tiny
     second term - the regime in which a correction term evaluated as log(1 + x) drops x altogether).  Cost and the
