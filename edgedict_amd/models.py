@@ -509,6 +509,9 @@ class _JointLossFn(torch.autograd.Function):
             slots = (V + 63) // 64
             parts = torch.empty(M, slots, 2, dtype=F32, device=dev)
             logits = torch.empty(M, V, dtype=cd, device=dev)
+            # (TrainEngine hangs the next batch's front-end here: beside this matrix-bound product it is nearly free;
+            # beside the encoder's recurrence, or beside the bandwidth-bound tanh kernel above, it cost what it saved)
+            ops.fire("before_logits_gemm")
             with ops.timed("joint_logits_gemm"):
                 _lib.call("gemm_nt_lse", hid, ops._ll(J), w2c, ops._ll(J), logits, ops._ll(V), M, V, J,
                           b2.detach(), parts)

@@ -34,6 +34,16 @@ def mark(tag):
 
 HOST = None     # set to {} to accumulate host wall time of selected native calls (bench.py)
 
+# one-shot host callbacks at named points of the step (the trainer hangs the next batch's front-end on one):
+# HOOKS[point] = callable, removed when fired
+HOOKS = {}
+
+
+def fire(point):
+    fn = HOOKS.pop(point, None)
+    if fn is not None:
+        fn()
+
 
 class host_timed:
     def __init__(self, tag):
