@@ -82,6 +82,7 @@ class BucketedAllReduce:
         for p in flat.params:
             self.expected[self.param_bucket[id(p)]] += 1
         self.pending = list(self.expected)
+        self._seen = set()                  # parameters counted in this step (_done)
         self.issued = [False] * len(bounds)
         late_b = {self.param_bucket[id(p)] for p in late if id(p) in self.param_bucket}
         self.issue_order = [b for b in range(len(bounds)) if b not in late_b] + sorted(late_b)
@@ -128,6 +129,13 @@ class BucketedAllReduce:
         b = self.param_bucket.get(id(p))
         if b is None or self.issued[b] or self.complete[b] is not None:
             return
+        # once per parameter and step: a parameter whose gradient was accumulated in place is reported through ready()
+        # AND (torch 2.10: the post-accumulate hook also fires for a None gradient) by its autograd hook - counted
+        # twice, a bucket would leave before its other parameters are final (found by tests/test_dp_gpu.py when the
+        # per-layer LSTM blocks and nn.Linear started to report, round 6)
+        if id(p) in self._seen:
+            return
+        self._seen.add(id(p))
         self.pending[b] -= 1
         if self.pending[b] > 0:
             return
@@ -199,6 +207,7 @@ class BucketedAllReduce:
             for h in self.handles:
                 h.wait()
         self.handles = []
+        self._seen = set()
         self.pending = list(self.expected)
         self.issued = [False] * len(self.bounds)
         self.complete = [None] * len(self.bounds)

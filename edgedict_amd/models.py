@@ -220,6 +220,7 @@ class _LSTMBlockFn(torch.autograd.Function):
                          split_k=ops.pick_split_k(4 * H, H, M))
                 ops.colsum(dG, out=b_ih.grad)
                 ops.colsum(dG, out=b_hh.grad)
+            _grads_ready((w_ih, w_hh, b_ih, b_hh), dG.device)      # no autograd hook fires for them (dp.py)
             return (dx, None, None, None, None, dgamma, dbeta, None, None, None, None, None)
         dw_ih = ops.gemm(dG.t(), x2.t(), out_dtype=F32, split_k=ops.pick_split_k(4 * H, I, M))
         dw_hh = ops.gemm(dG.t(), Hprev.view(M, H).t(), out_dtype=F32,
@@ -354,6 +355,7 @@ class _LinearFn(torch.autograd.Function):
                          split_k=ops.pick_split_k(w.shape[0], w.shape[1], M))
                 if has_b:
                     ops.colsum(dy2, out=b.grad)
+            _grads_ready((w, b) if has_b else (w,), dy2.device)     # no autograd hook fires for them (dp.py)
             return dx, None, None, None
         dw = ops.gemm(dy2.t(), x2.t(), out_dtype=F32,
                       split_k=ops.pick_split_k(w.shape[0], w.shape[1], M))

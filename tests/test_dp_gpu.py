@@ -88,7 +88,9 @@ def test_two_ranks_equal_one_process_on_the_whole_batch(hip_lib):
     # only the small remainder was flushed by finish()
     early, n_buckets, layer_buckets, norm_bucket, joint_bucket, ready_calls, by, names, expected = got[0][2]
     assert len(set(layer_buckets)) == 3, layer_buckets
-    assert ready_calls == 4, ready_calls                     # the joint's block + one call per encoder layer
+    # the joint's block + one call per encoder layer + (round 6) the blocks whose weight gradients are deferred to the
+    # auxiliary stream as well: the two projections and the two layers of the prediction network
+    assert ready_calls == 8, ready_calls
     assert joint_bucket in early and all(b in early for b in layer_buckets), (early, layer_buckets)
     # top layer first: the order the BPTT finishes the layers in
     pos = [early.index(b) for b in layer_buckets]
