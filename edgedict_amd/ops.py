@@ -4,6 +4,7 @@ Nothing here computes: each function validates shapes, allocates outputs with th
 caching allocator and forwards raw pointers to libedgedict_hip.so on the current stream.
 """
 import ctypes
+import threading
 import time
 
 import torch
@@ -34,13 +35,27 @@ def mark(tag):
 
 HOST = None     # set to {} to accumulate host wall time of selected native calls (bench.py)
 
-# one-shot host callbacks at named points of the step (the trainer hangs the next batch's front-end on one):
-# HOOKS[point] = callable, removed when fired
-HOOKS = {}
+# one-shot host callbacks at named points of the step (the trainer hangs the next batch's front-end on one); per host
+# thread - one thread per GPU may each drive an engine (nn.DataParallel style), and a hook belongs to its thread's step
+_hooks = threading.local()
+
+
+def set_hook(point, fn):
+    """Register ``fn`` to be called once, by this thread, when the step reaches ``point`` (``fire``)."""
+    d = getattr(_hooks, "d", None)
+    if d is None:
+        d = _hooks.d = {}
+    d[point] = fn
+
+
+def pop_hook(point):
+    """Remove and return this thread's hook for ``point`` (None if it has fired or was never set)."""
+    d = getattr(_hooks, "d", None)
+    return d.pop(point, None) if d else None
 
 
 def fire(point):
-    fn = HOOKS.pop(point, None)
+    fn = pop_hook(point)
     if fn is not None:
         fn()
 

@@ -208,11 +208,11 @@ class TrainEngine:
                 # the next batch's front-end: enqueued onto the auxiliary stream right in front of the joint's logits product
                 # (models.py _JointLossFn) - beside that matrix-bound kernel it is nearly free, beside the encoder's
                 # recurrence it cost the recurrence what it saved at the head of the step (profiles/r6_prefetch.txt)
-                ops.HOOKS["before_logits_gemm"] = lambda nb=next_batch: self._prefetch(nb[0], nb[1])
+                ops.set_hook("before_logits_gemm", lambda nb=next_batch: self._prefetch(nb[0], nb[1]))
             try:
                 loss = self.model(xs, ys[s:e], xlen, ylen[s:e])
             finally:
-                late = ops.HOOKS.pop("before_logits_gemm", None)
+                late = ops.pop_hook("before_logits_gemm")
             if late is not None:
                 late()                         # a forward pass that did not reach the hook (unfused path): behind it
             loss = loss / len(starts)
